@@ -1,0 +1,130 @@
+/*
+ * tokendagger_hip.h — C ABI of the MI355X-native tokenizer hot path (libtokendagger_hip.so).
+ *
+ * This is the drop-in boundary for the ONE path this repository accelerates: raw UTF-8 text ->
+ * regex pre-tokenization -> byte-pair merge -> token ids (reference: tiktoken::CoreBPE,
+ * /root/reference/src/tiktoken/tiktoken.hpp:38-88).  Plain pointers and sizes only; no torch,
+ * pybind or C++ types cross it.  Every entry point names the reference interface it replaces.
+ * INTEGRATION.md shows the reference-side binding (pybind11 / ctypes) a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns TD_OK (0) or a TD_E_* code; td_last_error() gives the message
+ *     (the C ABI equivalent of the reference's `TiktokenError` exception, tiktoken.hpp:32-35);
+ *   - text is UTF-8, documents are concatenated: document d = text[doc_offsets[d], doc_offsets[d+1]),
+ *     doc_offsets[0] == 0, doc_offsets[n_docs] == total bytes, offsets are int64;
+ *   - token ids are int32 and equal the `rank` values given at construction;
+ *   - there is no CPU fallback: without a usable HIP device td_create fails.
+ */
+#ifndef TOKENDAGGER_HIP_H
+#define TOKENDAGGER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TD_OK 0
+#define TD_E_INVALID 1      /* bad argument */
+#define TD_E_PATTERN 2      /* pat_str is not a split pattern the device scanner implements */
+#define TD_E_VOCAB 3        /* vocabulary cannot be represented */
+#define TD_E_UNKNOWN_BYTE 4 /* input contains a byte / part that is not in the vocabulary
+                               (reference: TiktokenError "No value found for pair", tiktoken.cpp:364) */
+#define TD_E_CAPACITY 5     /* output buffer too small */
+#define TD_E_SCRATCH 6      /* long-piece scratch exhausted; raise it with td_set_option */
+#define TD_E_HIP 7          /* HIP runtime failure */
+#define TD_E_BAD_TOKEN 8    /* decode: id not in the vocabulary (reference: "Invalid token for decoding", tiktoken.cpp:249) */
+#define TD_E_SPECIAL 9      /* allowed special token not in the special vocabulary (tiktoken.cpp:178-180) */
+
+/* encode modes */
+#define TD_MODE_ENCODE 0    /* CoreBPE::encode(text, {}): whole-piece lookup, then merge  (tiktoken.cpp:169-234) */
+#define TD_MODE_ORDINARY 1  /* CoreBPE::encode_ordinary(text): merge only               (tiktoken.cpp:156-167) */
+
+typedef struct td_tokenizer td_tokenizer;
+
+/*
+ * Replaces CoreBPE::CoreBPE(pattern, vocab, special_vocab)  (tiktoken.hpp:48-67, py_binding.cpp:22-24).
+ * The vocabulary is passed as concatenated token bytes + n+1 offsets + n ranks (what a list of
+ * VocabItem{rank, token_bytes} holds, tiktoken.hpp:12-16); specials likewise (token_string, rank).
+ * Builds the device tables and uploads them to HIP device `device` (-1: current device).
+ */
+int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, const int64_t* token_offsets,
+              const int32_t* ranks, int64_t n_special, const uint8_t* special_bytes,
+              const int64_t* special_offsets, const int32_t* special_ids, int device, td_tokenizer** out);
+
+/* Replaces CoreBPE::~CoreBPE (tiktoken.hpp:69-73). */
+void td_destroy(td_tokenizer* t);
+
+/* Message of the last failure on this handle (t == NULL: last td_create failure of this thread). */
+const char* td_last_error(const td_tokenizer* t);
+
+/*
+ * Bulk encode from HOST buffers: the batched form of CoreBPE::encode / encode_ordinary over n_docs
+ * independent documents (the reference reaches the same through a thread pool over single calls,
+ * tokendagger/wrapper.py:212-235).  out_tokens (capacity out_capacity ids) receives all ids,
+ * out_offsets[n_docs+1] the per-document token offsets, *n_tokens the total.  If the capacity is
+ * too small the call fails with TD_E_CAPACITY and *n_tokens holds the required size.
+ * Copies text to the device, runs the kernels, copies ids back; synchronous.
+ */
+int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
+                    int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens);
+
+/*
+ * The same on DEVICE-resident buffers, asynchronously on `hip_stream` (a hipStream_t; NULL = the
+ * default stream): d_text[n_bytes] (uint8), d_doc_offsets[n_docs+1] (int64), d_out_tokens[out_capacity]
+ * (int32), d_out_offsets[n_docs+1] (int64; element n_docs = total token count).  Nothing is
+ * synchronised; call td_device_status() after the stream has drained to learn about device-side
+ * errors.  Workspace is (re)allocated on demand — call td_reserve() first to keep hipMalloc out of
+ * a timed or captured region.
+ */
+int td_encode_device(td_tokenizer* t, const void* d_text, int64_t n_bytes, const void* d_doc_offsets,
+                     int64_t n_docs, int mode, void* d_out_tokens, int64_t out_capacity, void* d_out_offsets,
+                     void* hip_stream);
+
+/* Pre-allocates workspace for inputs up to max_bytes / max_docs. */
+int td_reserve(td_tokenizer* t, int64_t max_bytes, int64_t max_docs);
+
+/* Synchronises `hip_stream` and returns the device error raised by calls made since the last status
+ * check (TD_OK if none); *err_pos (optional) receives the byte offset it refers to. */
+int td_device_status(td_tokenizer* t, void* hip_stream, int64_t* err_pos);
+
+/*
+ * Replaces CoreBPE::decode_bytes(tokens) (tiktoken.cpp:236-255, py_binding.cpp:40-44) for host
+ * buffers: ids -> concatenated bytes.  *n_bytes receives the size (also on TD_E_CAPACITY).
+ */
+int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, uint8_t* out, int64_t out_capacity,
+                    int64_t* n_bytes);
+
+/*
+ * Replaces CoreBPE::encode(text, allowed_special) with a NON-empty allowed set (tiktoken.cpp:169-234,
+ * find_next_special_token :130-154) with tiktoken semantics: the text is cut at the earliest
+ * occurrences of allowed special strings, ordinary segments go through the kernels, each special
+ * contributes its id.  allowed_ids lists the special ids that are allowed.
+ * *last_piece_token_len (optional) is the second element of the reference's return pair.
+ */
+int td_encode_with_special(td_tokenizer* t, const uint8_t* text, int64_t n_bytes, const int32_t* allowed_ids,
+                           int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity, int64_t* n_tokens,
+                           int32_t* last_piece_token_len);
+
+/* Introspection (tests, benchmarks). */
+#define TD_INFO_N_PAIRS 1        /* entries of the (id,id)->rank pair table */
+#define TD_INFO_MERGE_CLOSED 2   /* 1 if encode == encode_ordinary for every input with this vocab */
+#define TD_INFO_MAX_ID 3
+#define TD_INFO_TILE_BYTES 4
+#define TD_INFO_WORKSPACE_BYTES 5
+#define TD_INFO_N_SPECIAL 6
+#define TD_INFO_LONG_PIECES 7    /* long pieces seen by the last td_encode_batch call */
+int64_t td_info(const td_tokenizer* t, int what);
+
+/* Options. */
+#define TD_OPT_LONG_POOL_BYTES 1 /* scratch for pieces longer than 64 bytes (default max(64 MiB, 2 x input)) */
+int td_set_option(td_tokenizer* t, int what, int64_t value);
+
+/* Special-token table access: replaces CoreBPE::special_tokens() (tiktoken.cpp:258-265). */
+int64_t td_special_count(const td_tokenizer* t);
+int td_special_get(const td_tokenizer* t, int64_t i, const char** str, int64_t* len, int32_t* id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOKENDAGGER_HIP_H */

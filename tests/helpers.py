@@ -1,0 +1,211 @@
+"""Shared test helpers: vocab, oracle handles, CPU twin loader, input generators."""
+from __future__ import annotations
+
+import ctypes
+import functools
+import random
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+from tokendagger_amd import vocab_io  # noqa: E402
+
+
+@functools.lru_cache(maxsize=None)
+def llama4():
+    """-> (pat_str, mergeable_ranks incl. special strings (as the reference's tests build it), special_tokens)"""
+    name, pat, ranks, special = vocab_io.load_tdv(vocab_io.default_vocab_path())
+    mr = dict(ranks)
+    for k, v in special.items():  # reference tests add specials into mergeable_ranks (test_tokendagger_vs_tiktoken.py:181-183)
+        mr[k.encode("utf-8")] = v
+    return pat, mr, special
+
+
+@functools.lru_cache(maxsize=None)
+def ref_tokenizer():
+    from oracle import ref
+    if not ref.available():
+        subprocess.check_call([str(ROOT / "oracle" / "build_ref.sh")])
+    pat, mr, special = llama4()
+    return ref.RefTokenizer(pat, mr, special)
+
+
+@functools.lru_cache(maxsize=None)
+def port_tokenizer():
+    from oracle import port
+    if not port.available():
+        subprocess.check_call([str(ROOT / "oracle" / "build_oracle.sh")])
+    _, mr, _ = llama4()
+    return port.OracleTokenizer(mr)
+
+
+def pack_docs(docs: list[bytes]):
+    offs = np.zeros(len(docs) + 1, dtype=np.int64)
+    np.cumsum([len(d) for d in docs], out=offs[1:])
+    return b"".join(docs), offs
+
+
+def pack_vocab(mergeable_ranks: dict[bytes, int]):
+    items = list(mergeable_ranks.items())
+    ranks = np.asarray([r for _, r in items], dtype=np.int32)
+    offs = np.zeros(len(items) + 1, dtype=np.int64)
+    np.cumsum([len(b) for b, _ in items], out=offs[1:])
+    blob = np.frombuffer(b"".join(b for b, _ in items) or b"\0", dtype=np.uint8).copy()
+    return blob, offs, ranks
+
+
+# ----------------------------------------------------------------------------- CPU twin -----
+TWIN_SO = ROOT / "tests" / "twin" / "_build" / "libtdtwin.so"
+
+
+def build_twin():
+    TWIN_SO.parent.mkdir(parents=True, exist_ok=True)
+    srcs = [ROOT / "tests/twin/td_twin.cpp", ROOT / "tokendagger_amd/csrc/td_tables.cpp"]
+    deps = srcs + [ROOT / "tokendagger_amd/csrc/td_common.h", ROOT / "tokendagger_amd/csrc/td_tables.h",
+                   ROOT / "tokendagger_amd/csrc/generated/unicode_classes.inc"]
+    if TWIN_SO.exists() and all(TWIN_SO.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+                           *map(str, srcs), "-o", str(TWIN_SO)])
+
+
+class Twin:
+    """CPU twin of the device algorithm (tests/twin/td_twin.cpp)."""
+
+    def __init__(self, pat_str: str, mergeable_ranks: dict[bytes, int], special: dict[str, int] | None = None):
+        build_twin()
+        lib = ctypes.CDLL(str(TWIN_SO))
+        lib.twin_create.restype = ctypes.c_void_p
+        lib.twin_create.argtypes = [ctypes.c_char_p, ctypes.c_int64] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] + \
+            [ctypes.c_void_p] * 3 + [ctypes.POINTER(ctypes.c_int)]
+        lib.twin_destroy.argtypes = [ctypes.c_void_p]
+        lib.twin_info.restype = ctypes.c_int64
+        lib.twin_info.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.twin_classify.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_void_p]
+        lib.twin_split_serial.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
+                                          ctypes.c_int64, ctypes.c_void_p]
+        lib.twin_split_tiled.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
+                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.twin_sync_violations.restype = ctypes.c_int64
+        lib.twin_sync_violations.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
+                                             ctypes.c_int64, ctypes.c_void_p]
+        lib.twin_encode.restype = ctypes.c_int64
+        lib.twin_encode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        self._lib = lib
+        special = special or {}
+        b, o, r = pack_vocab(mergeable_ranks)
+        sb, so, sr = pack_vocab({k.encode("utf-8"): v for k, v in special.items()})
+        rc = ctypes.c_int(0)
+        self._h = lib.twin_create(pat_str.encode("utf-8"), len(r), b.ctypes.data, o.ctypes.data, r.ctypes.data,
+                                  len(sr), sb.ctypes.data, so.ctypes.data, sr.ctypes.data, ctypes.byref(rc))
+        self.rc = rc.value
+        if not self._h:
+            raise RuntimeError(f"twin_create failed rc={rc.value}")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.twin_destroy(self._h)
+            self._h = None
+
+    def info(self, what: int) -> int:
+        return self._lib.twin_info(self._h, what)
+
+    @staticmethod
+    def _offs(data, offs):
+        if offs is None:
+            offs = np.asarray([0, len(data)], dtype=np.int64)
+        return np.ascontiguousarray(offs, dtype=np.int64)
+
+    def classify(self, data: bytes, offs=None) -> np.ndarray:
+        offs = self._offs(data, offs)
+        out = np.zeros(max(len(data), 1), dtype=np.uint8)
+        self._lib.twin_classify(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, out.ctypes.data)
+        return out[:len(data)]
+
+    def split_serial(self, data: bytes, offs=None) -> np.ndarray:
+        offs = self._offs(data, offs)
+        out = np.zeros(max(len(data), 1), dtype=np.uint8)
+        rc = self._lib.twin_split_serial(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, out.ctypes.data)
+        assert rc == 0, rc
+        return np.nonzero(out[:len(data)])[0]
+
+    def split_tiled(self, data: bytes, offs=None):
+        offs = self._offs(data, offs)
+        out = np.zeros(max(len(data), 1), dtype=np.uint8)
+        stats = np.zeros(4, dtype=np.int64)
+        rc = self._lib.twin_split_tiled(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, out.ctypes.data,
+                                        None, stats.ctypes.data)
+        assert rc == 0, rc
+        return np.nonzero(out[:len(data)])[0], stats
+
+    def sync_violations(self, data: bytes, offs=None) -> tuple[int, int]:
+        offs = self._offs(data, offs)
+        ns = ctypes.c_int64(0)
+        bad = self._lib.twin_sync_violations(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, ctypes.byref(ns))
+        return int(bad), ns.value
+
+    def encode_batch(self, data: bytes, offs=None, mode: int = 0):
+        offs = self._offs(data, offs)
+        out = np.empty(max(len(data), 1), dtype=np.int32)
+        oo = np.zeros(len(offs), dtype=np.int64)
+        n = self._lib.twin_encode(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, mode, out.ctypes.data,
+                                  out.size, oo.ctypes.data)
+        if n < 0:
+            raise RuntimeError(f"twin_encode error {-n}")
+        return out[:n].copy(), oo
+
+
+@functools.lru_cache(maxsize=None)
+def twin_llama4():
+    pat, mr, special = llama4()
+    return Twin(pat, mr, special)
+
+
+# ----------------------------------------------------------------------------- inputs -------
+# Building blocks for adversarial strings (all written as escapes so this file stays plain ASCII).
+FUZZ_ALPHABET = [
+    "a", "b", "z", "Z", "Q", "A", "the", "Hello", "WORLD", " ", "  ", "   ", "\n", "\r", "\r\n", "\n\n", "\t", "\x0b", "\x0c",
+    "'", "'s", "'S", "'t", "'re", "'RE", "'ve", "'m", "'ll", "'LL", "'d", "'ſ", "'x", "''", "/", "//", "!", "?", ".", ",", ";",
+    ":", "-", "_", "=", "(", ")", "{", "}", "[", "]", "<", ">", "|", "\\", "\"", "#", "$", "%", "&", "*", "+", "@", "^", "~", "`",
+    "0", "1", "23", "456", "7890", "٣", "५", "Ⅳ", "½", "²",
+    "中", "文", "日本語", "한국어", "é", "É", "ñ", "ü", "ß", "İ", "ı",
+    "ǅ", "ǈ", "ʰ", "ᵃ", "ª", "º",
+    "́", "̀", "̈", "ा", "े", "न", "म", "ส", "ั", "้", "ا", "ل", "َ",
+    "ש", "ָ",
+    " ", " ", "᠎", " ", " ", " ", " ", " ", " ", "　", "", "​", "‍", "﻿",
+    "\U0001F600", "\U0001F468‍\U0001F4BB", "\U0001F1FA\U0001F1F8", "\U0001F3F3️‍\U0001F308", "✨", "©", "™",
+    "€", "£", "→", "∑", "…", "—", "“", "”", "‘", "’", "。", "，", "、",
+    "\x00", "\x01", "\x7f", "\U00020000", "\U0010FFFF", "퟿", "", "�",
+]
+
+
+def fuzz_string(rng: random.Random, max_parts: int = 14) -> str:
+    return "".join(rng.choice(FUZZ_ALPHABET) for _ in range(rng.randint(1, max_parts)))
+
+
+def random_unicode_string(rng: random.Random, max_len: int = 24) -> str:
+    out = []
+    for _ in range(rng.randint(1, max_len)):
+        r = rng.random()
+        if r < 0.35:
+            cp = rng.randint(0x20, 0x7E)
+        elif r < 0.55:
+            cp = rng.choice([0x9, 0xA, 0xD, 0x20, 0x20, 0x27, 0x2F])
+        elif r < 0.8:
+            cp = rng.randint(0x80, 0x2FFF)
+        elif r < 0.95:
+            cp = rng.randint(0x3000, 0xFFFF)
+        else:
+            cp = rng.randint(0x10000, 0x10FFFF)
+        if 0xD800 <= cp <= 0xDFFF:
+            cp = 0x4E2D
+        out.append(chr(cp))
+    return "".join(out)

@@ -1,0 +1,176 @@
+"""GPU parity tests: everything goes through the C ABI (libtokendagger_hip.so via tokendagger_amd.capi) and is
+compared bit-for-bit with (a) golden vectors produced by the compiled reference, (b) the oracle restatement run
+live on seeded inputs, (c) size-independent properties at BASELINE sizes."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+import td_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tok():
+    from tokendagger_amd import capi
+    pat, mr, special = H.llama4()
+    return capi.HipTokenizer(pat, mr, special, device=0)
+
+
+def _check_batch(tok, O, text: bytes, offs, mode=0):
+    toks, toffs = tok.encode_batch(text, offs, mode=mode)
+    etoks, eoffs = O.encode_batch(text, offs)
+    assert np.array_equal(toffs, eoffs)
+    if not np.array_equal(toks, etoks):
+        n = min(len(toks), len(etoks))
+        bad = int(np.argmax(toks[:n] != etoks[:n])) if n and (toks[:n] != etoks[:n]).any() else n
+        d = int(np.searchsorted(eoffs, bad, side="right") - 1)
+        raise AssertionError(f"first differing token {bad} (doc {d}): got {toks[max(0, bad-3):bad+5]}, expected "
+                             f"{etoks[max(0, bad-3):bad+5]}; doc bytes {text[int(offs[d]):int(offs[d])+80]!r}")
+
+
+def test_golden_whole_batch(tok, golden):
+    text, offs = golden["text"], golden["offsets"]
+    toks, toffs = tok.encode_batch(text, offs)
+    assert np.array_equal(toffs, golden["enc_offsets"])
+    assert np.array_equal(toks, golden["enc"])
+    toks1, toffs1 = tok.encode_batch(text, offs, mode=1)  # encode_ordinary
+    assert np.array_equal(toffs1, golden["enc_offsets"]) and np.array_equal(toks1, golden["enc"])
+    assert tok.info(7) > 0, "golden batch contains pieces longer than 64 bytes (long-piece kernel ran)"
+
+
+def test_golden_one_document_per_call(tok, golden):
+    text, offs = golden["text"].tobytes(), golden["offsets"]
+    enc, eo = golden["enc"], golden["enc_offsets"]
+    for d in range(0, len(offs) - 1, 5):
+        got = tok.encode(text[offs[d]:offs[d + 1]])
+        assert np.array_equal(got, enc[eo[d]:eo[d + 1]]), golden["names"][d]
+
+
+def test_survey_known_answers(tok):
+    assert tok.encode(b"Hello, world!").tolist() == [19873, 24, 3817, 13]
+    assert tok.encode(b" ").tolist() == [220]
+    assert tok.encode(b"\n\t").tolist() == [198, 197]
+    assert tok.encode(b"").tolist() == []
+
+
+def test_fuzz_batches_vs_oracle(tok):
+    O = H.port_tokenizer()
+    rng = random.Random(2025)
+    for it in range(12):
+        docs = []
+        for _ in range(rng.randint(1, 400)):
+            r = rng.random()
+            if r < 0.05:
+                docs.append(b"")
+            elif r < 0.10:
+                docs.append((rng.choice(["a", " ", "=", "1", "\n", "A", "xY", "中"]) * rng.randint(50, 9000)).encode())
+            elif r < 0.5:
+                docs.append(H.random_unicode_string(rng, 200).encode("utf-8"))
+            else:
+                docs.append("".join(H.fuzz_string(rng) for _ in range(rng.randint(1, 40))).encode("utf-8"))
+        text, offs = H.pack_docs(docs)
+        _check_batch(tok, O, text, offs, mode=it % 2)
+
+
+@pytest.mark.parametrize("gen,size", [("english", 8 << 20), ("mixed", 4 << 20), ("code", 4 << 20)])
+def test_corpora_vs_oracle(tok, gen, size):
+    O = H.port_tokenizer()
+    x, o = getattr(td_corpus, gen)(size, seed=7)
+    _check_batch(tok, O, x.tobytes(), o)
+    # same bytes as ONE document and as reference-style equal slices: per-document results must still match
+    if gen == "english":
+        _check_batch(tok, O, x.tobytes(), np.asarray([0, len(x)], dtype=np.int64))
+        _check_batch(tok, O, x.tobytes(), td_corpus.chunk_offsets(len(x), 80))
+
+
+def test_tile_boundary_sweep(tok):
+    # slide document boundaries and piece kinds across the 4096-byte tile edge
+    O = H.port_tokenizer()
+    rng = random.Random(4)
+    fillers = ["word ", "a", "中文", " ", "\n", "1234567", "\U0001F600\n", "it's ", "x" * 70 + " ", "= " * 3]
+    docs = []
+    for k in range(60):
+        pre = "".join(rng.choice(fillers) for _ in range(900))
+        b = pre.encode("utf-8")
+        cut = 4096 - (k % 16) - 8 + (k // 16)
+        docs.append(b[:cut])
+        docs.append(rng.choice(fillers).encode("utf-8") * rng.randint(1, 40))
+    text, offs = H.pack_docs(docs)
+    _check_batch(tok, O, text, offs)
+
+
+def test_unaligned_text_pointer_and_empty_docs(tok):
+    O = H.port_tokenizer()
+    x, o = td_corpus.mixed(300000, seed=9)
+    offs = np.concatenate([[0, 0, 0], o[1:], [o[-1], o[-1]]]).astype(np.int64)  # leading / trailing empties
+    _check_batch(tok, O, x.tobytes(), offs)
+
+
+def test_full_size_properties(tok):
+    """256 MiB synthetic English (BASELINE config 2): round trip, batch-composition invariance, spot parity."""
+    import torch
+    n = 256 << 20
+    unit, uo = td_corpus.english(32 << 20, seed=0)
+    reps = n // len(unit)
+    x = np.tile(unit, reps)
+    offs = np.concatenate([uo[:-1] + r * len(unit) for r in range(reps)] + [[n]]).astype(np.int64)
+    d_text = torch.from_numpy(x).cuda()
+    d_offs = torch.from_numpy(offs).cuda()
+    cap = n // 3
+    d_tok = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_toff = torch.empty(len(offs), dtype=torch.int64, device="cuda")
+    tok.reserve(n, len(offs))
+    s = torch.cuda.current_stream().cuda_stream
+    tok.encode_device(d_text.data_ptr(), n, d_offs.data_ptr(), len(offs) - 1, d_tok.data_ptr(), cap, d_toff.data_ptr(), s)
+    tok.device_status(s)
+    toff = d_toff.cpu().numpy()
+    total = int(toff[-1])
+    assert 0 < total <= cap
+    toks = d_tok[:total].cpu().numpy()
+    # (1) periodic corpus -> periodic ids: every repetition of the 32 MiB unit tokenizes identically
+    per = np.searchsorted(offs, len(unit))
+    base = toks[toff[0]:toff[per]]
+    for r in range(1, reps):
+        seg = toks[toff[r * per]:toff[(r + 1) * per]]
+        assert len(seg) == len(base) and np.array_equal(seg, base), f"repetition {r} differs"
+    # (2) first 2 MiB of documents bit-exact vs the oracle
+    O = H.port_tokenizer()
+    k = int(np.searchsorted(offs, 2 << 20))
+    et, eo = O.encode_batch(x[:offs[k]].tobytes(), offs[:k + 1])
+    assert np.array_equal(eo, toff[:k + 1]) and np.array_equal(et, toks[:toff[k]])
+    # (3) decode(encode(unit)) == unit
+    assert tok.decode_bytes(base) == unit[:offs[per]].tobytes()
+    # (4) offsets are monotone and every non-empty doc has tokens
+    assert (np.diff(toff) > 0).all()
+
+
+def test_error_unknown_byte():
+    from tokendagger_amd import capi
+    pat, _, _ = H.llama4()
+    t = capi.HipTokenizer(pat, {b"a": 0, b"b": 1, b"ca": 2, b"ab": 3}, {}, device=0)
+    assert t.encode(b"cab").tolist() == [2, 1]
+    for bad in (b"c", b"abc", b"a" * 100 + b"c" + b"b" * 100):
+        with pytest.raises(capi.TokenDaggerHipError) as e:
+            t.encode(bad)
+        assert e.value.code == 4
+    assert t.encode(b"ab").tolist() == [3], "handle stays usable after an error"
+
+
+def test_capacity_error_and_retry(tok):
+    from tokendagger_amd import capi
+    with pytest.raises(capi.TokenDaggerHipError) as e:
+        tok.encode_batch(b"hello world " * 100, np.asarray([0, 1200], dtype=np.int64), capacity=10)
+    assert e.value.code == 5
+
+
+def test_decode(tok, golden):
+    for ids, exp in zip(golden["decode_ids"], golden["decode_bytes"]):
+        assert tok.decode_bytes(ids) == exp
+    from tokendagger_amd import capi
+    with pytest.raises(capi.TokenDaggerHipError) as e:
+        tok.decode_bytes([5, 99999999])
+    assert e.value.code == 8
+    assert tok.decode_bytes([]) == b""

@@ -1,0 +1,97 @@
+"""The oracle itself: plain-C restatement (oracle/td_oracle.c) pinned against the golden vectors that the
+compiled reference produced, and — when oracle/_ref is present — against the compiled reference live."""
+import random
+
+import numpy as np
+import pytest
+
+import cases
+import helpers as H
+from oracle import port, ref
+
+
+def _docs(golden):
+    text, offs = golden["text"].tobytes(), golden["offsets"]
+    for d in range(len(offs) - 1):
+        yield d, text[offs[d]:offs[d + 1]]
+
+
+def test_port_matches_golden_encode(golden):
+    O = H.port_tokenizer()
+    enc, eo = golden["enc"], golden["enc_offsets"]
+    for d, doc in _docs(golden):
+        got = O.encode(doc)
+        assert np.array_equal(got, enc[eo[d]:eo[d + 1]]), golden["names"][d]
+
+
+def test_port_matches_golden_split(golden):
+    H.port_tokenizer()
+    pe, po = golden["piece_ends"], golden["piece_offsets"]
+    for d, doc in _docs(golden):
+        assert np.array_equal(port.split(doc), pe[po[d]:po[d + 1]]), golden["names"][d]
+
+
+def test_port_encode_ordinary_same_as_encode_on_golden(golden):
+    O = H.port_tokenizer()
+    assert golden["ord_same"].all()
+    for d, doc in list(_docs(golden))[:400]:
+        assert np.array_equal(O.encode_ordinary(doc), O.encode(doc))
+
+
+def test_port_decode_known_answers(golden):
+    O = H.port_tokenizer()
+    for ids, exp in zip(golden["decode_ids"], golden["decode_bytes"]):
+        assert O.decode_bytes(ids) == exp
+    with pytest.raises(port.OracleError):
+        O.decode_bytes([999999999])
+
+
+def test_known_answers_from_survey():
+    # sample Llama-4 ids produced by the reference
+    O = H.port_tokenizer()
+    assert O.encode(b"Hello, world!").tolist() == [19873, 24, 3817, 13]
+    assert O.encode(b" ").tolist() == [220]
+    assert O.encode(b"\n\t").tolist() == [198, 197]
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_port_vs_compiled_reference_fuzz():
+    R, O = H.ref_tokenizer(), H.port_tokenizer()
+    assert R.pcre2_version()[1].startswith("14."), "class tables were probed from Unicode 14 PCRE2"
+    rng = random.Random(11)
+    for i in range(6000):
+        s = (H.fuzz_string(rng) if i % 2 else H.random_unicode_string(rng)).encode("utf-8")
+        assert np.array_equal(port.split(s), R.split(s)), repr(s)
+        assert np.array_equal(O.encode(s), R.encode(s)), repr(s)
+        if i % 10 == 0:
+            assert np.array_equal(O.encode_ordinary(s), R.encode_ordinary(s)), repr(s)
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_compiled_reference_still_matches_golden(golden):
+    R = H.ref_tokenizer()
+    enc, eo = golden["enc"], golden["enc_offsets"]
+    for d, doc in list(_docs(golden))[::7]:
+        assert np.array_equal(R.encode(doc), enc[eo[d]:eo[d + 1]])
+
+
+def test_unknown_byte_is_an_error_not_a_garbage_id():
+    # toy vocab without 'c': the reference returns a garbage id for the lone byte; oracle raises
+    O = port.OracleTokenizer({b"a": 0, b"b": 1, b"ab": 2})
+    assert O.encode(b"ab").tolist() == [2]
+    with pytest.raises(port.OracleError):
+        O.encode(b"c")
+    with pytest.raises(port.OracleError):
+        O.encode(b"abc")
+
+
+def test_class_table_spot_checks():
+    H.port_tokenizer()
+    C = port.class_of_cp
+    assert C(0x20) == 3 and C(0x0A) == 5 and C(0x0D) == 5 and C(0x09) == 4
+    assert C(0x180E) == 4, "U+180E is \\s under PCRE2 10.39 UCP (unlike Python/Rust)"
+    assert C(ord("'")) == 1 and C(ord("/")) == 2
+    assert C(ord("A")) == 6 and C(ord("a")) == 7 and C(0x4E2D) == 8 and C(0x0301) == 9 and C(ord("7")) == 10
+    assert C(0x01C5) == 6, "Lt counts as upper"
+    assert C(0x02B0) == 8, "Lm is in both letter classes"
+    assert C(0x1F600) == 0 and C(0x10FFFF) == 0

@@ -1,0 +1,230 @@
+// TEST INFRASTRUCTURE ONLY: CPU "twin" of the device algorithm.
+//
+// Compiles the SAME header code the kernels use (tokendagger_amd/csrc/td_common.h: classify_at,
+// is_sync, scan_piece, scan_lane, piece/pair table probes) plus the host table builder with the
+// host compiler and runs it lane by lane / tile by tile on the CPU, so that the not-gpu test-suite
+// can check the product's host logic (tables, scanner, sync-point speculation, tile ownership)
+// against the oracle without a GPU.  It is NOT reachable from the product: nothing under
+// tokendagger_amd/ links or loads it, and libtokendagger_hip.so has no CPU tokenization path.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../tokendagger_amd/csrc/td_common.h"
+#include "../../tokendagger_amd/csrc/td_tables.h"
+
+using namespace td;
+
+namespace {
+
+struct Twin {
+    HostTables H;
+    std::string err;
+};
+
+struct Src {  // byte + document-start source over the whole text
+    const uint8_t* text;
+    const uint8_t* docs;  // 1 byte per position
+    int64_t lo, hi;
+    uint32_t byte(int64_t i) const { return text[i]; }
+    bool doc(int64_t i) const { return docs[i] != 0; }
+};
+
+// accessor over a precomputed class+flag array of the whole text (the twin's "HBM slow path")
+struct GAcc {
+    using pos_t = int64_t;
+    const uint8_t* cls;
+    const uint8_t* text;
+    int64_t n, lim;
+    uint32_t cf(int64_t i) const { return i >= n ? (uint32_t)F_DOC : cls[i]; }
+    uint32_t byte(int64_t i) const { return i < n ? text[i] : 0u; }
+    int64_t scan(int64_t pos) const { return scan_piece(*this, pos); }
+};
+
+struct WAcc {  // one tile window
+    using pos_t = int;
+    uint8_t* cls;
+    const uint8_t* txt;
+    int lim;
+    int ext_start;
+    long long ext_end;
+    uint32_t cf(int i) const { return cls[i]; }
+    uint32_t byte(int i) const { return txt[i]; }
+    void mark(int i) { cls[i] |= F_START; }
+    void set_ext(int i, int64_t ge) { ext_start = i; ext_end = ge; }
+};
+
+void classify_all(const Tables& T, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs,
+                  std::vector<uint8_t>& cls) {
+    std::vector<uint8_t> doc((size_t)n + 1, 0);
+    for (int64_t d = 0; d < n_docs; ++d)
+        if (offs[d] < n) doc[(size_t)offs[d]] = 1;
+    Src s{text, doc.data(), 0, n};
+    cls.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t v = classify_at(T, s, i);
+        if (doc[(size_t)i]) v |= F_DOC;
+        cls[(size_t)i] = (uint8_t)v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void* twin_create(const char* pat, int64_t n_vocab, const uint8_t* bytes, const int64_t* offs, const int32_t* ranks,
+                  int64_t n_special, const uint8_t* sbytes, const int64_t* soffs, const int32_t* sranks, int* rc_out) {
+    Twin* t = new Twin;
+    int rc = build_tables(pat, n_vocab, bytes, offs, ranks, n_special, sbytes, soffs, sranks, t->H, t->err);
+    if (rc_out) *rc_out = rc;
+    if (rc != TD_OK) {
+        static thread_local std::string keep;
+        keep = t->err;
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+void twin_destroy(void* h) { delete (Twin*)h; }
+
+int64_t twin_info(void* h, int what) {
+    Twin* t = (Twin*)h;
+    switch (what) {
+        case 1: return (int64_t)t->H.n_pairs;
+        case 2: return t->H.merge_closed;
+        case 3: return t->H.max_id;
+        case 4: return t->H.piece_mask + 1;
+        case 5: return t->H.pair_mask + 1;
+    }
+    return -1;
+}
+
+// per-byte class + F_CONT + F_DOC exactly as phase 1 of the kernel defines them
+void twin_classify(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, uint8_t* out) {
+    Twin* t = (Twin*)h;
+    std::vector<uint8_t> cls;
+    classify_all(t->H.view(), text, n, offs, n_docs, cls);
+    if (n) memcpy(out, cls.data(), (size_t)n);
+}
+
+// piece starts by serial scanning from every document start (flags[i] = 1 where a piece starts)
+int twin_split_serial(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, uint8_t* flags) {
+    Twin* t = (Twin*)h;
+    std::vector<uint8_t> cls;
+    classify_all(t->H.view(), text, n, offs, n_docs, cls);
+    memset(flags, 0, (size_t)n);
+    GAcc g{cls.data(), text, n, n + 4};
+    int64_t p = 0;
+    while (p < n) {
+        flags[p] = 1;
+        int64_t e = scan_piece(g, p);
+        if (e <= p) return -1;
+        p = e;
+    }
+    return 0;
+}
+
+// piece starts found the way td_encode_tiles finds them: tile windows, one scan_lane per lane.
+// stats[0] = pieces that left their window (ext), stats[1] = lanes that used the HBM slow path for
+// the back-search, stats[2] = START marks outside [tile_lo, lim).
+int twin_split_tiled(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, uint8_t* flags,
+                     int64_t* ext_ends /* [n] or NULL: global end for ext pieces, else 0 */, int64_t* stats) {
+    Twin* t = (Twin*)h;
+    std::vector<uint8_t> cls;
+    classify_all(t->H.view(), text, n, offs, n_docs, cls);
+    memset(flags, 0, (size_t)n);
+    if (ext_ends) memset(ext_ends, 0, sizeof(int64_t) * (size_t)n);
+    GAcc g{cls.data(), text, n, n + 4};
+    const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
+    std::vector<uint8_t> wcls(K_WIN), wtxt(K_WIN);
+    for (int64_t tile = 0; tile < n_tiles; ++tile) {
+        const int64_t tile_g0 = tile * K_TILE, wg0 = tile_g0 - K_HL;
+        const int tile_hi = K_HL + (int)((n - tile_g0 < K_TILE) ? (n - tile_g0) : K_TILE);
+        for (int i = 0; i < K_WIN; ++i) {
+            const int64_t gi = wg0 + i;
+            if (gi < 0) { wcls[i] = C_OTHER; wtxt[i] = 0; }
+            else if (gi >= n) { wcls[i] = F_DOC; wtxt[i] = 0; }
+            else { wcls[i] = cls[(size_t)gi]; wtxt[i] = text[gi]; }
+        }
+        // NOTE: the kernel classifies the window from LDS; bytes within 3 of the window edges can
+        // differ from the whole-text classification, which is why the scanner is limited to < K_LIM
+        // and the back-search to >= 4.
+        WAcc w{wcls.data(), wtxt.data(), K_LIM, -1, 0};
+        // lanes run sequentially here; they only communicate through F_START marks, which no lane reads
+        // for its decisions (is_sync / scan_piece ignore F_START), so the order does not matter.
+        for (int tid = 0; tid < K_THREADS; ++tid) scan_lane(w, g, tid, tile_hi, wg0);
+        for (int i = K_HL; i < tile_hi; ++i)
+            if (wcls[i] & F_START) flags[wg0 + i] = 1;
+        if (w.ext_start >= 0) {
+            if (stats) stats[0]++;
+            if (ext_ends) ext_ends[wg0 + w.ext_start] = w.ext_end;
+        }
+        // piece lengths as phase 3 derives them: distance to the next START mark inside the window
+        for (int i = K_HL; i < tile_hi; ++i) {
+            if (!(wcls[i] & F_START) || i == w.ext_start) continue;
+            int j = i + 1;
+            while (j < K_WIN && !(wcls[j] & F_START)) ++j;
+            if (j >= K_WIN) return -2;  // a non-ext piece must be delimited inside the window
+        }
+    }
+    return 0;
+}
+
+// number of positions where is_sync() claims a piece start that the serial scan does not produce
+int64_t twin_sync_violations(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs,
+                             int64_t* n_sync) {
+    Twin* t = (Twin*)h;
+    std::vector<uint8_t> cls;
+    classify_all(t->H.view(), text, n, offs, n_docs, cls);
+    std::vector<uint8_t> flags((size_t)n + 1, 0);
+    GAcc g{cls.data(), text, n, n + 4};
+    for (int64_t p = 0; p < n;) { flags[(size_t)p] = 1; p = scan_piece(g, p); }
+    int64_t bad = 0, ns = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t vp = i > 0 ? cls[(size_t)i - 1] : 0u;
+        if (is_sync(vp, cls[(size_t)i])) { ++ns; if (!flags[(size_t)i]) ++bad; }
+    }
+    if (n_sync) *n_sync = ns;
+    return bad;
+}
+
+// whole pipeline on the host tables: tiled split -> piece table -> pair-table merge.
+// Returns number of tokens, or -(TD_E_*) on error.
+int64_t twin_encode(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, int mode,
+                    int32_t* out, int64_t cap, int64_t* out_offs) {
+    Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
+    std::vector<uint8_t> flags((size_t)n + 1, 0);
+    if (twin_split_tiled(h, text, n, offs, n_docs, flags.data(), nullptr, nullptr) != 0) return -TD_E_INVALID;
+    const bool fast = (mode == TD_MODE_ENCODE) || t->H.merge_closed;
+    std::vector<int64_t> tok_at((size_t)n + 1, 0);  // tokens emitted before byte i
+    int64_t k = 0;
+    std::vector<int32_t> tmp;
+    for (int64_t p = 0; p < n;) {
+        int64_t e = p + 1;
+        while (e < n && !flags[(size_t)e]) ++e;
+        tok_at[(size_t)p] = k;
+        const uint32_t len = (uint32_t)(e - p);
+        const uint8_t* pb = text + p;
+        tmp.clear();
+        if (len == 1) {
+            if (T.byte_id[pb[0]] >= T.pseudo_base) return -TD_E_UNKNOWN_BYTE;
+            tmp.push_back(T.byte_id[pb[0]]);
+        } else {
+            int32_t r = NO_RANK;
+            if (fast) r = piece_lookup(T, piece_key_host(pb, len), len, [pb](uint32_t i) { return (uint32_t)pb[i]; });
+            if (r != NO_RANK) tmp.push_back(r);
+            else if (merge_piece_host(T, pb, len, tmp) != TD_OK) return -TD_E_UNKNOWN_BYTE;
+        }
+        for (int32_t v : tmp) {
+            if (k >= cap) return -TD_E_CAPACITY;
+            out[k++] = v;
+        }
+        p = e;
+    }
+    for (int64_t d = 0; d <= n_docs; ++d) out_offs[d] = (offs[d] >= n) ? k : tok_at[(size_t)offs[d]];
+    return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+"""ctypes view of the C ABI in include/tokendagger_hip.h (libtokendagger_hip.so).
+
+This is the array-in / array-out surface used by bench.py, the GPU parity tests and the bulk
+methods of `tokendagger_amd.Tokenizer`.  It performs no tokenization itself: every call goes to the
+HIP library, and importing/constructing fails loudly when the library or a HIP device is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libtokendagger_hip.so"
+
+TD_OK = 0
+TD_E_CAPACITY = 5
+TD_MODE_ENCODE = 0
+TD_MODE_ORDINARY = 1
+TD_INFO_N_PAIRS, TD_INFO_MERGE_CLOSED, TD_INFO_MAX_ID, TD_INFO_TILE_BYTES = 1, 2, 3, 4
+TD_INFO_WORKSPACE_BYTES, TD_INFO_N_SPECIAL, TD_INFO_LONG_PIECES = 5, 6, 7
+TD_OPT_LONG_POOL_BYTES = 1
+
+EXPORTS = [
+    "td_create", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",
+    "td_device_status", "td_decode_bytes", "td_encode_with_special", "td_info", "td_set_option",
+    "td_special_count", "td_special_get",
+]
+
+
+class TokenDaggerHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'); "
+            "tokendagger_amd has no CPU fallback")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    lib.td_create.restype = i32
+    lib.td_create.argtypes = [ctypes.c_char_p, i64, vp, vp, vp, i64, vp, vp, vp, i32, ctypes.POINTER(vp)]
+    lib.td_destroy.argtypes = [vp]
+    lib.td_last_error.restype = ctypes.c_char_p
+    lib.td_last_error.argtypes = [vp]
+    lib.td_encode_batch.restype = i32
+    lib.td_encode_batch.argtypes = [vp, vp, vp, i64, i32, vp, i64, vp, ctypes.POINTER(i64)]
+    lib.td_encode_device.restype = i32
+    lib.td_encode_device.argtypes = [vp, vp, i64, vp, i64, i32, vp, i64, vp, vp]
+    lib.td_reserve.restype = i32
+    lib.td_reserve.argtypes = [vp, i64, i64]
+    lib.td_device_status.restype = i32
+    lib.td_device_status.argtypes = [vp, vp, ctypes.POINTER(i64)]
+    lib.td_decode_bytes.restype = i32
+    lib.td_decode_bytes.argtypes = [vp, vp, i64, vp, i64, ctypes.POINTER(i64)]
+    lib.td_encode_with_special.restype = i32
+    lib.td_encode_with_special.argtypes = [vp, vp, i64, vp, i64, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
+    lib.td_info.restype = i64
+    lib.td_info.argtypes = [vp, i32]
+    lib.td_set_option.restype = i32
+    lib.td_set_option.argtypes = [vp, i32, i64]
+    lib.td_special_count.restype = i64
+    lib.td_special_count.argtypes = [vp]
+    lib.td_special_get.restype = i32
+    lib.td_special_get.argtypes = [vp, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
+    _lib = lib
+    return lib
+
+
+def _pack(items: list[tuple[bytes, int]]):
+    ranks = np.asarray([r for _, r in items], dtype=np.int32)
+    offs = np.zeros(len(items) + 1, dtype=np.int64)
+    if items:
+        np.cumsum([len(b) for b, _ in items], out=offs[1:])
+    blob = np.frombuffer(b"".join(b for b, _ in items) or b"\0", dtype=np.uint8).copy()
+    return blob, offs, ranks
+
+
+def _as_u8(data) -> np.ndarray:
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(0, dtype=np.uint8)
+
+
+class HipTokenizer:
+    """Owns one `td_tokenizer` handle (device tables + workspace on one GPU)."""
+
+    def __init__(self, pat_str: str, mergeable_ranks: dict[bytes, int], special_tokens: dict[str, int] | None = None,
+                 device: int = -1):
+        self._lib = load_library()
+        self._h = None
+        special_tokens = special_tokens or {}
+        b, o, r = _pack(list(mergeable_ranks.items()))
+        sb, so, sr = _pack([(k.encode("utf-8"), v) for k, v in special_tokens.items()])
+        h = ctypes.c_void_p()
+        rc = self._lib.td_create(pat_str.encode("utf-8"), len(r), b.ctypes.data, o.ctypes.data, r.ctypes.data,
+                                 len(sr), sb.ctypes.data, so.ctypes.data, sr.ctypes.data, device, ctypes.byref(h))
+        if rc != TD_OK:
+            raise TokenDaggerHipError(rc, self._lib.td_last_error(None).decode("utf-8", "replace"))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.td_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc: int):
+        if rc != TD_OK:
+            raise TokenDaggerHipError(rc, self._lib.td_last_error(self._h).decode("utf-8", "replace"))
+
+    # ---- host-buffer API --------------------------------------------------------------------
+    def encode_batch(self, text, doc_offsets, mode: int = TD_MODE_ENCODE, capacity: int | None = None):
+        """text: bytes / uint8 array of all documents concatenated; doc_offsets: int64[n_docs+1].
+        -> (tokens int32[total], offsets int64[n_docs+1])"""
+        buf = _as_u8(text)
+        offs = np.ascontiguousarray(doc_offsets, dtype=np.int64)
+        n_docs = len(offs) - 1
+        n = int(offs[-1]) if len(offs) else 0
+        cap = capacity if capacity is not None else max(16, n // 3 + 16)
+        out_offs = np.empty(n_docs + 1, dtype=np.int64)
+        ntok = ctypes.c_int64(0)
+        for _ in range(2):
+            toks = np.empty(cap, dtype=np.int32)
+            rc = self._lib.td_encode_batch(self._h, buf.ctypes.data if n else None, offs.ctypes.data, n_docs, mode,
+                                           toks.ctypes.data, cap, out_offs.ctypes.data, ctypes.byref(ntok))
+            if rc == TD_E_CAPACITY and capacity is None and ntok.value > cap:
+                cap = ntok.value
+                continue
+            break
+        self._check(rc)
+        return toks[:ntok.value], out_offs
+
+    def encode(self, data, mode: int = TD_MODE_ENCODE) -> np.ndarray:
+        buf = _as_u8(data)
+        toks, _ = self.encode_batch(buf, np.asarray([0, len(buf)], dtype=np.int64), mode)
+        return toks
+
+    def encode_with_special(self, data, allowed_ids) -> tuple[np.ndarray, int]:
+        buf = _as_u8(data)
+        ids = np.ascontiguousarray(sorted(allowed_ids), dtype=np.int32)
+        cap = len(buf) + 16
+        toks = np.empty(cap, dtype=np.int32)
+        ntok = ctypes.c_int64(0)
+        last = ctypes.c_int32(0)
+        rc = self._lib.td_encode_with_special(self._h, buf.ctypes.data if len(buf) else None, len(buf),
+                                              ids.ctypes.data if len(ids) else None, len(ids), toks.ctypes.data, cap,
+                                              ctypes.byref(ntok), ctypes.byref(last))
+        self._check(rc)
+        return toks[:ntok.value].copy(), last.value
+
+    def decode_bytes(self, tokens) -> bytes:
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        nb = ctypes.c_int64(0)
+        cap = max(64, 8 * len(t))
+        for _ in range(2):
+            out = np.empty(cap, dtype=np.uint8)
+            rc = self._lib.td_decode_bytes(self._h, t.ctypes.data if len(t) else None, len(t), out.ctypes.data, cap,
+                                           ctypes.byref(nb))
+            if rc == TD_E_CAPACITY and nb.value > cap:
+                cap = nb.value
+                continue
+            break
+        self._check(rc)
+        return out[:nb.value].tobytes()
+
+    # ---- device-buffer API (pointers are raw device addresses, e.g. torch_tensor.data_ptr()) --
+    def reserve(self, max_bytes: int, max_docs: int):
+        self._check(self._lib.td_reserve(self._h, max_bytes, max_docs))
+
+    def encode_device(self, d_text: int, n_bytes: int, d_doc_offsets: int, n_docs: int, d_out_tokens: int,
+                      out_capacity: int, d_out_offsets: int, stream: int = 0, mode: int = TD_MODE_ENCODE):
+        """Asynchronous on `stream`; d_out_offsets[n_docs] receives the total token count."""
+        self._check(self._lib.td_encode_device(self._h, d_text, n_bytes, d_doc_offsets, n_docs, mode, d_out_tokens,
+                                               out_capacity, d_out_offsets, stream))
+
+    def device_status(self, stream: int = 0):
+        pos = ctypes.c_int64(0)
+        self._check(self._lib.td_device_status(self._h, stream, ctypes.byref(pos)))
+
+    # ---- misc -------------------------------------------------------------------------------
+    def info(self, what: int) -> int:
+        return int(self._lib.td_info(self._h, what))
+
+    def set_option(self, what: int, value: int):
+        self._check(self._lib.td_set_option(self._h, what, value))
+
+    def special_tokens(self) -> dict[str, int]:
+        out = {}
+        for i in range(self._lib.td_special_count(self._h)):
+            s = ctypes.c_char_p(); n = ctypes.c_int64(0); tid = ctypes.c_int32(0)
+            self._lib.td_special_get(self._h, i, ctypes.byref(s), ctypes.byref(n), ctypes.byref(tid))
+            out[ctypes.string_at(s, n.value).decode("utf-8")] = tid.value
+        return out

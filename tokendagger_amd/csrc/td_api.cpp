@@ -1,0 +1,514 @@
+// C-ABI host library (include/tokendagger_hip.h) over the gfx950 kernels.
+// Host code is C++; it owns the device tables, the per-call workspace and stream-ordered launches.
+// There is deliberately NO CPU tokenization path in this file: if HIP is unusable, td_create fails.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/tokendagger_hip.h"
+#include "td_kernels.h"
+#include "td_tables.h"
+
+using namespace td;
+
+namespace {
+
+thread_local std::string g_create_err;
+
+#define HIP_TRY(t, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (t)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+            return TD_E_HIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct td_tokenizer {
+    HostTables H;
+    Tables dT;  // device pointers
+    int device = 0;
+    std::vector<void*> table_allocs;
+    std::string err;
+    std::mutex mu;
+    // workspace (grown on demand)
+    DevBuf docbits, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl;
+    DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
+    DevBuf dec_tokens, dec_off, dec_out;
+    int64_t pool_bytes_opt = 0;
+    int64_t last_long = 0;
+    size_t ws_bytes = 0;
+};
+
+namespace {
+
+int ensure(td_tokenizer* t, DevBuf& b, size_t bytes) {
+    if (b.cap >= bytes && b.p) return TD_OK;
+    if (b.p) {
+        HIP_TRY(t, hipDeviceSynchronize());
+        HIP_TRY(t, hipFree(b.p));
+        t->ws_bytes -= b.cap;
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(t, hipMalloc(&b.p, want));
+    b.cap = want;
+    t->ws_bytes += want;
+    return TD_OK;
+}
+
+template <class V>
+int upload(td_tokenizer* t, const V* src, size_t count, const V** dst) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(V), 16);
+    HIP_TRY(t, hipMalloc(&p, bytes + 16));
+    HIP_TRY(t, hipMemcpy(p, src, count * sizeof(V), hipMemcpyHostToDevice));
+    t->table_allocs.push_back(p);
+    *dst = (const V*)p;
+    return TD_OK;
+}
+
+struct Ctl {  // small control block in device memory
+    int err;
+    int pad;
+    long long err_pos;
+    uint32_t long_count;
+    uint32_t pad2;
+    unsigned long long pool_used;
+};
+
+int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
+    const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
+    int rc;
+    if ((rc = ensure(t, t->docbits, (size_t)((n + 31) / 32 + 2) * 4))) return rc;
+    if ((rc = ensure(t, t->stage, (size_t)std::max<int64_t>(n_tiles, 1) * K_TILE * 4))) return rc;
+    if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
+    if ((rc = ensure(t, t->doc_slot, (size_t)(n_docs + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->long_list, (size_t)(n / (K_MAXSHORT + 1) + n_tiles + 16) * sizeof(LongEntry)))) return rc;
+    const int64_t pool_bytes = t->pool_bytes_opt > 0 ? t->pool_bytes_opt : std::max<int64_t>(64ll << 20, 2 * n);
+    if ((rc = ensure(t, t->pool, (size_t)pool_bytes))) return rc;
+    if ((rc = ensure(t, t->ctl, sizeof(Ctl)))) return rc;
+    return TD_OK;
+}
+
+int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const void* d_offs, int64_t n_docs, int mode,
+                         void* d_out, int64_t out_cap, void* d_out_offs, hipStream_t stream) {
+    if (n < 0 || n_docs < 0 || (n > 0 && (!d_text || !d_offs)) || !d_out_offs || (mode != TD_MODE_ENCODE && mode != TD_MODE_ORDINARY)) {
+        t->err = "td_encode_device: bad argument";
+        return TD_E_INVALID;
+    }
+    HIP_TRY(t, hipSetDevice(t->device));
+    if (n == 0) {  // nothing but empty documents
+        HIP_TRY(t, hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * 8, stream));
+        return TD_OK;
+    }
+    int rc = reserve_ws(t, n, n_docs);
+    if (rc) return rc;
+    const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
+    if (n_tiles > 0x7FFFFFF0ll) { t->err = "input too large"; return TD_E_INVALID; }
+    EncodeArgs a;
+    memset(&a, 0, sizeof a);
+    a.T = t->dT;
+    a.text = (const uint8_t*)d_text;
+    a.n = n;
+    a.doc_offsets = (const int64_t*)d_offs;
+    a.n_docs = n_docs;
+    a.docbits = (uint32_t*)t->docbits.p;
+    a.stage = (uint32_t*)t->stage.p;
+    a.tile_count = (uint32_t*)t->tile_count.p;
+    a.tile_extra = (uint32_t*)t->tile_extra.p;
+    a.tile_base = (int64_t*)t->tile_base.p;
+    a.doc_slot = (uint32_t*)t->doc_slot.p;
+    a.long_list = (LongEntry*)t->long_list.p;
+    a.long_cap = (uint32_t)std::min<size_t>(t->long_list.cap / sizeof(LongEntry), 0x7FFFFFF0u);
+    Ctl* ctl = (Ctl*)t->ctl.p;
+    a.long_count = &ctl->long_count;
+    a.pool = (uint32_t*)t->pool.p;
+    a.pool_cap = t->pool.cap / 4;
+    a.pool_used = &ctl->pool_used;
+    a.out_tokens = (int32_t*)d_out;
+    a.out_cap = d_out ? out_cap : 0;
+    a.out_offsets = (int64_t*)d_out_offs;
+    a.err = &ctl->err;
+    a.err_pos = &ctl->err_pos;
+    a.n_tiles = (int)n_tiles;
+    // encode_ordinary has no whole-piece fast path (tiktoken.cpp:156-167); when every token is
+    // reproduced by the merge loop the fast path cannot change the result and stays on.
+    a.use_fastpath = (mode == TD_MODE_ENCODE) || t->H.merge_closed;
+    a.text_aligned = (((uintptr_t)d_text) & 15) == 0;
+    HIP_TRY(t, hipMemsetAsync(t->docbits.p, 0, (size_t)((n + 31) / 32 + 2) * 4, stream));
+    HIP_TRY(t, hipMemsetAsync(t->tile_extra.p, 0, (size_t)(n_tiles + 1) * 4, stream));
+    // keep a sticky error (err / err_pos) but reset the per-call counters
+    HIP_TRY(t, hipMemsetAsync(&ctl->long_count, 0, sizeof(Ctl) - offsetof(Ctl, long_count), stream));
+    HIP_TRY(t, launch_encode(a, stream));
+    return TD_OK;
+}
+
+int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) {
+    HIP_TRY(t, hipSetDevice(t->device));
+    HIP_TRY(t, hipStreamSynchronize(stream));
+    if (!t->ctl.p) return TD_OK;
+    Ctl c;
+    HIP_TRY(t, hipMemcpy(&c, t->ctl.p, sizeof c, hipMemcpyDeviceToHost));
+    t->last_long = c.long_count;
+    if (err_pos) *err_pos = c.err_pos;
+    if (c.err != 0) {
+        HIP_TRY(t, hipMemset(t->ctl.p, 0, sizeof(Ctl)));
+        switch (c.err) {
+            case TD_E_UNKNOWN_BYTE:
+                t->err = "No value found for piece at byte offset " + std::to_string(c.err_pos) + ": byte sequence is not in the vocabulary";
+                break;
+            case TD_E_CAPACITY:
+                t->err = "output capacity too small: " + std::to_string(c.err_pos) + " tokens needed";
+                break;
+            case TD_E_SCRATCH:
+                t->err = "long-piece scratch exhausted near byte offset " + std::to_string(c.err_pos) + " (raise TD_OPT_LONG_POOL_BYTES)";
+                break;
+            default:
+                t->err = "device error " + std::to_string(c.err) + " at byte offset " + std::to_string(c.err_pos);
+        }
+        return c.err;
+    }
+    return TD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, const int64_t* token_offsets,
+              const int32_t* ranks, int64_t n_special, const uint8_t* special_bytes, const int64_t* special_offsets,
+              const int32_t* special_ids, int device, td_tokenizer** out) {
+    if (!out) return TD_E_INVALID;
+    *out = nullptr;
+    if (!pat_str || !token_bytes || !token_offsets || !ranks || n_vocab <= 0 || n_special < 0) {
+        g_create_err = "td_create: bad argument";
+        return TD_E_INVALID;
+    }
+    td_tokenizer* t = new td_tokenizer;
+    std::string err;
+    int rc = build_tables(pat_str, n_vocab, token_bytes, token_offsets, ranks, n_special, special_bytes, special_offsets,
+                          special_ids, t->H, err);
+    if (rc != TD_OK) {
+        g_create_err = err;
+        delete t;
+        return rc;
+    }
+    auto fail = [&](int code) {
+        g_create_err = t->err;
+        td_destroy(t);
+        return code;
+    };
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0) {
+        t->err = std::string("no usable HIP device (") + hipGetErrorString(he) + "); this library has no CPU path";
+        return fail(TD_E_HIP);
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= ndev) { t->err = "device index out of range"; return fail(TD_E_INVALID); }
+    t->device = device;
+    if (hipSetDevice(device) != hipSuccess) { t->err = "hipSetDevice failed"; return fail(TD_E_HIP); }
+    const HostTables& H = t->H;
+    const Tables hv = H.view();
+    Tables d;
+    memset(&d, 0, sizeof d);
+    d.piece_mask = H.piece_mask;
+    d.pair_mask = H.pair_mask;
+    d.max_id = H.max_id;
+    d.pseudo_base = H.pseudo_base;
+    d.max_token_len = H.max_token_len;
+    if ((rc = upload(t, H.ascii_cls.data(), H.ascii_cls.size(), &d.ascii_cls))) return fail(rc);
+    if ((rc = upload(t, hv.ucls1, (size_t)4352, &d.ucls1))) return fail(rc);
+    {
+        // size of stage 2 = (max block index + 1) * 256
+        unsigned maxb = 0;
+        for (int i = 0; i < 4352; ++i) maxb = std::max<unsigned>(maxb, hv.ucls1[i]);
+        if ((rc = upload(t, hv.ucls2, (size_t)(maxb + 1) * 256, &d.ucls2))) return fail(rc);
+    }
+    if ((rc = upload(t, H.byte_id.data(), H.byte_id.size(), &d.byte_id))) return fail(rc);
+    if ((rc = upload(t, H.byte_pair.data(), H.byte_pair.size(), &d.byte_pair))) return fail(rc);
+    if ((rc = upload(t, H.piece_slots.data(), H.piece_slots.size(), &d.piece_slots))) return fail(rc);
+    if ((rc = upload(t, H.pair_slots.data(), H.pair_slots.size(), &d.pair_slots))) return fail(rc);
+    if ((rc = upload(t, H.tok_off.data(), H.tok_off.size(), &d.tok_off))) return fail(rc);
+    if ((rc = upload(t, H.tok_bytes.data(), H.tok_bytes.size(), &d.tok_bytes))) return fail(rc);
+    t->dT = d;
+    if ((rc = ensure(t, t->ctl, sizeof(Ctl)))) return fail(rc);
+    if (hipMemset(t->ctl.p, 0, sizeof(Ctl)) != hipSuccess) { t->err = "hipMemset failed"; return fail(TD_E_HIP); }
+    *out = t;
+    return TD_OK;
+}
+
+void td_destroy(td_tokenizer* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : t->table_allocs) (void)hipFree(p);
+    DevBuf* bufs[] = {&t->docbits, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
+                      &t->pool, &t->ctl, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
+                      &t->dec_off, &t->dec_out};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    delete t;
+}
+
+const char* td_last_error(const td_tokenizer* t) { return t ? t->err.c_str() : g_create_err.c_str(); }
+
+int td_reserve(td_tokenizer* t, int64_t max_bytes, int64_t max_docs) {
+    if (!t || max_bytes < 0 || max_docs < 0) return TD_E_INVALID;
+    std::lock_guard<std::mutex> g(t->mu);
+    HIP_TRY(t, hipSetDevice(t->device));
+    return reserve_ws(t, std::max<int64_t>(max_bytes, 1), max_docs);
+}
+
+int td_encode_device(td_tokenizer* t, const void* d_text, int64_t n_bytes, const void* d_doc_offsets, int64_t n_docs,
+                     int mode, void* d_out_tokens, int64_t out_capacity, void* d_out_offsets, void* hip_stream) {
+    if (!t) return TD_E_INVALID;
+    std::lock_guard<std::mutex> g(t->mu);
+    return encode_device_locked(t, d_text, n_bytes, d_doc_offsets, n_docs, mode, d_out_tokens, out_capacity,
+                                d_out_offsets, (hipStream_t)hip_stream);
+}
+
+int td_device_status(td_tokenizer* t, void* hip_stream, int64_t* err_pos) {
+    if (!t) return TD_E_INVALID;
+    std::lock_guard<std::mutex> g(t->mu);
+    return device_status_locked(t, (hipStream_t)hip_stream, err_pos);
+}
+
+int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
+                    int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
+    if (!t || !doc_offsets || n_docs < 0 || !out_offsets || out_capacity < 0) return TD_E_INVALID;
+    std::lock_guard<std::mutex> g(t->mu);
+    const int64_t n = doc_offsets[n_docs];
+    if (doc_offsets[0] != 0 || n < 0 || (n > 0 && !text)) { t->err = "doc_offsets must start at 0 and be non-decreasing"; return TD_E_INVALID; }
+    for (int64_t d = 0; d < n_docs; ++d)
+        if (doc_offsets[d + 1] < doc_offsets[d]) { t->err = "doc_offsets must be non-decreasing"; return TD_E_INVALID; }
+    HIP_TRY(t, hipSetDevice(t->device));
+    int rc;
+    if ((rc = ensure(t, t->h2d_text, (size_t)n + 64))) return rc;
+    if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;
+    if ((rc = ensure(t, t->d_offsets, (size_t)(n_docs + 1) * 8))) return rc;
+    // worst case one token per byte; typical text needs a quarter of that
+    const int64_t dev_cap = std::max<int64_t>(n, 1);
+    if ((rc = ensure(t, t->d_tokens, (size_t)dev_cap * 4))) return rc;
+    hipStream_t s = nullptr;
+    if (n > 0) HIP_TRY(t, hipMemcpyAsync(t->h2d_text.p, text, (size_t)n, hipMemcpyHostToDevice, s));
+    HIP_TRY(t, hipMemcpyAsync(t->h2d_offs.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    rc = encode_device_locked(t, t->h2d_text.p, n, t->h2d_offs.p, n_docs, mode, t->d_tokens.p, dev_cap, t->d_offsets.p, s);
+    if (rc) return rc;
+    rc = device_status_locked(t, s, nullptr);
+    if (rc) return rc;
+    HIP_TRY(t, hipMemcpy(out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    const int64_t total = out_offsets[n_docs];
+    if (n_tokens) *n_tokens = total;
+    if (total > out_capacity) {
+        t->err = "output capacity too small: " + std::to_string(total) + " tokens needed";
+        return TD_E_CAPACITY;
+    }
+    if (total > 0) {
+        if (!out_tokens) return TD_E_INVALID;
+        HIP_TRY(t, hipMemcpy(out_tokens, t->d_tokens.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    }
+    return TD_OK;
+}
+
+int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, uint8_t* out, int64_t out_capacity,
+                    int64_t* n_bytes) {
+    if (!t || n_tokens < 0 || (n_tokens > 0 && !tokens)) return TD_E_INVALID;
+    std::lock_guard<std::mutex> g(t->mu);
+    if (n_bytes) *n_bytes = 0;
+    if (n_tokens == 0) return TD_OK;
+    HIP_TRY(t, hipSetDevice(t->device));
+    // size first (host table; ids are validated here so the device never sees a bad id)
+    const HostTables& H = t->H;
+    int64_t total = 0;
+    for (int64_t i = 0; i < n_tokens; ++i) {
+        const int32_t id = tokens[i];
+        if (id < 0 || id > H.max_id || H.tok_off[id + 1] == H.tok_off[id]) {
+            t->err = "Invalid token for decoding: " + std::to_string(id);
+            return TD_E_BAD_TOKEN;
+        }
+        total += H.tok_off[id + 1] - H.tok_off[id];
+    }
+    if (n_bytes) *n_bytes = total;
+    if (total > out_capacity) { t->err = "decode capacity too small"; return TD_E_CAPACITY; }
+    int rc;
+    if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4))) return rc;
+    if ((rc = ensure(t, t->dec_off, (size_t)(n_tokens + 2) * 8))) return rc;
+    if ((rc = ensure(t, t->dec_out, (size_t)total + 16))) return rc;
+    HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
+    DecodeArgs a;
+    memset(&a, 0, sizeof a);
+    a.T = t->dT;
+    a.tokens = (const int32_t*)t->dec_tokens.p;
+    a.n = n_tokens;
+    a.byte_off = (int64_t*)t->dec_off.p;
+    a.out = (uint8_t*)t->dec_out.p;
+    a.out_cap = total;
+    Ctl* ctl = (Ctl*)t->ctl.p;
+    a.err = &ctl->err;
+    a.err_pos = &ctl->err_pos;
+    HIP_TRY(t, launch_decode(a, nullptr));
+    rc = device_status_locked(t, nullptr, nullptr);
+    if (rc) return rc;
+    if (total > 0) HIP_TRY(t, hipMemcpy(out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost));
+    return TD_OK;
+}
+
+int td_encode_with_special(td_tokenizer* t, const uint8_t* text, int64_t n_bytes, const int32_t* allowed_ids,
+                           int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity, int64_t* n_tokens,
+                           int32_t* last_piece_token_len) {
+    if (!t || n_bytes < 0 || n_allowed < 0 || (n_allowed > 0 && !allowed_ids)) return TD_E_INVALID;
+    // 1. host: cut the text at the earliest occurrences of allowed special strings (tiktoken semantics;
+    //    the reference's own loop, tiktoken.cpp:130-154,187-231, has iterator-invalidation UB)
+    std::vector<const std::string*> strs;
+    std::vector<int32_t> ids;
+    {
+        std::lock_guard<std::mutex> g(t->mu);
+        for (int64_t k = 0; k < n_allowed; ++k) {
+            bool found = false;
+            for (size_t s = 0; s < t->H.special_ids.size(); ++s)
+                if (t->H.special_ids[s] == allowed_ids[k]) {
+                    strs.push_back(&t->H.special_strs[s]);
+                    ids.push_back(allowed_ids[k]);
+                    found = true;
+                    break;
+                }
+            if (!found) {
+                t->err = "Special token id " + std::to_string(allowed_ids[k]) + " not found in special encoder";
+                return TD_E_SPECIAL;
+            }
+        }
+    }
+    const char* base = (const char*)text;
+    std::vector<int64_t> next(strs.size(), -2);  // -2: not searched yet, -1: no further occurrence
+    std::vector<uint8_t> seg_text;
+    std::vector<int64_t> seg_offs{0};
+    std::vector<int32_t> seg_special;  // special id following each segment, -1 for the last one
+    seg_text.reserve((size_t)n_bytes);
+    int64_t start = 0;
+    for (;;) {
+        int64_t best = -1;
+        size_t best_k = 0;
+        for (size_t k = 0; k < strs.size(); ++k) {
+            if (strs[k]->empty()) continue;
+            if (next[k] != -1 && next[k] < start) {
+                const void* hit = (start <= n_bytes) ? memmem(base + start, (size_t)(n_bytes - start), strs[k]->data(), strs[k]->size()) : nullptr;
+                next[k] = hit ? (int64_t)((const char*)hit - base) : -1;
+            }
+            if (next[k] >= 0 && (best < 0 || next[k] < best || (next[k] == best && strs[k]->size() > strs[best_k]->size()))) {
+                best = next[k];
+                best_k = k;
+            }
+        }
+        const int64_t end = best >= 0 ? best : n_bytes;
+        seg_text.insert(seg_text.end(), text + start, text + end);
+        seg_offs.push_back((int64_t)seg_text.size());
+        if (best < 0) { seg_special.push_back(-1); break; }
+        seg_special.push_back(ids[best_k]);
+        start = end + (int64_t)strs[best_k]->size();
+    }
+    // 2. device: all ordinary segments as one batch
+    const int64_t nseg = (int64_t)seg_special.size();
+    std::vector<int32_t> toks((size_t)std::max<int64_t>((int64_t)seg_text.size(), 1));
+    std::vector<int64_t> toffs((size_t)nseg + 1);
+    int64_t ntok = 0;
+    int rc = td_encode_batch(t, seg_text.data(), seg_offs.data(), nseg, TD_MODE_ENCODE, toks.data(), (int64_t)toks.size(),
+                             toffs.data(), &ntok);
+    if (rc) return rc;
+    // 3. stitch
+    int64_t k = 0;
+    const int64_t need = ntok + (nseg - 1);
+    if (n_tokens) *n_tokens = need;
+    if (need > out_capacity) { t->err = "output capacity too small"; return TD_E_CAPACITY; }
+    for (int64_t s = 0; s < nseg; ++s) {
+        for (int64_t i = toffs[s]; i < toffs[s + 1]; ++i) out_tokens[k++] = toks[(size_t)i];
+        if (seg_special[s] >= 0) out_tokens[k++] = seg_special[s];
+    }
+    if (last_piece_token_len) {
+        // metadata only (second element of the reference's return pair, tiktoken.cpp:185,213,218,225):
+        // number of ids of the last regex piece of the trailing ordinary segment, 0 after a special.
+        *last_piece_token_len = 0;
+        const int64_t s_lo = seg_offs[nseg - 1], s_hi = seg_offs[nseg];
+        if (s_hi > s_lo) {
+            struct HostAcc {
+                using pos_t = int64_t;
+                const Tables* T; const uint8_t* p; int64_t lo, hi, lim;
+                uint32_t byte(int64_t i) const { return i < hi ? p[i] : 0u; }
+                bool doc(int64_t i) const { return i == lo; }
+                uint32_t cf(int64_t i) const {
+                    if (i >= hi) return F_DOC;
+                    uint32_t v = classify_at(*T, *this, i);
+                    if (i == lo) v |= F_DOC;
+                    return v;
+                }
+            };
+            const Tables hv = t->H.view();
+            HostAcc A{&hv, seg_text.data(), s_lo, s_hi, s_hi + 4};
+            int64_t p = s_lo, last = s_lo;
+            while (p < s_hi) { last = p; p = scan_piece(A, p); }
+            // ids of that piece == the tail of the batch result that starts at its first byte; count them
+            // by re-deriving the piece's merge on the host tables (metadata, not the id path)
+            std::vector<int32_t> tmp;
+            const uint32_t len = (uint32_t)(s_hi - last);
+            const uint8_t* pb = seg_text.data() + last;
+            int32_t whole = (len == 1) ? t->H.byte_id[pb[0]]
+                                       : piece_lookup(hv, piece_key_host(pb, len), len, [pb](uint32_t i) { return (uint32_t)pb[i]; });
+            if (whole != NO_RANK) *last_piece_token_len = 1;
+            else if (merge_piece_host(hv, pb, len, tmp) == TD_OK) *last_piece_token_len = (int32_t)tmp.size();
+        }
+    }
+    return TD_OK;
+}
+
+int64_t td_info(const td_tokenizer* t, int what) {
+    if (!t) return -1;
+    switch (what) {
+        case TD_INFO_N_PAIRS: return (int64_t)t->H.n_pairs;
+        case TD_INFO_MERGE_CLOSED: return t->H.merge_closed ? 1 : 0;
+        case TD_INFO_MAX_ID: return t->H.max_id;
+        case TD_INFO_TILE_BYTES: return K_TILE;
+        case TD_INFO_WORKSPACE_BYTES: return (int64_t)t->ws_bytes;
+        case TD_INFO_N_SPECIAL: return (int64_t)t->H.special_ids.size();
+        case TD_INFO_LONG_PIECES: return t->last_long;
+    }
+    return -1;
+}
+
+int td_set_option(td_tokenizer* t, int what, int64_t value) {
+    if (!t) return TD_E_INVALID;
+    std::lock_guard<std::mutex> g(t->mu);
+    if (what == TD_OPT_LONG_POOL_BYTES && value >= (1 << 20)) {
+        t->pool_bytes_opt = value;
+        return TD_OK;
+    }
+    return TD_E_INVALID;
+}
+
+int64_t td_special_count(const td_tokenizer* t) { return t ? (int64_t)t->H.special_ids.size() : 0; }
+
+int td_special_get(const td_tokenizer* t, int64_t i, const char** str, int64_t* len, int32_t* id) {
+    if (!t || i < 0 || i >= (int64_t)t->H.special_ids.size()) return TD_E_INVALID;
+    if (str) *str = t->H.special_strs[(size_t)i].data();
+    if (len) *len = (int64_t)t->H.special_strs[(size_t)i].size();
+    if (id) *id = t->H.special_ids[(size_t)i];
+    return TD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+// tokendagger_amd — shared host/device definitions for the MI355X tokenizer hot path.
+//
+// Everything in here is written once and compiled twice: by hipcc for the gfx950 kernels
+// (td_kernels.hip) and by the host compiler for the table builder (td_tables.cpp) and the
+// CPU "twin" used by the not-gpu tests (tests/twin/td_twin.cpp).  No code here comes from the
+// reference; it re-expresses what the reference's hot path computes
+// (/root/reference/src/tiktoken/tiktoken.cpp:70-128 split_text, :169-234 encode, :282-378 merge)
+// in a form that maps onto 64-wide wavefronts:
+//   * the PCRE2 split pattern becomes a deterministic byte-wise scanner over a 1-byte/byte
+//     class+flag array (scan_piece), restartable at provable synchronisation points (is_sync);
+//   * the byte-string keyed emhash8 encoder map (tiktoken.hpp:41) becomes two open-addressing
+//     tables in HBM: piece bytes -> rank (whole-piece fast path, tiktoken.cpp:209-215) and
+//     (left id, right id) -> rank (the merge loop's get_rank, tiktoken.cpp:282-296).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/tokendagger_hip.h"  // TD_OK / TD_E_* codes shared by kernels, host library and C ABI
+
+#if defined(__HIP__)  // HIP language mode (hipcc compiles .cpp as HIP too)
+#define TD_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define TD_HD inline
+#endif
+
+namespace td {
+
+// ------------------------------------------------------------------ character classes -------
+// 4-bit class of a code point (tools/gen_unicode_classes.py, probed from PCRE2 10.39 / Unicode 14)
+enum : uint32_t {
+    C_OTHER = 0,  // anything else: punctuation, symbols, controls, unassigned (in X and P)
+    C_APOS = 1,   // U+0027 (in X and P; starts a contraction)
+    C_SLASH = 2,  // U+002F (in X and P; also in the [\r\n/]* trailer)
+    C_SP = 3,     // U+0020
+    C_WS = 4,     // other \s that is not CR/LF
+    C_CRLF = 5,   // U+000A, U+000D
+    C_UP = 6,     // Lu | Lt
+    C_LW = 7,     // Ll
+    C_LB = 8,     // Lm | Lo   (member of both letter classes of the pattern)
+    C_MK = 9,     // M         (both letter classes, and also prefix / punctuation class)
+    C_NUM = 10,   // N
+};
+// flag bits stored next to the class in the per-byte class array
+enum : uint32_t {
+    CLS_MASK = 0x0F,
+    F_CONT = 0x10,   // byte continues the character of the previous byte (carries that char's class)
+    F_MISS = 0x20,   // piece starting here missed the whole-piece table -> needs the merge loop
+    F_START = 0x40,  // a regex piece starts at this byte
+    F_DOC = 0x80,    // a document starts at this byte (== end of subject for the previous document)
+};
+
+#define TD_BIT(c) (1u << (c))
+constexpr uint32_t M_U = TD_BIT(C_UP) | TD_BIT(C_LB) | TD_BIT(C_MK);                  // [\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]
+constexpr uint32_t M_W = TD_BIT(C_LW) | TD_BIT(C_LB) | TD_BIT(C_MK);                  // [\p{Ll}\p{Lm}\p{Lo}\p{M}]
+constexpr uint32_t M_L = TD_BIT(C_UP) | TD_BIT(C_LW) | TD_BIT(C_LB);                  // \p{L}
+constexpr uint32_t M_S = TD_BIT(C_SP) | TD_BIT(C_WS) | TD_BIT(C_CRLF);                // \s
+constexpr uint32_t M_P = 0x7FFu & ~(TD_BIT(C_CRLF) | M_L | TD_BIT(C_NUM));            // [^\r\n\p{L}\p{N}]
+constexpr uint32_t M_X = 0x7FFu & ~(M_S | M_L | TD_BIT(C_NUM));                       // [^\s\p{L}\p{N}]
+constexpr uint32_t M_TRAIL = TD_BIT(C_CRLF) | TD_BIT(C_SLASH);                        // [\r\n/]
+TD_HD bool in_set(uint32_t mask, uint32_t c) { return (mask >> c) & 1u; }
+
+// ------------------------------------------------------------------ table layouts -----------
+constexpr int32_t NO_RANK = 0x7FFFFFFF;       // the reference's INT_MAX "no such pair" (tiktoken.cpp:293)
+constexpr uint32_t TOK_NONE = 0xFFFFFFFFu;    // empty slot in the byte-indexed token array
+constexpr uint32_t TOK_LONGREF = 0x80000000u; // | index into the long-piece list
+constexpr int ID_BITS = 21;                   // ids / ranks must be < 2^21 (pair slots pack 2 ids + rank in 64 bit)
+constexpr uint64_t PAIR_EMPTY = ~0ull;
+
+struct PieceSlot {  // 16 B; len == 0 marks an empty slot
+    uint64_t key;   // len <= 8: the bytes, little-endian, zero padded; len > 8: hash_bytes()
+    uint32_t rank;
+    uint32_t len;
+};
+
+struct Tables {
+    const uint8_t* ascii_cls;     // [128]
+    const uint16_t* ucls1;        // [4352]   code point >> 8 -> block
+    const uint8_t* ucls2;         // [nblocks*256]
+    const int32_t* byte_id;       // [256]    id of the 1-byte token, or pseudo id (>= pseudo_base) if absent
+    const int32_t* byte_pair;     // [65536]  rank of the 2-byte token (b0<<8|b1) or NO_RANK
+    const PieceSlot* piece_slots; // open addressing, linear probing
+    const uint64_t* pair_slots;   // (left<<42 | right<<21 | rank), PAIR_EMPTY if empty
+    const uint32_t* tok_off;      // [max_id+2] byte offsets of token id's bytes (decode + long-key verify)
+    const uint8_t* tok_bytes;
+    uint32_t piece_mask;
+    uint32_t pair_mask;
+    int32_t max_id;               // largest real id
+    int32_t pseudo_base;          // ids >= pseudo_base stand for single bytes that are not tokens
+    uint32_t max_token_len;
+    uint32_t pad_;
+};
+
+// ------------------------------------------------------------------ hashing -----------------
+TD_HD uint32_t hash_piece(uint64_t key, uint32_t len) {
+    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint32_t h = lo * 0x9E3779B1u;
+    h ^= (hi * 0x85EBCA77u) >> 7 | (hi * 0x85EBCA77u) << 25;
+    h ^= len * 0xC2B2AE3Du;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h;
+}
+TD_HD uint32_t hash_pair(uint32_t left, uint32_t right) {
+    uint32_t h = left * 0x9E3779B1u + right * 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h;
+}
+// 64-bit key of a piece longer than 8 bytes; `get(i)` returns byte i.
+template <class Get>
+TD_HD uint64_t hash_bytes(const Get& get, uint32_t len) {
+    uint64_t k = 0x243F6A8885A308D3ull ^ len;
+    for (uint32_t i = 0; i < len; i += 8) {
+        uint64_t w = 0;
+        for (uint32_t j = 0; j < 8 && i + j < len; ++j) w |= (uint64_t)get(i + j) << (8 * j);
+        k = ((k << 23) | (k >> 41)) ^ w;
+        k *= 0x9E3779B97F4A7C15ull;
+    }
+    return k ^ (k >> 31);
+}
+
+// (left id, right id) -> rank of the concatenation, NO_RANK if it is not a token.
+TD_HD int32_t pair_lookup(const Tables& T, uint32_t left, uint32_t right) {
+    const uint64_t key = ((uint64_t)left << ID_BITS) | right;
+    uint32_t h = hash_pair(left, right) & T.pair_mask;
+    for (;;) {
+        const uint64_t e = T.pair_slots[h];
+        if (e == PAIR_EMPTY) return NO_RANK;
+        if ((e >> ID_BITS) == key) return (int32_t)(e & ((1u << ID_BITS) - 1));
+        h = (h + 1) & T.pair_mask;
+    }
+}
+
+// piece bytes -> rank, NO_RANK if the piece is not a token.  `get(i)` returns byte i of the piece.
+template <class Get>
+TD_HD int32_t piece_lookup(const Tables& T, uint64_t key, uint32_t len, const Get& get) {
+    uint32_t h = hash_piece(key, len) & T.piece_mask;
+    for (;;) {
+        const PieceSlot s = T.piece_slots[h];
+        if (s.len == 0) return NO_RANK;
+        if (s.key == key && s.len == len) {
+            if (len <= 8) return (int32_t)s.rank;
+            const uint8_t* tb = T.tok_bytes + T.tok_off[s.rank];
+            bool same = true;
+            for (uint32_t i = 0; i < len; ++i)
+                if (tb[i] != get(i)) { same = false; break; }
+            if (same) return (int32_t)s.rank;
+        }
+        h = (h + 1) & T.piece_mask;
+    }
+}
+
+// ------------------------------------------------------------------ UTF-8 classification ----
+// Declared sequence length of a lead byte (1 for ASCII and for bytes that cannot lead).
+TD_HD uint32_t utf8_declared_len(uint32_t b) {
+    if (b >= 0xC2 && b <= 0xDF) return 2;
+    if (b >= 0xE0 && b <= 0xEF) return 3;
+    if (b >= 0xF0 && b <= 0xF4) return 4;
+    return 1;
+}
+TD_HD uint32_t class_of_cp(const Tables& T, uint32_t cp) {
+    if (cp > 0x10FFFFu || (cp >= 0xD800u && cp <= 0xDFFFu)) return C_OTHER;
+    return T.ucls2[(uint32_t)T.ucls1[cp >> 8] * 256u + (cp & 255u)];
+}
+// Class (+F_CONT) of the byte at index i.  S provides: lo (first readable index), hi (one past the
+// last readable index), byte(i), doc(i) (document starts at i).  A lead byte followed by fewer
+// continuation bytes than it declares forms one C_OTHER character with the ones that are there;
+// stray continuation bytes and invalid lead bytes are 1-byte C_OTHER characters; characters never
+// cross a document start.  (The reference assumes valid UTF-8: PCRE2_NO_UTF_CHECK, tiktoken.cpp:91.)
+template <class S>
+TD_HD uint32_t classify_at(const Tables& T, const S& s, int64_t i) {
+    const uint32_t b = s.byte(i);
+    if (b < 0x80) return T.ascii_cls[b];
+    int64_t lead = i;
+    if ((b & 0xC0) == 0x80) {
+        bool found = false;
+        if (!s.doc(i)) {
+            for (int k = 1; k <= 3; ++k) {
+                const int64_t j = i - k;
+                if (j < s.lo) break;
+                const uint32_t c = s.byte(j);
+                if ((c & 0xC0) != 0x80) {
+                    if (utf8_declared_len(c) > (uint32_t)k) { found = true; lead = j; }
+                    break;
+                }
+                if (s.doc(j)) break;  // a continuation byte that starts a document is a stray
+            }
+        }
+        if (!found) return C_OTHER;
+    }
+    const uint32_t lb = s.byte(lead);
+    const uint32_t need = utf8_declared_len(lb) - 1;
+    if (need == 0) return C_OTHER;
+    uint32_t cp = lb & (0xFFu >> (need + 2));
+    uint32_t got = 0;
+    while (got < need) {
+        const int64_t j = lead + 1 + got;
+        if (j >= s.hi || s.doc(j)) break;
+        const uint32_t c = s.byte(j);
+        if ((c & 0xC0) != 0x80) break;
+        cp = (cp << 6) | (c & 0x3F);
+        ++got;
+    }
+    const uint32_t cont = (lead != i) ? F_CONT : 0u;
+    if (got < need) return C_OTHER | cont;
+    return class_of_cp(T, cp) | cont;
+}
+
+// ------------------------------------------------------------------ synchronisation points --
+// A position whose class/flag byte is `v` (previous byte's: `vp`) is PROVABLY a piece start,
+// whatever came before, when one of these holds (each follows from which alternatives of the
+// Llama-4 pattern can contain the two characters; verified by tests/test_twin.py against PCRE2):
+//   R1 a document starts here;
+//   R2 a non-CR/LF whitespace char follows a non-whitespace char (whitespace is only ever consumed
+//      at the start of a piece or inside a whitespace-only piece);
+//   R3 any non-whitespace char other than '/' follows CR/LF (CR/LF cannot be a prefix char; it only
+//      occurs inside whitespace pieces or in the [\r\n/]* trailer, which continues only with \r \n /);
+//   R4 a digit run starts or ends here (digits only occur in \p{N}{1,3} pieces);
+//   R5 punctuation other than ' follows a true letter (letters only occur in alternatives 1-2,
+//      which continue only with letter-class chars or a contraction).
+TD_HD bool is_sync(uint32_t vp, uint32_t v) {
+    if (v & F_CONT) return false;
+    if (v & F_DOC) return true;
+    const uint32_t c = v & CLS_MASK, p = vp & CLS_MASK;
+    if ((c == C_SP || c == C_WS) && !in_set(M_S, p)) return true;
+    if (p == C_CRLF && !in_set(M_S, c) && c != C_SLASH) return true;
+    if ((c == C_NUM) != (p == C_NUM)) return true;
+    if ((c == C_OTHER || c == C_SLASH) && in_set(M_L, p)) return true;
+    return false;
+}
+
+// ------------------------------------------------------------------ the scanner -------------
+// Accessor A: pos_t; lim (positions >= lim are not readable); cf(i) class+flags; byte(i) raw byte.
+// Positions past the end of the text read as F_DOC sentinels, so "end of subject" is always a
+// set F_DOC flag at a position > pos.  Every function returns the piece end (> pos), 0 for "this
+// alternative does not match" (helpers only), or -1 when the answer depends on bytes at/after lim.
+
+template <class A>
+TD_HD typename A::pos_t scan_contraction(const A& a, typename A::pos_t e) {
+    // (?i:'s|'t|'re|'ve|'m|'ll|'d)?  — caseless under UTF+UCP, so U+017F also matches the s.
+    if (e + 3 > a.lim) return -1;
+    uint32_t v = a.cf(e);
+    if ((v & F_DOC) || (v & CLS_MASK) != C_APOS) return e;
+    v = a.cf(e + 1);
+    if (v & F_DOC) return e;
+    const uint32_t b1 = a.byte(e + 1);
+    const uint32_t v2 = a.cf(e + 2);
+    if (b1 < 0x80) {
+        const uint32_t l1 = b1 | 0x20;
+        if (l1 == 's' || l1 == 't' || l1 == 'm' || l1 == 'd') return e + 2;
+        if (v2 & F_DOC) return e;
+        const uint32_t b2 = a.byte(e + 2);
+        if (b2 < 0x80) {
+            const uint32_t l2 = b2 | 0x20;
+            if ((l1 == 'r' && l2 == 'e') || (l1 == 'v' && l2 == 'e') || (l1 == 'l' && l2 == 'l')) return e + 3;
+        }
+        return e;
+    }
+    if (b1 == 0xC5 && !(v2 & F_DOC) && a.byte(e + 2) == 0xBF) return e + 3;
+    return e;
+}
+
+// alternatives 1 (U* W+) and 2 (U+ W*) from `st` (== pos, or the byte after the 1-char prefix)
+template <class A>
+TD_HD typename A::pos_t scan_letters(const A& a, typename A::pos_t pos, typename A::pos_t st, int alt) {
+    using P = typename A::pos_t;
+    P q = st, lastw_end = 0;
+    uint32_t c = 255;
+    bool eos = false;
+    for (;;) {
+        if (q >= a.lim) return -1;
+        const uint32_t v = a.cf(q);
+        if (q > pos && (v & F_DOC)) { eos = true; break; }
+        c = v & CLS_MASK;
+        if (!in_set(M_U, c)) break;
+        if (in_set(M_W, c)) lastw_end = q + 1;
+        ++q;
+    }
+    P e;
+    const bool w_follows = !eos && in_set(M_W, c);
+    if (alt == 1) {
+        if (w_follows) e = q;
+        else if (lastw_end) return scan_contraction(a, lastw_end);  // greedy U* gives back to its last W-class char
+        else return 0;
+    } else {
+        if (q == st) return 0;
+        e = q;
+    }
+    if (w_follows) {
+        for (;;) {
+            if (e >= a.lim) return -1;
+            const uint32_t v = a.cf(e);
+            if ((e > pos && (v & F_DOC)) || !in_set(M_W, v & CLS_MASK)) break;
+            ++e;
+        }
+    }
+    return scan_contraction(a, e);
+}
+
+// End of the piece that starts at `pos` (a character start, pos < lim).
+template <class A>
+TD_HD typename A::pos_t scan_piece(const A& a, typename A::pos_t pos) {
+    using P = typename A::pos_t;
+    const uint32_t c0 = a.cf(pos) & CLS_MASK;
+    P p1 = pos + 1;  // end of the first character
+    for (;;) {
+        if (p1 >= a.lim) return -1;
+        if (!(a.cf(p1) & F_CONT)) break;
+        ++p1;
+    }
+    if (c0 != C_CRLF && c0 != C_NUM) {
+        const bool prefixable = in_set(M_P, c0);
+        // only worth trying when a letter-class char is at pos or right after the prefix char
+        const uint32_t v1 = a.cf(p1);
+        const bool l0 = in_set(M_U | M_W, c0);
+        const bool l1 = prefixable && !(v1 & F_DOC) && in_set(M_U | M_W, v1 & CLS_MASK);
+        if (l0 || l1) {
+            for (int alt = 1; alt <= 2; ++alt) {
+                if (l1) {
+                    const P r = scan_letters(a, pos, p1, alt);
+                    if (r != 0) return r;
+                }
+                if (l0) {
+                    const P r = scan_letters(a, pos, pos, alt);
+                    if (r != 0) return r;
+                }
+            }
+        }
+    }
+    if (c0 == C_NUM) {  // \p{N}{1,3}
+        P e = p1;
+        for (int k = 1; k < 3; ++k) {
+            if (e >= a.lim) return -1;
+            const uint32_t v = a.cf(e);
+            if ((v & F_DOC) || (v & CLS_MASK) != C_NUM) break;
+            ++e;
+            for (;;) {
+                if (e >= a.lim) return -1;
+                if (!(a.cf(e) & F_CONT)) break;
+                ++e;
+            }
+        }
+        return e;
+    }
+    //  ?[^\s\p{L}\p{N}]+[\r\n/]*
+    for (int wsp = 1; wsp >= 0; --wsp) {
+        if (wsp && c0 != C_SP) continue;
+        const P st = wsp ? pos + 1 : pos;
+        P e = st;
+        for (;;) {
+            if (e >= a.lim) return -1;
+            const uint32_t v = a.cf(e);
+            if (e > pos && (v & F_DOC)) break;
+            if (!in_set(M_X, v & CLS_MASK)) break;
+            ++e;
+        }
+        if (e == st) continue;
+        for (;;) {
+            if (e >= a.lim) return -1;
+            const uint32_t v = a.cf(e);
+            if ((v & F_DOC) || !in_set(M_TRAIL, v & CLS_MASK)) break;
+            ++e;
+        }
+        return e;
+    }
+    // \s*[\r\n]+ | \s+(?!\S) | \s+   on the maximal whitespace run starting at pos
+    if (in_set(M_S, c0)) {
+        P q = pos, last_crlf_end = 0, last_lead = pos;
+        bool eos = false;
+        for (;;) {
+            if (q >= a.lim) return -1;
+            const uint32_t v = a.cf(q);
+            if (q > pos && (v & F_DOC)) { eos = true; break; }
+            const uint32_t c = v & CLS_MASK;
+            if (!in_set(M_S, c)) break;
+            if (c == C_CRLF) last_crlf_end = q + 1;
+            if (!(v & F_CONT)) last_lead = q;
+            ++q;
+        }
+        if (last_crlf_end) return last_crlf_end;
+        if (eos) return q;
+        if (last_lead > pos) return last_lead;
+        return q;
+    }
+    return p1;  // not reachable for this pattern; mirrors the no-progress rule (tiktoken.cpp:120-122)
+}
+
+// ------------------------------------------------------------------ tile geometry -----------
+// One workgroup of td_encode_tiles handles one tile of text at a time.
+constexpr int K_THREADS = 256;                 // 4 wavefronts
+constexpr int K_CHUNK = 16;                    // text bytes whose boundaries one lane is responsible for
+constexpr int K_TILE = K_THREADS * K_CHUNK;    // 4096 text bytes per tile
+constexpr int K_HL = 64;                       // left halo (sync-point back-search)
+constexpr int K_HR = 192;                      // right halo (piece overrun / look-ahead)
+constexpr int K_WIN = K_HL + K_TILE + K_HR;    // bytes staged in LDS per tile
+constexpr int K_LIM = K_WIN - 4;               // the scanner may read window positions < K_LIM
+constexpr int K_MAXSHORT = 64;                 // pieces up to this many bytes merge inside one wavefront
+
+// One lane's share of the boundary scan of a tile (phase 2 of td_encode_tiles; the CPU twin runs the
+// same code lane by lane).  Window coordinates: index i <-> global byte wg0 + i; the tile owns
+// [K_HL, tile_hi).  W: window accessor (pos_t = int; cf, byte, lim) plus mark(i) (set F_START) and
+// set_ext(i, global_end) (the one piece that leaves the window).  G: accessor over the whole text in
+// HBM (pos_t = int64_t; cf, byte, lim, scan(pos)) for what the window cannot answer.
+//   lane 0 starts at the last provable sync point at or before the tile start (left halo, else HBM);
+//   lane t > 0 starts at the first provable sync point inside its chunk, if any;
+//   every lane scans piece by piece until it lands on a provable sync point at/after its chunk end
+//   (the lane owning that chunk started there) or leaves the tile.
+template <class W, class G>
+TD_HD void scan_lane(W& w, const G& g, int tid, int tile_hi, int64_t wg0) {
+    const int c0 = K_HL + tid * K_CHUNK, c1 = c0 + K_CHUNK;
+    int s = -1;
+    if (tid == 0) {
+        for (int i = c0; i >= 4; --i)
+            if (is_sync(w.cf(i - 1), w.cf(i))) { s = i; break; }
+        if (s < 0) {  // no sync point in the left halo: walk back through HBM (inside a giant piece)
+            int64_t gs = 0;
+            for (int64_t gi = wg0 + 3; gi > 0; --gi)
+                if (is_sync(g.cf(gi - 1), g.cf(gi))) { gs = gi; break; }
+            int64_t p = gs;
+            const int64_t tile_g0 = wg0 + K_HL;
+            while (p < tile_g0) p = g.scan(p);
+            s = (p - wg0 < (int64_t)tile_hi) ? (int)(p - wg0) : -1;
+        }
+    } else if (c0 < tile_hi) {
+        const int cend = c1 < tile_hi ? c1 : tile_hi;
+        for (int i = c0; i < cend; ++i)
+            if (is_sync(w.cf(i - 1), w.cf(i))) { s = i; break; }
+    }
+    if (s < 0) return;
+    int p = s;
+    for (;;) {
+        if (p >= tile_hi) { w.mark(p); break; }                       // delimits the last owned piece
+        if (p >= c1 && is_sync(w.cf(p - 1), w.cf(p))) break;           // the lane owning p starts there
+        if (p >= K_HL) w.mark(p);
+        int e = scan_piece(w, p);
+        if (e < 0) {
+            const int64_t ge = g.scan(wg0 + p);
+            if (ge - wg0 > (int64_t)K_LIM) {                           // piece leaves the window: one per tile at most
+                if (p >= K_HL) w.set_ext(p, ge);
+                break;
+            }
+            e = (int)(ge - wg0);
+        }
+        p = e;
+    }
+}
+
+}  // namespace td

@@ -1,0 +1,61 @@
+// Launch interface between the host library (td_api.cpp) and the gfx950 kernels (td_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "td_common.h"
+
+namespace td {
+
+struct LongEntry {      // a piece longer than K_MAXSHORT bytes, merged by td_long_pieces
+    int64_t gs;         // global byte offset of the piece
+    uint32_t len;       // bytes
+    uint32_t ntok;      // out: number of tokens
+    uint64_t pool_off;  // out: offset (in u32) of its tokens inside the pool
+};
+
+struct EncodeArgs {
+    Tables T;
+    const uint8_t* text;        // [n] UTF-8, all documents concatenated
+    int64_t n;
+    const int64_t* doc_offsets; // [n_docs+1], doc_offsets[0]==0, doc_offsets[n_docs]==n
+    int64_t n_docs;
+    uint32_t* docbits;          // [(n+31)/32+1] bit i set <=> a document starts at byte i
+    uint32_t* stage;            // [n_tiles*K_TILE] per-tile compacted slots (token ids / long markers)
+    uint32_t* tile_count;       // [n_tiles] slots in the tile
+    uint32_t* tile_extra;       // [n_tiles] sum(ntok-1) over the tile's long pieces
+    int64_t* tile_base;         // [n_tiles+1] exclusive scan of count+extra
+    uint32_t* doc_slot;         // [n_docs] slot index (inside its tile) of each document's first token
+    LongEntry* long_list;
+    uint32_t long_cap;
+    uint32_t* long_count;
+    uint32_t* pool;             // long-piece scratch + token store
+    uint64_t pool_cap;          // in u32
+    unsigned long long* pool_used;
+    int32_t* out_tokens;        // [out_cap]
+    int64_t out_cap;
+    int64_t* out_offsets;       // [n_docs+1] token offset of each document; [n_docs] = total
+    int* err;                   // err[0] = first TD_E_* raised on device (0 = ok)
+    long long* err_pos;         // byte offset it refers to
+    int n_tiles;
+    int use_fastpath;           // whole-piece lookup before the merge loop (CoreBPE::encode) or not
+    int text_aligned;           // text pointer is 16-byte aligned
+};
+
+struct DecodeArgs {
+    Tables T;
+    const int32_t* tokens;      // [n]
+    int64_t n;
+    int64_t* byte_off;          // [n+1] scratch: exclusive scan of token byte lengths
+    uint8_t* out;               // [out_cap]
+    int64_t out_cap;
+    int* err;
+    long long* err_pos;
+};
+
+// All launches are asynchronous on `stream`; none of them synchronises or allocates.
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream);
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
+int encode_grid_blocks();  // persistent grid size used by the fused kernel
+
+}  // namespace td

@@ -1,0 +1,673 @@
+// gfx950 (MI355X) kernels of the tokenizer hot path.  Integer / byte work, HBM- and latency-bound:
+// no MFMA anywhere.  Pipeline per encode call (all on one stream, no host round trips):
+//
+//   td_mark_docs     doc_offsets -> one bit per document start
+//   td_encode_tiles  persistent workgroups, one 4 KiB text tile at a time:
+//                      coalesced 16 B/lane loads of the tile (+halos) into LDS
+//                      -> per-byte class/flag array (ASCII LUT in LDS, 2-stage Unicode table in L2)
+//                      -> piece boundaries: every lane runs the deterministic scanner from the
+//                         first PROVABLE synchronisation point of its 16-byte chunk (td_common.h)
+//                      -> whole-piece table probe, one lane per piece (CoreBPE::encode fast path)
+//                      -> byte-pair merge of the misses: a wavefront takes a 64-byte window of
+//                         pieces, one lane per byte, ranks from the (id,id) pair table, segmented
+//                         wavefront min-reduce picks the lowest-rank leftmost pair of every piece
+//                      -> block scan + compaction of the byte-indexed token array to the tile's
+//                         staging area
+//   td_long_pieces   pieces longer than 64 bytes: one wavefront per piece, parts in HBM scratch
+//   td_scan_tiles    device-wide exclusive scan of per-tile token counts
+//   td_pack_tokens   staging -> densely packed int32 ids + int64 per-document token offsets
+//
+// Reference behaviour being reproduced: /root/reference/src/tiktoken/tiktoken.cpp:70-128
+// (split_text), :169-234 (encode), :282-378 (get_rank / bpe_merge / byte_pair_encode).
+#include <hip/hip_runtime.h>
+
+#include "td_kernels.h"
+
+namespace td {
+
+// ------------------------------------------------------------------ accessors ---------------
+struct LdsAcc {
+    using pos_t = int;
+    uint8_t* cls;
+    const uint8_t* txt;
+    int lim;
+    int* ext_start;
+    long long* ext_end;
+    __device__ __forceinline__ uint32_t cf(int i) const { return cls[i]; }
+    __device__ __forceinline__ uint32_t byte(int i) const { return txt[i]; }
+    __device__ __forceinline__ void mark(int i) { cls[i] = cls[i] | F_START; }
+    __device__ __forceinline__ void set_ext(int i, int64_t ge) { *ext_start = i; *ext_end = ge; }
+};
+struct LdsSrc {
+    const uint8_t* txt;
+    const uint32_t* docw;
+    int64_t lo, hi;
+    __device__ __forceinline__ uint32_t byte(int64_t i) const { return txt[i]; }
+    __device__ __forceinline__ bool doc(int64_t i) const { return (docw[i >> 5] >> (i & 31)) & 1u; }
+};
+struct GlobSrc {
+    const uint8_t* text;
+    const uint32_t* docbits;
+    int64_t lo, hi;
+    __device__ __forceinline__ uint32_t byte(int64_t i) const { return text[i]; }
+    __device__ __forceinline__ bool doc(int64_t i) const { return (docbits[i >> 5] >> (i & 31)) & 1u; }
+};
+// Slow path: classes computed on the fly from HBM (pieces / look-ahead that leave the LDS window).
+struct GlobAcc {
+    using pos_t = int64_t;
+    const Tables* T;
+    GlobSrc s;
+    int64_t n;
+    int64_t lim;
+    __device__ __noinline__ uint32_t cf(int64_t i) const {
+        if (i >= n) return F_DOC;
+        uint32_t v = classify_at(*T, s, i);
+        if (s.doc(i)) v |= F_DOC;
+        return v;
+    }
+    __device__ __forceinline__ uint32_t byte(int64_t i) const { return i < n ? s.text[i] : 0u; }
+    __device__ __noinline__ int64_t scan(int64_t pos) const { return scan_piece(*this, pos); }
+};
+
+__device__ __forceinline__ void raise(const EncodeArgs& a, int code, int64_t pos) {
+    if (atomicCAS(a.err, 0, code) == 0) *a.err_pos = pos;
+}
+
+// exclusive block scan over K_THREADS values (4 wavefronts); total returned to every thread
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(x, d);
+        if (lane >= d) x += t;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < K_THREADS / 64; ++w) {
+        const uint32_t sw = s_wave[w];
+        if (w < wave) woff += sw;
+        tot += sw;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + x - v;
+}
+
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* a, int64_t n, int64_t key) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------ td_mark_docs ------------
+__global__ void td_mark_docs(const int64_t* doc_offsets, int64_t n_docs, int64_t n, uint32_t* docbits) {
+    for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < n_docs; d += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = doc_offsets[d];
+        if (p >= 0 && p < n) atomicOr(&docbits[p >> 5], 1u << (p & 31));
+    }
+}
+
+// ------------------------------------------------------------------ td_encode_tiles ---------
+__global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cls[K_WIN];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tok[K_TILE + K_MAXSHORT];
+    __shared__ uint32_t s_doc[K_WIN / 32 + 2];
+    __shared__ int32_t s_byteid[256];
+    __shared__ uint8_t s_lut[128];
+    __shared__ uint32_t s_wave[8];
+    __shared__ int s_ext_start;
+    __shared__ long long s_ext_end;
+    __shared__ uint32_t s_haslong;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const Tables& T = a.T;
+
+    if (tid < 128) s_lut[tid] = T.ascii_cls[tid];
+    s_byteid[tid] = T.byte_id[tid];
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t tile_g0 = (int64_t)tile * K_TILE;
+        const int64_t wg0 = tile_g0 - K_HL;  // global offset of window index 0 (multiple of 64)
+        const int tile_hi = K_HL + (int)((a.n - tile_g0 < K_TILE) ? (a.n - tile_g0) : K_TILE);
+
+        // ---- phase 0: stage text window, document bits; clear token slots -----------------
+        for (int v = tid; v < K_WIN / 16; v += K_THREADS) {
+            const int64_t g = wg0 + (int64_t)v * 16;
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (g >= 0 && g + 16 <= a.n && a.text_aligned) {
+                x = *reinterpret_cast<const uint4*>(a.text + g);
+            } else if (g + 16 > 0 && g < a.n) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16; ++k) {
+                    const int64_t gg = g + k;
+                    if (gg >= 0 && gg < a.n) w[k >> 2] |= (uint32_t)a.text[gg] << ((k & 3) * 8);
+                }
+                x = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            reinterpret_cast<uint4*>(s_txt)[v] = x;
+        }
+        {
+            const int64_t nwords = (a.n + 31) >> 5;
+            for (int w = tid; w < K_WIN / 32; w += K_THREADS) {
+                const int64_t gw = (wg0 >> 5) + w;
+                s_doc[w] = (gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
+            }
+        }
+        {
+            const uint4 none = make_uint4(TOK_NONE, TOK_NONE, TOK_NONE, TOK_NONE);
+            for (int v = tid; v < (K_TILE + K_MAXSHORT) / 4; v += K_THREADS) reinterpret_cast<uint4*>(s_tok)[v] = none;
+        }
+        if (tid == 0) { s_ext_start = -1; s_ext_end = 0; s_haslong = 0; }
+        __syncthreads();
+
+        // ---- phase 1: per-byte class + flags ------------------------------------------------
+        {
+            LdsSrc src;
+            src.txt = s_txt;
+            src.docw = s_doc;
+            src.lo = (wg0 < 0) ? -wg0 : 0;
+            src.hi = (a.n - wg0 < K_WIN) ? (a.n - wg0) : K_WIN;
+            for (int d = tid; d < K_WIN / 4; d += K_THREADS) {
+                const uint32_t w = reinterpret_cast<const uint32_t*>(s_txt)[d];
+                uint32_t out;
+                if (!(w & 0x80808080u)) {
+                    out = (uint32_t)s_lut[w & 0x7F] | ((uint32_t)s_lut[(w >> 8) & 0x7F] << 8) |
+                          ((uint32_t)s_lut[(w >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[(w >> 24) & 0x7F] << 24);
+                } else {
+                    out = 0;
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t b = (w >> (8 * k)) & 0xFF;
+                        const int64_t i = (int64_t)d * 4 + k;
+                        uint32_t c;
+                        if (b < 0x80) c = s_lut[b];
+                        else if (i >= src.lo && i < src.hi) c = classify_at(T, src, i);
+                        else c = C_OTHER;
+                        out |= c << (8 * k);
+                    }
+                }
+                const uint32_t db = (s_doc[d >> 3] >> ((d & 7) * 4)) & 0xFu;
+                out |= ((db & 1u) << 7) | ((db & 2u) << 14) | ((db & 4u) << 21) | ((db & 8u) << 28);
+                // bytes past the end of the text: "end of subject" sentinels
+                const int64_t g = wg0 + (int64_t)d * 4;
+                if (g + 4 > a.n) {
+                    for (int k = 0; k < 4; ++k)
+                        if (g + k >= a.n) out = (out & ~(0xFFu << (8 * k))) | ((uint32_t)F_DOC << (8 * k));
+                }
+                reinterpret_cast<uint32_t*>(s_cls)[d] = out;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: piece boundaries ------------------------------------------------------
+        const int c0 = K_HL + tid * K_CHUNK, c1 = c0 + K_CHUNK;
+        {
+            LdsAcc L;
+            L.cls = s_cls; L.txt = s_txt; L.lim = K_LIM; L.ext_start = &s_ext_start; L.ext_end = &s_ext_end;
+            GlobAcc G;
+            G.T = &T; G.s.text = a.text; G.s.docbits = a.docbits; G.s.lo = 0; G.s.hi = a.n; G.n = a.n; G.lim = a.n + 4;
+            scan_lane(L, G, tid, tile_hi, wg0);
+        }
+        __syncthreads();
+
+        // ---- phase 3: whole-piece lookup, one lane per piece ---------------------------------
+        if (c0 < tile_hi) {
+            const int cend = c1 < tile_hi ? c1 : tile_hi;
+            const int ext_start = s_ext_start;
+            for (int i = c0; i < cend; ++i) {
+                const uint32_t v = s_cls[i];
+                if (!(v & F_START)) continue;
+                uint32_t len;
+                if (i == ext_start) {
+                    const long long l = s_ext_end - (wg0 + i);
+                    if (l > 0x7FFFFFFFll) { raise(a, TD_E_SCRATCH, wg0 + i); continue; }
+                    len = (uint32_t)l;
+                } else {
+                    int j = i + 1;
+                    while (j < K_WIN && !(s_cls[j] & F_START)) ++j;
+                    if (j >= K_WIN) { raise(a, TD_E_INVALID, wg0 + i); continue; }
+                    len = (uint32_t)(j - i);
+                }
+                if (len > (uint32_t)K_MAXSHORT) {
+                    const uint32_t idx = atomicAdd(a.long_count, 1u);
+                    if (idx < a.long_cap) {
+                        LongEntry le;
+                        le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
+                        a.long_list[idx] = le;
+                        s_tok[i - K_HL] = TOK_LONGREF | idx;
+                        s_haslong = 1;
+                    } else {
+                        raise(a, TD_E_SCRATCH, wg0 + i);
+                    }
+                    continue;
+                }
+                const uint8_t* pb = s_txt + i;
+                if (len == 1) {
+                    const int32_t id = s_byteid[pb[0]];
+                    if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
+                    s_tok[i - K_HL] = (uint32_t)id;
+                    continue;
+                }
+                if (a.use_fastpath) {
+                    auto get = [pb](uint32_t k) { return (uint32_t)pb[k]; };
+                    uint64_t key;
+                    if (len <= 8) {
+                        const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
+                        const uint32_t sh = (i & 3) * 8;
+                        const uint64_t lo64 = ((uint64_t)wp[1] << 32) | wp[0];
+                        const uint64_t hi64 = ((uint64_t)wp[2] << 32) | wp[1];
+                        const uint32_t klo = (uint32_t)(lo64 >> sh), khi = (uint32_t)(hi64 >> sh);
+                        key = ((uint64_t)khi << 32) | klo;
+                        if (len < 8) key &= (1ull << (8 * len)) - 1;
+                    } else {
+                        key = hash_bytes(get, len);
+                    }
+                    const int32_t r = piece_lookup(T, key, len, get);
+                    if (r != NO_RANK) { s_tok[i - K_HL] = (uint32_t)r; continue; }
+                }
+                s_cls[i] = (uint8_t)(v | F_MISS);
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 4: byte-pair merge of missed pieces, a wavefront per 64-byte window -------
+        {
+            const int seg_lo = K_HL + wave * (K_TILE / 4);
+            const int seg_hi = (seg_lo + K_TILE / 4 < tile_hi) ? seg_lo + K_TILE / 4 : tile_hi;
+            int pos = seg_lo;
+            const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);  // lanes <= mine
+            while (pos < seg_hi) {
+                const int idx = pos + lane;
+                const uint32_t v = s_cls[idx];
+                const bool st = (v & F_START) != 0;
+                const bool mst = st && (v & F_MISS) && idx < seg_hi;
+                const uint64_t missm = __ballot(mst);
+                if (missm == 0) { pos += 64; continue; }
+                const int f = __ffsll((unsigned long long)missm) - 1;
+                if (f > 0) { pos += f; continue; }  // re-align: first missed piece at lane 0
+                const uint64_t startm = __ballot(st);
+                const bool next_is_start = (s_cls[pos + 64] & F_START) != 0;
+                const uint64_t below = startm & le;  // bit 0 is set
+                const int ps = 63 - __clzll((unsigned long long)below);
+                const uint64_t above = startm & ~le;
+                int pe;
+                bool fits;
+                if (above) { pe = __ffsll((unsigned long long)above) - 1; fits = true; }
+                else { pe = 64; fits = next_is_start; }
+                const bool active = fits && ((missm >> ps) & 1ull);
+                const uint64_t pendm = __ballot(mst && !active);
+
+                const uint32_t b = s_txt[idx];
+                uint32_t id = (uint32_t)s_byteid[b];
+                bool alive = active;
+                const uint32_t bn = __shfl_down(b, 1);
+                int32_t rank = NO_RANK;
+                if (active && lane + 1 < pe) rank = T.byte_pair[(b << 8) | bn];
+                for (;;) {
+                    const uint32_t key = (alive && rank != NO_RANK) ? (((uint32_t)rank << 6) | (uint32_t)lane) : 0xFFFFFFFFu;
+                    uint32_t m = key;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {  // segmented inclusive min over [ps, lane]
+                        const uint32_t t = __shfl_up(m, d);
+                        if (lane - d >= ps) m = t < m ? t : m;
+                    }
+                    m = __shfl(m, (pe - 1) & 63);  // lowest-rank, leftmost pair of my piece
+                    const bool has = active && m != 0xFFFFFFFFu;
+                    if (!__any(has)) break;
+                    const uint64_t A = __ballot(alive);
+                    const int w = (int)(m & 63u);
+                    const uint64_t aw = A & ~((w == 63) ? ~0ull : ((2ull << w) - 1));
+                    const int nx = aw ? __ffsll((unsigned long long)aw) - 1 : 64;
+                    if (has) {
+                        if (lane == nx) alive = false;       // right part is absorbed
+                        if (lane == w) id = m >> 6;          // merged token id == its rank
+                    }
+                    const uint64_t A2 = __ballot(alive);
+                    const uint64_t an = A2 & ~le;
+                    const int nl = an ? __ffsll((unsigned long long)an) - 1 : 64;
+                    const uint32_t idn = __shfl(id, nl & 63);
+                    if (has && alive && (lane == w || nl == w))  // only the merged part and its left neighbour re-rank
+                        rank = (nl < pe) ? pair_lookup(T, id, idn) : NO_RANK;
+                }
+                if (alive) {
+                    if ((int32_t)id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + idx);
+                    s_tok[idx - K_HL] = id;
+                }
+                pos = pendm ? pos + (__ffsll((unsigned long long)pendm) - 1) : pos + 64;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 5: compact the byte-indexed token array into the tile's staging area -----
+        {
+            uint32_t vals[K_CHUNK];
+#pragma unroll
+            for (int k = 0; k < K_CHUNK / 4; ++k) {
+                const uint4 x = reinterpret_cast<const uint4*>(s_tok)[tid * (K_CHUNK / 4) + k];
+                vals[4 * k] = x.x; vals[4 * k + 1] = x.y; vals[4 * k + 2] = x.z; vals[4 * k + 3] = x.w;
+            }
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int k = 0; k < K_CHUNK; ++k) cnt += (vals[k] != TOK_NONE) ? 1u : 0u;
+            uint32_t total;
+            const uint32_t off = block_excl_scan(cnt, s_wave, total);
+            uint32_t* dst = a.stage + (size_t)tile * K_TILE + off;
+            uint32_t k2 = 0;
+#pragma unroll
+            for (int k = 0; k < K_CHUNK; ++k) {
+                if (c0 + k < tile_hi && (s_cls[c0 + k] & F_DOC)) {
+                    const int64_t gpos = wg0 + c0 + k;
+                    int64_t d = lower_bound_i64(a.doc_offsets, a.n_docs, gpos);
+                    while (d < a.n_docs && a.doc_offsets[d] == gpos) a.doc_slot[d++] = off + k2;
+                }
+                if (vals[k] != TOK_NONE) dst[k2++] = vals[k];
+            }
+            if (tid == 0) a.tile_count[tile] = total | (s_haslong ? 0x80000000u : 0u);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ td_long_pieces ----------
+// One wavefront per piece longer than K_MAXSHORT bytes.  Parts live in HBM scratch (4 u32 arrays
+// of `len`: id, rank, next, prev); every round the lanes stride over the part array for the
+// lowest-rank leftmost pair, lane 0 applies the merge.  O(len^2/64) like the reference's O(len^2)
+// (tiktoken.cpp:322-343) but rare: only runs, base64 blobs, very long identifiers.
+__global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
+    const Tables& T = a.T;
+    const int lane = threadIdx.x & 63;
+    const uint32_t nlong = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
+    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t j = wave_global; j < nlong; j += nwaves) {
+        const int64_t gs = a.long_list[j].gs;
+        const uint32_t len = a.long_list[j].len;
+        const uint8_t* p = a.text + gs;
+        // whole-piece table first (CoreBPE::encode, tiktoken.cpp:209-215)
+        int32_t whole = NO_RANK;
+        if (a.use_fastpath && len <= T.max_token_len) {
+            if (lane == 0) {
+                auto get = [p](uint32_t k) { return (uint32_t)p[k]; };
+                whole = piece_lookup(T, hash_bytes(get, len), len, get);
+            }
+            whole = __shfl(whole, 0);
+        }
+        const uint64_t need = (whole != NO_RANK) ? 1ull : 4ull * len;
+        unsigned long long off = 0;
+        if (lane == 0) off = atomicAdd(a.pool_used, (unsigned long long)need);
+        off = __shfl(off, 0);
+        if (off + need > a.pool_cap) {
+            if (lane == 0) raise(a, TD_E_SCRATCH, gs);
+            continue;
+        }
+        uint32_t ntok = 0;
+        if (whole != NO_RANK) {
+            if (lane == 0) a.pool[off] = (uint32_t)whole;
+            ntok = 1;
+        } else {
+            volatile uint32_t* id = a.pool + off;
+            volatile uint32_t* rk = id + len;
+            volatile uint32_t* nx = rk + len;
+            volatile uint32_t* pv = nx + len;
+            for (uint32_t i = lane; i < len; i += 64) {
+                const uint32_t b = p[i];
+                id[i] = (uint32_t)T.byte_id[b];
+                rk[i] = (i + 1 < len) ? (uint32_t)T.byte_pair[(b << 8) | p[i + 1]] : (uint32_t)NO_RANK;
+                nx[i] = i + 1;
+                pv[i] = i - 1;  // 0xFFFFFFFF for i == 0
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            for (;;) {
+                // lowest rank, leftmost: 64-bit key (rank << 32 | position); dead parts have rank NO_RANK..
+                unsigned long long best = ~0ull;
+                for (uint32_t i = lane; i < len; i += 64) {
+                    const uint32_t r = rk[i];
+                    if (r != (uint32_t)NO_RANK && id[i] != TOK_NONE) {
+                        const unsigned long long k = ((unsigned long long)r << 32) | i;
+                        best = k < best ? k : best;
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const unsigned long long o = __shfl_xor(best, d);
+                    best = o < best ? o : best;
+                }
+                if (best == ~0ull) break;
+                if (lane == 0) {
+                    const uint32_t w = (uint32_t)best, r = (uint32_t)(best >> 32);
+                    const uint32_t n1 = nx[w];         // absorbed part
+                    const uint32_t n2 = nx[n1];        // new right neighbour (== len if none)
+                    const uint32_t pw = pv[w];
+                    id[w] = r;
+                    id[n1] = TOK_NONE;
+                    rk[n1] = (uint32_t)NO_RANK;
+                    nx[w] = n2;
+                    if (n2 < len) pv[n2] = w;
+                    rk[w] = (n2 < len) ? (uint32_t)pair_lookup(T, r, id[n2]) : (uint32_t)NO_RANK;
+                    if (pw != 0xFFFFFFFFu) rk[pw] = (uint32_t)pair_lookup(T, id[pw], r);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+            if (lane == 0) {  // compact surviving ids to the front of the id array (k <= i always)
+                uint32_t k = 0;
+                for (uint32_t i = 0; i < len; i = nx[i]) {
+                    const uint32_t v = id[i];
+                    if ((int32_t)v >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gs + i);
+                    id[k++] = v;
+                }
+                ntok = k;
+            }
+            ntok = __shfl(ntok, 0);
+        }
+        if (lane == 0) {
+            a.long_list[j].ntok = ntok;
+            a.long_list[j].pool_off = off;
+            if (ntok > 1) atomicAdd(&a.tile_extra[gs / K_TILE], ntok - 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ td_scan_tiles -----------
+// Device-wide exclusive scan of per-tile token counts (one 1024-thread workgroup; n_tiles is
+// N/4096, i.e. 262144 entries for a 1 GiB corpus).
+__global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
+    __shared__ unsigned long long s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (a.n_tiles + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < a.n_tiles) ? lo + per : a.n_tiles;
+    unsigned long long sum = 0;
+    for (int t = lo; t < hi; ++t) sum += (a.tile_count[t] & 0x7FFFFFFFu) + a.tile_extra[t];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long t = (tid >= d) ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    unsigned long long run = s_part[tid] - sum;
+    for (int t = lo; t < hi; ++t) {
+        a.tile_base[t] = (int64_t)run;
+        run += (a.tile_count[t] & 0x7FFFFFFFu) + a.tile_extra[t];
+    }
+    if (tid == 1023) {
+        const int64_t total = (int64_t)s_part[1023];
+        a.tile_base[a.n_tiles] = total;
+        if (total > a.out_cap) raise(a, TD_E_CAPACITY, total);
+    }
+}
+
+// ------------------------------------------------------------------ td_pack_tokens ----------
+__global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
+    __shared__ uint32_t s_off[K_TILE];
+    __shared__ uint32_t s_wave[8];
+    const int tid = threadIdx.x;
+    const int64_t total = a.tile_base[a.n_tiles];
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const uint32_t tc = a.tile_count[tile];
+        const uint32_t cnt = tc & 0x7FFFFFFFu;
+        const bool haslong = (tc >> 31) != 0;
+        const int64_t base = a.tile_base[tile];
+        const uint32_t* src = a.stage + (size_t)tile * K_TILE;
+        if (!haslong) {
+            for (uint32_t i = tid; i < cnt; i += K_THREADS) {
+                const int64_t o = base + i;
+                if (o < a.out_cap) a.out_tokens[o] = (int32_t)src[i];
+            }
+        } else {
+            // slots expand: a long marker becomes that piece's ntok tokens
+            uint32_t sz[K_CHUNK];
+            uint32_t mine = 0;
+            for (int k = 0; k < K_CHUNK; ++k) {
+                const uint32_t i = tid * K_CHUNK + k;
+                uint32_t s = 0;
+                if (i < cnt) {
+                    const uint32_t v = src[i];
+                    s = (v & TOK_LONGREF) ? a.long_list[v & 0x7FFFFFFFu].ntok : 1u;
+                }
+                sz[k] = s;
+                mine += s;
+            }
+            uint32_t tot;
+            uint32_t run = block_excl_scan(mine, s_wave, tot);
+            for (int k = 0; k < K_CHUNK; ++k) {
+                s_off[tid * K_CHUNK + k] = run;
+                run += sz[k];
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += K_THREADS) {
+                const uint32_t v = src[i];
+                if (!(v & TOK_LONGREF)) {
+                    const int64_t o = base + s_off[i];
+                    if (o < a.out_cap) a.out_tokens[o] = (int32_t)v;
+                }
+            }
+            for (uint32_t i = 0; i < cnt; ++i) {  // uniform loop; markers are rare
+                const uint32_t v = src[i];
+                if (v & TOK_LONGREF) {
+                    const LongEntry le = a.long_list[v & 0x7FFFFFFFu];
+                    const uint32_t* ps = a.pool + le.pool_off;
+                    for (uint32_t k = tid; k < le.ntok; k += K_THREADS) {
+                        const int64_t o = base + s_off[i] + k;
+                        if (o < a.out_cap) a.out_tokens[o] = (int32_t)ps[k];
+                    }
+                }
+            }
+        }
+        // documents starting inside this tile
+        {
+            const int64_t g_lo = (int64_t)tile * K_TILE;
+            const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
+            const int64_t d_lo = lower_bound_i64(a.doc_offsets, a.n_docs, g_lo);
+            const int64_t d_hi = lower_bound_i64(a.doc_offsets, a.n_docs, g_hi);
+            for (int64_t d = d_lo + tid; d < d_hi; d += K_THREADS) {
+                const uint32_t slot = a.doc_slot[d];
+                a.out_offsets[d] = base + (haslong ? s_off[slot] : slot);
+            }
+            if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
+                const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
+                for (int64_t d = d_end + tid; d <= a.n_docs; d += K_THREADS) a.out_offsets[d] = total;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ launches ----------------
+static int g_blocks_cached = 0;
+int encode_grid_blocks() {
+    if (!g_blocks_cached) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            g_blocks_cached = prop.multiProcessorCount * 5;
+        else
+            g_blocks_cached = 256 * 5;
+    }
+    return g_blocks_cached;
+}
+
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream) {
+    if (a.n_tiles <= 0) return hipSuccess;
+    {
+        const int64_t nd = a.n_docs;
+        int blocks = (int)((nd + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(td_mark_docs, dim3(blocks), dim3(256), 0, stream, a.doc_offsets, nd, a.n, a.docbits);
+    }
+    const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
+    hipLaunchKernelGGL(td_encode_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(td_long_pieces, dim3(256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(td_scan_tiles, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(td_pack_tokens, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ decode ------------------
+// ids -> bytes (CoreBPE::decode_bytes, tiktoken.cpp:236-255): per-token byte lengths, exclusive
+// scan, then every token copies its bytes from the rank -> bytes store.  Ids are validated on the
+// host before launch (td_api.cpp), the device check is a backstop.
+__global__ void td_decode_len(const DecodeArgs a) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t id = a.tokens[i];
+        int64_t len = 0;
+        if (id < 0 || id > a.T.max_id) {
+            if (atomicCAS(a.err, 0, TD_E_BAD_TOKEN) == 0) *a.err_pos = i;
+        } else {
+            len = (int64_t)a.T.tok_off[id + 1] - a.T.tok_off[id];
+        }
+        a.byte_off[i + 1] = len;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.byte_off[0] = 0;
+}
+__global__ __launch_bounds__(1024) void td_decode_scan(const DecodeArgs a) {
+    __shared__ unsigned long long s_part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (a.n + 1023) / 1024;
+    const int64_t lo = tid * per, hi = (lo + per < a.n) ? lo + per : a.n;
+    unsigned long long sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += (unsigned long long)a.byte_off[i + 1];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long t = (tid >= d) ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    unsigned long long run = s_part[tid] - sum;
+    for (int64_t i = lo; i < hi; ++i) {
+        run += (unsigned long long)a.byte_off[i + 1];
+        a.byte_off[i + 1] = (int64_t)run;
+    }
+}
+__global__ void td_decode_copy(const DecodeArgs a) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t id = a.tokens[i];
+        if (id < 0 || id > a.T.max_id) continue;
+        const uint8_t* src = a.T.tok_bytes + a.T.tok_off[id];
+        const int64_t o = a.byte_off[i], len = a.byte_off[i + 1] - o;
+        for (int64_t k = 0; k < len; ++k)
+            if (o + k < a.out_cap) a.out[o + k] = src[k];
+    }
+}
+
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
+    if (a.n <= 0) return hipSuccess;
+    int blocks = (int)((a.n + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(td_decode_len, dim3(blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(td_decode_scan, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(td_decode_copy, dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace td

@@ -1,0 +1,222 @@
+// Host-side table construction.  See td_tables.h.
+#include "td_tables.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+#include "generated/unicode_classes.inc"
+
+namespace td {
+
+static const char kO200k[] =
+    "[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]*[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?"
+    "|[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]+[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?"
+    "|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n/]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+
+const char* o200k_pattern() { return kO200k; }
+
+PatternKind classify_pattern(const std::string& pat) {
+    if (pat == kO200k) return PATTERN_O200K;
+    return PATTERN_UNSUPPORTED;
+}
+
+uint64_t piece_key_host(const uint8_t* p, uint32_t len) {
+    if (len <= 8) {
+        uint64_t k = 0;
+        for (uint32_t i = 0; i < len; ++i) k |= (uint64_t)p[i] << (8 * i);
+        return k;
+    }
+    return hash_bytes([p](uint32_t i) { return (uint32_t)p[i]; }, len);
+}
+
+Tables HostTables::view() const {
+    Tables T;
+    memset(&T, 0, sizeof T);
+    T.ascii_cls = ascii_cls.data();
+    T.ucls1 = td_ucls_stage1;
+    T.ucls2 = td_ucls_stage2;
+    T.byte_id = byte_id.data();
+    T.byte_pair = byte_pair.data();
+    T.piece_slots = piece_slots.data();
+    T.pair_slots = pair_slots.data();
+    T.tok_off = tok_off.data();
+    T.tok_bytes = tok_bytes.data();
+    T.piece_mask = piece_mask;
+    T.pair_mask = pair_mask;
+    T.max_id = max_id;
+    T.pseudo_base = pseudo_base;
+    T.max_token_len = max_token_len;
+    return T;
+}
+
+static uint32_t pow2_at_least(uint64_t n) {
+    uint32_t c = 16;
+    while (c < n) c <<= 1;
+    return c;
+}
+
+int merge_piece_host(const Tables& T, const uint8_t* piece, uint32_t n, std::vector<int32_t>& out) {
+    // ids of the current parts + rank of (part i, part i+1); leftmost minimum merges first
+    // (strict '<' scans in tiktoken.cpp:312,338).
+    std::vector<int32_t> id(n), rk(n, NO_RANK);
+    for (uint32_t i = 0; i < n; ++i) id[i] = T.byte_id[piece[i]];
+    for (uint32_t i = 0; i + 1 < n; ++i) rk[i] = T.byte_pair[((uint32_t)piece[i] << 8) | piece[i + 1]];
+    for (;;) {
+        int32_t best = NO_RANK;
+        size_t bi = 0;
+        for (size_t i = 0; i + 1 < id.size(); ++i)
+            if (rk[i] < best) { best = rk[i]; bi = i; }
+        if (best == NO_RANK) break;
+        id[bi] = best;
+        id.erase(id.begin() + bi + 1);
+        rk.erase(rk.begin() + bi + 1);
+        rk[bi] = (bi + 1 < id.size()) ? pair_lookup(T, (uint32_t)id[bi], (uint32_t)id[bi + 1]) : NO_RANK;
+        if (bi > 0) rk[bi - 1] = pair_lookup(T, (uint32_t)id[bi - 1], (uint32_t)id[bi]);
+    }
+    for (int32_t v : id) {
+        if (v >= T.pseudo_base) return TD_E_UNKNOWN_BYTE;
+        out.push_back(v);
+    }
+    return TD_OK;
+}
+
+int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_bytes, const int64_t* token_offsets,
+                 const int32_t* ranks, int64_t n_special, const uint8_t* special_bytes,
+                 const int64_t* special_offsets, const int32_t* special_ranks, HostTables& H, std::string& err) {
+    H = HostTables();
+    H.pattern = pattern ? pattern : "";
+    H.pattern_kind = classify_pattern(H.pattern);
+    if (H.pattern_kind == PATTERN_UNSUPPORTED) {
+        err = "split pattern is not supported by the device pre-tokenizer (supported: the o200k/Llama-4 pattern); "
+              "there is no CPU regex fallback";
+        return TD_E_PATTERN;
+    }
+    if (n_vocab <= 0) { err = "empty vocabulary"; return TD_E_VOCAB; }
+
+    // ASCII classes straight from the Unicode table
+    H.ascii_cls.resize(128);
+    for (uint32_t c = 0; c < 128; ++c) H.ascii_cls[c] = td_ucls_stage2[(uint32_t)td_ucls_stage1[0] * 256u + c];
+
+    int32_t max_rank = -1;
+    uint32_t max_len = 0;
+    for (int64_t v = 0; v < n_vocab; ++v) {
+        const int64_t len = token_offsets[v + 1] - token_offsets[v];
+        if (len <= 0) { err = "vocabulary contains an empty token"; return TD_E_VOCAB; }
+        if (ranks[v] < 0) { err = "negative rank"; return TD_E_VOCAB; }
+        max_rank = std::max(max_rank, ranks[v]);
+        max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+    }
+    int32_t max_id = max_rank;
+    for (int64_t s = 0; s < n_special; ++s) max_id = std::max(max_id, special_ranks[s]);
+    H.max_rank = max_rank;
+    H.pseudo_base = max_id + 1;
+    if ((int64_t)H.pseudo_base + 256 >= (1ll << ID_BITS)) {
+        err = "token ids must be < 2^21 - 256";
+        return TD_E_VOCAB;
+    }
+    H.max_id = max_id;
+    H.max_token_len = max_len;
+
+    // rank -> bytes store (regular tokens first; specials fill ids the regular vocab leaves free)
+    std::vector<uint32_t> len_of((size_t)max_id + 1, 0);
+    std::vector<int64_t> src_of((size_t)max_id + 1, -1);  // >=0: regular vocab index; <=-2: -(special index)-2
+    for (int64_t v = 0; v < n_vocab; ++v) {
+        if (len_of[ranks[v]] != 0) { err = "duplicate rank " + std::to_string(ranks[v]); return TD_E_VOCAB; }
+        len_of[ranks[v]] = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
+        src_of[ranks[v]] = v;
+    }
+    for (int64_t s = 0; s < n_special; ++s) {
+        const int32_t id = special_ranks[s];
+        if (id < 0) { err = "negative special id"; return TD_E_VOCAB; }
+        H.special_strs.emplace_back((const char*)special_bytes + special_offsets[s],
+                                    (size_t)(special_offsets[s + 1] - special_offsets[s]));
+        H.special_ids.push_back(id);
+        if (len_of[id] == 0) {
+            len_of[id] = (uint32_t)(special_offsets[s + 1] - special_offsets[s]);
+            src_of[id] = -s - 2;
+        }
+    }
+    H.tok_off.assign((size_t)max_id + 2, 0);
+    for (int32_t id = 0; id <= max_id; ++id) H.tok_off[id + 1] = H.tok_off[id] + len_of[id];
+    H.tok_bytes.assign((size_t)H.tok_off[max_id + 1] + 16, 0);
+    for (int32_t id = 0; id <= max_id; ++id) {
+        if (src_of[id] >= 0)
+            memcpy(&H.tok_bytes[H.tok_off[id]], token_bytes + token_offsets[src_of[id]], len_of[id]);
+        else if (src_of[id] <= -2)
+            memcpy(&H.tok_bytes[H.tok_off[id]], special_bytes + special_offsets[-src_of[id] - 2], len_of[id]);
+    }
+
+    // piece table: bytes -> rank
+    const uint32_t pcap = pow2_at_least((uint64_t)n_vocab * 2);
+    H.piece_mask = pcap - 1;
+    H.piece_slots.assign(pcap, PieceSlot{0, 0, 0});
+    H.byte_id.assign(256, 0);
+    for (int b = 0; b < 256; ++b) H.byte_id[b] = H.pseudo_base + b;
+    H.byte_pair.assign(65536, NO_RANK);
+    for (int64_t v = 0; v < n_vocab; ++v) {
+        const uint8_t* p = token_bytes + token_offsets[v];
+        const uint32_t len = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
+        const uint64_t key = piece_key_host(p, len);
+        uint32_t h = hash_piece(key, len) & H.piece_mask;
+        for (;;) {
+            PieceSlot& s = H.piece_slots[h];
+            if (s.len == 0) { s.key = key; s.rank = (uint32_t)ranks[v]; s.len = len; break; }
+            if (s.key == key && s.len == len &&
+                (len <= 8 || memcmp(&H.tok_bytes[H.tok_off[s.rank]], p, len) == 0)) {
+                err = "duplicate token bytes in vocabulary";
+                return TD_E_VOCAB;
+            }
+            h = (h + 1) & H.piece_mask;
+        }
+        if (len == 1) H.byte_id[p[0]] = ranks[v];
+        if (len == 2) H.byte_pair[((uint32_t)p[0] << 8) | p[1]] = ranks[v];
+    }
+
+    // pair table: every split of every token whose halves are both "parts" the merge loop can
+    // hold: a token, or a single byte (even one that is not a token -> pseudo id), because the
+    // reference keys get_rank by the bytes of two adjacent parts (tiktoken.cpp:282-296).
+    Tables T = H.view();
+    auto id_of = [&](const uint8_t* p, uint32_t len) -> int32_t {
+        if (len == 1) return H.byte_id[p[0]];
+        return piece_lookup(T, piece_key_host(p, len), len, [p](uint32_t i) { return (uint32_t)p[i]; });
+    };
+    std::vector<std::pair<uint64_t, uint32_t>> pairs;
+    pairs.reserve((size_t)n_vocab * 3);
+    for (int64_t v = 0; v < n_vocab; ++v) {
+        const uint8_t* p = token_bytes + token_offsets[v];
+        const uint32_t len = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
+        for (uint32_t k = 1; k < len; ++k) {
+            const int32_t l = id_of(p, k);
+            if (l == NO_RANK) continue;
+            const int32_t r = id_of(p + k, len - k);
+            if (r == NO_RANK) continue;
+            pairs.emplace_back(((uint64_t)(uint32_t)l << ID_BITS) | (uint32_t)r, (uint32_t)ranks[v]);
+        }
+    }
+    H.n_pairs = pairs.size();
+    const uint32_t qcap = pow2_at_least((uint64_t)pairs.size() * 2 + 2);
+    H.pair_mask = qcap - 1;
+    H.pair_slots.assign(qcap, PAIR_EMPTY);
+    for (auto& pr : pairs) {
+        const uint32_t l = (uint32_t)(pr.first >> ID_BITS), r = (uint32_t)(pr.first & ((1u << ID_BITS) - 1));
+        uint32_t h = hash_pair(l, r) & H.pair_mask;
+        while (H.pair_slots[h] != PAIR_EMPTY) h = (h + 1) & H.pair_mask;
+        H.pair_slots[h] = (pr.first << ID_BITS) | pr.second;
+    }
+
+    // Is the whole-piece fast path redundant (encode == encode_ordinary on every input)?
+    T = H.view();
+    H.merge_closed = true;
+    std::vector<int32_t> tmp;
+    for (int64_t v = 0; v < n_vocab && H.merge_closed; ++v) {
+        const uint32_t len = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
+        if (len < 2) continue;
+        tmp.clear();
+        const int rc = merge_piece_host(T, token_bytes + token_offsets[v], len, tmp);
+        if (rc != TD_OK || tmp.size() != 1 || tmp[0] != ranks[v]) H.merge_closed = false;
+    }
+    return TD_OK;
+}
+
+}  // namespace td
