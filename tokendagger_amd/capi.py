@@ -38,6 +38,27 @@ class TokenDaggerHipError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must not hold two HIP runtimes: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 +
+    libhsa-runtime64, and a second copy (the system one this library is linked against) cannot see the GPU
+    once the first has claimed it.  When torch is installed, load ITS runtime first, globally, so that our
+    DT_NEEDED libamdhip64.so.7 binds to it.  Set TOKENDAGGER_NO_TORCH=1 to use the system ROCm runtime."""
+    import os
+    if os.environ.get("TOKENDAGGER_NO_TORCH") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        hip = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+        if hip.exists():
+            import torch  # noqa: F401  (loads the bundled runtime with the right rpaths)
+            ctypes.CDLL(str(hip), mode=ctypes.RTLD_GLOBAL)
+    except Exception:  # torch broken or absent: fall back to the system runtime
+        return
+
+
 def load_library():
     global _lib
     if _lib is not None:
@@ -46,6 +67,7 @@ def load_library():
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'); "
             "tokendagger_amd has no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(str(LIB_PATH))
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     lib.td_create.restype = i32

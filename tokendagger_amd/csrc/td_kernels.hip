@@ -356,6 +356,12 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
             uint32_t cnt = 0;
 #pragma unroll
             for (int k = 0; k < K_CHUNK; ++k) cnt += (vals[k] != TOK_NONE) ? 1u : 0u;
+            // tokens of the tile's last piece may sit past the tile end (slots K_TILE .. K_TILE+63):
+            // they follow everything else in byte order, so the last lane appends them
+            uint32_t tail = 0;
+            if (tid == K_THREADS - 1)
+                for (int k = 0; k < K_MAXSHORT; ++k) tail += (s_tok[K_TILE + k] != TOK_NONE) ? 1u : 0u;
+            cnt += tail;
             uint32_t total;
             const uint32_t off = block_excl_scan(cnt, s_wave, total);
             uint32_t* dst = a.stage + (size_t)tile * K_TILE + off;
@@ -369,6 +375,11 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
                 }
                 if (vals[k] != TOK_NONE) dst[k2++] = vals[k];
             }
+            if (tail)
+                for (int k = 0; k < K_MAXSHORT; ++k) {
+                    const uint32_t v = s_tok[K_TILE + k];
+                    if (v != TOK_NONE) dst[k2++] = v;
+                }
             if (tid == 0) a.tile_count[tile] = total | (s_haslong ? 0x80000000u : 0u);
         }
         __syncthreads();
