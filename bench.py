@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""Headline benchmark: GB/s of raw UTF-8 text tokenized (Llama-4-Scout vocab) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W           (N=1 default)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (td_encode_device: regex pre-tokenization + byte-pair merge +
+packing, all kernels) over this rank's shard of the corpus, which is RESIDENT IN HBM when the timed
+region starts.  Workload at N=1 = BASELINE.json configs[1]: Llama-4-Scout vocab, 256 MiB synthetic
+English (the reference's generator shape, td_corpus.english).  For N>1 every rank holds its own
+256 MiB shard (documents shard trivially; weak scaling), the step ends with the path's only
+collective: an RCCL all-gather of per-rank {documents, tokens} -> global token offsets.
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_corpus(kind: str, n_bytes: int, seed: int):
+    """Seeded synthetic corpus: a 32 MiB generator block tiled to n_bytes (documents stay independent)."""
+    import td_corpus
+    unit_bytes = min(n_bytes, 32 << 20)
+    unit, uo = getattr(td_corpus, kind)(unit_bytes, seed=seed)
+    reps = (n_bytes + unit_bytes - 1) // unit_bytes
+    if reps == 1:
+        return unit, uo
+    x = np.tile(unit, reps)[:n_bytes]
+    offs = np.concatenate([uo[:-1] + r * unit_bytes for r in range(reps)] + [[n_bytes]])
+    offs = np.unique(offs[offs <= n_bytes]).astype(np.int64)
+    if kind != "english":  # non-ASCII corpora: never cut a document inside a character
+        while (x[-1] & 0xC0) == 0x80 or x[-1] >= 0xC0:
+            x[-1] = 0x20
+            if len(x) >= 2 and x[-2] < 0x80:
+                break
+            x[-2] = 0x20
+    return np.ascontiguousarray(x), offs
+
+
+def cpu_baseline(x: np.ndarray, offs: np.ndarray, ranks: dict, special: dict, pat: str):
+    """Reference C++ path (oracle/_ref = unmodified tiktoken.cpp) on this box's host cores, bounded sample."""
+    cores = os.cpu_count() or 1
+    sample_docs = int(np.searchsorted(offs, min(int(offs[-1]), 96 << 20)))
+    sample_docs = max(1, min(sample_docs, len(offs) - 1))
+    s_offs = offs[:sample_docs + 1]
+    s_bytes = int(s_offs[-1])
+    try:
+        from oracle import ref
+        if not ref.available():
+            raise RuntimeError("oracle/_ref not built")
+        mr = dict(ranks)
+        for k, v in special.items():
+            mr[k.encode("utf-8")] = v
+        R = ref.RefTokenizer(pat, mr, special)
+        warm = int(np.searchsorted(s_offs, 1 << 20))
+        R.encode_batch(x, s_offs[:max(2, warm)], n_threads=cores, want_tokens=False)
+        best = None
+        for _ in range(2):
+            sec, _, _ = R.encode_batch(x, s_offs, n_threads=cores, want_tokens=False)
+            best = sec if best is None else min(best, sec)
+        kind = "reference"
+        used = cores
+    except Exception as e:  # compiled reference unusable here: time the single-threaded C restatement instead
+        from oracle import port
+        import subprocess
+        if not port.available():
+            subprocess.check_call([str(ROOT / "oracle" / "build_oracle.sh")], stdout=subprocess.DEVNULL)
+        O = port.OracleTokenizer(ranks)
+        sample_docs = max(1, int(np.searchsorted(offs, 8 << 20)))
+        s_offs = offs[:sample_docs + 1]
+        s_bytes = int(s_offs[-1])
+        t0 = time.perf_counter()
+        O.encode_batch(x[:s_bytes].tobytes(), s_offs)
+        best = time.perf_counter() - t0
+        kind, used = "port", 1
+        sys.stderr.write(f"[bench] compiled reference unavailable ({e}); cpu_baseline uses the C restatement\n")
+    return {
+        "value": round(s_bytes / best / 1e9, 4), "unit": "GB/s", "cores": used, "kind": kind,
+        "sample": f"first {s_bytes / 2**20:.0f} MiB of the same corpus ({sample_docs} documents), "
+                  f"CoreBPE::encode per document on {used} std::threads, best of 2",
+        "cpu_model": _cpu_model(),
+    }
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--corpus", default="english", choices=["english", "mixed", "code"])
+    ap.add_argument("--size-mb", type=int, default=256, help="MiB of text per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from tokendagger_amd import capi, vocab_io
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    name, pat, ranks, special = vocab_io.load_tdv(vocab_io.default_vocab_path())
+    tok = capi.HipTokenizer(pat, ranks, special, device=dev.index)
+
+    n = a.size_mb << 20
+    x, offs = build_corpus(a.corpus, n, seed=1000 + rank)
+    n_docs = len(offs) - 1
+    d_text = torch.from_numpy(x).to(dev)
+    d_offs = torch.from_numpy(offs).to(dev)
+    cap = n // 2 + 1024
+    d_tok = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_toff = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
+    tok.reserve(n, n_docs + 1)
+    tok.set_option(capi.TD_OPT_PROFILE, 1)
+    stream = torch.cuda.current_stream(dev)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    gathered = torch.zeros(2 * world, dtype=torch.int64, device=dev) if world > 1 else None
+
+    def step():
+        tok.encode_device(d_text.data_ptr(), n, d_offs.data_ptr(), n_docs, d_tok.data_ptr(), cap, d_toff.data_ptr(),
+                          stream.cuda_stream)
+        if world > 1:  # the path's only exchange: per-rank {docs, tokens} -> global offsets
+            counts[0] = n_docs
+            counts[1:2] = d_toff[n_docs:n_docs + 1]
+            dist.all_gather_into_tensor(gathered, counts)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    tok.device_status(stream.cuda_stream)
+    tok.profile_read()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    tok.device_status(stream.cuda_stream)
+    k_ms, k_n = tok.profile_read()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    n_tok = int(d_toff[n_docs].item())
+    if rank == 0:
+        # parity spot-check of what was just timed (oracle = checker only, outside the timed region)
+        verified = None
+        if not a.no_verify:
+            from oracle import port
+            import subprocess
+            if not port.available():
+                subprocess.check_call([str(ROOT / "oracle" / "build_oracle.sh")], stdout=subprocess.DEVNULL)
+            O = port.OracleTokenizer(ranks)
+            k = max(1, int(np.searchsorted(offs, 1 << 20)))
+            et, eo = O.encode_batch(x[:offs[k]].tobytes(), offs[:k + 1])
+            got_off = d_toff[:k + 1].cpu().numpy()
+            got = d_tok[:int(got_off[-1])].cpu().numpy()
+            verified = bool(np.array_equal(eo, got_off) and np.array_equal(et, got))
+            if not verified:
+                raise SystemExit("bench: GPU token ids differ from the oracle on the verification sample")
+        ms_step = elapsed / a.steps * 1e3
+        value = world * n / (elapsed / a.steps) / 1e9
+        b_alg = n + 4 * n_tok + 8 * (n_docs + 1)  # read text once, write ids once, write offsets
+        k_avg_ms = k_ms / max(k_n, 1)
+        achieved = b_alg / (k_avg_ms * 1e-3) / 1e9 if k_n else None
+        traffic = None
+        tfile = ROOT / "profiles" / "hbm_traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(f"{a.corpus}_{a.size_mb}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "GB/s raw text tokenized (Llama-4 vocab)",
+            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": f"synthetic (seeded td_corpus.{a.corpus}, 32 MiB generator block tiled)",
+            "config": {"workload": f"Llama-4-Scout vocab, {a.size_mb} MiB synthetic {a.corpus} text per GPU, "
+                                   f"{n_docs} documents, CoreBPE::encode semantics, input resident in HBM",
+                       "bytes_per_gpu": n, "tokens_per_gpu": n_tok, "docs_per_gpu": n_docs,
+                       "parallelism": f"dp{world} (documents sharded, RCCL all-gather of counts)" if world > 1 else "single GPU",
+                       "verified_vs_oracle": verified},
+            "roofline": {"bound": "hbm", "kernel": "td_encode_tiles", "achieved": round(achieved, 2) if achieved else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": b_alg,
+                         "kernel_ms_avg": round(k_avg_ms, 4), "launches_timed": k_n},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(x, offs, ranks, special, pat)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,11 +21,12 @@ TD_MODE_ORDINARY = 1
 TD_INFO_N_PAIRS, TD_INFO_MERGE_CLOSED, TD_INFO_MAX_ID, TD_INFO_TILE_BYTES = 1, 2, 3, 4
 TD_INFO_WORKSPACE_BYTES, TD_INFO_N_SPECIAL, TD_INFO_LONG_PIECES = 5, 6, 7
 TD_OPT_LONG_POOL_BYTES = 1
+TD_OPT_PROFILE = 2
 
 EXPORTS = [
     "td_create", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",
     "td_device_status", "td_decode_bytes", "td_encode_with_special", "td_info", "td_set_option",
-    "td_special_count", "td_special_get",
+    "td_special_count", "td_special_get", "td_profile_read",
 ]
 
 
@@ -91,6 +92,8 @@ def load_library():
     lib.td_info.argtypes = [vp, i32]
     lib.td_set_option.restype = i32
     lib.td_set_option.argtypes = [vp, i32, i64]
+    lib.td_profile_read.restype = i32
+    lib.td_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     lib.td_special_count.restype = i64
     lib.td_special_count.argtypes = [vp]
     lib.td_special_get.restype = i32
@@ -217,6 +220,12 @@ class HipTokenizer:
 
     def set_option(self, what: int, value: int):
         self._check(self._lib.td_set_option(self._h, what, value))
+
+    def profile_read(self) -> tuple[float, int]:
+        """-> (sum of fused tile-kernel durations in ms, launches) since the last read (needs TD_OPT_PROFILE=1)."""
+        ms = ctypes.c_double(0); n = ctypes.c_int64(0)
+        self._check(self._lib.td_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def special_tokens(self) -> dict[str, int]:
         out = {}

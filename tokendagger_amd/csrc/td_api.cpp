@@ -47,6 +47,8 @@ struct td_tokenizer {
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
     int64_t last_long = 0;
     size_t ws_bytes = 0;
 };
@@ -154,7 +156,13 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     HIP_TRY(t, hipMemsetAsync(t->tile_extra.p, 0, (size_t)(n_tiles + 1) * 4, stream));
     // keep a sticky error (err / err_pos) but reset the per-call counters
     HIP_TRY(t, hipMemsetAsync(&ctl->long_count, 0, sizeof(Ctl) - offsetof(Ctl, long_count), stream));
-    HIP_TRY(t, launch_encode(a, stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (t->profile) {
+        if (!t->ev_free.empty()) { e0 = t->ev_free.back().first; e1 = t->ev_free.back().second; t->ev_free.pop_back(); }
+        else { HIP_TRY(t, hipEventCreate(&e0)); HIP_TRY(t, hipEventCreate(&e1)); }
+        t->ev_pending.emplace_back(e0, e1);
+    }
+    HIP_TRY(t, launch_encode(a, stream, e0, e1));
     return TD_OK;
 }
 
@@ -260,6 +268,8 @@ void td_destroy(td_tokenizer* t) {
     (void)hipSetDevice(t->device);
     (void)hipDeviceSynchronize();
     for (void* p : t->table_allocs) (void)hipFree(p);
+    for (auto& pr : t->ev_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : t->ev_free) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     DevBuf* bufs[] = {&t->docbits, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
                       &t->pool, &t->ctl, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                       &t->dec_off, &t->dec_out};
@@ -498,7 +508,30 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
         t->pool_bytes_opt = value;
         return TD_OK;
     }
+    if (what == TD_OPT_PROFILE) {
+        t->profile = value != 0;
+        return TD_OK;
+    }
     return TD_E_INVALID;
+}
+
+int td_profile_read(td_tokenizer* t, double* kernel_ms_sum, int64_t* launches) {
+    if (!t) return TD_E_INVALID;
+    std::lock_guard<std::mutex> g(t->mu);
+    double sum = 0;
+    int64_t n = 0;
+    for (auto& pr : t->ev_pending) {
+        HIP_TRY(t, hipEventSynchronize(pr.second));
+        float ms = 0;
+        HIP_TRY(t, hipEventElapsedTime(&ms, pr.first, pr.second));
+        sum += ms;
+        ++n;
+        t->ev_free.push_back(pr);
+    }
+    t->ev_pending.clear();
+    if (kernel_ms_sum) *kernel_ms_sum = sum;
+    if (launches) *launches = n;
+    return TD_OK;
 }
 
 int64_t td_special_count(const td_tokenizer* t) { return t ? (int64_t)t->H.special_ids.size() : 0; }

@@ -54,7 +54,8 @@ struct DecodeArgs {
 };
 
 // All launches are asynchronous on `stream`; none of them synchronises or allocates.
-hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream);
+// ev0/ev1 (optional): recorded right before / after the fused tile kernel
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
 int encode_grid_blocks();  // persistent grid size used by the fused kernel
 

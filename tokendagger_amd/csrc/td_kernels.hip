@@ -605,7 +605,7 @@ int encode_grid_blocks() {
     return g_blocks_cached;
 }
 
-hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream) {
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (a.n_tiles <= 0) return hipSuccess;
     {
         const int64_t nd = a.n_docs;
@@ -615,7 +615,9 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(td_mark_docs, dim3(blocks), dim3(256), 0, stream, a.doc_offsets, nd, a.n, a.docbits);
     }
     const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
+    if (ev0) (void)hipEventRecord(ev0, stream);
     hipLaunchKernelGGL(td_encode_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+    if (ev1) (void)hipEventRecord(ev1, stream);
     hipLaunchKernelGGL(td_long_pieces, dim3(256), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(td_scan_tiles, dim3(1), dim3(1024), 0, stream, a);
     hipLaunchKernelGGL(td_pack_tokens, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
