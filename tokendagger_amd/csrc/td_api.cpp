@@ -43,11 +43,12 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl;
+    DevBuf docbits, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
     bool profile = false;
+    int stop_after = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
     int64_t last_long = 0;
     size_t ws_bytes = 0;
@@ -100,6 +101,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
     if ((rc = ensure(t, t->doc_slot, (size_t)(n_docs + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->tile_first_doc, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->long_list, (size_t)(n / (K_MAXSHORT + 1) + n_tiles + 16) * sizeof(LongEntry)))) return rc;
     const int64_t pool_bytes = t->pool_bytes_opt > 0 ? t->pool_bytes_opt : std::max<int64_t>(64ll << 20, 2 * n);
     if ((rc = ensure(t, t->pool, (size_t)pool_bytes))) return rc;
@@ -135,6 +137,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.tile_extra = (uint32_t*)t->tile_extra.p;
     a.tile_base = (int64_t*)t->tile_base.p;
     a.doc_slot = (uint32_t*)t->doc_slot.p;
+    a.tile_first_doc = (uint32_t*)t->tile_first_doc.p;
     a.long_list = (LongEntry*)t->long_list.p;
     a.long_cap = (uint32_t)std::min<size_t>(t->long_list.cap / sizeof(LongEntry), 0x7FFFFFF0u);
     Ctl* ctl = (Ctl*)t->ctl.p;
@@ -152,8 +155,10 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     // reproduced by the merge loop the fast path cannot change the result and stays on.
     a.use_fastpath = (mode == TD_MODE_ENCODE) || t->H.merge_closed;
     a.text_aligned = (((uintptr_t)d_text) & 15) == 0;
+    a.stop_after = t->stop_after;
     HIP_TRY(t, hipMemsetAsync(t->docbits.p, 0, (size_t)((n + 31) / 32 + 2) * 4, stream));
     HIP_TRY(t, hipMemsetAsync(t->tile_extra.p, 0, (size_t)(n_tiles + 1) * 4, stream));
+    HIP_TRY(t, hipMemsetAsync(t->tile_first_doc.p, 0xFF, (size_t)(n_tiles + 1) * 4, stream));
     // keep a sticky error (err / err_pos) but reset the per-call counters
     HIP_TRY(t, hipMemsetAsync(&ctl->long_count, 0, sizeof(Ctl) - offsetof(Ctl, long_count), stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -271,7 +276,7 @@ void td_destroy(td_tokenizer* t) {
     for (auto& pr : t->ev_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& pr : t->ev_free) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     DevBuf* bufs[] = {&t->docbits, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
-                      &t->pool, &t->ctl, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
+                      &t->pool, &t->ctl, &t->tile_first_doc, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                       &t->dec_off, &t->dec_out};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -506,6 +511,10 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     std::lock_guard<std::mutex> g(t->mu);
     if (what == TD_OPT_LONG_POOL_BYTES && value >= (1 << 20)) {
         t->pool_bytes_opt = value;
+        return TD_OK;
+    }
+    if (what == 99) {  // undocumented: phase ablation for kernel tuning (results are garbage when != 0)
+        t->stop_after = (int)value;
         return TD_OK;
     }
     if (what == TD_OPT_PROFILE) {

@@ -26,6 +26,7 @@ struct EncodeArgs {
     uint32_t* tile_extra;       // [n_tiles] sum(ntok-1) over the tile's long pieces
     int64_t* tile_base;         // [n_tiles+1] exclusive scan of count+extra
     uint32_t* doc_slot;         // [n_docs] slot index (inside its tile) of each document's first token
+    uint32_t* tile_first_doc;   // [n_tiles] index of the first document starting in the tile (0xFFFFFFFF: none)
     LongEntry* long_list;
     uint32_t long_cap;
     uint32_t* long_count;
@@ -40,6 +41,7 @@ struct EncodeArgs {
     int n_tiles;
     int use_fastpath;           // whole-piece lookup before the merge loop (CoreBPE::encode) or not
     int text_aligned;           // text pointer is 16-byte aligned
+    int stop_after;             // debug/ablation: leave the tile loop after phase N (0 = run everything)
 };
 
 struct DecodeArgs {

@@ -106,10 +106,18 @@ __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* a, int64_t n, 
 }
 
 // ------------------------------------------------------------------ td_mark_docs ------------
-__global__ void td_mark_docs(const int64_t* doc_offsets, int64_t n_docs, int64_t n, uint32_t* docbits) {
+__global__ void td_mark_docs(const int64_t* doc_offsets, int64_t n_docs, int64_t n, uint32_t* docbits,
+                             uint32_t* tile_first_doc) {
     for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < n_docs; d += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = doc_offsets[d];
-        if (p >= 0 && p < n) atomicOr(&docbits[p >> 5], 1u << (p & 31));
+        if (p >= 0 && p < n) {
+            atomicOr(&docbits[p >> 5], 1u << (p & 31));
+            // first document of each tile (tile_first_doc is preset to 0xFFFFFFFF); only documents whose
+            // predecessor lies in an earlier tile can be the first one
+            const int64_t tile = p / K_TILE;
+            if (d == 0 || doc_offsets[d - 1] / K_TILE != tile || doc_offsets[d - 1] < 0)
+                atomicMin(&tile_first_doc[tile], (uint32_t)d);
+        }
     }
 }
 
@@ -118,6 +126,9 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
     __shared__ __attribute__((aligned(16))) uint8_t s_cls[K_WIN];
     __shared__ __attribute__((aligned(16))) uint32_t s_tok[K_TILE + K_MAXSHORT];
+    __shared__ uint16_t s_plist[K_TILE + 2];   // window positions of the tile's piece starts (+ end delimiter)
+    __shared__ uint32_t s_off[K_THREADS];       // phase 5: token slots before each lane's chunk
+    __shared__ uint16_t s_valid[K_THREADS];     // phase 5: which of the lane's 16 byte slots hold a token
     __shared__ uint32_t s_doc[K_WIN / 32 + 2];
     __shared__ int32_t s_byteid[256];
     __shared__ uint8_t s_lut[128];
@@ -205,6 +216,7 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
             }
         }
         __syncthreads();
+        if (a.stop_after == 1) continue;
 
         // ---- phase 2: piece boundaries ------------------------------------------------------
         const int c0 = K_HL + tid * K_CHUNK, c1 = c0 + K_CHUNK;
@@ -216,24 +228,49 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
             scan_lane(L, G, tid, tile_hi, wg0);
         }
         __syncthreads();
+        if (a.stop_after == 2) continue;
 
         // ---- phase 3: whole-piece lookup, one lane per piece ---------------------------------
-        if (c0 < tile_hi) {
-            const int cend = c1 < tile_hi ? c1 : tile_hi;
+        // 3a: dense list of the tile's piece starts (so that every lane has a piece to look up)
+        uint32_t np_total;
+        {
+            uint32_t smask = 0;  // START bits of my 16 bytes
+            if (c0 < tile_hi) {
+                const uint4 cv = *reinterpret_cast<const uint4*>(s_cls + c0);
+                const uint32_t w[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t f = (w[k] >> 6) & 0x01010101u;            // bit 0 of each byte = START
+                    smask |= (((f * 0x01020408u) >> 24) & 0xFu) << (4 * k);  // gather the 4 bits (byte j -> bit j)
+                }
+                if (c1 > tile_hi) smask &= (1u << (tile_hi - c0)) - 1u;
+            }
+            const uint32_t cnt = __popc(smask);
+            const uint32_t base = block_excl_scan(cnt, s_wave, np_total);
+            uint32_t k = base;
+            while (smask) {
+                const int b = __ffs(smask) - 1;
+                smask &= smask - 1;
+                s_plist[k++] = (uint16_t)(c0 + b);
+            }
+            if (tid == 0) {  // end delimiter of the last owned piece: first START at/after the tile end
+                int e = tile_hi;
+                if (s_ext_start < 0)
+                    while (e < K_WIN - 1 && !(s_cls[e] & F_START)) ++e;
+                s_plist[np_total] = (uint16_t)e;
+            }
+        }
+        __syncthreads();
+        // 3b: probe, piece k -> lane k mod 256
+        {
             const int ext_start = s_ext_start;
-            for (int i = c0; i < cend; ++i) {
-                const uint32_t v = s_cls[i];
-                if (!(v & F_START)) continue;
-                uint32_t len;
+            for (uint32_t k = tid; k < np_total; k += K_THREADS) {
+                const int i = s_plist[k];
+                uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
                 if (i == ext_start) {
                     const long long l = s_ext_end - (wg0 + i);
                     if (l > 0x7FFFFFFFll) { raise(a, TD_E_SCRATCH, wg0 + i); continue; }
                     len = (uint32_t)l;
-                } else {
-                    int j = i + 1;
-                    while (j < K_WIN && !(s_cls[j] & F_START)) ++j;
-                    if (j >= K_WIN) { raise(a, TD_E_INVALID, wg0 + i); continue; }
-                    len = (uint32_t)(j - i);
                 }
                 if (len > (uint32_t)K_MAXSHORT) {
                     const uint32_t idx = atomicAdd(a.long_count, 1u);
@@ -256,7 +293,7 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
                     continue;
                 }
                 if (a.use_fastpath) {
-                    auto get = [pb](uint32_t k) { return (uint32_t)pb[k]; };
+                    auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
                     uint64_t key;
                     if (len <= 8) {
                         const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
@@ -272,10 +309,11 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
                     const int32_t r = piece_lookup(T, key, len, get);
                     if (r != NO_RANK) { s_tok[i - K_HL] = (uint32_t)r; continue; }
                 }
-                s_cls[i] = (uint8_t)(v | F_MISS);
+                s_cls[i] = (uint8_t)(s_cls[i] | F_MISS);
             }
         }
         __syncthreads();
+        if (a.stop_after == 3) continue;
 
         // ---- phase 4: byte-pair merge of missed pieces, a wavefront per 64-byte window -------
         {
@@ -344,6 +382,7 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
             }
         }
         __syncthreads();
+        if (a.stop_after == 4) continue;
 
         // ---- phase 5: compact the byte-indexed token array into the tile's staging area -----
         {
@@ -353,9 +392,10 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
                 const uint4 x = reinterpret_cast<const uint4*>(s_tok)[tid * (K_CHUNK / 4) + k];
                 vals[4 * k] = x.x; vals[4 * k + 1] = x.y; vals[4 * k + 2] = x.z; vals[4 * k + 3] = x.w;
             }
-            uint32_t cnt = 0;
+            uint32_t vmask = 0;
 #pragma unroll
-            for (int k = 0; k < K_CHUNK; ++k) cnt += (vals[k] != TOK_NONE) ? 1u : 0u;
+            for (int k = 0; k < K_CHUNK; ++k) vmask |= (vals[k] != TOK_NONE) ? (1u << k) : 0u;
+            uint32_t cnt = __popc(vmask);
             // tokens of the tile's last piece may sit past the tile end (slots K_TILE .. K_TILE+63):
             // they follow everything else in byte order, so the last lane appends them
             uint32_t tail = 0;
@@ -364,23 +404,29 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
             cnt += tail;
             uint32_t total;
             const uint32_t off = block_excl_scan(cnt, s_wave, total);
+            s_off[tid] = off;
+            s_valid[tid] = (uint16_t)vmask;
             uint32_t* dst = a.stage + (size_t)tile * K_TILE + off;
             uint32_t k2 = 0;
 #pragma unroll
-            for (int k = 0; k < K_CHUNK; ++k) {
-                if (c0 + k < tile_hi && (s_cls[c0 + k] & F_DOC)) {
-                    const int64_t gpos = wg0 + c0 + k;
-                    int64_t d = lower_bound_i64(a.doc_offsets, a.n_docs, gpos);
-                    while (d < a.n_docs && a.doc_offsets[d] == gpos) a.doc_slot[d++] = off + k2;
-                }
+            for (int k = 0; k < K_CHUNK; ++k)
                 if (vals[k] != TOK_NONE) dst[k2++] = vals[k];
-            }
             if (tail)
                 for (int k = 0; k < K_MAXSHORT; ++k) {
                     const uint32_t v = s_tok[K_TILE + k];
                     if (v != TOK_NONE) dst[k2++] = v;
                 }
             if (tid == 0) a.tile_count[tile] = total | (s_haslong ? 0x80000000u : 0u);
+            __syncthreads();
+            // token slot of every document that starts in this tile (documents are consecutive from the
+            // tile's first one, recorded by td_mark_docs; empty documents share a position)
+            const int64_t tile_end_g = tile_g0 + (tile_hi - K_HL);
+            for (int64_t d = (int64_t)a.tile_first_doc[tile] + tid; d < a.n_docs; d += K_THREADS) {
+                const int64_t p = a.doc_offsets[d];
+                if (p >= tile_end_g) break;
+                const int lp = (int)(p - tile_g0);
+                a.doc_slot[d] = s_off[lp >> 4] + __popc((uint32_t)s_valid[lp >> 4] & ((1u << (lp & 15)) - 1u));
+            }
         }
         __syncthreads();
     }
@@ -576,9 +622,8 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         {
             const int64_t g_lo = (int64_t)tile * K_TILE;
             const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
-            const int64_t d_lo = lower_bound_i64(a.doc_offsets, a.n_docs, g_lo);
-            const int64_t d_hi = lower_bound_i64(a.doc_offsets, a.n_docs, g_hi);
-            for (int64_t d = d_lo + tid; d < d_hi; d += K_THREADS) {
+            for (int64_t d = (int64_t)a.tile_first_doc[tile] + tid; d < a.n_docs; d += K_THREADS) {
+                if (a.doc_offsets[d] >= g_hi) break;
                 const uint32_t slot = a.doc_slot[d];
                 a.out_offsets[d] = base + (haslong ? s_off[slot] : slot);
             }
@@ -612,7 +657,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
         int blocks = (int)((nd + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(td_mark_docs, dim3(blocks), dim3(256), 0, stream, a.doc_offsets, nd, a.n, a.docbits);
+        hipLaunchKernelGGL(td_mark_docs, dim3(blocks), dim3(256), 0, stream, a.doc_offsets, nd, a.n, a.docbits, a.tile_first_doc);
     }
     const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
     if (ev0) (void)hipEventRecord(ev0, stream);
