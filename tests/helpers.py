@@ -96,6 +96,9 @@ class Twin:
         lib.twin_sync_violations.restype = ctypes.c_int64
         lib.twin_sync_violations.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
                                              ctypes.c_int64, ctypes.c_void_p]
+        lib.twin_bits_check.restype = ctypes.c_int64
+        lib.twin_bits_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         lib.twin_encode.restype = ctypes.c_int64
         lib.twin_encode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
@@ -151,6 +154,14 @@ class Twin:
         ns = ctypes.c_int64(0)
         bad = self._lib.twin_sync_violations(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, ctypes.byref(ns))
         return int(bad), ns.value
+
+    def bits_check(self, data: bytes, offs=None) -> tuple[int, int, int]:
+        """-> (mismatches, unresolved, checked) of the bit-parallel scanner against the byte scanner"""
+        offs = self._offs(data, offs)
+        un = ctypes.c_int64(0); ck = ctypes.c_int64(0)
+        bad = self._lib.twin_bits_check(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, ctypes.byref(un),
+                                        ctypes.byref(ck))
+        return int(bad), un.value, ck.value
 
     def encode_batch(self, data: bytes, offs=None, mode: int = 0):
         offs = self._offs(data, offs)

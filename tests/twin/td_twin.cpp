@@ -227,4 +227,58 @@ int64_t twin_encode(void* h, const uint8_t* text, int64_t n, const int64_t* offs
     return k;
 }
 
+// bit-parallel scanner vs byte scanner on every true piece start, with the 64-byte mask window placed
+// at several offsets before the piece.  Returns mismatches; *n_unres counts "-1 (window too short)".
+int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, int64_t* n_unres,
+                        int64_t* n_checked) {
+    Twin* t = (Twin*)h;
+    std::vector<uint8_t> cls;
+    classify_all(t->H.view(), text, n, offs, n_docs, cls);
+    GAcc g{cls.data(), text, n, n + 4};
+    int64_t bad = 0, unres = 0, checked = 0;
+    const int backs[4] = {0, 3, 17, 40};
+    for (int64_t p = 0; p < n;) {
+        const int64_t e = scan_piece(g, p);
+        for (int bi = 0; bi < 4; ++bi) {
+            const int64_t base = p - backs[bi];
+            if (base < 0) continue;
+            BitWin w;
+            for (int k = 0; k < MK_COUNT; ++k) w.m[k] = 0;
+            for (int i = 0; i < 64; ++i) {
+                const uint32_t v = g.cf(base + i), vp = (base + i > 0) ? g.cf(base + i - 1) : 0u;
+                const uint32_t bits = mask_bits_of(vp, v);
+                for (int k = 0; k < MK_COUNT; ++k) w.m[k] |= (uint64_t)((bits >> k) & 1u) << i;
+            }
+            {   // the kernel derives SYNC with sync_word() from the other masks: must equal is_sync() per byte
+                const uint64_t SL = w.m[MK_TR] & ~w.m[MK_CR];
+                const uint32_t vprev = base > 0 ? g.cf(base - 1) : 0u;
+                const uint32_t pf = base > 0 ? (feature_of_class(vprev & CLS_MASK) | ((vprev & F_CONT) ? FB_C : 0u)) : 0u;
+                const uint64_t sy = sync_word(w.m[MK_U], w.m[MK_W], w.m[MK_X], w.m[MK_S], w.m[MK_N], w.m[MK_CR], SL,
+                                              w.m[MK_C], w.m[MK_D], w.m[MK_A], pf);
+                if (sy != w.m[MK_SYNC]) ++bad;
+                // and the feature byte must reproduce the class-set masks
+                for (int i = 0; i < 64; ++i) {
+                    const uint32_t v = g.cf(base + i);
+                    const uint32_t fb = feature_of_class(v & CLS_MASK);
+                    const bool okf = (((w.m[MK_U] >> i) & 1) == ((fb & FB_U) != 0)) && (((w.m[MK_W] >> i) & 1) == ((fb & FB_W) != 0)) &&
+                                     (((w.m[MK_X] >> i) & 1) == ((fb & FB_X) != 0)) && (((w.m[MK_S] >> i) & 1) == ((fb & FB_S) != 0)) &&
+                                     (((w.m[MK_N] >> i) & 1) == ((fb & FB_N) != 0)) && (((w.m[MK_CR] >> i) & 1) == ((fb & FB_CR) != 0)) &&
+                                     (((SL >> i) & 1) == ((fb & FB_SL) != 0));
+                    if (!okf) ++bad;
+                }
+            }
+            int avail = 64;
+            auto bytes = [&](int i) { return g.byte(base + i); };
+            const int r = scan_piece_bits(w, bytes, (int)(p - base), avail);
+            ++checked;
+            if (r < 0) { ++unres; if (e - base < 58 - 3) { /* short piece must resolve unless look-ahead is long */ } }
+            else if (base + r != e) ++bad;
+        }
+        p = e;
+    }
+    if (n_unres) *n_unres = unres;
+    if (n_checked) *n_checked = checked;
+    return bad;
+}
+
 }  // extern "C"

@@ -64,12 +64,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    import os
+    lib_path = Path(os.environ.get("TD_HIP_LIB", str(LIB_PATH)))  # TD_HIP_LIB: kernel-tuning builds only
+    if not lib_path.exists():
         raise ImportError(
-            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'); "
+            f"{lib_path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'); "
             "tokendagger_amd has no CPU fallback")
     _share_hip_runtime_with_torch()
-    lib = ctypes.CDLL(str(LIB_PATH))
+    lib = ctypes.CDLL(str(lib_path))
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     lib.td_create.restype = i32
     lib.td_create.argtypes = [ctypes.c_char_p, i64, vp, vp, vp, i64, vp, vp, vp, i32, ctypes.POINTER(vp)]
@@ -93,7 +95,7 @@ def load_library():
     lib.td_set_option.restype = i32
     lib.td_set_option.argtypes = [vp, i32, i64]
     lib.td_profile_read.restype = i32
-    lib.td_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
+    lib.td_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     lib.td_special_count.restype = i64
     lib.td_special_count.argtypes = [vp]
     lib.td_special_get.restype = i32
@@ -221,11 +223,11 @@ class HipTokenizer:
     def set_option(self, what: int, value: int):
         self._check(self._lib.td_set_option(self._h, what, value))
 
-    def profile_read(self) -> tuple[float, int]:
-        """-> (sum of fused tile-kernel durations in ms, launches) since the last read (needs TD_OPT_PROFILE=1)."""
-        ms = ctypes.c_double(0); n = ctypes.c_int64(0)
-        self._check(self._lib.td_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
-        return ms.value, n.value
+    def profile_read(self) -> tuple[float, float, int]:
+        """-> (sum of td_split_tiles ms, sum of td_encode_tiles ms, calls) since the last read (TD_OPT_PROFILE=1)."""
+        a = ctypes.c_double(0); b = ctypes.c_double(0); n = ctypes.c_int64(0)
+        self._check(self._lib.td_profile_read(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
+        return a.value, b.value, n.value
 
     def special_tokens(self) -> dict[str, int]:
         out = {}

@@ -43,13 +43,14 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc;
+    DevBuf docbits, startbits, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
     bool profile = false;
     int stop_after = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
+    struct Ev3 { hipEvent_t e[3]; };
+    std::vector<Ev3> ev_pending, ev_free;
     int64_t last_long = 0;
     size_t ws_bytes = 0;
 };
@@ -96,6 +97,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
     int rc;
     if ((rc = ensure(t, t->docbits, (size_t)((n + 31) / 32 + 2) * 4))) return rc;
+    if ((rc = ensure(t, t->startbits, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
     if ((rc = ensure(t, t->stage, (size_t)std::max<int64_t>(n_tiles, 1) * K_TILE * 4))) return rc;
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
@@ -132,6 +134,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.doc_offsets = (const int64_t*)d_offs;
     a.n_docs = n_docs;
     a.docbits = (uint32_t*)t->docbits.p;
+    a.startbits = (uint32_t*)t->startbits.p;
     a.stage = (uint32_t*)t->stage.p;
     a.tile_count = (uint32_t*)t->tile_count.p;
     a.tile_extra = (uint32_t*)t->tile_extra.p;
@@ -161,13 +164,13 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     HIP_TRY(t, hipMemsetAsync(t->tile_first_doc.p, 0xFF, (size_t)(n_tiles + 1) * 4, stream));
     // keep a sticky error (err / err_pos) but reset the per-call counters
     HIP_TRY(t, hipMemsetAsync(&ctl->long_count, 0, sizeof(Ctl) - offsetof(Ctl, long_count), stream));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    td_tokenizer::Ev3 ev{{nullptr, nullptr, nullptr}};
     if (t->profile) {
-        if (!t->ev_free.empty()) { e0 = t->ev_free.back().first; e1 = t->ev_free.back().second; t->ev_free.pop_back(); }
-        else { HIP_TRY(t, hipEventCreate(&e0)); HIP_TRY(t, hipEventCreate(&e1)); }
-        t->ev_pending.emplace_back(e0, e1);
+        if (!t->ev_free.empty()) { ev = t->ev_free.back(); t->ev_free.pop_back(); }
+        else for (auto& e : ev.e) HIP_TRY(t, hipEventCreate(&e));
+        t->ev_pending.push_back(ev);
     }
-    HIP_TRY(t, launch_encode(a, stream, e0, e1));
+    HIP_TRY(t, launch_encode(a, stream, ev.e[0], ev.e[1], ev.e[2]));
     return TD_OK;
 }
 
@@ -273,9 +276,9 @@ void td_destroy(td_tokenizer* t) {
     (void)hipSetDevice(t->device);
     (void)hipDeviceSynchronize();
     for (void* p : t->table_allocs) (void)hipFree(p);
-    for (auto& pr : t->ev_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    for (auto& pr : t->ev_free) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    DevBuf* bufs[] = {&t->docbits, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
+    for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
+    for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
                       &t->pool, &t->ctl, &t->tile_first_doc, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                       &t->dec_off, &t->dec_out};
     for (DevBuf* b : bufs)
@@ -524,21 +527,24 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     return TD_E_INVALID;
 }
 
-int td_profile_read(td_tokenizer* t, double* kernel_ms_sum, int64_t* launches) {
+int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum, int64_t* launches) {
     if (!t) return TD_E_INVALID;
     std::lock_guard<std::mutex> g(t->mu);
-    double sum = 0;
+    double s0 = 0, s1 = 0;
     int64_t n = 0;
-    for (auto& pr : t->ev_pending) {
-        HIP_TRY(t, hipEventSynchronize(pr.second));
+    for (auto& ev : t->ev_pending) {
+        HIP_TRY(t, hipEventSynchronize(ev.e[2]));
         float ms = 0;
-        HIP_TRY(t, hipEventElapsedTime(&ms, pr.first, pr.second));
-        sum += ms;
+        HIP_TRY(t, hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
+        s0 += ms;
+        HIP_TRY(t, hipEventElapsedTime(&ms, ev.e[1], ev.e[2]));
+        s1 += ms;
         ++n;
-        t->ev_free.push_back(pr);
+        t->ev_free.push_back(ev);
     }
     t->ev_pending.clear();
-    if (kernel_ms_sum) *kernel_ms_sum = sum;
+    if (split_ms_sum) *split_ms_sum = s0;
+    if (encode_ms_sum) *encode_ms_sum = s1;
     if (launches) *launches = n;
     return TD_OK;
 }

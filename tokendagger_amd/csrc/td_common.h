@@ -386,6 +386,198 @@ TD_HD typename A::pos_t scan_piece(const A& a, typename A::pos_t pos) {
     return p1;  // not reachable for this pattern; mirrors the no-progress rule (tiktoken.cpp:120-122)
 }
 
+// ------------------------------------------------------------------ bit-parallel scanner ----
+// The same matcher on per-class BITMASKS (one bit per byte) instead of per-byte class codes: run ends
+// become count-trailing-zero operations, so a piece costs a few dozen ALU ops instead of a dependent
+// LDS read per byte.  A BitWin holds, for 64 consecutive window bytes starting at `base`, one 64-bit
+// word per class set; bit i <-> byte base+i.  scan_piece_bits answers for a piece starting at offset
+// `o` inside the window, or returns -1 when it would need bits at/after `avail` (caller reloads the
+// window at the piece start, and falls back to scan_piece when a single piece outgrows 64 bytes).
+enum : int {
+    MK_U = 0,   // M_U
+    MK_W,       // M_W
+    MK_X,       // M_X
+    MK_S,       // M_S
+    MK_N,       // C_NUM
+    MK_CR,      // C_CRLF
+    MK_TR,      // M_TRAIL
+    MK_C,       // F_CONT
+    MK_D,       // F_DOC   (end of subject when seen at an offset > o)
+    MK_A,       // C_APOS
+    MK_SP,      // C_SP
+    MK_SYNC,    // is_sync(prev, this)
+    MK_COUNT
+};
+struct BitWin {
+    uint64_t m[MK_COUNT];
+};
+
+TD_HD int td_ctz64(uint64_t x) {  // 64 for x == 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return x ? (int)__builtin_ctzll(x) : 64;
+#else
+    return x ? (int)__builtin_ctzll(x) : 64;
+#endif
+}
+TD_HD int td_top64(uint64_t x) { return 64 - (int)__builtin_clzll(x); }  // index of highest set bit + 1 (x != 0)
+// first index >= f whose bit in m is 0 (64 if none below 64)
+TD_HD int td_run_end(uint64_t m, int f) { return f >= 64 ? 64 : f + td_ctz64(~(m >> f)); }
+TD_HD uint64_t td_bits_below(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+// Mask bits of one byte from its class+flag byte `v` and its predecessor's `vp` (the kernel turns these
+// into the 64-bit words with one wavefront ballot per mask; the CPU twin ORs them bit by bit).
+TD_HD uint32_t mask_bits_of(uint32_t vp, uint32_t v) {
+    const uint32_t c = v & CLS_MASK;
+    uint32_t r = 0;
+    r |= in_set(M_U, c) ? (1u << MK_U) : 0u;
+    r |= in_set(M_W, c) ? (1u << MK_W) : 0u;
+    r |= in_set(M_X, c) ? (1u << MK_X) : 0u;
+    r |= in_set(M_S, c) ? (1u << MK_S) : 0u;
+    r |= (c == C_NUM) ? (1u << MK_N) : 0u;
+    r |= (c == C_CRLF) ? (1u << MK_CR) : 0u;
+    r |= in_set(M_TRAIL, c) ? (1u << MK_TR) : 0u;
+    r |= (v & F_CONT) ? (1u << MK_C) : 0u;
+    r |= (v & F_DOC) ? (1u << MK_D) : 0u;
+    r |= (c == C_APOS) ? (1u << MK_A) : 0u;
+    r |= (c == C_SP) ? (1u << MK_SP) : 0u;
+    r |= is_sync(vp, v) ? (1u << MK_SYNC) : 0u;
+    return r;
+}
+// Mask version of scan_contraction: `bytes(i)` returns the raw byte at window offset i.
+template <class B>
+TD_HD int scan_contraction_bits(const BitWin& w, const B& bytes, int e, int avail) {
+    if (e + 3 > avail) return -1;
+    if (!((w.m[MK_A] >> e) & 1ull) || ((w.m[MK_D] >> e) & 1ull)) return e;
+    if ((w.m[MK_D] >> (e + 1)) & 1ull) return e;
+    const uint32_t b1 = bytes(e + 1);
+    const bool d2 = (w.m[MK_D] >> (e + 2)) & 1ull;
+    if (b1 < 0x80) {
+        const uint32_t l1 = b1 | 0x20;
+        if (l1 == 's' || l1 == 't' || l1 == 'm' || l1 == 'd') return e + 2;
+        if (d2) return e;
+        const uint32_t b2 = bytes(e + 2);
+        if (b2 < 0x80) {
+            const uint32_t l2 = b2 | 0x20;
+            if ((l1 == 'r' && l2 == 'e') || (l1 == 'v' && l2 == 'e') || (l1 == 'l' && l2 == 'l')) return e + 3;
+        }
+        return e;
+    }
+    if (b1 == 0xC5 && !d2 && bytes(e + 2) == 0xBF) return e + 3;
+    return e;
+}
+
+// End offset (window-relative) of the piece starting at offset o (< avail), or -1 (needs bits >= avail).
+template <class B>
+TD_HD int scan_piece_bits(const BitWin& w, const B& bytes, int o, int avail) {
+    // end-of-subject marks count only after the piece start
+    const uint64_t E = w.m[MK_D] & ~td_bits_below(o + 1);
+    const uint64_t U = w.m[MK_U] & ~E, W = w.m[MK_W] & ~E, X = w.m[MK_X] & ~E, S = w.m[MK_S] & ~E;
+    const uint64_t N = w.m[MK_N] & ~E, C = w.m[MK_C];
+    const bool u0 = (U >> o) & 1, w0 = (W >> o) & 1, x0 = (X >> o) & 1, s0 = (S >> o) & 1, n0 = (N >> o) & 1;
+    const bool cr0 = (w.m[MK_CR] >> o) & 1;
+    const int p1 = td_run_end(C, o + 1);  // end of the first character
+    if (p1 >= avail) return -1;
+    if (!cr0 && !n0) {
+        const bool prefixable = x0 || s0;  // [^\r\n\p{L}\p{N}] = X or non-CR/LF whitespace
+        const bool l0 = u0 || w0;
+        const bool l1 = prefixable && (((U | W) >> p1) & 1);
+        if (l0 || l1) {
+            // candidates in backtracking order: alt1 from p1, alt1 from o, alt2 from p1, alt2 from o
+            int e1 = 0, e2 = 0;  // first successful alt-1 / alt-2 end (0 = none)
+            for (int k = 0; k < 2; ++k) {
+                const bool use = k == 0 ? l1 : l0;
+                if (!use) continue;
+                const int st = k == 0 ? p1 : o;
+                const int q = td_run_end(U, st);
+                if (q >= avail) return -1;
+                const bool wf = (W >> q) & 1;
+                int ew = q;
+                if (wf) {
+                    ew = td_run_end(W, q);
+                    if (ew >= avail) return -1;
+                }
+                if (!e1) {
+                    if (wf) e1 = ew;
+                    else {
+                        const uint64_t both = U & W & td_bits_below(q) & ~td_bits_below(st);
+                        if (both) e1 = td_top64(both);
+                    }
+                }
+                if (!e2 && q > st) e2 = ew;
+                if (e1) break;  // alt 1 with the earlier candidate wins over everything that follows
+            }
+            const int e = e1 ? e1 : e2;
+            if (e) return scan_contraction_bits(w, bytes, e, avail);
+        }
+    }
+    if (n0) {  // \p{N}{1,3}
+        int e = p1;
+        for (int k = 1; k < 3; ++k) {
+            if (e >= avail) return -1;
+            if (!((N >> e) & 1)) break;
+            e = td_run_end(C, e + 1);
+            if (e >= avail) return -1;
+        }
+        return e;
+    }
+    {  //  ?[^\s\p{L}\p{N}]+[\r\n/]*
+        const bool sp0 = (w.m[MK_SP] >> o) & 1;
+        int st = -1, e = 0;
+        if (sp0 && ((X >> (o + 1)) & 1)) st = o + 1;
+        else if (x0) st = o;
+        if (st >= 0) {
+            e = td_run_end(X, st);
+            if (e >= avail) return -1;
+            e = td_run_end(w.m[MK_TR] & ~E, e);
+            if (e >= avail) return -1;
+            return e;
+        }
+    }
+    if (s0) {  // \s*[\r\n]+ | \s+(?!\S) | \s+
+        const int q = td_run_end(S, o);
+        if (q >= avail) return -1;
+        const uint64_t in_run = td_bits_below(q) & ~td_bits_below(o);
+        const uint64_t crs = w.m[MK_CR] & in_run;
+        if (crs) return td_top64(crs);
+        if ((E >> q) & 1) return q;
+        const uint64_t leads = ~C & in_run;
+        const int last_lead = td_top64(leads) - 1;
+        if (last_lead > o) return last_lead;
+        return q;
+    }
+    return p1;
+}
+
+// Feature byte: the class-set memberships of one byte, one bit each (what phase 1 of the kernel keeps
+// per byte; a wavefront ballot per bit turns 64 of them into the mask words).
+enum : uint32_t { FB_U = 1, FB_W = 2, FB_X = 4, FB_S = 8, FB_N = 16, FB_CR = 32, FB_SL = 64, FB_C = 128 };
+TD_HD uint32_t feature_of_class(uint32_t c) {
+    switch (c) {
+        case C_OTHER: case C_APOS: return FB_X;
+        case C_SLASH: return FB_X | FB_SL;
+        case C_SP: case C_WS: return FB_S;
+        case C_CRLF: return FB_S | FB_CR;
+        case C_UP: return FB_U;
+        case C_LW: return FB_W;
+        case C_LB: return FB_U | FB_W;
+        case C_MK: return FB_U | FB_W | FB_X;
+        case C_NUM: return FB_N;
+    }
+    return FB_X;
+}
+// SYNC mask word from the class mask words of the same 64 bytes; `pf` = feature byte of the byte just
+// before the word (0 if none).  Bit-for-bit the same predicate as is_sync().
+TD_HD uint64_t sync_word(uint64_t U, uint64_t W, uint64_t X, uint64_t S, uint64_t N, uint64_t CR, uint64_t SL,
+                         uint64_t C, uint64_t D, uint64_t A, uint32_t pf) {
+    const uint64_t L = (U | W) & ~X;
+    const uint64_t pS = (S << 1) | ((pf & FB_S) ? 1ull : 0ull);
+    const uint64_t pCR = (CR << 1) | ((pf & FB_CR) ? 1ull : 0ull);
+    const uint64_t pN = (N << 1) | ((pf & FB_N) ? 1ull : 0ull);
+    const uint64_t pL = (L << 1) | (((pf & (FB_U | FB_W)) && !(pf & FB_X)) ? 1ull : 0ull);
+    uint64_t sy = (S & ~CR & ~pS) | (pCR & ~S & ~SL) | (N ^ pN) | (X & ~(U | W) & ~A & pL);
+    return (sy & ~C) | D;
+}
+
 // ------------------------------------------------------------------ tile geometry -----------
 // One workgroup of td_encode_tiles handles one tile of text at a time.
 constexpr int K_THREADS = 256;                 // 4 wavefronts

@@ -21,6 +21,7 @@ struct EncodeArgs {
     const int64_t* doc_offsets; // [n_docs+1], doc_offsets[0]==0, doc_offsets[n_docs]==n
     int64_t n_docs;
     uint32_t* docbits;          // [(n+31)/32+1] bit i set <=> a document starts at byte i
+    uint32_t* startbits;        // [(n+31)/32+8] bit i set <=> a regex piece starts at byte i (td_split_tiles -> td_encode_tiles)
     uint32_t* stage;            // [n_tiles*K_TILE] per-tile compacted slots (token ids / long markers)
     uint32_t* tile_count;       // [n_tiles] slots in the tile
     uint32_t* tile_extra;       // [n_tiles] sum(ntok-1) over the tile's long pieces
@@ -57,7 +58,8 @@ struct DecodeArgs {
 
 // All launches are asynchronous on `stream`; none of them synchronises or allocates.
 // ev0/ev1 (optional): recorded right before / after the fused tile kernel
-hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                         hipEvent_t ev2 = nullptr);  // ev0 | td_split_tiles | ev1 | td_encode_tiles | ev2
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
 int encode_grid_blocks();  // persistent grid size used by the fused kernel
 

@@ -20,30 +20,35 @@
 // Reference behaviour being reproduced: /root/reference/src/tiktoken/tiktoken.cpp:70-128
 // (split_text), :169-234 (encode), :282-378 (get_rank / bpe_merge / byte_pair_encode).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "td_kernels.h"
 
 namespace td {
 
 // ------------------------------------------------------------------ accessors ---------------
-struct LdsAcc {
-    using pos_t = int;
-    uint8_t* cls;
-    const uint8_t* txt;
-    int lim;
-    int* ext_start;
-    long long* ext_end;
-    __device__ __forceinline__ uint32_t cf(int i) const { return cls[i]; }
-    __device__ __forceinline__ uint32_t byte(int i) const { return txt[i]; }
-    __device__ __forceinline__ void mark(int i) { cls[i] = cls[i] | F_START; }
-    __device__ __forceinline__ void set_ext(int i, int64_t ge) { *ext_start = i; *ext_end = ge; }
-};
 struct LdsSrc {
     const uint8_t* txt;
     const uint32_t* docw;
     int64_t lo, hi;
     __device__ __forceinline__ uint32_t byte(int64_t i) const { return txt[i]; }
     __device__ __forceinline__ bool doc(int64_t i) const { return (docw[i >> 5] >> (i & 31)) & 1u; }
+};
+// Byte-scanner view of the LDS window (fallback only: pieces / look-ahead longer than a 64-byte mask
+// window).  Classes are recomputed from the staged text; s_doc carries document starts and the
+// end-of-text sentinels.
+struct LdsAcc {
+    using pos_t = int;
+    const Tables* T;
+    LdsSrc src;
+    int lim;
+    __device__ __noinline__ uint32_t cf(int i) const {
+        const uint32_t d = src.doc(i) ? (uint32_t)F_DOC : 0u;
+        if (i >= src.hi) return F_DOC;
+        if (i < src.lo) return C_OTHER;
+        return classify_at(*T, src, i) | d;
+    }
+    __device__ __forceinline__ uint32_t byte(int i) const { return src.txt[i]; }
 };
 struct GlobSrc {
     const uint8_t* text;
@@ -121,35 +126,50 @@ __global__ void td_mark_docs(const int64_t* doc_offsets, int64_t n_docs, int64_t
     }
 }
 
-// ------------------------------------------------------------------ td_encode_tiles ---------
-__global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a) {
+// ------------------------------------------------------------------ shared helpers ----------
+constexpr int K_MWORDS = K_WIN / 64;  // 64-byte mask words per window
+
+// 64 consecutive bits of a u32 bit array starting at bit `pos`
+__device__ __forceinline__ uint64_t bits64(const uint32_t* arr, int pos) {
+    const int w = pos >> 5, sh = pos & 31;
+    const uint64_t lo = ((uint64_t)arr[w + 1] << 32) | arr[w];
+    const uint64_t hi = arr[w + 2];
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
+// the 64-byte mask window that starts at window byte `base`
+__device__ __forceinline__ void load_bitwin(BitWin& w, const uint64_t* s_mask, int base) {
+    const int word = base >> 6, sh = base & 63;
+    const uint64_t* lo = s_mask + word * MK_COUNT;
+    const uint64_t* hi = lo + MK_COUNT;
+#pragma unroll
+    for (int k = 0; k < MK_COUNT; ++k) w.m[k] = sh ? (lo[k] >> sh) | (hi[k] << (64 - sh)) : lo[k];
+}
+
+// ------------------------------------------------------------------ td_split_tiles ----------
+// Pre-tokenizer: the regex split of the reference (CoreBPE::split_text, tiktoken.cpp:70-128) as a
+// data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
+// piece starts.  One workgroup per 4 KiB tile (+64 B left / 192 B right halo), persistent grid.
+__global__ __launch_bounds__(K_THREADS) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cls[K_WIN];
-    __shared__ __attribute__((aligned(16))) uint32_t s_tok[K_TILE + K_MAXSHORT];
-    __shared__ uint16_t s_plist[K_TILE + 2];   // window positions of the tile's piece starts (+ end delimiter)
-    __shared__ uint32_t s_off[K_THREADS];       // phase 5: token slots before each lane's chunk
-    __shared__ uint16_t s_valid[K_THREADS];     // phase 5: which of the lane's 16 byte slots hold a token
+    __shared__ __attribute__((aligned(16))) uint64_t s_mask[(K_MWORDS + 1) * MK_COUNT];  // class masks, word-major
+    __shared__ __attribute__((aligned(16))) uint8_t s_fb[K_WIN];                          // feature byte per text byte
+    __shared__ uint32_t s_start[K_WIN / 32 + 3];  // bit i: a piece starts at window byte i
     __shared__ uint32_t s_doc[K_WIN / 32 + 2];
-    __shared__ int32_t s_byteid[256];
-    __shared__ uint8_t s_lut[128];
-    __shared__ uint32_t s_wave[8];
-    __shared__ int s_ext_start;
-    __shared__ long long s_ext_end;
-    __shared__ uint32_t s_haslong;
+    __shared__ uint8_t s_lut[128];                // ASCII byte -> feature byte
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const Tables& T = a.T;
-
-    if (tid < 128) s_lut[tid] = T.ascii_cls[tid];
-    s_byteid[tid] = T.byte_id[tid];
+    if (tid < 128) s_lut[tid] = (uint8_t)feature_of_class(T.ascii_cls[tid]);
 
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
         const int64_t wg0 = tile_g0 - K_HL;  // global offset of window index 0 (multiple of 64)
         const int tile_hi = K_HL + (int)((a.n - tile_g0 < K_TILE) ? (a.n - tile_g0) : K_TILE);
+        const int c0 = K_HL + tid * K_CHUNK, c1 = c0 + K_CHUNK;
 
-        // ---- phase 0: stage text window, document bits; clear token slots -----------------
+        // ---- phase 0: stage the text window and the document bits -----------------------------
         for (int v = tid; v < K_WIN / 16; v += K_THREADS) {
             const int64_t g = wg0 + (int64_t)v * 16;
             uint4 x = make_uint4(0, 0, 0, 0);
@@ -169,66 +189,220 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
             const int64_t nwords = (a.n + 31) >> 5;
             for (int w = tid; w < K_WIN / 32; w += K_THREADS) {
                 const int64_t gw = (wg0 >> 5) + w;
-                s_doc[w] = (gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
+                uint32_t dw = (gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
+                const int64_t g = wg0 + (int64_t)w * 32;  // bytes past the end of the text: "end of subject" sentinels
+                if (g + 32 > a.n) dw |= (g >= a.n) ? 0xFFFFFFFFu : ~((1u << (int)(a.n - g)) - 1u);
+                s_doc[w] = dw;
+            }
+            for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
+        }
+        __syncthreads();
+
+        // ---- phase 1a: feature byte per text byte (ASCII: LUT in LDS; otherwise 2-stage Unicode table in L2)
+        LdsSrc src;
+        src.txt = s_txt;
+        src.docw = s_doc;
+        src.lo = (wg0 < 0) ? -wg0 : 0;
+        src.hi = (a.n - wg0 < K_WIN) ? (a.n - wg0) : K_WIN;
+        for (int d = tid; d < K_WIN / 4; d += K_THREADS) {
+            const uint32_t w = reinterpret_cast<const uint32_t*>(s_txt)[d];
+            uint32_t out;
+            if (!(w & 0x80808080u)) {
+                out = (uint32_t)s_lut[w & 0x7F] | ((uint32_t)s_lut[(w >> 8) & 0x7F] << 8) |
+                      ((uint32_t)s_lut[(w >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[(w >> 24) & 0x7F] << 24);
+            } else {
+                out = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t b = (w >> (8 * k)) & 0xFF;
+                    const int64_t i = (int64_t)d * 4 + k;
+                    uint32_t f;
+                    if (b < 0x80) f = s_lut[b];
+                    else if (i >= src.lo && i < src.hi) {
+                        const uint32_t c = classify_at(T, src, i);
+                        f = feature_of_class(c & CLS_MASK) | ((c & F_CONT) ? (uint32_t)FB_C : 0u);
+                    } else f = FB_X;
+                    out |= f << (8 * k);
+                }
+            }
+            reinterpret_cast<uint32_t*>(s_fb)[d] = out;
+        }
+        if (tid < MK_COUNT) s_mask[K_MWORDS * MK_COUNT + tid] = 0;  // zero word behind the last one
+        __syncthreads();
+
+        // ---- phase 1b: class mask words: one wavefront ballot per class set and 64-byte word ----------
+        {
+            constexpr int NW = K_MWORDS / (K_THREADS / 64);  // 17 words per wavefront
+            static_assert(NW * (K_THREADS / 64) == K_MWORDS, "words must divide evenly");
+            uint32_t ff[NW], bb[NW], pfv[NW];
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {  // all LDS reads first: they are independent
+                const int idx = (wave + it * (K_THREADS / 64)) * 64 + lane;
+                ff[it] = s_fb[idx];
+                bb[it] = s_txt[idx];
+                pfv[it] = (lane == 0 && idx > 0) ? (uint32_t)s_fb[idx - 1] : 0u;  // byte in front of the word
+            }
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const int w = wave + it * (K_THREADS / 64);
+                const uint32_t fb = ff[it], b = bb[it];
+                const uint32_t pf = __builtin_amdgcn_readfirstlane(pfv[it]);
+                const uint64_t mU = __ballot(fb & FB_U), mW = __ballot(fb & FB_W), mX = __ballot(fb & FB_X);
+                const uint64_t mS = __ballot(fb & FB_S), mN = __ballot(fb & FB_N), mCR = __ballot(fb & FB_CR);
+                const uint64_t mSL = __ballot(fb & FB_SL), mC = __ballot(fb & FB_C);
+                const uint64_t mA = __ballot(b == 0x27), mSP = __ballot(b == 0x20);
+                const uint64_t mD = ((uint64_t)s_doc[2 * w + 1] << 32) | s_doc[2 * w];
+                const uint64_t mSY = sync_word(mU, mW, mX, mS, mN, mCR, mSL, mC, mD, mA, pf);
+                if (lane == 0) {
+                    static_assert(MK_U == 0 && MK_W == 1 && MK_X == 2 && MK_S == 3 && MK_N == 4 && MK_CR == 5 && MK_TR == 6 &&
+                                  MK_C == 7 && MK_D == 8 && MK_A == 9 && MK_SP == 10 && MK_SYNC == 11, "mask order");
+                    ulonglong2* o = reinterpret_cast<ulonglong2*>(s_mask + w * MK_COUNT);
+                    o[0] = make_ulonglong2(mU, mW); o[1] = make_ulonglong2(mX, mS); o[2] = make_ulonglong2(mN, mCR);
+                    o[3] = make_ulonglong2(mCR | mSL, mC); o[4] = make_ulonglong2(mD, mA); o[5] = make_ulonglong2(mSP, mSY);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: piece boundaries (bit-parallel scanner; byte scanner / HBM as fallbacks) --
+        {
+            LdsAcc L;
+            L.T = &T; L.src = src; L.lim = K_LIM;
+            GlobAcc G;
+            G.T = &T; G.s.text = a.text; G.s.docbits = a.docbits; G.s.lo = 0; G.s.hi = a.n; G.n = a.n; G.lim = a.n + 4;
+            int s = -1;
+            if (tid == 0) {
+                // last provable sync point at or before the tile start (window bytes 4..64)
+                const uint64_t w0 = s_mask[0 * MK_COUNT + MK_SYNC] & ~0xFull;
+                if (s_mask[1 * MK_COUNT + MK_SYNC] & 1ull) s = 64;
+                else if (w0) s = td_top64(w0) - 1;
+                else {
+                    int64_t gs = 0;
+                    for (int64_t gi = wg0 + 3; gi > 0; --gi)
+                        if (is_sync(G.cf(gi - 1), G.cf(gi))) { gs = gi; break; }
+                    int64_t p = gs;
+                    while (p < tile_g0) p = G.scan(p);
+                    s = (p - wg0 < (int64_t)tile_hi) ? (int)(p - wg0) : -1;
+                }
+            } else if (c0 < tile_hi) {
+                uint32_t sy = (uint32_t)(s_mask[(c0 >> 6) * MK_COUNT + MK_SYNC] >> (c0 & 63)) & 0xFFFFu;
+                if (c1 > tile_hi) sy &= (1u << (tile_hi - c0)) - 1u;
+                if (sy) s = c0 + __ffs(sy) - 1;
+            }
+            if (s >= 0) {
+                auto mark = [&](int q) { atomicOr(&s_start[q >> 5], 1u << (q & 31)); };
+                BitWin wv;
+                int base = s;
+                load_bitwin(wv, s_mask, base);
+                int p = s;
+                for (;;) {
+                    if (p >= tile_hi) { mark(p); break; }  // delimits the last owned piece
+                    if (p - base > 36) { base = p; load_bitwin(wv, s_mask, base); }
+                    if (p >= c1 && ((wv.m[MK_SYNC] >> (p - base)) & 1ull)) break;  // the lane owning p starts there
+                    if (p >= K_HL) mark(p);
+                    const int avail = (K_LIM - base < 64) ? (K_LIM - base) : 64;
+                    auto bytes = [&](int q) { return (uint32_t)s_txt[base + q]; };
+                    int r = scan_piece_bits(wv, bytes, p - base, avail);
+                    if (r < 0 && p != base) {
+                        base = p;
+                        load_bitwin(wv, s_mask, base);
+                        const int avail2 = (K_LIM - base < 64) ? (K_LIM - base) : 64;
+                        r = scan_piece_bits(wv, bytes, 0, avail2);
+                    }
+                    int e;
+                    if (r >= 0) e = base + r;
+                    else {
+                        e = scan_piece(L, p);  // piece or look-ahead longer than a mask window
+                        if (e < 0) {
+                            const int64_t ge = G.scan(wg0 + p);
+                            if (ge - wg0 > (int64_t)K_LIM) break;  // piece leaves the window: the rest belongs to later tiles
+                            e = (int)(ge - wg0);
+                        }
+                    }
+                    p = e;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- publish the tile's own START bits (tile-aligned words: no other workgroup writes them) ----
+        if (tid < K_TILE / 32) {
+            const int64_t g = tile_g0 + (int64_t)tid * 32;
+            if (g < a.n) {
+                uint32_t v = s_start[K_HL / 32 + tid];
+                if (g + 32 > a.n) v &= (1u << (int)(a.n - g)) - 1u;
+                a.startbits[(tile_g0 >> 5) + tid] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ td_encode_tiles ---------
+// Token kernel: pieces (from the START bitmap) -> token ids, compacted per tile.
+//   whole-piece table probe, one lane per piece      (CoreBPE::encode fast path, tiktoken.cpp:209-215)
+//   byte-pair merge of the misses, a wavefront per 64-byte window, one lane per byte, segmented
+//   wavefront min-reduce for the lowest-rank leftmost pair (bpe_merge, tiktoken.cpp:298-368)
+//   block scan + compaction into the tile's staging area; token slot of every document start.
+constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per tile by this kernel
+
+#ifndef TD_TILES_MIN_WAVES
+#define TD_TILES_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles(const EncodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_BWIN + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tok[K_TILE + K_MAXSHORT];
+    __shared__ uint32_t s_start[K_BWIN / 32 + 3];  // bit i: a piece starts at tile byte i
+    __shared__ uint32_t s_miss[K_BWIN / 32 + 3];   // bit i: the piece starting at i missed the whole-piece table
+    __shared__ uint16_t s_plist[K_TILE + 2];       // tile positions of the piece starts (+ end delimiter)
+    __shared__ uint32_t s_off[K_THREADS];          // phase 5: token slots before each lane's chunk
+    __shared__ uint16_t s_valid[K_THREADS];        // phase 5: which of the lane's 16 byte slots hold a token
+    __shared__ int32_t s_byteid[256];
+    __shared__ uint32_t s_wave[8];
+    __shared__ long long s_ext_end;                // global end of the tile's last piece when it leaves the window (else 0)
+    __shared__ uint32_t s_haslong;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const Tables& T = a.T;
+    s_byteid[tid] = T.byte_id[tid];
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t tile_g0 = (int64_t)tile * K_TILE;
+        const int64_t wg0 = tile_g0;                 // window index 0 == first byte of the tile
+        constexpr int K_HL = 0;                      // (shadows the split kernel's left halo: none here)
+        const int tile_hi = (int)((a.n - tile_g0 < K_TILE) ? (a.n - tile_g0) : K_TILE);
+        const int c0 = tid * K_CHUNK, c1 = c0 + K_CHUNK;
+
+        // ---- phase 0: stage text + START bits of the tile (+128 B look-ahead); clear token slots ----
+        for (int v = tid; v < (K_BWIN + 16) / 16; v += K_THREADS) {
+            const int64_t g = wg0 + (int64_t)v * 16;
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (g + 16 <= a.n && a.text_aligned) {
+                x = *reinterpret_cast<const uint4*>(a.text + g);
+            } else if (g < a.n) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16; ++k)
+                    if (g + k < a.n) w[k >> 2] |= (uint32_t)a.text[g + k] << ((k & 3) * 8);
+                x = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            reinterpret_cast<uint4*>(s_txt)[v] = x;
+        }
+        {
+            const int64_t nwords = (a.n + 31) >> 5;
+            for (int w = tid; w < K_BWIN / 32 + 3; w += K_THREADS) {
+                const int64_t gw = (wg0 >> 5) + w;
+                uint32_t sw = (gw < nwords) ? a.startbits[gw] : 0u;
+                const int64_t g = wg0 + (int64_t)w * 32;
+                if (a.n >= g && a.n < g + 32) sw |= 1u << (int)(a.n - g);  // the end of the text delimits the last piece
+                s_start[w] = sw;
+                s_miss[w] = 0;
             }
         }
         {
             const uint4 none = make_uint4(TOK_NONE, TOK_NONE, TOK_NONE, TOK_NONE);
             for (int v = tid; v < (K_TILE + K_MAXSHORT) / 4; v += K_THREADS) reinterpret_cast<uint4*>(s_tok)[v] = none;
         }
-        if (tid == 0) { s_ext_start = -1; s_ext_end = 0; s_haslong = 0; }
+        if (tid == 0) { s_ext_end = 0; s_haslong = 0; }
         __syncthreads();
-
-        // ---- phase 1: per-byte class + flags ------------------------------------------------
-        {
-            LdsSrc src;
-            src.txt = s_txt;
-            src.docw = s_doc;
-            src.lo = (wg0 < 0) ? -wg0 : 0;
-            src.hi = (a.n - wg0 < K_WIN) ? (a.n - wg0) : K_WIN;
-            for (int d = tid; d < K_WIN / 4; d += K_THREADS) {
-                const uint32_t w = reinterpret_cast<const uint32_t*>(s_txt)[d];
-                uint32_t out;
-                if (!(w & 0x80808080u)) {
-                    out = (uint32_t)s_lut[w & 0x7F] | ((uint32_t)s_lut[(w >> 8) & 0x7F] << 8) |
-                          ((uint32_t)s_lut[(w >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[(w >> 24) & 0x7F] << 24);
-                } else {
-                    out = 0;
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t b = (w >> (8 * k)) & 0xFF;
-                        const int64_t i = (int64_t)d * 4 + k;
-                        uint32_t c;
-                        if (b < 0x80) c = s_lut[b];
-                        else if (i >= src.lo && i < src.hi) c = classify_at(T, src, i);
-                        else c = C_OTHER;
-                        out |= c << (8 * k);
-                    }
-                }
-                const uint32_t db = (s_doc[d >> 3] >> ((d & 7) * 4)) & 0xFu;
-                out |= ((db & 1u) << 7) | ((db & 2u) << 14) | ((db & 4u) << 21) | ((db & 8u) << 28);
-                // bytes past the end of the text: "end of subject" sentinels
-                const int64_t g = wg0 + (int64_t)d * 4;
-                if (g + 4 > a.n) {
-                    for (int k = 0; k < 4; ++k)
-                        if (g + k >= a.n) out = (out & ~(0xFFu << (8 * k))) | ((uint32_t)F_DOC << (8 * k));
-                }
-                reinterpret_cast<uint32_t*>(s_cls)[d] = out;
-            }
-        }
-        __syncthreads();
-        if (a.stop_after == 1) continue;
-
-        // ---- phase 2: piece boundaries ------------------------------------------------------
-        const int c0 = K_HL + tid * K_CHUNK, c1 = c0 + K_CHUNK;
-        {
-            LdsAcc L;
-            L.cls = s_cls; L.txt = s_txt; L.lim = K_LIM; L.ext_start = &s_ext_start; L.ext_end = &s_ext_end;
-            GlobAcc G;
-            G.T = &T; G.s.text = a.text; G.s.docbits = a.docbits; G.s.lo = 0; G.s.hi = a.n; G.n = a.n; G.lim = a.n + 4;
-            scan_lane(L, G, tid, tile_hi, wg0);
-        }
-        __syncthreads();
-        if (a.stop_after == 2) continue;
 
         // ---- phase 3: whole-piece lookup, one lane per piece ---------------------------------
         // 3a: dense list of the tile's piece starts (so that every lane has a piece to look up)
@@ -236,64 +410,66 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
         {
             uint32_t smask = 0;  // START bits of my 16 bytes
             if (c0 < tile_hi) {
-                const uint4 cv = *reinterpret_cast<const uint4*>(s_cls + c0);
-                const uint32_t w[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t f = (w[k] >> 6) & 0x01010101u;            // bit 0 of each byte = START
-                    smask |= (((f * 0x01020408u) >> 24) & 0xFu) << (4 * k);  // gather the 4 bits (byte j -> bit j)
-                }
+                smask = (s_start[c0 >> 5] >> (c0 & 31)) & 0xFFFFu;
                 if (c1 > tile_hi) smask &= (1u << (tile_hi - c0)) - 1u;
             }
             const uint32_t cnt = __popc(smask);
-            const uint32_t base = block_excl_scan(cnt, s_wave, np_total);
-            uint32_t k = base;
+            const uint32_t pbase = block_excl_scan(cnt, s_wave, np_total);
+            uint32_t k = pbase;
             while (smask) {
                 const int b = __ffs(smask) - 1;
                 smask &= smask - 1;
                 s_plist[k++] = (uint16_t)(c0 + b);
             }
-            if (tid == 0) {  // end delimiter of the last owned piece: first START at/after the tile end
+            if (tid == 0) {
+                // end of the last owned piece: first START at/after the tile end; beyond the staged window
+                // (a piece longer than 128 bytes) walk the bitmap in HBM
                 int e = tile_hi;
-                if (s_ext_start < 0)
-                    while (e < K_WIN - 1 && !(s_cls[e] & F_START)) ++e;
+                while (e < K_BWIN && !((s_start[e >> 5] >> (e & 31)) & 1u)) ++e;
+                if (e >= K_BWIN && np_total > 0) {
+                    int64_t g = wg0 + K_BWIN;
+                    const int64_t nwords = (a.n + 31) >> 5;
+                    int64_t found = a.n;
+                    for (int64_t gw = g >> 5; gw < nwords; ++gw) {
+                        uint32_t sw = a.startbits[gw];
+                        if (gw == (g >> 5)) sw &= ~((1u << (g & 31)) - 1u);
+                        if (sw) { const int64_t f = gw * 32 + (__ffs(sw) - 1); if (f < a.n) found = f; break; }
+                    }
+                    s_ext_end = found;
+                    e = K_BWIN;  // placeholder; 3b uses s_ext_end for the last piece
+                }
                 s_plist[np_total] = (uint16_t)e;
             }
         }
         __syncthreads();
-        // 3b: probe, piece k -> lane k mod 256
+        // 3b: probe, piece k -> lane k mod 256; four pieces per lane at a time so that the table loads of a
+        //     batch are in flight together (the probes are latency-, not bandwidth-bound)
         {
-            const int ext_start = s_ext_start;
-            for (uint32_t k = tid; k < np_total; k += K_THREADS) {
-                const int i = s_plist[k];
-                uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
-                if (i == ext_start) {
-                    const long long l = s_ext_end - (wg0 + i);
-                    if (l > 0x7FFFFFFFll) { raise(a, TD_E_SCRATCH, wg0 + i); continue; }
-                    len = (uint32_t)l;
-                }
-                if (len > (uint32_t)K_MAXSHORT) {
-                    const uint32_t idx = atomicAdd(a.long_count, 1u);
-                    if (idx < a.long_cap) {
-                        LongEntry le;
-                        le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
-                        a.long_list[idx] = le;
-                        s_tok[i - K_HL] = TOK_LONGREF | idx;
-                        s_haslong = 1;
-                    } else {
-                        raise(a, TD_E_SCRATCH, wg0 + i);
+            const long long ext_end = s_ext_end;
+            constexpr int NB = 4;
+            for (uint32_t k0 = tid; k0 < np_total; k0 += NB * K_THREADS) {
+                int pi[NB];
+                uint32_t plen[NB];
+                uint64_t pkey[NB];
+                PieceSlot slot[NB];
+                uint32_t ph[NB];
+                bool probe[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const uint32_t k = k0 + u * K_THREADS;
+                    probe[u] = false;
+                    pi[u] = -1;
+                    if (k >= np_total) continue;
+                    const int i = s_plist[k];
+                    uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
+                    if (ext_end && k == np_total - 1) {
+                        const long long l = ext_end - (wg0 + i);
+                        if (l > 0x7FFFFFFFll) { raise(a, TD_E_SCRATCH, wg0 + i); continue; }
+                        len = (uint32_t)l;
                     }
-                    continue;
-                }
-                const uint8_t* pb = s_txt + i;
-                if (len == 1) {
-                    const int32_t id = s_byteid[pb[0]];
-                    if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
-                    s_tok[i - K_HL] = (uint32_t)id;
-                    continue;
-                }
-                if (a.use_fastpath) {
-                    auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
+                    pi[u] = i;
+                    plen[u] = len;
+                    if (len > (uint32_t)K_MAXSHORT || len == 1 || !a.use_fastpath) continue;
                     uint64_t key;
                     if (len <= 8) {
                         const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
@@ -304,12 +480,51 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
                         key = ((uint64_t)khi << 32) | klo;
                         if (len < 8) key &= (1ull << (8 * len)) - 1;
                     } else {
-                        key = hash_bytes(get, len);
+                        const uint8_t* pb = s_txt + i;
+                        key = hash_bytes([pb](uint32_t q) { return (uint32_t)pb[q]; }, len);
                     }
-                    const int32_t r = piece_lookup(T, key, len, get);
-                    if (r != NO_RANK) { s_tok[i - K_HL] = (uint32_t)r; continue; }
+                    pkey[u] = key;
+                    ph[u] = hash_piece(key, len) & T.piece_mask;
+                    probe[u] = true;
                 }
-                s_cls[i] = (uint8_t)(s_cls[i] | F_MISS);
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                    if (probe[u]) slot[u] = T.piece_slots[ph[u]];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int i = pi[u];
+                    if (i < 0) continue;
+                    const uint32_t len = plen[u];
+                    if (len > (uint32_t)K_MAXSHORT) {
+                        const uint32_t idx = atomicAdd(a.long_count, 1u);
+                        if (idx < a.long_cap) {
+                            LongEntry le;
+                            le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
+                            a.long_list[idx] = le;
+                            s_tok[i - K_HL] = TOK_LONGREF | idx;
+                            s_haslong = 1;
+                        } else {
+                            raise(a, TD_E_SCRATCH, wg0 + i);
+                        }
+                        continue;
+                    }
+                    const uint8_t* pb = s_txt + i;
+                    if (len == 1) {
+                        const int32_t id = s_byteid[pb[0]];
+                        if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
+                        s_tok[i - K_HL] = (uint32_t)id;
+                        continue;
+                    }
+                    if (probe[u]) {
+                        int32_t r;
+                        const PieceSlot s0 = slot[u];
+                        if (s0.len == 0) r = NO_RANK;                                               // empty slot: not a token
+                        else if (s0.key == pkey[u] && s0.len == len && len <= 8) r = (int32_t)s0.rank;  // the common case
+                        else r = piece_lookup(T, pkey[u], len, [pb](uint32_t q) { return (uint32_t)pb[q]; });
+                        if (r != NO_RANK) { s_tok[i - K_HL] = (uint32_t)r; continue; }
+                    }
+                    atomicOr(&s_miss[i >> 5], 1u << (i & 31));
+                }
             }
         }
         __syncthreads();
@@ -322,16 +537,14 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
             int pos = seg_lo;
             const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);  // lanes <= mine
             while (pos < seg_hi) {
-                const int idx = pos + lane;
-                const uint32_t v = s_cls[idx];
-                const bool st = (v & F_START) != 0;
-                const bool mst = st && (v & F_MISS) && idx < seg_hi;
-                const uint64_t missm = __ballot(mst);
+                uint64_t missm = bits64(s_miss, pos);
+                if (seg_hi - pos < 64) missm &= td_bits_below(seg_hi - pos);  // pieces that START in my segment
                 if (missm == 0) { pos += 64; continue; }
                 const int f = __ffsll((unsigned long long)missm) - 1;
                 if (f > 0) { pos += f; continue; }  // re-align: first missed piece at lane 0
-                const uint64_t startm = __ballot(st);
-                const bool next_is_start = (s_cls[pos + 64] & F_START) != 0;
+                const uint64_t startm = bits64(s_start, pos);
+                const bool next_is_start = (s_start[(pos + 64) >> 5] >> ((pos + 64) & 31)) & 1u;
+                const int idx = pos + lane;
                 const uint64_t below = startm & le;  // bit 0 is set
                 const int ps = 63 - __clzll((unsigned long long)below);
                 const uint64_t above = startm & ~le;
@@ -340,7 +553,7 @@ __global__ __launch_bounds__(K_THREADS) void td_encode_tiles(const EncodeArgs a)
                 if (above) { pe = __ffsll((unsigned long long)above) - 1; fits = true; }
                 else { pe = 64; fits = next_is_start; }
                 const bool active = fits && ((missm >> ps) & 1ull);
-                const uint64_t pendm = __ballot(mst && !active);
+                const uint64_t pendm = __ballot(((missm >> lane) & 1ull) && !active);
 
                 const uint32_t b = s_txt[idx];
                 uint32_t id = (uint32_t)s_byteid[b];
@@ -637,20 +850,31 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
 }
 
 // ------------------------------------------------------------------ launches ----------------
-static int g_blocks_cached = 0;
+static int g_blocks_split = 0, g_blocks_encode = 0;
+static int resident_blocks(const void* fn, int fallback_per_cu) {
+    // persistent grid = exactly the workgroups that are resident at once (a larger grid would run in
+    // uneven rounds: tiles are dealt round-robin to blockIdx)
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K_THREADS, 0) == hipSuccess && per_cu > 0)
+        return prop.multiProcessorCount * per_cu;
+    return 256 * fallback_per_cu;
+}
 int encode_grid_blocks() {
-    if (!g_blocks_cached) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            g_blocks_cached = prop.multiProcessorCount * 5;
-        else
-            g_blocks_cached = 256 * 5;
-    }
-    return g_blocks_cached;
+    if (!g_blocks_encode) g_blocks_encode = resident_blocks((const void*)td_encode_tiles, 3);
+    const char* e = getenv("TD_BLOCKS_PER_CU");
+    if (e && atoi(e) > 0) return 256 * atoi(e);
+    return g_blocks_encode;
+}
+static int split_grid_blocks() {
+    if (!g_blocks_split) g_blocks_split = resident_blocks((const void*)td_split_tiles, 3);
+    const char* e = getenv("TD_SPLIT_BLOCKS_PER_CU");
+    if (e && atoi(e) > 0) return 256 * atoi(e);
+    return g_blocks_split;
 }
 
-hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2) {
     if (a.n_tiles <= 0) return hipSuccess;
     {
         const int64_t nd = a.n_docs;
@@ -659,13 +883,18 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(td_mark_docs, dim3(blocks), dim3(256), 0, stream, a.doc_offsets, nd, a.n, a.docbits, a.tile_first_doc);
     }
+    const int sblocks = a.n_tiles < split_grid_blocks() ? a.n_tiles : split_grid_blocks();
     const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
     if (ev0) (void)hipEventRecord(ev0, stream);
-    hipLaunchKernelGGL(td_encode_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(td_split_tiles, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
     if (ev1) (void)hipEventRecord(ev1, stream);
-    hipLaunchKernelGGL(td_long_pieces, dim3(256), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(td_scan_tiles, dim3(1), dim3(1024), 0, stream, a);
-    hipLaunchKernelGGL(td_pack_tokens, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+    if (a.stop_after != 2) {
+        hipLaunchKernelGGL(td_encode_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+        if (ev2) (void)hipEventRecord(ev2, stream);
+        hipLaunchKernelGGL(td_long_pieces, dim3(256), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(td_scan_tiles, dim3(1), dim3(1024), 0, stream, a);
+        hipLaunchKernelGGL(td_pack_tokens, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+    } else if (ev2) (void)hipEventRecord(ev2, stream);
     return hipGetLastError();
 }
 

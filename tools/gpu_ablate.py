@@ -1,6 +1,8 @@
 """Kernel tuning aid: time td_encode_tiles with the tile loop cut after phase N (results are garbage for N != 0)."""
 import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from tokendagger_amd import capi, vocab_io
 import bench
@@ -16,7 +18,8 @@ cap = n // 2 + 1024 if kind == 'english' else n
 dk = torch.empty(cap, dtype=torch.int32, device='cuda'); dto = torch.empty(nd + 1, dtype=torch.int64, device='cuda')
 tok.reserve(n, nd + 1); tok.set_option(capi.TD_OPT_PROFILE, 1)
 s = torch.cuda.current_stream().cuda_stream
-for stop in [1, 2, 3, 4, 0]:
+stops = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [2, 3, 4, 0]
+for stop in stops:
     tok.set_option(99, stop)
     for _ in range(2):
         tok.encode_device(dt.data_ptr(), n, do.data_ptr(), nd, dk.data_ptr(), cap, dto.data_ptr(), s)
@@ -25,8 +28,8 @@ for stop in [1, 2, 3, 4, 0]:
     for _ in range(5):
         tok.encode_device(dt.data_ptr(), n, do.data_ptr(), nd, dk.data_ptr(), cap, dto.data_ptr(), s)
     torch.cuda.synchronize(); el = (time.perf_counter() - t0) / 5
-    ms, k = tok.profile_read()
-    print(f"{kind} {mb}MiB stop_after={stop}: tile kernel {ms/k:.3f} ms, whole step {el*1e3:.3f} ms, {n/el/1e9:.1f} GB/s", flush=True)
+    ms0, ms1, k = tok.profile_read()
+    print(f"{kind} {mb}MiB stop_after={stop}: split {ms0/k:.3f} ms + encode {ms1/k:.3f} ms, whole step {el*1e3:.3f} ms, {n/el/1e9:.1f} GB/s", flush=True)
 try:
     tok.device_status(s)
 except Exception as e:
