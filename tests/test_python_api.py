@@ -1,0 +1,91 @@
+"""Drop-in Python surface (tokendagger_amd.Tokenizer / Encoding, `import tokendagger as tiktoken`) on the GPU."""
+import numpy as np
+import pytest
+
+import cases
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def enc():
+    import tokendagger as tiktoken
+    pat, mr, special = H.llama4()
+    return tiktoken.Encoding(name="llama4", pat_str=pat, mergeable_ranks=mr, special_tokens=special)
+
+
+def test_encode_matches_golden_strings(enc, golden):
+    text, offs = golden["text"].tobytes(), golden["offsets"]
+    gold, go = golden["enc"], golden["enc_offsets"]
+    names = list(golden["names"])
+    for name, s in cases.all_strings():
+        d = names.index(name)
+        exp = gold[go[d]:go[d + 1]].tolist()
+        assert enc.encode(s) == exp, name
+        assert enc.encode_ordinary(s) == exp, name
+        assert enc.encode(s, allowed_special=set(), disallowed_special=set()) == exp
+
+
+def test_batch_and_numpy_forms(enc):
+    O = H.port_tokenizer()
+    texts = [s for _, s in cases.all_strings()]
+    got = enc.encode_batch(texts, num_threads=4)
+    assert got == [O.encode(t.encode("utf-8")).tolist() for t in texts]
+    assert enc.encode_ordinary_batch(texts[:50]) == got[:50]
+    arr = enc.encode_to_numpy("Hello, world!")
+    assert arr.dtype == np.int32 and arr.tolist() == [19873, 24, 3817, 13]
+    blob, offs = H.pack_docs([t.encode("utf-8") for t in texts])
+    toks, toffs = enc.encode_batch_to_numpy(blob, offs)
+    assert toks.tolist() == [x for g in got for x in g] and toffs[-1] == len(toks)
+
+
+def test_decode_and_roundtrip(enc, golden):
+    for ids, exp in zip(golden["decode_ids"], golden["decode_bytes"]):
+        assert enc.decode_bytes(list(ids)) == exp
+    for s in ["Hello, world!", "The quick brown fox jumps over the lazy dog.", "Unicode: 你好 \U0001F30D"]:
+        assert enc.decode(enc.encode(s)) == s
+    assert enc.decode_batch([[19873, 24, 3817, 13], [220]]) == ["Hello, world!", " "]
+    assert enc.decode_single_token_bytes(220) == b" "
+    import tokendagger
+    with pytest.raises(tokendagger.TokenDaggerError):
+        enc.decode([10 ** 8])
+
+
+def test_special_tokens_tiktoken_semantics(enc):
+    O = H.port_tokenizer()
+    _, _, special = H.llama4()
+    bos, eos = special["<|begin_of_text|>"], special["<|end_of_text|>"]
+    s = "<|begin_of_text|>Hello<|end_of_text|> tail <|begin_of_text|>"
+    exp = [bos] + O.encode(b"Hello").tolist() + [eos] + O.encode(b" tail ").tolist() + [bos]
+    assert enc.encode(s, allowed_special="all") == exp
+    assert enc.encode(s, allowed_special={"<|begin_of_text|>", "<|end_of_text|>"}) == exp
+    assert enc.encode_with_special_tokens(s) == exp
+    only_eos = O.encode(b"<|begin_of_text|>Hello").tolist() + [eos] + O.encode(b" tail <|begin_of_text|>").tolist()
+    assert enc.encode(s, allowed_special={"<|end_of_text|>"}) == only_eos
+    assert enc.encode(s) == O.encode(s.encode()).tolist(), "default: specials are ordinary text"
+    with pytest.raises(ValueError):
+        enc.encode(s, disallowed_special="all")
+    import tokendagger
+    with pytest.raises(tokendagger.TokenDaggerError):
+        enc.encode("x", allowed_special={"<|no_such_token|>"})
+    # second element of CoreBPE.encode's return pair: ids of the last regex piece (0 after a special)
+    toks, last = enc._core_bpe.encode("Hello world", set())
+    assert toks == O.encode(b"Hello world").tolist() and last == 1
+    assert enc._core_bpe.encode(s, {"<|begin_of_text|>"})[1] == 0
+    assert enc._core_bpe.encode("abc \U0001F468‍\U0001F4BB", set())[1] == len(O.encode("\U0001F468‍\U0001F4BB".encode()))
+
+
+def test_attributes_and_errors(enc):
+    import tokendagger
+    assert enc.n_vocab == 201134 and enc.max_token_value == 201133
+    assert enc.is_special_token(200000) and not enc.is_special_token(5)
+    assert "<|begin_of_text|>" in enc.special_tokens_set and len(enc.special_tokens()) == 1134
+    assert repr(enc) == "<TokenDagger 'llama4'>"
+    with pytest.raises(tokendagger.TokenDaggerError):
+        tokendagger.Encoding(name="bad", pat_str=r"\w+|\s+", mergeable_ranks={b"a": 0})
+    t = tokendagger.create_tokenizer("toy", enc.pattern, [{"rank": 0, "token_bytes": [97]}, {"rank": 1, "token_bytes": [98]},
+                                                           {"rank": 2, "token_bytes": [97, 98], "token_string": "ab"}])
+    assert t.encode("ab") == [2] and t.encode("ba") == [1, 0]
+    with pytest.raises(tokendagger.TokenDaggerError):
+        t.encode("abc")

@@ -71,7 +71,7 @@ def load_library():
             f"{lib_path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'); "
             "tokendagger_amd has no CPU fallback")
     _share_hip_runtime_with_torch()
-    lib = ctypes.CDLL(str(lib_path))
+    lib = ctypes.CDLL(str(lib_path), mode=ctypes.RTLD_GLOBAL)
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     lib.td_create.restype = i32
     lib.td_create.argtypes = [ctypes.c_char_p, i64, vp, vp, vp, i64, vp, vp, vp, i32, ctypes.POINTER(vp)]

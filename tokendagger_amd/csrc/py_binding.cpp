@@ -1,0 +1,255 @@
+// Python extension `_tokendagger_core`: the reference's FFI surface (class names, method names,
+// argument meaning, exception type: /root/reference/src/py_binding.cpp:7-49) re-implemented over the
+// C ABI of libtokendagger_hip.so (include/tokendagger_hip.h).  No tokenization happens in this file;
+// it marshals Python objects to flat buffers, releases the GIL and calls td_*.
+//
+//   VocabItem            rank:int, token_bytes:list[int], token_string:str         (py_binding.cpp:11-15)
+//   TiktokenError        raised for every TD_E_* status                             (py_binding.cpp:18)
+//   CoreBPE(pattern, vocab, special_vocab)                                          (py_binding.cpp:22-24)
+//     .encode_ordinary(text) -> list[int]                                           (:25-29)
+//     .encode(text, allowed_special:set[str]) -> (list[int], last_piece_token_len)  (:30-39)
+//     .decode_bytes(tokens) -> list[int]                                            (:40-44)
+//     .special_tokens() -> list[str]                                                (:45-46)
+//     .encode_with_special_tokens(text) -> list[int]                                (:47-49)
+//   plus array-in/array-out methods the reference does not have (encode_batch_*, *_numpy), because a
+//   Python list of ints per document caps throughput far below what the GPU path delivers.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cstring>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "tokendagger_hip.h"
+
+namespace py = pybind11;
+
+struct VocabItem {
+    int rank = 0;
+    std::vector<unsigned char> token_bytes;
+    std::string token_string;
+};
+
+class TiktokenError : public std::runtime_error {
+public:
+    explicit TiktokenError(const std::string& m) : std::runtime_error(m) {}
+};
+
+namespace {
+
+void pack(const std::vector<VocabItem>& v, bool use_string, std::vector<uint8_t>& bytes, std::vector<int64_t>& offs,
+          std::vector<int32_t>& ranks) {
+    offs.assign(1, 0);
+    for (const auto& it : v) {
+        if (use_string) bytes.insert(bytes.end(), it.token_string.begin(), it.token_string.end());
+        else bytes.insert(bytes.end(), it.token_bytes.begin(), it.token_bytes.end());
+        offs.push_back((int64_t)bytes.size());
+        ranks.push_back(it.rank);
+    }
+    if (bytes.empty()) bytes.push_back(0);
+}
+
+class CoreBPE {
+public:
+    CoreBPE(const std::string& pattern, const std::vector<VocabItem>& vocab, const std::vector<VocabItem>& special, int device) {
+        std::vector<uint8_t> b, sb;
+        std::vector<int64_t> o, so;
+        std::vector<int32_t> r, sr;
+        pack(vocab, false, b, o, r);
+        pack(special, true, sb, so, sr);
+        int rc;
+        {
+            py::gil_scoped_release rel;
+            rc = td_create(pattern.c_str(), (int64_t)r.size(), b.data(), o.data(), r.data(), (int64_t)sr.size(), sb.data(),
+                           so.data(), sr.data(), device, &h_);
+        }
+        if (rc != TD_OK) throw TiktokenError(td_last_error(nullptr));
+        for (const auto& it : special) special_ids_[it.token_string] = it.rank;
+    }
+    ~CoreBPE() { td_destroy(h_); }
+    CoreBPE(const CoreBPE&) = delete;
+    CoreBPE& operator=(const CoreBPE&) = delete;
+
+    [[noreturn]] void fail() const { throw TiktokenError(td_last_error(h_)); }
+
+    // one document, host buffers
+    std::vector<int> encode_mode(const std::string& text, int mode) {
+        std::vector<int32_t> out(text.size() / 3 + 16);
+        int64_t offs[2] = {0, (int64_t)text.size()}, toffs[2], n = 0;
+        int rc;
+        {
+            py::gil_scoped_release rel;
+            rc = td_encode_batch(h_, (const uint8_t*)text.data(), offs, 1, mode, out.data(), (int64_t)out.size(), toffs, &n);
+            if (rc == TD_E_CAPACITY && n > (int64_t)out.size()) {
+                out.resize((size_t)n);
+                rc = td_encode_batch(h_, (const uint8_t*)text.data(), offs, 1, mode, out.data(), (int64_t)out.size(), toffs, &n);
+            }
+        }
+        if (rc != TD_OK) fail();
+        return std::vector<int>(out.begin(), out.begin() + n);
+    }
+
+    std::pair<std::vector<int>, int> encode(const std::string& text, const std::set<std::string>& allowed) {
+        std::vector<int32_t> ids;
+        for (const auto& s : allowed) {
+            auto it = special_ids_.find(s);
+            if (it == special_ids_.end()) throw TiktokenError("Special token '" + s + "' not found in special encoder");
+            ids.push_back(it->second);
+        }
+        std::vector<int32_t> out(text.size() + 16);
+        int64_t n = 0;
+        int32_t last = 0;
+        int rc;
+        {
+            py::gil_scoped_release rel;
+            rc = td_encode_with_special(h_, (const uint8_t*)text.data(), (int64_t)text.size(), ids.data(), (int64_t)ids.size(),
+                                        out.data(), (int64_t)out.size(), &n, &last);
+        }
+        if (rc != TD_OK) fail();
+        return {std::vector<int>(out.begin(), out.begin() + n), (int)last};
+    }
+
+    std::vector<unsigned char> decode_bytes(const std::vector<int>& tokens) {
+        std::vector<int32_t> t(tokens.begin(), tokens.end());
+        std::vector<unsigned char> out(t.size() * 8 + 64);
+        int64_t nb = 0;
+        int rc;
+        {
+            py::gil_scoped_release rel;
+            rc = td_decode_bytes(h_, t.data(), (int64_t)t.size(), out.data(), (int64_t)out.size(), &nb);
+            if (rc == TD_E_CAPACITY && nb > (int64_t)out.size()) {
+                out.resize((size_t)nb);
+                rc = td_decode_bytes(h_, t.data(), (int64_t)t.size(), out.data(), (int64_t)out.size(), &nb);
+            }
+        }
+        if (rc != TD_OK) fail();
+        out.resize((size_t)nb);
+        return out;
+    }
+
+    std::vector<std::string> special_tokens() const {
+        std::vector<std::string> v;
+        for (const auto& kv : special_ids_) v.push_back(kv.first);
+        return v;
+    }
+
+    std::vector<int> encode_with_special_tokens(const std::string& text) {
+        std::set<std::string> all;
+        for (const auto& kv : special_ids_) all.insert(kv.first);
+        return encode(text, all).first;
+    }
+
+    // ---- bulk surface (not in the reference) --------------------------------------------------
+    // concatenated UTF-8 + int64 offsets in, (int32 ids, int64 offsets) out
+    py::tuple encode_batch_numpy(py::array_t<uint8_t, py::array::c_style | py::array::forcecast> text,
+                                 py::array_t<int64_t, py::array::c_style | py::array::forcecast> offsets, int mode) {
+        const int64_t n_docs = (int64_t)offsets.size() - 1;
+        if (n_docs < 0) throw TiktokenError("offsets must have n_docs+1 entries");
+        const int64_t nbytes = offsets.size() ? offsets.data()[n_docs] : 0;
+        if (nbytes > (int64_t)text.size()) throw TiktokenError("offsets exceed the text buffer");
+        py::array_t<int64_t> toffs(n_docs + 1);
+        std::vector<int32_t> out((size_t)(nbytes / 3 + 16));
+        int64_t n = 0;
+        int rc;
+        {
+            py::gil_scoped_release rel;
+            rc = td_encode_batch(h_, text.data(), offsets.data(), n_docs, mode, out.data(), (int64_t)out.size(), toffs.mutable_data(), &n);
+            if (rc == TD_E_CAPACITY && n > (int64_t)out.size()) {
+                out.resize((size_t)n);
+                rc = td_encode_batch(h_, text.data(), offsets.data(), n_docs, mode, out.data(), (int64_t)out.size(),
+                                     toffs.mutable_data(), &n);
+            }
+        }
+        if (rc != TD_OK) fail();
+        py::array_t<int32_t> toks(n);
+        if (n) memcpy(toks.mutable_data(), out.data(), (size_t)n * 4);
+        return py::make_tuple(toks, toffs);
+    }
+
+    // list[str] in, list[list[int]] out through ONE device batch
+    std::vector<std::vector<int>> encode_batch(const std::vector<std::string>& texts, int mode) {
+        std::vector<int64_t> offs(1, 0);
+        size_t total = 0;
+        for (const auto& s : texts) total += s.size();
+        std::vector<uint8_t> buf;
+        buf.reserve(total + 1);
+        for (const auto& s : texts) {
+            buf.insert(buf.end(), s.begin(), s.end());
+            offs.push_back((int64_t)buf.size());
+        }
+        std::vector<int32_t> out(total / 3 + 16);
+        std::vector<int64_t> toffs(texts.size() + 1);
+        int64_t n = 0;
+        int rc;
+        {
+            py::gil_scoped_release rel;
+            rc = td_encode_batch(h_, buf.data(), offs.data(), (int64_t)texts.size(), mode, out.data(), (int64_t)out.size(), toffs.data(), &n);
+            if (rc == TD_E_CAPACITY && n > (int64_t)out.size()) {
+                out.resize((size_t)n);
+                rc = td_encode_batch(h_, buf.data(), offs.data(), (int64_t)texts.size(), mode, out.data(), (int64_t)out.size(),
+                                     toffs.data(), &n);
+            }
+        }
+        if (rc != TD_OK) fail();
+        std::vector<std::vector<int>> res(texts.size());
+        for (size_t d = 0; d < texts.size(); ++d) res[d].assign(out.begin() + toffs[d], out.begin() + toffs[d + 1]);
+        return res;
+    }
+
+    py::bytes decode_to_bytes(py::array_t<int32_t, py::array::c_style | py::array::forcecast> tokens) {
+        std::string out((size_t)tokens.size() * 8 + 64, '\0');
+        int64_t nb = 0;
+        int rc;
+        {
+            py::gil_scoped_release rel;
+            rc = td_decode_bytes(h_, tokens.data(), (int64_t)tokens.size(), (uint8_t*)&out[0], (int64_t)out.size(), &nb);
+            if (rc == TD_E_CAPACITY && nb > (int64_t)out.size()) {
+                out.resize((size_t)nb);
+                rc = td_decode_bytes(h_, tokens.data(), (int64_t)tokens.size(), (uint8_t*)&out[0], (int64_t)out.size(), &nb);
+            }
+        }
+        if (rc != TD_OK) fail();
+        out.resize((size_t)nb);
+        return py::bytes(out);
+    }
+
+    int64_t info(int what) const { return td_info(h_, what); }
+    uintptr_t handle() const { return (uintptr_t)h_; }
+
+private:
+    td_tokenizer* h_ = nullptr;
+    std::map<std::string, int32_t> special_ids_;
+};
+
+}  // namespace
+
+PYBIND11_MODULE(_tokendagger_core, m) {
+    m.doc() = "tokendagger_amd low-level bindings: the TokenDagger CoreBPE surface over the MI355X HIP library";
+
+    py::class_<VocabItem>(m, "VocabItem")
+        .def(py::init<>())
+        .def_readwrite("rank", &VocabItem::rank)
+        .def_readwrite("token_bytes", &VocabItem::token_bytes)
+        .def_readwrite("token_string", &VocabItem::token_string);
+
+    py::register_exception<TiktokenError>(m, "TiktokenError");
+
+    py::class_<CoreBPE>(m, "CoreBPE")
+        .def(py::init<const std::string&, const std::vector<VocabItem>&, const std::vector<VocabItem>&, int>(),
+             py::arg("pattern"), py::arg("vocab"), py::arg("special_vocab"), py::arg("device") = -1)
+        .def("encode_ordinary", [](CoreBPE& self, const std::string& text) { return self.encode_mode(text, TD_MODE_ORDINARY); },
+             py::arg("text"))
+        .def("encode", &CoreBPE::encode, py::arg("text"), py::arg("allowed_special"))
+        .def("decode_bytes", &CoreBPE::decode_bytes, py::arg("tokens"))
+        .def("special_tokens", &CoreBPE::special_tokens)
+        .def("encode_with_special_tokens", &CoreBPE::encode_with_special_tokens, py::arg("text"))
+        .def("encode_batch", &CoreBPE::encode_batch, py::arg("texts"), py::arg("mode") = TD_MODE_ENCODE)
+        .def("encode_batch_numpy", &CoreBPE::encode_batch_numpy, py::arg("text"), py::arg("offsets"), py::arg("mode") = TD_MODE_ENCODE)
+        .def("decode_to_bytes", &CoreBPE::decode_to_bytes, py::arg("tokens"))
+        .def("info", &CoreBPE::info, py::arg("what"))
+        .def("handle", &CoreBPE::handle);
+}

@@ -150,7 +150,10 @@ __device__ __forceinline__ void load_bitwin(BitWin& w, const uint64_t* s_mask, i
 // Pre-tokenizer: the regex split of the reference (CoreBPE::split_text, tiktoken.cpp:70-128) as a
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
 // piece starts.  One workgroup per 4 KiB tile (+64 B left / 192 B right halo), persistent grid.
-__global__ __launch_bounds__(K_THREADS) void td_split_tiles(const EncodeArgs a) {
+#ifndef TD_SPLIT_MIN_WAVES
+#define TD_SPLIT_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
     __shared__ __attribute__((aligned(16))) uint64_t s_mask[(K_MWORDS + 1) * MK_COUNT];  // class masks, word-major
     __shared__ __attribute__((aligned(16))) uint8_t s_fb[K_WIN];                          // feature byte per text byte
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(K_THREADS) void td_split_tiles(const EncodeArgs a) 
 constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per tile by this kernel
 
 #ifndef TD_TILES_MIN_WAVES
-#define TD_TILES_MIN_WAVES 1
+#define TD_TILES_MIN_WAVES 4
 #endif
 __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_BWIN + 16];
