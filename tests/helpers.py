@@ -99,6 +99,9 @@ class Twin:
         lib.twin_bits_check.restype = ctypes.c_int64
         lib.twin_bits_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        lib.twin_arrmask_check.restype = ctypes.c_int64
+        lib.twin_arrmask_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
+                                           ctypes.c_int64, ctypes.c_void_p]
         lib.twin_encode.restype = ctypes.c_int64
         lib.twin_encode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
@@ -162,6 +165,13 @@ class Twin:
         bad = self._lib.twin_bits_check(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, ctypes.byref(un),
                                         ctypes.byref(ck))
         return int(bad), un.value, ck.value
+
+    def arrmask_check(self, data: bytes, offs=None) -> tuple[int, int]:
+        """-> (mismatches, checked) of the array-mask scanner (no run-length limit) against the byte scanner"""
+        offs = self._offs(data, offs)
+        ck = ctypes.c_int64(0)
+        bad = self._lib.twin_arrmask_check(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, ctypes.byref(ck))
+        return int(bad), ck.value
 
     def encode_batch(self, data: bytes, offs=None, mode: int = 0):
         offs = self._offs(data, offs)

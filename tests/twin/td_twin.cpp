@@ -281,4 +281,34 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
     return bad;
 }
 
+// ArrMaskP (mask words in an array, unlimited run length) vs byte scanner on every true piece start of the text.
+int64_t twin_arrmask_check(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, int64_t* n_checked) {
+    Twin* t = (Twin*)h;
+    std::vector<uint8_t> cls;
+    classify_all(t->H.view(), text, n, offs, n_docs, cls);
+    GAcc g{cls.data(), text, n, n + 4};
+    const int64_t nw = (n + 4 + 63) / 64 + 1;
+    std::vector<uint64_t> arr((size_t)nw * MK_COUNT, 0);
+    for (int64_t i = 0; i < nw * 64; ++i) {
+        const uint32_t v = g.cf(i), vp = i > 0 ? g.cf(i - 1) : 0u;
+        const uint32_t bits = mask_bits_of(vp, v);
+        for (int k = 0; k < MK_COUNT; ++k)
+            if ((bits >> k) & 1u) arr[(size_t)(i >> 6) * MK_COUNT + k] |= 1ull << (i & 63);
+    }
+    int64_t bad = 0, checked = 0;
+    auto bytes = [&](int i) { return g.byte(i); };
+    for (int64_t p = 0; p < n;) {
+        const int64_t e = scan_piece(g, p);
+        if (n + 4 < 0x7FFFFFFF) {
+            ArrMaskP mp(arr.data(), (int)p, (int)(n + 4));
+            const int r = scan_piece_p(mp, bytes);
+            ++checked;
+            if (r != (int)e) ++bad;
+        }
+        p = e;
+    }
+    if (n_checked) *n_checked = checked;
+    return bad;
+}
+
 }  // extern "C"

@@ -38,6 +38,7 @@ struct DevBuf {
 struct td_tokenizer {
     HostTables H;
     Tables dT;  // device pointers
+    const Tables* dTp = nullptr;  // the same descriptor, in device memory
     int device = 0;
     std::vector<void*> table_allocs;
     std::string err;
@@ -128,7 +129,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     if (n_tiles > 0x7FFFFFF0ll) { t->err = "input too large"; return TD_E_INVALID; }
     EncodeArgs a;
     memset(&a, 0, sizeof a);
-    a.T = t->dT;
+    a.Tp = t->dTp;
     a.text = (const uint8_t*)d_text;
     a.n = n;
     a.doc_offsets = (const int64_t*)d_offs;
@@ -265,6 +266,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if ((rc = upload(t, H.tok_off.data(), H.tok_off.size(), &d.tok_off))) return fail(rc);
     if ((rc = upload(t, H.tok_bytes.data(), H.tok_bytes.size(), &d.tok_bytes))) return fail(rc);
     t->dT = d;
+    if ((rc = upload(t, &t->dT, 1, &t->dTp))) return fail(rc);
     if ((rc = ensure(t, t->ctl, sizeof(Ctl)))) return fail(rc);
     if (hipMemset(t->ctl.p, 0, sizeof(Ctl)) != hipSuccess) { t->err = "hipMemset failed"; return fail(TD_E_HIP); }
     *out = t;
@@ -373,7 +375,7 @@ int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, ui
     HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
     DecodeArgs a;
     memset(&a, 0, sizeof a);
-    a.T = t->dT;
+    a.Tp = t->dTp;
     a.tokens = (const int32_t*)t->dec_tokens.p;
     a.n = n_tokens;
     a.byte_off = (int64_t*)t->dec_off.p;

@@ -443,14 +443,90 @@ TD_HD uint32_t mask_bits_of(uint32_t vp, uint32_t v) {
     r |= is_sync(vp, v) ? (1u << MK_SYNC) : 0u;
     return r;
 }
-// Mask version of scan_contraction: `bytes(i)` returns the raw byte at window offset i.
-template <class B>
-TD_HD int scan_contraction_bits(const BitWin& w, const B& bytes, int e, int avail) {
-    if (e + 3 > avail) return -1;
-    if (!((w.m[MK_A] >> e) & 1ull) || ((w.m[MK_D] >> e) & 1ull)) return e;
-    if ((w.m[MK_D] >> (e + 1)) & 1ull) return e;
+// Mask providers.  A provider answers bit / run questions about the class masks around one piece start `o`;
+// end-of-subject marks (MK_D) count only at positions > o.  Positions >= lim are unreadable: run_end may
+// return a value >= lim, which the scanner reports as -1 ("needs more look-ahead").
+//   WinP : the 64-bit register window (BitWin) — run ends are single ctz operations
+//   (the kernel's LdsMaskP walks the mask words in LDS and has no length limit below the staged window)
+struct WinP {
+    const BitWin& w;
+    int o, lim;
+    uint64_t E;  // end-of-subject bits after o
+    TD_HD WinP(const BitWin& w_, int o_, int avail) : w(w_), o(o_), lim(avail), E(w_.m[MK_D] & ~td_bits_below(o_ + 1)) {}
+    TD_HD bool bit(int k, int i) const { return (w.m[k] >> i) & 1ull; }
+    TD_HD bool ebit(int i) const { return (E >> i) & 1ull; }
+    TD_HD int run_end(int k, int from) const { return td_run_end(w.m[k] & ~E, from); }
+    TD_HD int last_and(int k1, int k2, int lo, int hi) const {  // highest i in [lo,hi) with both bits set, -1 if none
+        const uint64_t m = w.m[k1] & w.m[k2] & td_bits_below(hi) & ~td_bits_below(lo);
+        return m ? td_top64(m) - 1 : -1;
+    }
+    TD_HD int last_set(int k, int lo, int hi) const {
+        const uint64_t m = w.m[k] & td_bits_below(hi) & ~td_bits_below(lo);
+        return m ? td_top64(m) - 1 : -1;
+    }
+    TD_HD int last_clear(int k, int lo, int hi) const {
+        const uint64_t m = ~w.m[k] & td_bits_below(hi) & ~td_bits_below(lo);
+        return m ? td_top64(m) - 1 : -1;
+    }
+};
+
+// Provider over a word-major mask array (word i>>6 of mask k at arr[(i>>6)*MK_COUNT + k]): no limit on run
+// length below `lim`.  Used for pieces / look-ahead that do not fit a 64-bit register window.
+struct ArrMaskP {
+    const uint64_t* arr;
+    int o, lim;
+    TD_HD ArrMaskP(const uint64_t* a, int o_, int lim_) : arr(a), o(o_), lim(lim_) {}
+    TD_HD uint64_t word(int k, int wi) const { return arr[wi * MK_COUNT + k]; }
+    TD_HD uint64_t eword(int wi) const {  // end-of-subject bits after o
+        const int wo = o >> 6;
+        if (wi < wo) return 0;
+        const uint64_t d = word(MK_D, wi);
+        return wi == wo ? d & ~td_bits_below((o & 63) + 1) : d;
+    }
+    TD_HD bool bit(int k, int i) const { return (word(k, i >> 6) >> (i & 63)) & 1ull; }
+    TD_HD bool ebit(int i) const { return i > o && bit(MK_D, i); }
+    TD_HD int run_end(int k, int from) const {
+        int i = from;
+        while (i < lim) {
+            const int wi = i >> 6, sh = i & 63;
+            const uint64_t m = (word(k, wi) & ~eword(wi)) >> sh;
+            const int t = td_ctz64(~m);
+            if (t < 64 - sh) return i + t;
+            i += 64 - sh;
+        }
+        return i;
+    }
+    template <class F>
+    TD_HD int last_where(const F& f, int lo, int hi) const {  // highest i in [lo,hi) whose bit in f(word index) is set
+        if (hi <= lo) return -1;
+        for (int wi = (hi - 1) >> 6; wi >= (lo >> 6); --wi) {
+            uint64_t m = f(wi);
+            const int base = wi << 6;
+            if (hi - base < 64) m &= td_bits_below(hi - base);
+            if (lo > base) m &= ~td_bits_below(lo - base);
+            if (m) return base + td_top64(m) - 1;
+        }
+        return -1;
+    }
+    TD_HD int last_and(int k1, int k2, int lo, int hi) const {
+        return last_where([&](int wi) { return word(k1, wi) & word(k2, wi); }, lo, hi);
+    }
+    TD_HD int last_set(int k, int lo, int hi) const {
+        return last_where([&](int wi) { return word(k, wi); }, lo, hi);
+    }
+    TD_HD int last_clear(int k, int lo, int hi) const {
+        return last_where([&](int wi) { return ~word(k, wi); }, lo, hi);
+    }
+};
+
+// (?i:'s|'t|'re|'ve|'m|'ll|'d)? on masks; `bytes(i)` returns the raw byte at position i.
+template <class P, class B>
+TD_HD int scan_contraction_p(const P& p, const B& bytes, int e) {
+    if (e + 3 > p.lim) return -1;
+    if (!p.bit(MK_A, e) || p.bit(MK_D, e)) return e;
+    if (p.bit(MK_D, e + 1)) return e;
     const uint32_t b1 = bytes(e + 1);
-    const bool d2 = (w.m[MK_D] >> (e + 2)) & 1ull;
+    const bool d2 = p.bit(MK_D, e + 2);
     if (b1 < 0x80) {
         const uint32_t l1 = b1 | 0x20;
         if (l1 == 's' || l1 == 't' || l1 == 'm' || l1 == 'd') return e + 2;
@@ -466,21 +542,19 @@ TD_HD int scan_contraction_bits(const BitWin& w, const B& bytes, int e, int avai
     return e;
 }
 
-// End offset (window-relative) of the piece starting at offset o (< avail), or -1 (needs bits >= avail).
-template <class B>
-TD_HD int scan_piece_bits(const BitWin& w, const B& bytes, int o, int avail) {
-    // end-of-subject marks count only after the piece start
-    const uint64_t E = w.m[MK_D] & ~td_bits_below(o + 1);
-    const uint64_t U = w.m[MK_U] & ~E, W = w.m[MK_W] & ~E, X = w.m[MK_X] & ~E, S = w.m[MK_S] & ~E;
-    const uint64_t N = w.m[MK_N] & ~E, C = w.m[MK_C];
-    const bool u0 = (U >> o) & 1, w0 = (W >> o) & 1, x0 = (X >> o) & 1, s0 = (S >> o) & 1, n0 = (N >> o) & 1;
-    const bool cr0 = (w.m[MK_CR] >> o) & 1;
-    const int p1 = td_run_end(C, o + 1);  // end of the first character
-    if (p1 >= avail) return -1;
+// End of the piece starting at p.o, in the provider's coordinates, or -1 (needs positions >= p.lim).
+template <class P, class B>
+TD_HD int scan_piece_p(const P& p, const B& bytes) {
+    const int o = p.o, lim = p.lim;
+    const bool u0 = p.bit(MK_U, o), w0 = p.bit(MK_W, o), x0 = p.bit(MK_X, o), s0 = p.bit(MK_S, o), n0 = p.bit(MK_N, o);
+    const bool cr0 = p.bit(MK_CR, o);
+    int p1 = o + 1;  // end of the first character
+    while (p1 < lim && p.bit(MK_C, p1)) ++p1;
+    if (p1 >= lim) return -1;
     if (!cr0 && !n0) {
         const bool prefixable = x0 || s0;  // [^\r\n\p{L}\p{N}] = X or non-CR/LF whitespace
         const bool l0 = u0 || w0;
-        const bool l1 = prefixable && (((U | W) >> p1) & 1);
+        const bool l1 = prefixable && !p.ebit(p1) && (p.bit(MK_U, p1) || p.bit(MK_W, p1));
         if (l0 || l1) {
             // candidates in backtracking order: alt1 from p1, alt1 from o, alt2 from p1, alt2 from o
             int e1 = 0, e2 = 0;  // first successful alt-1 / alt-2 end (0 = none)
@@ -488,64 +562,69 @@ TD_HD int scan_piece_bits(const BitWin& w, const B& bytes, int o, int avail) {
                 const bool use = k == 0 ? l1 : l0;
                 if (!use) continue;
                 const int st = k == 0 ? p1 : o;
-                const int q = td_run_end(U, st);
-                if (q >= avail) return -1;
-                const bool wf = (W >> q) & 1;
+                const int q = p.run_end(MK_U, st);
+                if (q >= lim) return -1;
+                const bool wf = p.bit(MK_W, q) && !p.ebit(q);
                 int ew = q;
                 if (wf) {
-                    ew = td_run_end(W, q);
-                    if (ew >= avail) return -1;
+                    ew = p.run_end(MK_W, q);
+                    if (ew >= lim) return -1;
                 }
                 if (!e1) {
                     if (wf) e1 = ew;
                     else {
-                        const uint64_t both = U & W & td_bits_below(q) & ~td_bits_below(st);
-                        if (both) e1 = td_top64(both);
+                        const int lw = p.last_and(MK_U, MK_W, st, q);
+                        if (lw >= 0) e1 = lw + 1;
                     }
                 }
                 if (!e2 && q > st) e2 = ew;
                 if (e1) break;  // alt 1 with the earlier candidate wins over everything that follows
             }
             const int e = e1 ? e1 : e2;
-            if (e) return scan_contraction_bits(w, bytes, e, avail);
+            if (e) return scan_contraction_p(p, bytes, e);
         }
     }
     if (n0) {  // \p{N}{1,3}
         int e = p1;
         for (int k = 1; k < 3; ++k) {
-            if (e >= avail) return -1;
-            if (!((N >> e) & 1)) break;
-            e = td_run_end(C, e + 1);
-            if (e >= avail) return -1;
+            if (e >= lim) return -1;
+            if (!p.bit(MK_N, e) || p.ebit(e)) break;
+            ++e;
+            while (e < lim && p.bit(MK_C, e)) ++e;
+            if (e >= lim) return -1;
         }
         return e;
     }
     {  //  ?[^\s\p{L}\p{N}]+[\r\n/]*
-        const bool sp0 = (w.m[MK_SP] >> o) & 1;
-        int st = -1, e = 0;
-        if (sp0 && ((X >> (o + 1)) & 1)) st = o + 1;
+        int st = -1;
+        if (p.bit(MK_SP, o) && p.bit(MK_X, o + 1) && !p.ebit(o + 1)) st = o + 1;
         else if (x0) st = o;
         if (st >= 0) {
-            e = td_run_end(X, st);
-            if (e >= avail) return -1;
-            e = td_run_end(w.m[MK_TR] & ~E, e);
-            if (e >= avail) return -1;
+            int e = p.run_end(MK_X, st);
+            if (e >= lim) return -1;
+            e = p.run_end(MK_TR, e);
+            if (e >= lim) return -1;
             return e;
         }
     }
     if (s0) {  // \s*[\r\n]+ | \s+(?!\S) | \s+
-        const int q = td_run_end(S, o);
-        if (q >= avail) return -1;
-        const uint64_t in_run = td_bits_below(q) & ~td_bits_below(o);
-        const uint64_t crs = w.m[MK_CR] & in_run;
-        if (crs) return td_top64(crs);
-        if ((E >> q) & 1) return q;
-        const uint64_t leads = ~C & in_run;
-        const int last_lead = td_top64(leads) - 1;
+        const int q = p.run_end(MK_S, o);
+        if (q >= lim) return -1;
+        const int lc = p.last_set(MK_CR, o, q);
+        if (lc >= 0) return lc + 1;
+        if (p.ebit(q)) return q;
+        const int last_lead = p.last_clear(MK_C, o, q);
         if (last_lead > o) return last_lead;
         return q;
     }
     return p1;
+}
+
+// register-window form (the fast path of td_split_tiles)
+template <class B>
+TD_HD int scan_piece_bits(const BitWin& w, const B& bytes, int o, int avail) {
+    const WinP p(w, o, avail);
+    return scan_piece_p(p, bytes);
 }
 
 // Feature byte: the class-set memberships of one byte, one bit each (what phase 1 of the kernel keeps

@@ -15,7 +15,8 @@ struct LongEntry {      // a piece longer than K_MAXSHORT bytes, merged by td_lo
 };
 
 struct EncodeArgs {
-    Tables T;
+    const Tables* Tp;           // the table descriptor lives in device memory (keeps the kernel argument block small
+                                // and lets out-of-line helpers take a pointer without spilling kernargs to scratch)
     const uint8_t* text;        // [n] UTF-8, all documents concatenated
     int64_t n;
     const int64_t* doc_offsets; // [n_docs+1], doc_offsets[0]==0, doc_offsets[n_docs]==n
@@ -46,7 +47,7 @@ struct EncodeArgs {
 };
 
 struct DecodeArgs {
-    Tables T;
+    const Tables* Tp;
     const int32_t* tokens;      // [n]
     int64_t n;
     int64_t* byte_off;          // [n+1] scratch: exclusive scan of token byte lengths

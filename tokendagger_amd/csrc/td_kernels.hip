@@ -163,7 +163,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const Tables& T = a.T;
+    const Tables& T = *a.Tp;
     if (tid < 128) s_lut[tid] = (uint8_t)feature_of_class(T.ascii_cls[tid]);
 
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -268,8 +268,6 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
 
         // ---- phase 2: piece boundaries (bit-parallel scanner; byte scanner / HBM as fallbacks) --
         {
-            LdsAcc L;
-            L.T = &T; L.src = src; L.lim = K_LIM;
             GlobAcc G;
             G.T = &T; G.s.text = a.text; G.s.docbits = a.docbits; G.s.lo = 0; G.s.hi = a.n; G.n = a.n; G.lim = a.n + 4;
             int s = -1;
@@ -314,7 +312,9 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     int e;
                     if (r >= 0) e = base + r;
                     else {
-                        e = scan_piece(L, p);  // piece or look-ahead longer than a mask window
+                        // piece or look-ahead longer than a 64-byte register window: same matcher on the mask words in LDS
+                        const ArrMaskP mp(s_mask, p, K_LIM);
+                        e = scan_piece_p(mp, [&](int q) { return (uint32_t)s_txt[q]; });
                         if (e < 0) {
                             const int64_t ge = G.scan(wg0 + p);
                             if (ge - wg0 > (int64_t)K_LIM) break;  // piece leaves the window: the rest belongs to later tiles
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const Tables& T = a.T;
+    const Tables& T = *a.Tp;
     s_byteid[tid] = T.byte_id[tid];
 
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -649,30 +649,137 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
 }
 
 // ------------------------------------------------------------------ td_long_pieces ----------
-// One wavefront per piece longer than K_MAXSHORT bytes.  Parts live in HBM scratch (4 u32 arrays
-// of `len`: id, rank, next, prev); every round the lanes stride over the part array for the
-// lowest-rank leftmost pair, lane 0 applies the merge.  O(len^2/64) like the reference's O(len^2)
-// (tiktoken.cpp:322-343) but rare: only runs, base64 blobs, very long identifiers.
+// Pieces longer than K_MAXSHORT bytes (runs of one character, long identifiers, CJK sentences ...).
+// The merge is inherently sequential per piece (one lowest-rank pair per round, tiktoken.cpp:322-343), so
+// the kernel buys throughput with pieces in flight: parts live in LDS, kept dense (a merge shifts the tail
+// left by one), and a piece gets a 16-lane group (<= 256 B, four pieces per wavefront) or a whole wavefront
+// (<= 1024 B).  Per round: strided min over the rank array, shuffle min-reduce (key = rank<<10 | position,
+// so ties go left), shift, two pair-table probes.  Anything longer falls back to parts in an HBM pool.
+constexpr int LP_SMALL = 256;    // bytes handled by a 16-lane group
+constexpr int LP_MEDIUM = 1024;  // bytes handled by a wavefront
+constexpr int LP_SLOTS = 16;     // ceil(LP_SMALL/16) == ceil(LP_MEDIUM/64)
+
+template <int G>
+__device__ __forceinline__ uint32_t lp_merge_lds(const Tables& T, volatile uint32_t* id, volatile uint32_t* rk, uint32_t m, int gl) {
+    for (;;) {
+        uint32_t best = 0xFFFFFFFFu;
+        for (uint32_t q = gl; q + 1 < m; q += G) {
+            const uint32_t r = rk[q];
+            if (r != (uint32_t)NO_RANK) {
+                const uint32_t key = (r << 10) | q;
+                best = key < best ? key : best;
+            }
+        }
+#pragma unroll
+        for (int d = G / 2; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(best, d, G);
+            best = o < best ? o : best;
+        }
+        if (best == 0xFFFFFFFFu) break;
+        const uint32_t w = best & 1023u, r = best >> 10;
+        // close the gap left by the absorbed part w+1: read everything first, then write (lanes overlap)
+        uint32_t ti[LP_SLOTS], tr[LP_SLOTS];
+#pragma unroll
+        for (int u = 0; u < LP_SLOTS; ++u) {
+            const uint32_t q = w + 2 + gl + u * G;
+            ti[u] = q < m ? id[q] : 0u;
+            tr[u] = q < m ? rk[q] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < LP_SLOTS; ++u) {
+            const uint32_t q = w + 2 + gl + u * G;
+            if (q < m) { id[q - 1] = ti[u]; rk[q - 1] = tr[u]; }
+        }
+        --m;
+        if (gl == 0) {
+            id[w] = r;
+            rk[w] = (w + 1 < m) ? (uint32_t)pair_lookup(T, r, id[w + 1]) : (uint32_t)NO_RANK;
+        } else if (gl == 1 && w > 0) {
+            rk[w - 1] = (uint32_t)pair_lookup(T, id[w - 1], r);
+        }
+    }
+    return m;
+}
+
+// one group of G lanes handles entry j entirely in LDS; returns through the entry + tile_extra
+template <int G>
+__device__ __forceinline__ void lp_do_piece(const EncodeArgs& a, const Tables& T, uint32_t j, volatile uint32_t* id,
+                                            volatile uint32_t* rk, int gl) {
+    const int64_t gs = a.long_list[j].gs;
+    const uint32_t len = a.long_list[j].len;
+    const uint8_t* p = a.text + gs;
+    int32_t whole = NO_RANK;
+    if (a.use_fastpath && len <= T.max_token_len) {  // whole-piece table first (CoreBPE::encode, tiktoken.cpp:209-215)
+        if (gl == 0) {
+            auto get = [p](uint32_t k) { return (uint32_t)p[k]; };
+            whole = piece_lookup(T, hash_bytes(get, len), len, get);
+        }
+        whole = __shfl(whole, 0, G);
+    }
+    uint32_t m;
+    if (whole != NO_RANK) {
+        m = 1;
+        if (gl == 0) id[0] = (uint32_t)whole;
+    } else {
+        for (uint32_t q = gl; q < len; q += G) {
+            const uint32_t b = p[q];
+            id[q] = (uint32_t)T.byte_id[b];
+            rk[q] = (q + 1 < len) ? (uint32_t)T.byte_pair[(b << 8) | p[q + 1]] : (uint32_t)NO_RANK;
+        }
+        m = lp_merge_lds<G>(T, id, rk, len, gl);
+    }
+    unsigned long long off = 0;
+    if (gl == 0) off = atomicAdd(a.pool_used, (unsigned long long)m);
+    off = __shfl(off, 0, G);
+    if (off + m > a.pool_cap) {
+        if (gl == 0) raise(a, TD_E_SCRATCH, gs);
+        return;
+    }
+    for (uint32_t q = gl; q < m; q += G) {
+        const uint32_t v = id[q];
+        if ((int32_t)v >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gs);
+        a.pool[off + q] = v;
+    }
+    if (gl == 0) {
+        a.long_list[j].ntok = m;
+        a.long_list[j].pool_off = off;
+        if (m > 1) atomicAdd(&a.tile_extra[gs / K_TILE], m - 1);
+    }
+}
+
 __global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
-    const Tables& T = a.T;
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t s_parts[4][2 * LP_MEDIUM];  // per wavefront: ids | ranks
+    const Tables& T = *a.Tp;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nlong = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
-    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + wv;
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+
+    // pass 1: pieces <= 256 B, a 16-lane group each
+    {
+        const int grp = lane >> 4, gl = lane & 15;
+        volatile uint32_t* id = &s_parts[wv][grp * 2 * LP_SMALL];
+        volatile uint32_t* rk = id + LP_SMALL;
+        for (uint32_t j = wave_global * 4 + grp; j < nlong; j += nwaves * 4)
+            if (a.long_list[j].len <= LP_SMALL) lp_do_piece<16>(a, T, j, id, rk, gl);
+    }
+    // pass 2: pieces <= 1024 B, a wavefront each
+    {
+        volatile uint32_t* id = &s_parts[wv][0];
+        volatile uint32_t* rk = id + LP_MEDIUM;
+        for (uint32_t j = wave_global; j < nlong; j += nwaves) {
+            const uint32_t len = a.long_list[j].len;
+            if (len > LP_SMALL && len <= LP_MEDIUM) lp_do_piece<64>(a, T, j, id, rk, lane);
+        }
+    }
+    // pass 3: anything longer: parts in the HBM pool (4 u32 arrays of `len`: id, rank, next, prev), lane 0 applies
+    // each merge.  O(len^2/64) like the reference's O(len^2), but only for single pieces above 1 KiB.
     for (uint32_t j = wave_global; j < nlong; j += nwaves) {
         const int64_t gs = a.long_list[j].gs;
         const uint32_t len = a.long_list[j].len;
+        if (len <= LP_MEDIUM) continue;
         const uint8_t* p = a.text + gs;
-        // whole-piece table first (CoreBPE::encode, tiktoken.cpp:209-215)
-        int32_t whole = NO_RANK;
-        if (a.use_fastpath && len <= T.max_token_len) {
-            if (lane == 0) {
-                auto get = [p](uint32_t k) { return (uint32_t)p[k]; };
-                whole = piece_lookup(T, hash_bytes(get, len), len, get);
-            }
-            whole = __shfl(whole, 0);
-        }
-        const uint64_t need = (whole != NO_RANK) ? 1ull : 4ull * len;
+        const uint64_t need = 4ull * len;
         unsigned long long off = 0;
         if (lane == 0) off = atomicAdd(a.pool_used, (unsigned long long)need);
         off = __shfl(off, 0);
@@ -681,10 +788,7 @@ __global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
             continue;
         }
         uint32_t ntok = 0;
-        if (whole != NO_RANK) {
-            if (lane == 0) a.pool[off] = (uint32_t)whole;
-            ntok = 1;
-        } else {
+        {
             volatile uint32_t* id = a.pool + off;
             volatile uint32_t* rk = id + len;
             volatile uint32_t* nx = rk + len;
@@ -698,7 +802,6 @@ __global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             for (;;) {
-                // lowest rank, leftmost: 64-bit key (rank << 32 | position); dead parts have rank NO_RANK..
                 unsigned long long best = ~0ull;
                 for (uint32_t i = lane; i < len; i += 64) {
                     const uint32_t r = rk[i];
@@ -781,6 +884,8 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
 __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
     __shared__ uint32_t s_off[K_TILE];
     __shared__ uint32_t s_wave[8];
+    __shared__ uint32_t s_mark[64];
+    __shared__ uint32_t s_nmark;
     const int tid = threadIdx.x;
     const int64_t total = a.tile_base[a.n_tiles];
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -822,15 +927,23 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
                     if (o < a.out_cap) a.out_tokens[o] = (int32_t)v;
                 }
             }
-            for (uint32_t i = 0; i < cnt; ++i) {  // uniform loop; markers are rare
-                const uint32_t v = src[i];
-                if (v & TOK_LONGREF) {
-                    const LongEntry le = a.long_list[v & 0x7FFFFFFFu];
-                    const uint32_t* ps = a.pool + le.pool_off;
-                    for (uint32_t k = tid; k < le.ntok; k += K_THREADS) {
-                        const int64_t o = base + s_off[i] + k;
-                        if (o < a.out_cap) a.out_tokens[o] = (int32_t)ps[k];
-                    }
+            // long-piece markers of this tile, listed once, then expanded cooperatively
+            if (tid == 0) s_nmark = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += K_THREADS)
+                if (src[i] & TOK_LONGREF) {
+                    const uint32_t q = atomicAdd(&s_nmark, 1u);
+                    if (q < 64) s_mark[q] = i;
+                }
+            __syncthreads();
+            const uint32_t nm = s_nmark < 64 ? s_nmark : 64;  // a tile holds at most 4096/65 = 63 long pieces
+            for (uint32_t q = 0; q < nm; ++q) {
+                const uint32_t i = s_mark[q];
+                const LongEntry le = a.long_list[src[i] & 0x7FFFFFFFu];
+                const uint32_t* ps = a.pool + le.pool_off;
+                for (uint32_t k = tid; k < le.ntok; k += K_THREADS) {
+                    const int64_t o = base + s_off[i] + k;
+                    if (o < a.out_cap) a.out_tokens[o] = (int32_t)ps[k];
                 }
             }
         }
@@ -894,7 +1007,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
     if (a.stop_after != 2) {
         hipLaunchKernelGGL(td_encode_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
         if (ev2) (void)hipEventRecord(ev2, stream);
-        hipLaunchKernelGGL(td_long_pieces, dim3(256), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(td_long_pieces, dim3(256 * 5), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(td_scan_tiles, dim3(1), dim3(1024), 0, stream, a);
         hipLaunchKernelGGL(td_pack_tokens, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
     } else if (ev2) (void)hipEventRecord(ev2, stream);
@@ -909,10 +1022,10 @@ __global__ void td_decode_len(const DecodeArgs a) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t id = a.tokens[i];
         int64_t len = 0;
-        if (id < 0 || id > a.T.max_id) {
+        if (id < 0 || id > a.Tp->max_id) {
             if (atomicCAS(a.err, 0, TD_E_BAD_TOKEN) == 0) *a.err_pos = i;
         } else {
-            len = (int64_t)a.T.tok_off[id + 1] - a.T.tok_off[id];
+            len = (int64_t)a.Tp->tok_off[id + 1] - a.Tp->tok_off[id];
         }
         a.byte_off[i + 1] = len;
     }
@@ -942,8 +1055,8 @@ __global__ __launch_bounds__(1024) void td_decode_scan(const DecodeArgs a) {
 __global__ void td_decode_copy(const DecodeArgs a) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t id = a.tokens[i];
-        if (id < 0 || id > a.T.max_id) continue;
-        const uint8_t* src = a.T.tok_bytes + a.T.tok_off[id];
+        if (id < 0 || id > a.Tp->max_id) continue;
+        const uint8_t* src = a.Tp->tok_bytes + a.Tp->tok_off[id];
         const int64_t o = a.byte_off[i], len = a.byte_off[i + 1] - o;
         for (int64_t k = 0; k < len; ++k)
             if (o + k < a.out_cap) a.out[o + k] = src[k];
