@@ -17,6 +17,7 @@ dt = torch.from_numpy(x).cuda(); do = torch.from_numpy(offs).cuda()
 cap = n // 2 + 1024 if kind == 'english' else n
 dk = torch.empty(cap, dtype=torch.int32, device='cuda'); dto = torch.empty(nd + 1, dtype=torch.int64, device='cuda')
 tok.reserve(n, nd + 1); tok.set_option(capi.TD_OPT_PROFILE, 1)
+if os.environ.get('TD_MERGE_MODE'): tok.set_option(98, int(os.environ['TD_MERGE_MODE']))
 s = torch.cuda.current_stream().cuda_stream
 stops = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [2, 3, 4, 0]
 for stop in stops:
