@@ -858,112 +858,142 @@ __global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
 }
 
 // ------------------------------------------------------------------ td_scan_tiles -----------
-// Device-wide exclusive scan of per-tile token counts (one 1024-thread workgroup; n_tiles is
-// N/4096, i.e. 262144 entries for a 1 GiB corpus).
+// Device-wide exclusive scan of the per-tile token counts (n_tiles = N/4096: 65 536 entries for 256 MiB).
+// One 1024-thread workgroup walks the array in coalesced 4096-entry chunks (16 B per lane), wavefront shuffle
+// scans + one LDS hop per chunk, running carry across chunks.
 __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
-    __shared__ unsigned long long s_part[1024];
-    const int tid = threadIdx.x;
-    const int per = (a.n_tiles + 1023) / 1024;
-    const int lo = tid * per, hi = (lo + per < a.n_tiles) ? lo + per : a.n_tiles;
-    unsigned long long sum = 0;
-    for (int t = lo; t < hi; ++t) sum += (a.tile_count[t] & 0x7FFFFFFFu) + a.tile_extra[t];
-    s_part[tid] = sum;
+    __shared__ unsigned long long s_wsum[16];
+    __shared__ unsigned long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const unsigned long long t = (tid >= d) ? s_part[tid - d] : 0;
+    for (int c0 = 0; c0 < a.n_tiles; c0 += 4096) {
+        const int e0 = c0 + tid * 4;
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (e0 + 4 <= a.n_tiles) {
+            const uint4 cnt = *reinterpret_cast<const uint4*>(a.tile_count + e0);
+            const uint4 ext = *reinterpret_cast<const uint4*>(a.tile_extra + e0);
+            v[0] = (cnt.x & 0x7FFFFFFFu) + ext.x; v[1] = (cnt.y & 0x7FFFFFFFu) + ext.y;
+            v[2] = (cnt.z & 0x7FFFFFFFu) + ext.z; v[3] = (cnt.w & 0x7FFFFFFFu) + ext.w;
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (e0 + k < a.n_tiles) v[k] = (a.tile_count[e0 + k] & 0x7FFFFFFFu) + a.tile_extra[e0 + k];
+        }
+        const unsigned long long mine = (unsigned long long)v[0] + v[1] + v[2] + v[3];
+        unsigned long long x = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(x, d);
+            if (lane >= d) x += t;
+        }
+        if (lane == 63) s_wsum[wv] = x;
         __syncthreads();
-        s_part[tid] += t;
+        unsigned long long woff = s_carry;
+        for (int w = 0; w < wv; ++w) woff += s_wsum[w];
+        unsigned long long run = woff + x - mine;  // exclusive prefix of my first element
+        for (int k = 0; k < 4; ++k) {
+            if (e0 + k < a.n_tiles) a.tile_base[e0 + k] = (int64_t)run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = run;  // inclusive total through this chunk
         __syncthreads();
     }
-    unsigned long long run = s_part[tid] - sum;
-    for (int t = lo; t < hi; ++t) {
-        a.tile_base[t] = (int64_t)run;
-        run += (a.tile_count[t] & 0x7FFFFFFFu) + a.tile_extra[t];
-    }
-    if (tid == 1023) {
-        const int64_t total = (int64_t)s_part[1023];
+    if (tid == 0) {
+        const int64_t total = (int64_t)s_carry;
         a.tile_base[a.n_tiles] = total;
         if (total > a.out_cap) raise(a, TD_E_CAPACITY, total);
     }
 }
 
 // ------------------------------------------------------------------ td_pack_tokens ----------
+// staging -> densely packed ids + per-document token offsets.  One WAVEFRONT per tile (a tile's ids are only a
+// few KB: many small independent copies in flight beat few large ones); tiles that contain long-piece markers
+// are left to a second, workgroup-wide pass that expands them.
 __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
     __shared__ uint32_t s_off[K_TILE];
     __shared__ uint32_t s_wave[8];
     __shared__ uint32_t s_mark[64];
     __shared__ uint32_t s_nmark;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t total = a.tile_base[a.n_tiles];
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int nwaves = gridDim.x * (K_THREADS / 64);
+    // pass 1: plain tiles
+    for (int tile = blockIdx.x * (K_THREADS / 64) + wv; tile < a.n_tiles; tile += nwaves) {
         const uint32_t tc = a.tile_count[tile];
-        const uint32_t cnt = tc & 0x7FFFFFFFu;
-        const bool haslong = (tc >> 31) != 0;
+        if (tc >> 31) continue;
+        const uint32_t cnt = tc;
         const int64_t base = a.tile_base[tile];
         const uint32_t* src = a.stage + (size_t)tile * K_TILE;
-        if (!haslong) {
-            for (uint32_t i = tid; i < cnt; i += K_THREADS) {
-                const int64_t o = base + i;
-                if (o < a.out_cap) a.out_tokens[o] = (int32_t)src[i];
-            }
-        } else {
-            // slots expand: a long marker becomes that piece's ntok tokens
-            uint32_t sz[K_CHUNK];
-            uint32_t mine = 0;
-            for (int k = 0; k < K_CHUNK; ++k) {
-                const uint32_t i = tid * K_CHUNK + k;
-                uint32_t s = 0;
-                if (i < cnt) {
-                    const uint32_t v = src[i];
-                    s = (v & TOK_LONGREF) ? a.long_list[v & 0x7FFFFFFFu].ntok : 1u;
-                }
-                sz[k] = s;
-                mine += s;
-            }
-            uint32_t tot;
-            uint32_t run = block_excl_scan(mine, s_wave, tot);
-            for (int k = 0; k < K_CHUNK; ++k) {
-                s_off[tid * K_CHUNK + k] = run;
-                run += sz[k];
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < cnt; i += K_THREADS) {
+        if (base + cnt <= a.out_cap)
+            for (uint32_t i = lane; i < cnt; i += 64) a.out_tokens[base + i] = (int32_t)src[i];
+        const int64_t g_lo = (int64_t)tile * K_TILE;
+        const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
+        for (int64_t d = (int64_t)a.tile_first_doc[tile] + lane; d < a.n_docs; d += 64) {
+            if (a.doc_offsets[d] >= g_hi) break;
+            a.out_offsets[d] = base + a.doc_slot[d];
+        }
+        if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
+            const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
+            for (int64_t d = d_end + lane; d <= a.n_docs; d += 64) a.out_offsets[d] = total;
+        }
+    }
+    // pass 2: tiles with long pieces (slots expand: a marker becomes that piece's ntok ids)
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const uint32_t tc = a.tile_count[tile];
+        if (!(tc >> 31)) continue;  // uniform per workgroup
+        const uint32_t cnt = tc & 0x7FFFFFFFu;
+        const int64_t base = a.tile_base[tile];
+        const uint32_t* src = a.stage + (size_t)tile * K_TILE;
+        uint32_t sz[K_CHUNK];
+        uint32_t mine = 0;
+        if (tid == 0) s_nmark = 0;
+        for (int k = 0; k < K_CHUNK; ++k) {
+            const uint32_t i = tid * K_CHUNK + k;
+            uint32_t sl = 0;
+            if (i < cnt) {
                 const uint32_t v = src[i];
-                if (!(v & TOK_LONGREF)) {
-                    const int64_t o = base + s_off[i];
-                    if (o < a.out_cap) a.out_tokens[o] = (int32_t)v;
-                }
+                sl = (v & TOK_LONGREF) ? a.long_list[v & 0x7FFFFFFFu].ntok : 1u;
             }
-            // long-piece markers of this tile, listed once, then expanded cooperatively
-            if (tid == 0) s_nmark = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < cnt; i += K_THREADS)
-                if (src[i] & TOK_LONGREF) {
-                    const uint32_t q = atomicAdd(&s_nmark, 1u);
-                    if (q < 64) s_mark[q] = i;
-                }
-            __syncthreads();
-            const uint32_t nm = s_nmark < 64 ? s_nmark : 64;  // a tile holds at most 4096/65 = 63 long pieces
-            for (uint32_t q = 0; q < nm; ++q) {
-                const uint32_t i = s_mark[q];
-                const LongEntry le = a.long_list[src[i] & 0x7FFFFFFFu];
-                const uint32_t* ps = a.pool + le.pool_off;
-                for (uint32_t k = tid; k < le.ntok; k += K_THREADS) {
-                    const int64_t o = base + s_off[i] + k;
-                    if (o < a.out_cap) a.out_tokens[o] = (int32_t)ps[k];
-                }
+            sz[k] = sl;
+            mine += sl;
+        }
+        uint32_t tot;
+        uint32_t run = block_excl_scan(mine, s_wave, tot);
+        for (int k = 0; k < K_CHUNK; ++k) {
+            s_off[tid * K_CHUNK + k] = run;
+            run += sz[k];
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += K_THREADS) {
+            const uint32_t v = src[i];
+            if (v & TOK_LONGREF) {
+                const uint32_t q = atomicAdd(&s_nmark, 1u);
+                if (q < 64) s_mark[q] = i;
+            } else {
+                const int64_t o = base + s_off[i];
+                if (o < a.out_cap) a.out_tokens[o] = (int32_t)v;
             }
         }
-        // documents starting inside this tile
+        __syncthreads();
+        const uint32_t nm = s_nmark < 64 ? s_nmark : 64;  // a tile holds at most 4096/65 = 63 long pieces
+        for (uint32_t q = 0; q < nm; ++q) {
+            const uint32_t i = s_mark[q];
+            const LongEntry le = a.long_list[src[i] & 0x7FFFFFFFu];
+            const uint32_t* ps = a.pool + le.pool_off;
+            for (uint32_t k = tid; k < le.ntok; k += K_THREADS) {
+                const int64_t o = base + s_off[i] + k;
+                if (o < a.out_cap) a.out_tokens[o] = (int32_t)ps[k];
+            }
+        }
         {
             const int64_t g_lo = (int64_t)tile * K_TILE;
             const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
             for (int64_t d = (int64_t)a.tile_first_doc[tile] + tid; d < a.n_docs; d += K_THREADS) {
                 if (a.doc_offsets[d] >= g_hi) break;
-                const uint32_t slot = a.doc_slot[d];
-                a.out_offsets[d] = base + (haslong ? s_off[slot] : slot);
+                a.out_offsets[d] = base + s_off[a.doc_slot[d]];
             }
-            if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
+            if (tile == a.n_tiles - 1) {
                 const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
                 for (int64_t d = d_end + tid; d <= a.n_docs; d += K_THREADS) a.out_offsets[d] = total;
             }
@@ -1016,7 +1046,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
         if (ev2) (void)hipEventRecord(ev2, stream);
         hipLaunchKernelGGL(td_long_pieces, dim3(256 * 5), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(td_scan_tiles, dim3(1), dim3(1024), 0, stream, a);
-        hipLaunchKernelGGL(td_pack_tokens, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
     } else if (ev2) (void)hipEventRecord(ev2, stream);
     return hipGetLastError();
 }
