@@ -146,6 +146,22 @@ __device__ __forceinline__ void load_bitwin(BitWin& w, const uint64_t* s_mask, i
     for (int k = 0; k < MK_COUNT; ++k) w.m[k] = sh ? (lo[k] >> sh) | (hi[k] << (64 - sh)) : lo[k];
 }
 
+// 16 text bytes at global offset g (zero outside [0, n)); one coalesced 16 B/lane load when the base is aligned
+__device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (g >= 0 && g + 16 <= a.n && a.text_aligned) {
+        x = *reinterpret_cast<const uint4*>(a.text + g);
+    } else if (g + 16 > 0 && g < a.n) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 16; ++k) {
+            const int64_t gg = g + k;
+            if (gg >= 0 && gg < a.n) w[k >> 2] |= (uint32_t)a.text[gg] << ((k & 3) * 8);
+        }
+        x = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return x;
+}
+
 // ------------------------------------------------------------------ td_split_tiles ----------
 // Pre-tokenizer: the regex split of the reference (CoreBPE::split_text, tiktoken.cpp:70-128) as a
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
@@ -166,27 +182,29 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
     const Tables& T = *a.Tp;
     if (tid < 128) s_lut[tid] = (uint8_t)feature_of_class(T.ascii_cls[tid]);
 
+    static_assert(K_WIN / 16 <= 2 * K_THREADS, "two prefetch registers per lane cover the window");
+    uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
+    if ((int)blockIdx.x < a.n_tiles) {
+        const int64_t w0 = (int64_t)blockIdx.x * K_TILE - K_HL;
+        pf0 = load_text16(a, w0 + (int64_t)tid * 16);
+        if (tid < K_WIN / 16 - K_THREADS) pf1 = load_text16(a, w0 + (int64_t)(K_THREADS + tid) * 16);
+    }
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
         const int64_t wg0 = tile_g0 - K_HL;  // global offset of window index 0 (multiple of 64)
         const int tile_hi = K_HL + (int)((a.n - tile_g0 < K_TILE) ? (a.n - tile_g0) : K_TILE);
         const int c0 = K_HL + tid * K_CHUNK, c1 = c0 + K_CHUNK;
 
-        // ---- phase 0: stage the text window and the document bits -----------------------------
-        for (int v = tid; v < K_WIN / 16; v += K_THREADS) {
-            const int64_t g = wg0 + (int64_t)v * 16;
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (g >= 0 && g + 16 <= a.n && a.text_aligned) {
-                x = *reinterpret_cast<const uint4*>(a.text + g);
-            } else if (g + 16 > 0 && g < a.n) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (int k = 0; k < 16; ++k) {
-                    const int64_t gg = g + k;
-                    if (gg >= 0 && gg < a.n) w[k >> 2] |= (uint32_t)a.text[gg] << ((k & 3) * 8);
-                }
-                x = make_uint4(w[0], w[1], w[2], w[3]);
+        // ---- phase 0: stage the text window and the document bits.  The text of this tile was requested one
+        //      iteration ago (registers pf0/pf1), so its HBM latency is hidden behind the previous tile -----------
+        reinterpret_cast<uint4*>(s_txt)[tid] = pf0;
+        if (tid < K_WIN / 16 - K_THREADS) reinterpret_cast<uint4*>(s_txt)[K_THREADS + tid] = pf1;
+        {
+            const int64_t nwg0 = wg0 + (int64_t)gridDim.x * K_TILE;  // next tile of this workgroup
+            if (tile + (int)gridDim.x < a.n_tiles) {
+                pf0 = load_text16(a, nwg0 + (int64_t)tid * 16);
+                if (tid < K_WIN / 16 - K_THREADS) pf1 = load_text16(a, nwg0 + (int64_t)(K_THREADS + tid) * 16);
             }
-            reinterpret_cast<uint4*>(s_txt)[v] = x;
         }
         {
             const int64_t nwords = (a.n + 31) >> 5;
@@ -368,6 +386,12 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
     const Tables& T = *a.Tp;
     s_byteid[tid] = T.byte_id[tid];
 
+    uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
+    if ((int)blockIdx.x < a.n_tiles) {
+        const int64_t w0 = (int64_t)blockIdx.x * K_TILE;
+        pf0 = load_text16(a, w0 + (int64_t)tid * 16);
+        if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, w0 + (int64_t)(K_THREADS + tid) * 16);
+    }
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
         const int64_t wg0 = tile_g0;                 // window index 0 == first byte of the tile
@@ -375,19 +399,16 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         const int tile_hi = (int)((a.n - tile_g0 < K_TILE) ? (a.n - tile_g0) : K_TILE);
         const int c0 = tid * K_CHUNK, c1 = c0 + K_CHUNK;
 
-        // ---- phase 0: stage text + START bits of the tile (+128 B look-ahead); clear token slots ----
-        for (int v = tid; v < (K_BWIN + 16) / 16; v += K_THREADS) {
-            const int64_t g = wg0 + (int64_t)v * 16;
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (g + 16 <= a.n && a.text_aligned) {
-                x = *reinterpret_cast<const uint4*>(a.text + g);
-            } else if (g < a.n) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (int k = 0; k < 16; ++k)
-                    if (g + k < a.n) w[k >> 2] |= (uint32_t)a.text[g + k] << ((k & 3) * 8);
-                x = make_uint4(w[0], w[1], w[2], w[3]);
+        // ---- phase 0: stage text + START bits of the tile (+128 B look-ahead); clear token slots.  Text was
+        //      requested one iteration ago (pf0/pf1) -----------------------------------------------------------
+        reinterpret_cast<uint4*>(s_txt)[tid] = pf0;
+        if (tid < (K_BWIN + 16) / 16 - K_THREADS) reinterpret_cast<uint4*>(s_txt)[K_THREADS + tid] = pf1;
+        {
+            const int64_t nwg0 = wg0 + (int64_t)gridDim.x * K_TILE;
+            if (tile + (int)gridDim.x < a.n_tiles) {
+                pf0 = load_text16(a, nwg0 + (int64_t)tid * 16);
+                if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, nwg0 + (int64_t)(K_THREADS + tid) * 16);
             }
-            reinterpret_cast<uint4*>(s_txt)[v] = x;
         }
         {
             const int64_t nwords = (a.n + 31) >> 5;
