@@ -262,8 +262,9 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
                     const uint32_t fb = feature_of_class(v & CLS_MASK);
                     const bool okf = (((w.m[MK_U] >> i) & 1) == ((fb & FB_U) != 0)) && (((w.m[MK_W] >> i) & 1) == ((fb & FB_W) != 0)) &&
                                      (((w.m[MK_X] >> i) & 1) == ((fb & FB_X) != 0)) && (((w.m[MK_S] >> i) & 1) == ((fb & FB_S) != 0)) &&
-                                     (((w.m[MK_N] >> i) & 1) == ((fb & FB_N) != 0)) && (((w.m[MK_CR] >> i) & 1) == ((fb & FB_CR) != 0)) &&
-                                     (((SL >> i) & 1) == ((fb & FB_SL) != 0));
+                                     (((w.m[MK_N] >> i) & 1) == fb_is_num(fb)) && (((w.m[MK_CR] >> i) & 1) == ((fb & FB_CR) != 0)) &&
+                                     (((SL >> i) & 1) == ((fb & FB_SL) != 0)) && (((w.m[MK_A] >> i) & 1) == fb_is_apos(fb)) &&
+                                     (((w.m[MK_SP] >> i) & 1) == fb_is_sp(fb));
                     if (!okf) ++bad;
                 }
             }

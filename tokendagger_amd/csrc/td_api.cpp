@@ -44,7 +44,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc;
+    DevBuf docbits, startbits, slow_list, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -89,8 +89,8 @@ struct Ctl {  // small control block in device memory
     int err;
     int pad;
     long long err_pos;
-    uint32_t long_count;
-    uint32_t pad2;
+    uint32_t long_count;   // --- from here on: reset before every call
+    uint32_t slow_count;
     unsigned long long pool_used;
 };
 
@@ -99,6 +99,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     int rc;
     if ((rc = ensure(t, t->docbits, (size_t)((n + 31) / 32 + 2) * 4))) return rc;
     if ((rc = ensure(t, t->startbits, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
+    if ((rc = ensure(t, t->slow_list, (size_t)(n_tiles * 8 + 64) * 8))) return rc;
     if ((rc = ensure(t, t->stage, (size_t)std::max<int64_t>(n_tiles, 1) * K_TILE * 4))) return rc;
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
@@ -136,6 +137,8 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.n_docs = n_docs;
     a.docbits = (uint32_t*)t->docbits.p;
     a.startbits = (uint32_t*)t->startbits.p;
+    a.slow_list = (int64_t*)t->slow_list.p;
+    a.slow_cap = (uint32_t)std::min<size_t>(t->slow_list.cap / 8, 0x7FFFFFF0u);
     a.stage = (uint32_t*)t->stage.p;
     a.tile_count = (uint32_t*)t->tile_count.p;
     a.tile_extra = (uint32_t*)t->tile_extra.p;
@@ -146,6 +149,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.long_cap = (uint32_t)std::min<size_t>(t->long_list.cap / sizeof(LongEntry), 0x7FFFFFF0u);
     Ctl* ctl = (Ctl*)t->ctl.p;
     a.long_count = &ctl->long_count;
+    a.slow_count = &ctl->slow_count;
     a.pool = (uint32_t*)t->pool.p;
     a.pool_cap = t->pool.cap / 4;
     a.pool_used = &ctl->pool_used;
@@ -280,7 +284,7 @@ void td_destroy(td_tokenizer* t) {
     for (void* p : t->table_allocs) (void)hipFree(p);
     for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
     for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
+    DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
                       &t->pool, &t->ctl, &t->tile_first_doc, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                       &t->dec_off, &t->dec_out};
     for (DevBuf* b : bufs)

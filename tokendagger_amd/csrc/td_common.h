@@ -627,14 +627,18 @@ TD_HD int scan_piece_bits(const BitWin& w, const B& bytes, int o, int avail) {
     return scan_piece_p(p, bytes);
 }
 
-// Feature byte: the class-set memberships of one byte, one bit each (what phase 1 of the kernel keeps
-// per byte; a wavefront ballot per bit turns 64 of them into the mask words).
+// Feature byte: the class-set memberships of one byte, one bit each (what phase 1 of the kernel keeps per byte;
+// a wavefront ballot per bit turns 64 of them into the mask words).  FB_N doubles as a tag: X|N = apostrophe,
+// S|N = U+0020 (neither X nor S ever coincides with a real number class), so no second LDS read of the text is
+// needed for those two masks.
 enum : uint32_t { FB_U = 1, FB_W = 2, FB_X = 4, FB_S = 8, FB_N = 16, FB_CR = 32, FB_SL = 64, FB_C = 128 };
 TD_HD uint32_t feature_of_class(uint32_t c) {
     switch (c) {
-        case C_OTHER: case C_APOS: return FB_X;
+        case C_OTHER: return FB_X;
+        case C_APOS: return FB_X | FB_N;
         case C_SLASH: return FB_X | FB_SL;
-        case C_SP: case C_WS: return FB_S;
+        case C_SP: return FB_S | FB_N;
+        case C_WS: return FB_S;
         case C_CRLF: return FB_S | FB_CR;
         case C_UP: return FB_U;
         case C_LW: return FB_W;
@@ -644,6 +648,9 @@ TD_HD uint32_t feature_of_class(uint32_t c) {
     }
     return FB_X;
 }
+TD_HD bool fb_is_num(uint32_t f) { return (f & (FB_N | FB_X | FB_S)) == FB_N; }
+TD_HD bool fb_is_apos(uint32_t f) { return (f & (FB_N | FB_X)) == (FB_N | FB_X); }
+TD_HD bool fb_is_sp(uint32_t f) { return (f & (FB_N | FB_S)) == (FB_N | FB_S); }
 // SYNC mask word from the class mask words of the same 64 bytes; `pf` = feature byte of the byte just
 // before the word (0 if none).  Bit-for-bit the same predicate as is_sync().
 TD_HD uint64_t sync_word(uint64_t U, uint64_t W, uint64_t X, uint64_t S, uint64_t N, uint64_t CR, uint64_t SL,
@@ -651,7 +658,7 @@ TD_HD uint64_t sync_word(uint64_t U, uint64_t W, uint64_t X, uint64_t S, uint64_
     const uint64_t L = (U | W) & ~X;
     const uint64_t pS = (S << 1) | ((pf & FB_S) ? 1ull : 0ull);
     const uint64_t pCR = (CR << 1) | ((pf & FB_CR) ? 1ull : 0ull);
-    const uint64_t pN = (N << 1) | ((pf & FB_N) ? 1ull : 0ull);
+    const uint64_t pN = (N << 1) | (fb_is_num(pf) ? 1ull : 0ull);
     const uint64_t pL = (L << 1) | (((pf & (FB_U | FB_W)) && !(pf & FB_X)) ? 1ull : 0ull);
     uint64_t sy = (S & ~CR & ~pS) | (pCR & ~S & ~SL) | (N ^ pN) | (X & ~(U | W) & ~A & pL);
     return (sy & ~C) | D;

@@ -23,6 +23,9 @@ struct EncodeArgs {
     int64_t n_docs;
     uint32_t* docbits;          // [(n+31)/32+1] bit i set <=> a document starts at byte i
     uint32_t* startbits;        // [(n+31)/32+8] bit i set <=> a regex piece starts at byte i (td_split_tiles -> td_encode_tiles)
+    int64_t* slow_list;         // [slow_cap] positions handed from td_split_tiles to td_split_slow: (byte << 1) | kind
+    uint32_t slow_cap;
+    uint32_t* slow_count;
     uint32_t* stage;            // [n_tiles*K_TILE] per-tile compacted slots (token ids / long markers)
     uint32_t* tile_count;       // [n_tiles] slots in the tile
     uint32_t* tile_extra;       // [n_tiles] sum(ntok-1) over the tile's long pieces

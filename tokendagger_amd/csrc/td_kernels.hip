@@ -254,54 +254,63 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         {
             constexpr int NW = K_MWORDS / (K_THREADS / 64);  // 17 words per wavefront
             static_assert(NW * (K_THREADS / 64) == K_MWORDS, "words must divide evenly");
-            uint32_t ff[NW], bb[NW], pfv[NW];
+            constexpr int NB1 = 9;                            // two batches keep the register arrays short
 #pragma unroll
-            for (int it = 0; it < NW; ++it) {  // all LDS reads first: they are independent
-                const int idx = (wave + it * (K_THREADS / 64)) * 64 + lane;
-                ff[it] = s_fb[idx];
-                bb[it] = s_txt[idx];
-                pfv[it] = (lane == 0 && idx > 0) ? (uint32_t)s_fb[idx - 1] : 0u;  // byte in front of the word
-            }
+            for (int b0 = 0; b0 < NW; b0 += NB1) {
+                uint32_t ff[NB1], pfv[NB1];
 #pragma unroll
-            for (int it = 0; it < NW; ++it) {
-                const int w = wave + it * (K_THREADS / 64);
-                const uint32_t fb = ff[it], b = bb[it];
-                const uint32_t pf = __builtin_amdgcn_readfirstlane(pfv[it]);
-                const uint64_t mU = __ballot(fb & FB_U), mW = __ballot(fb & FB_W), mX = __ballot(fb & FB_X);
-                const uint64_t mS = __ballot(fb & FB_S), mN = __ballot(fb & FB_N), mCR = __ballot(fb & FB_CR);
-                const uint64_t mSL = __ballot(fb & FB_SL), mC = __ballot(fb & FB_C);
-                const uint64_t mA = __ballot(b == 0x27), mSP = __ballot(b == 0x20);
-                const uint64_t mD = ((uint64_t)s_doc[2 * w + 1] << 32) | s_doc[2 * w];
-                const uint64_t mSY = sync_word(mU, mW, mX, mS, mN, mCR, mSL, mC, mD, mA, pf);
-                if (lane == 0) {
-                    static_assert(MK_U == 0 && MK_W == 1 && MK_X == 2 && MK_S == 3 && MK_N == 4 && MK_CR == 5 && MK_TR == 6 &&
-                                  MK_C == 7 && MK_D == 8 && MK_A == 9 && MK_SP == 10 && MK_SYNC == 11, "mask order");
-                    ulonglong2* o = reinterpret_cast<ulonglong2*>(s_mask + w * MK_COUNT);
-                    o[0] = make_ulonglong2(mU, mW); o[1] = make_ulonglong2(mX, mS); o[2] = make_ulonglong2(mN, mCR);
-                    o[3] = make_ulonglong2(mCR | mSL, mC); o[4] = make_ulonglong2(mD, mA); o[5] = make_ulonglong2(mSP, mSY);
+                for (int u = 0; u < NB1; ++u) {  // all LDS reads of the batch first: they are independent
+                    const int it = b0 + u;
+                    if (it < NW) {
+                        const int idx = (wave + it * (K_THREADS / 64)) * 64 + lane;
+                        ff[u] = s_fb[idx];
+                        pfv[u] = (lane == 0 && idx > 0) ? (uint32_t)s_fb[idx - 1] : 0u;  // byte in front of the word
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NB1; ++u) {
+                    const int it = b0 + u;
+                    if (it >= NW) continue;
+                    const int w = wave + it * (K_THREADS / 64);
+                    const uint32_t fb = ff[u];
+                    const uint32_t pf = __builtin_amdgcn_readfirstlane(pfv[u]);
+                    const uint64_t mU = __ballot(fb & FB_U), mW = __ballot(fb & FB_W), mX = __ballot(fb & FB_X);
+                    const uint64_t mS = __ballot(fb & FB_S), mN = __ballot(fb_is_num(fb)), mCR = __ballot(fb & FB_CR);
+                    const uint64_t mSL = __ballot(fb & FB_SL), mC = __ballot(fb & FB_C);
+                    const uint64_t mA = __ballot(fb_is_apos(fb)), mSP = __ballot(fb_is_sp(fb));
+                    const uint64_t mD = ((uint64_t)s_doc[2 * w + 1] << 32) | s_doc[2 * w];
+                    const uint64_t mSY = sync_word(mU, mW, mX, mS, mN, mCR, mSL, mC, mD, mA, pf);
+                    if (lane == 0) {
+                        static_assert(MK_U == 0 && MK_W == 1 && MK_X == 2 && MK_S == 3 && MK_N == 4 && MK_CR == 5 && MK_TR == 6 &&
+                                      MK_C == 7 && MK_D == 8 && MK_A == 9 && MK_SP == 10 && MK_SYNC == 11, "mask order");
+                        ulonglong2* o = reinterpret_cast<ulonglong2*>(s_mask + w * MK_COUNT);
+                        o[0] = make_ulonglong2(mU, mW); o[1] = make_ulonglong2(mX, mS); o[2] = make_ulonglong2(mN, mCR);
+                        o[3] = make_ulonglong2(mCR | mSL, mC); o[4] = make_ulonglong2(mD, mA); o[5] = make_ulonglong2(mSP, mSY);
+                    }
                 }
             }
         }
         __syncthreads();
 
-        // ---- phase 2: piece boundaries (bit-parallel scanner; byte scanner / HBM as fallbacks) --
+        // ---- phase 2: piece boundaries.  Fast path: bit-parallel scanner on a 64-byte register window; pieces or
+        //      look-ahead beyond that use the same matcher on the mask words in LDS.  What even the LDS window
+        //      cannot answer (no sync point in the left halo, a piece or its look-ahead leaving the window) flags
+        //      the tile for td_split_slow, which redoes it byte by byte from HBM. ---------------------------------
         {
-            GlobAcc G;
-            G.T = &T; G.s.text = a.text; G.s.docbits = a.docbits; G.s.lo = 0; G.s.hi = a.n; G.n = a.n; G.lim = a.n + 4;
             int s = -1;
+            // hand-off to td_split_slow: (global position << 1) | kind; kind 1 = "find the first piece start at/after
+            // this tile start", kind 0 = "this piece start is known, its end is not"
+            auto defer = [&](int64_t g, int kind) {
+                const uint32_t q = atomicAdd(a.slow_count, 1u);
+                if (q < a.slow_cap) a.slow_list[q] = (g << 1) | kind;
+                else raise(a, TD_E_SCRATCH, g);
+            };
             if (tid == 0) {
                 // last provable sync point at or before the tile start (window bytes 4..64)
                 const uint64_t w0 = s_mask[0 * MK_COUNT + MK_SYNC] & ~0xFull;
                 if (s_mask[1 * MK_COUNT + MK_SYNC] & 1ull) s = 64;
                 else if (w0) s = td_top64(w0) - 1;
-                else {
-                    int64_t gs = 0;
-                    for (int64_t gi = wg0 + 3; gi > 0; --gi)
-                        if (is_sync(G.cf(gi - 1), G.cf(gi))) { gs = gi; break; }
-                    int64_t p = gs;
-                    while (p < tile_g0) p = G.scan(p);
-                    s = (p - wg0 < (int64_t)tile_hi) ? (int)(p - wg0) : -1;
-                }
+                else defer(tile_g0, 1);
             } else if (c0 < tile_hi) {
                 uint32_t sy = (uint32_t)(s_mask[(c0 >> 6) * MK_COUNT + MK_SYNC] >> (c0 & 63)) & 0xFFFFu;
                 if (c1 > tile_hi) sy &= (1u << (tile_hi - c0)) - 1u;
@@ -330,14 +339,9 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     int e;
                     if (r >= 0) e = base + r;
                     else {
-                        // piece or look-ahead longer than a 64-byte register window: same matcher on the mask words in LDS
                         const ArrMaskP mp(s_mask, p, K_LIM);
                         e = scan_piece_p(mp, [&](int q) { return (uint32_t)s_txt[q]; });
-                        if (e < 0) {
-                            const int64_t ge = G.scan(wg0 + p);
-                            if (ge - wg0 > (int64_t)K_LIM) break;  // piece leaves the window: the rest belongs to later tiles
-                            e = (int)(ge - wg0);
-                        }
+                        if (e < 0) { if (p >= K_HL) defer(wg0 + p, 0); break; }
                     }
                     p = e;
                 }
@@ -354,6 +358,46 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
             }
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ td_split_slow -----------
+// What the LDS-window pre-tokenizer could not decide (next to or inside a piece longer than its halos): one lane
+// per deferred position continues from HBM with the byte scanner (classes computed on the fly) and ORs the
+// missing START bits in, until it lands on a provable sync point — from there on the fast kernel's bits are
+// right.  Exact, slow per byte, and proportional to the length of the offending piece.
+__global__ void td_split_slow(const EncodeArgs a) {
+    const Tables& T = *a.Tp;
+    const uint32_t nslow = *a.slow_count < a.slow_cap ? *a.slow_count : a.slow_cap;
+    GlobAcc G;
+    G.T = &T; G.s.text = a.text; G.s.docbits = a.docbits; G.s.lo = 0; G.s.hi = a.n; G.n = a.n; G.lim = a.n + 4;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nslow; j += gridDim.x * blockDim.x) {
+        const int64_t ent = a.slow_list[j];
+        const int64_t g = ent >> 1;
+        const int64_t tile_g0 = g - (g % K_TILE);
+        const int64_t tile_end = (tile_g0 + K_TILE < a.n) ? tile_g0 + K_TILE : a.n;
+        int64_t p;
+        if (ent & 1) {  // no sync point in the tile's left halo: walk back to one, then forward to the tile
+            p = 0;
+            for (int64_t gi = g; gi > 0; --gi)
+                if (is_sync(G.cf(gi - 1), G.cf(gi))) { p = gi; break; }
+            while (p < g) p = G.scan(p);
+        } else {        // piece start known (and already marked), its end is not
+            p = G.scan(g);
+        }
+        while (p < tile_end) {
+            // stop where a lane of the fast kernel STARTED: the first provable sync point of a 16-byte chunk other
+            // than the tile's first chunk (lane 0 starts from the left halo, never inside its own chunk)
+            if (p != g && is_sync(G.cf(p - 1), G.cf(p))) {
+                const int64_t cs = p - ((p - tile_g0) % K_CHUNK);
+                bool first = cs != tile_g0;
+                for (int64_t q = cs; first && q < p; ++q)
+                    if (is_sync(G.cf(q - 1), G.cf(q))) first = false;
+                if (first) break;
+            }
+            atomicOr(&a.startbits[p >> 5], 1u << (p & 31));
+            p = G.scan(p);
+        }
     }
 }
 
@@ -1061,6 +1105,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
     const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
     if (ev0) (void)hipEventRecord(ev0, stream);
     hipLaunchKernelGGL(td_split_tiles, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(td_split_slow, dim3(64), dim3(64), 0, stream, a);
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (a.stop_after != 2) {
         hipLaunchKernelGGL(td_encode_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
