@@ -137,6 +137,13 @@ __device__ __forceinline__ uint64_t bits64(const uint32_t* arr, int pos) {
     return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
+// pieces / look-ahead longer than a 64-byte register window: the same matcher on the mask words in LDS (cold path,
+// kept out of line so that the hot loop stays small)
+__device__ __noinline__ int scan_piece_lds(const uint64_t* s_mask, const uint8_t* s_txt, int p) {
+    const ArrMaskP mp(s_mask, p, K_LIM);
+    return scan_piece_p(mp, [s_txt](int q) { return (uint32_t)s_txt[q]; });
+}
+
 // the 64-byte mask window that starts at window byte `base`
 __device__ __forceinline__ void load_bitwin(BitWin& w, const uint64_t* s_mask, int base) {
     const int word = base >> 6, sh = base & 63;
@@ -327,20 +334,17 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     if (p - base > 36) { base = p; load_bitwin(wv, s_mask, base); }
                     if (p >= c1 && ((wv.m[MK_SYNC] >> (p - base)) & 1ull)) break;  // the lane owning p starts there
                     if (p >= K_HL) mark(p);
-                    const int avail = (K_LIM - base < 64) ? (K_LIM - base) : 64;
-                    auto bytes = [&](int q) { return (uint32_t)s_txt[base + q]; };
-                    int r = scan_piece_bits(wv, bytes, p - base, avail);
-                    if (r < 0 && p != base) {
+                    int e = -1;
+                    for (int attempt = 0; attempt < 2; ++attempt) {  // second attempt: window re-based at the piece start
+                        const int avail = (K_LIM - base < 64) ? (K_LIM - base) : 64;
+                        const int r = scan_piece_bits(wv, [&](int q) { return (uint32_t)s_txt[base + q]; }, p - base, avail);
+                        if (r >= 0) { e = base + r; break; }
+                        if (p == base) break;
                         base = p;
                         load_bitwin(wv, s_mask, base);
-                        const int avail2 = (K_LIM - base < 64) ? (K_LIM - base) : 64;
-                        r = scan_piece_bits(wv, bytes, 0, avail2);
                     }
-                    int e;
-                    if (r >= 0) e = base + r;
-                    else {
-                        const ArrMaskP mp(s_mask, p, K_LIM);
-                        e = scan_piece_p(mp, [&](int q) { return (uint32_t)s_txt[q]; });
+                    if (e < 0) {
+                        e = scan_piece_lds(s_mask, s_txt, p);  // longer than a register window: mask words in LDS
                         if (e < 0) { if (p >= K_HL) defer(wg0 + p, 0); break; }
                     }
                     p = e;
