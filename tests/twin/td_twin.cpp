@@ -268,6 +268,29 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
                     if (!okf) ++bad;
                 }
             }
+            {   // the kernel's per-8-byte path: feature bytes -> 8x8 transpose -> mask slices -> sync_byte
+                for (int sl = 0; sl < 8; ++sl) {
+                    uint64_t F = 0;
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t v = g.cf(base + sl * 8 + i);
+                        F |= (uint64_t)(feature_of_class(v & CLS_MASK) | ((v & F_CONT) ? FB_C : 0u)) << (8 * i);
+                    }
+                    const uint64_t P = transpose8x8(F);
+                    const uint32_t pU = P & 0xFF, pW = (P >> 8) & 0xFF, pX = (P >> 16) & 0xFF, pS = (P >> 24) & 0xFF;
+                    const uint32_t pNr = (P >> 32) & 0xFF, pCR = (P >> 40) & 0xFF, pSL = (P >> 48) & 0xFF, pC = (P >> 56) & 0xFF;
+                    const uint32_t mN = pNr & ~pX & ~pS, mA = pNr & pX, mSP = pNr & pS;
+                    const int64_t pos = base + sl * 8;
+                    const uint32_t vprev = pos > 0 ? g.cf(pos - 1) : 0u;
+                    const uint32_t pf = pos > 0 ? (feature_of_class(vprev & CLS_MASK) | ((vprev & F_CONT) ? FB_C : 0u)) : 0u;
+                    const uint32_t D = (uint32_t)(w.m[MK_D] >> (8 * sl)) & 0xFF;
+                    const uint32_t sy = sync_byte(pU, pW, pX, pS, mN, pCR, pSL, pC, D, mA, pf);
+                    auto sl8 = [&](int k) { return (uint32_t)(w.m[k] >> (8 * sl)) & 0xFFu; };
+                    if (pU != sl8(MK_U) || pW != sl8(MK_W) || pX != sl8(MK_X) || pS != sl8(MK_S) || mN != sl8(MK_N) ||
+                        pCR != sl8(MK_CR) || (pCR | pSL) != sl8(MK_TR) || pC != sl8(MK_C) || mA != sl8(MK_A) ||
+                        mSP != sl8(MK_SP) || sy != sl8(MK_SYNC))
+                        ++bad;
+                }
+            }
             int avail = 64;
             auto bytes = [&](int i) { return g.byte(base + i); };
             const int r = scan_piece_bits(w, bytes, (int)(p - base), avail);

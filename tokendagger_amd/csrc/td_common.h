@@ -651,6 +651,28 @@ TD_HD uint32_t feature_of_class(uint32_t c) {
 TD_HD bool fb_is_num(uint32_t f) { return (f & (FB_N | FB_X | FB_S)) == FB_N; }
 TD_HD bool fb_is_apos(uint32_t f) { return (f & (FB_N | FB_X)) == (FB_N | FB_X); }
 TD_HD bool fb_is_sp(uint32_t f) { return (f & (FB_N | FB_S)) == (FB_N | FB_S); }
+// 8x8 bit-matrix transpose: input = 8 bytes (byte j = row j), output byte k = column k (bit j of it = bit k of
+// input byte j).  Turns 8 feature bytes into the 8 per-feature bit planes of those 8 text bytes.
+TD_HD uint64_t transpose8x8(uint64_t x) {
+    uint64_t t;
+    t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x ^= t ^ (t << 7);
+    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x ^= t ^ (t << 14);
+    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x ^= t ^ (t << 28);
+    return x;
+}
+// 8-bit slice of the SYNC mask from the 8-bit slices of the class masks (same predicate as sync_word / is_sync);
+// `pf` = feature byte of the byte in front of the slice.
+TD_HD uint32_t sync_byte(uint32_t U, uint32_t W, uint32_t X, uint32_t S, uint32_t N, uint32_t CR, uint32_t SL,
+                         uint32_t C, uint32_t D, uint32_t A, uint32_t pf) {
+    const uint32_t L = (U | W) & ~X;
+    const uint32_t pS = (S << 1) | ((pf & FB_S) ? 1u : 0u);
+    const uint32_t pCR = (CR << 1) | ((pf & FB_CR) ? 1u : 0u);
+    const uint32_t pN = (N << 1) | (fb_is_num(pf) ? 1u : 0u);
+    const uint32_t pL = (L << 1) | (((pf & (FB_U | FB_W)) && !(pf & FB_X)) ? 1u : 0u);
+    const uint32_t sy = (S & ~CR & ~pS) | (pCR & ~S & ~SL) | (N ^ pN) | (X & ~(U | W) & ~A & pL);
+    return ((sy & ~C) | D) & 0xFFu;
+}
+
 // SYNC mask word from the class mask words of the same 64 bytes; `pf` = feature byte of the byte just
 // before the word (0 if none).  Bit-for-bit the same predicate as is_sync().
 TD_HD uint64_t sync_word(uint64_t U, uint64_t W, uint64_t X, uint64_t S, uint64_t N, uint64_t CR, uint64_t SL,

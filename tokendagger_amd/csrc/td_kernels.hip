@@ -74,6 +74,14 @@ struct GlobAcc {
     __device__ __noinline__ int64_t scan(int64_t pos) const { return scan_piece(*this, pos); }
 };
 
+// feature byte of a non-ASCII byte of the LDS window (out of line: the UTF-8 / 2-stage-table walk is only needed for
+// non-ASCII text and must not be replicated into the hot ASCII path)
+__device__ __noinline__ uint32_t feature_at(const Tables& T, const LdsSrc& src, int idx) {
+    if (idx < src.lo || idx >= src.hi) return FB_X;
+    const uint32_t c = classify_at(T, src, idx);
+    return feature_of_class(c & CLS_MASK) | ((c & F_CONT) ? (uint32_t)FB_C : 0u);
+}
+
 __device__ __forceinline__ void raise(const EncodeArgs& a, int code, int64_t pos) {
     if (atomicCAS(a.err, 0, code) == 0) *a.err_pos = pos;
 }
@@ -179,13 +187,12 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
     __shared__ __attribute__((aligned(16))) uint64_t s_mask[(K_MWORDS + 1) * MK_COUNT];  // class masks, word-major
-    __shared__ __attribute__((aligned(16))) uint8_t s_fb[K_WIN];                          // feature byte per text byte
     __shared__ uint32_t s_start[K_WIN / 32 + 3];  // bit i: a piece starts at window byte i
     __shared__ uint32_t s_doc[K_WIN / 32 + 2];
     __shared__ uint8_t s_lut[128];                // ASCII byte -> feature byte
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     const Tables& T = *a.Tp;
     if (tid < 128) s_lut[tid] = (uint8_t)feature_of_class(T.ascii_cls[tid]);
 
@@ -226,78 +233,57 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         }
         __syncthreads();
 
-        // ---- phase 1a: feature byte per text byte (ASCII: LUT in LDS; otherwise 2-stage Unicode table in L2)
+        // ---- phase 1: class masks.  Every lane takes 8 text bytes: feature byte per byte (ASCII: 128-B LUT in LDS;
+        //      otherwise UTF-8 decode + 2-stage Unicode table in L2), an 8x8 bit transpose turns the 8 feature bytes
+        //      into the 8-bit slices of the class masks, the SYNC slice follows from them and the neighbour's last
+        //      byte; 12 byte stores put the slices into the word-major mask array ------------------------------------
         LdsSrc src;
         src.txt = s_txt;
         src.docw = s_doc;
         src.lo = (wg0 < 0) ? -wg0 : 0;
         src.hi = (a.n - wg0 < K_WIN) ? (a.n - wg0) : K_WIN;
-        for (int d = tid; d < K_WIN / 4; d += K_THREADS) {
-            const uint32_t w = reinterpret_cast<const uint32_t*>(s_txt)[d];
-            uint32_t out;
-            if (!(w & 0x80808080u)) {
-                out = (uint32_t)s_lut[w & 0x7F] | ((uint32_t)s_lut[(w >> 8) & 0x7F] << 8) |
-                      ((uint32_t)s_lut[(w >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[(w >> 24) & 0x7F] << 24);
-            } else {
-                out = 0;
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t b = (w >> (8 * k)) & 0xFF;
-                    const int64_t i = (int64_t)d * 4 + k;
-                    uint32_t f;
-                    if (b < 0x80) f = s_lut[b];
-                    else if (i >= src.lo && i < src.hi) {
-                        const uint32_t c = classify_at(T, src, i);
-                        f = feature_of_class(c & CLS_MASK) | ((c & F_CONT) ? (uint32_t)FB_C : 0u);
-                    } else f = FB_X;
-                    out |= f << (8 * k);
-                }
-            }
-            reinterpret_cast<uint32_t*>(s_fb)[d] = out;
-        }
         if (tid < MK_COUNT) s_mask[K_MWORDS * MK_COUNT + tid] = 0;  // zero word behind the last one
-        __syncthreads();
-
-        // ---- phase 1b: class mask words: one wavefront ballot per class set and 64-byte word ----------
-        {
-            constexpr int NW = K_MWORDS / (K_THREADS / 64);  // 17 words per wavefront
-            static_assert(NW * (K_THREADS / 64) == K_MWORDS, "words must divide evenly");
-            constexpr int NB1 = 9;                            // two batches keep the register arrays short
-#pragma unroll
-            for (int b0 = 0; b0 < NW; b0 += NB1) {
-                uint32_t ff[NB1], pfv[NB1];
-#pragma unroll
-                for (int u = 0; u < NB1; ++u) {  // all LDS reads of the batch first: they are independent
-                    const int it = b0 + u;
-                    if (it < NW) {
-                        const int idx = (wave + it * (K_THREADS / 64)) * 64 + lane;
-                        ff[u] = s_fb[idx];
-                        pfv[u] = (lane == 0 && idx > 0) ? (uint32_t)s_fb[idx - 1] : 0u;  // byte in front of the word
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < NB1; ++u) {
-                    const int it = b0 + u;
-                    if (it >= NW) continue;
-                    const int w = wave + it * (K_THREADS / 64);
-                    const uint32_t fb = ff[u];
-                    const uint32_t pf = __builtin_amdgcn_readfirstlane(pfv[u]);
-                    const uint64_t mU = __ballot(fb & FB_U), mW = __ballot(fb & FB_W), mX = __ballot(fb & FB_X);
-                    const uint64_t mS = __ballot(fb & FB_S), mN = __ballot(fb_is_num(fb)), mCR = __ballot(fb & FB_CR);
-                    const uint64_t mSL = __ballot(fb & FB_SL), mC = __ballot(fb & FB_C);
-                    const uint64_t mA = __ballot(fb_is_apos(fb)), mSP = __ballot(fb_is_sp(fb));
-                    const uint64_t mD = ((uint64_t)s_doc[2 * w + 1] << 32) | s_doc[2 * w];
-                    const uint64_t mSY = sync_word(mU, mW, mX, mS, mN, mCR, mSL, mC, mD, mA, pf);
-                    if (lane == 0) {
-                        static_assert(MK_U == 0 && MK_W == 1 && MK_X == 2 && MK_S == 3 && MK_N == 4 && MK_CR == 5 && MK_TR == 6 &&
-                                      MK_C == 7 && MK_D == 8 && MK_A == 9 && MK_SP == 10 && MK_SYNC == 11, "mask order");
-                        ulonglong2* o = reinterpret_cast<ulonglong2*>(s_mask + w * MK_COUNT);
-                        o[0] = make_ulonglong2(mU, mW); o[1] = make_ulonglong2(mX, mS); o[2] = make_ulonglong2(mN, mCR);
-                        o[3] = make_ulonglong2(mCR | mSL, mC); o[4] = make_ulonglong2(mD, mA); o[5] = make_ulonglong2(mSP, mSY);
-                    }
+        for (int it = tid; it < K_WIN / 8; it += K_THREADS) {
+            const uint2 t8 = reinterpret_cast<const uint2*>(s_txt)[it];
+            uint32_t flo, fhi;
+            if (!((t8.x | t8.y) & 0x80808080u)) {
+                flo = (uint32_t)s_lut[t8.x & 0x7F] | ((uint32_t)s_lut[(t8.x >> 8) & 0x7F] << 8) |
+                      ((uint32_t)s_lut[(t8.x >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.x >> 24] << 24);
+                fhi = (uint32_t)s_lut[t8.y & 0x7F] | ((uint32_t)s_lut[(t8.y >> 8) & 0x7F] << 8) |
+                      ((uint32_t)s_lut[(t8.y >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.y >> 24] << 24);
+            } else {
+                flo = fhi = 0;
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t b = ((k < 4 ? t8.x : t8.y) >> (8 * (k & 3))) & 0xFF;
+                    const uint32_t f = (b < 0x80) ? (uint32_t)s_lut[b] : feature_at(T, src, it * 8 + k);
+                    if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4));
                 }
             }
+            // feature byte of the byte in front of my 8 (for the sync predicate)
+            uint32_t pf = __shfl_up(fhi >> 24, 1);
+            if (lane == 0) {
+                pf = 0;
+                if (it > 0) {
+                    const uint32_t pb = s_txt[it * 8 - 1];
+                    pf = (pb < 0x80) ? (uint32_t)s_lut[pb] : feature_at(T, src, it * 8 - 1);
+                }
+            }
+            const uint64_t P = transpose8x8(((uint64_t)fhi << 32) | flo);  // byte k = bit plane of feature bit k
+            const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
+            const uint32_t mU = plo & 0xFF, mW = (plo >> 8) & 0xFF, mX = (plo >> 16) & 0xFF, mS = plo >> 24;
+            const uint32_t nraw = phi & 0xFF, mCR = (phi >> 8) & 0xFF, mSL = (phi >> 16) & 0xFF, mC = phi >> 24;
+            const uint32_t mN = nraw & ~mX & ~mS, mA = nraw & mX, mSP = nraw & mS;
+            const uint32_t mD = reinterpret_cast<const uint8_t*>(s_doc)[it];
+            const uint32_t mSY = sync_byte(mU, mW, mX, mS, mN, mCR, mSL, mC, mD, mA, pf);
+            static_assert(MK_U == 0 && MK_W == 1 && MK_X == 2 && MK_S == 3 && MK_N == 4 && MK_CR == 5 && MK_TR == 6 &&
+                          MK_C == 7 && MK_D == 8 && MK_A == 9 && MK_SP == 10 && MK_SYNC == 11, "mask order");
+            uint8_t* o = reinterpret_cast<uint8_t*>(s_mask + (it >> 3) * MK_COUNT) + (it & 7);
+            o[0 * 8] = (uint8_t)mU; o[1 * 8] = (uint8_t)mW; o[2 * 8] = (uint8_t)mX; o[3 * 8] = (uint8_t)mS;
+            o[4 * 8] = (uint8_t)mN; o[5 * 8] = (uint8_t)mCR; o[6 * 8] = (uint8_t)(mCR | mSL); o[7 * 8] = (uint8_t)mC;
+            o[8 * 8] = (uint8_t)mD; o[9 * 8] = (uint8_t)mA; o[10 * 8] = (uint8_t)mSP; o[11 * 8] = (uint8_t)mSY;
         }
         __syncthreads();
+        if (a.stop_after == 12) continue;
 
         // ---- phase 2: piece boundaries.  Fast path: bit-parallel scanner on a 64-byte register window; pieces or
         //      look-ahead beyond that use the same matcher on the mask words in LDS.  What even the LDS window
@@ -1111,7 +1097,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
     hipLaunchKernelGGL(td_split_tiles, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
     hipLaunchKernelGGL(td_split_slow, dim3(64), dim3(64), 0, stream, a);
     if (ev1) (void)hipEventRecord(ev1, stream);
-    if (a.stop_after != 2) {
+    if (a.stop_after != 2 && a.stop_after != 11 && a.stop_after != 12) {
         hipLaunchKernelGGL(td_encode_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
         if (ev2) (void)hipEventRecord(ev2, stream);
         hipLaunchKernelGGL(td_long_pieces, dim3(256 * 5), dim3(256), 0, stream, a);
