@@ -64,6 +64,7 @@ constexpr uint32_t TOK_NONE = 0xFFFFFFFFu;    // empty slot in the byte-indexed 
 constexpr uint32_t TOK_LONGREF = 0x80000000u; // | index into the long-piece list
 constexpr int ID_BITS = 21;                   // ids / ranks must be < 2^21 (pair slots pack 2 ids + rank in 64 bit)
 constexpr uint64_t PAIR_EMPTY = ~0ull;
+constexpr int K_HOT = 512;                    // slots of the LDS-resident hot-piece table (BPE rank ~ frequency rank)
 
 struct PieceSlot {  // 16 B; len == 0 marks an empty slot
     uint64_t key;   // len <= 8: the bytes, little-endian, zero padded; len > 8: hash_bytes()
@@ -79,6 +80,7 @@ struct Tables {
     const int32_t* byte_pair;     // [65536]  rank of the 2-byte token (b0<<8|b1) or NO_RANK
     const PieceSlot* piece_slots; // open addressing, linear probing
     const uint64_t* pair_slots;   // (left<<42 | right<<21 | rank), PAIR_EMPTY if empty
+    const PieceSlot* hot_slots;   // [K_HOT] direct-mapped copy of the lowest-rank tokens of <= 8 bytes (staged in LDS)
     const uint32_t* tok_off;      // [max_id+2] byte offsets of token id's bytes (decode + long-key verify)
     const uint8_t* tok_bytes;
     uint32_t piece_mask;
@@ -119,6 +121,8 @@ TD_HD uint64_t hash_bytes(const Get& get, uint32_t len) {
     }
     return k ^ (k >> 31);
 }
+
+TD_HD uint32_t hot_index(uint64_t key, uint32_t len) { return (hash_piece(key, len) >> 9) & (K_HOT - 1); }
 
 // (left id, right id) -> rank of the concatenation, NO_RANK if it is not a token.
 TD_HD int32_t pair_lookup(const Tables& T, uint32_t left, uint32_t right) {

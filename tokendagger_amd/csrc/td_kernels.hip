@@ -407,9 +407,11 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
     __shared__ __attribute__((aligned(16))) uint32_t s_tok[K_TILE + K_MAXSHORT];
     __shared__ uint32_t s_start[K_BWIN / 32 + 3];  // bit i: a piece starts at tile byte i
     __shared__ uint32_t s_miss[K_BWIN / 32 + 3];   // bit i: the piece starting at i missed the whole-piece table
-    __shared__ uint16_t s_plist[K_TILE + 2];       // tile positions of the piece starts (+ end delimiter)
-    __shared__ uint32_t s_off[K_THREADS];          // phase 5: token slots before each lane's chunk
-    __shared__ uint16_t s_valid[K_THREADS];        // phase 5: which of the lane's 16 byte slots hold a token
+    __shared__ __attribute__((aligned(16))) uint16_t s_plist[K_TILE + 8];  // tile positions of the piece starts (+ end delimiter)
+    // phase 5 reuses the (then dead) piece list: token slots before each lane's chunk / which of its 16 slots hold a token
+    uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_plist);
+    uint16_t* const s_valid = s_plist + 2 * K_THREADS;
+    __shared__ __attribute__((aligned(16))) PieceSlot s_hot[K_HOT];        // lowest-rank short tokens, direct-mapped
     __shared__ int32_t s_byteid[256];
     __shared__ uint32_t s_wave[8];
     __shared__ long long s_ext_end;                // global end of the tile's last piece when it leaves the window (else 0)
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
     const int lane = tid & 63, wave = tid >> 6;
     const Tables& T = *a.Tp;
     s_byteid[tid] = T.byte_id[tid];
+    for (int q = tid; q < K_HOT; q += K_THREADS) s_hot[q] = T.hot_slots[q];
 
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
     if ((int)blockIdx.x < a.n_tiles) {
@@ -461,6 +464,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         }
         if (tid == 0) { s_ext_end = 0; s_haslong = 0; }
         __syncthreads();
+        if (a.stop_after == 30) continue;
 
         // ---- phase 3: whole-piece lookup, one lane per piece ---------------------------------
         // 3a: dense list of the tile's piece starts (so that every lane has a piece to look up)
@@ -500,6 +504,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
             }
         }
         __syncthreads();
+        if (a.stop_after == 31) continue;
         // 3b: probe, piece k -> lane k mod 256; four pieces per lane at a time so that the table loads of a
         //     batch are in flight together (the probes are latency-, not bandwidth-bound)
         {
@@ -542,7 +547,12 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                         key = hash_bytes([pb](uint32_t q) { return (uint32_t)pb[q]; }, len);
                     }
                     pkey[u] = key;
-                    ph[u] = hash_piece(key, len) & T.piece_mask;
+                    const uint32_t hsh = hash_piece(key, len);
+                    if (len <= 8) {  // LDS-resident hot table first: no L2 round trip for the most frequent pieces
+                        const PieceSlot hs = s_hot[(hsh >> 9) & (K_HOT - 1)];
+                        if (hs.key == key && hs.len == len) { s_tok[i - K_HL] = hs.rank; pi[u] = -1; continue; }
+                    }
+                    ph[u] = hsh & T.piece_mask;
                     probe[u] = true;
                 }
 #pragma unroll

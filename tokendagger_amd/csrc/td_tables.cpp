@@ -39,6 +39,7 @@ Tables HostTables::view() const {
     T.byte_id = byte_id.data();
     T.byte_pair = byte_pair.data();
     T.piece_slots = piece_slots.data();
+    T.hot_slots = hot_slots.data();
     T.pair_slots = pair_slots.data();
     T.tok_off = tok_off.data();
     T.tok_bytes = tok_bytes.data();
@@ -171,6 +172,22 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
         }
         if (len == 1) H.byte_id[p[0]] = ranks[v];
         if (len == 2) H.byte_pair[((uint32_t)p[0] << 8) | p[1]] = ranks[v];
+    }
+
+    // hot-piece table: direct-mapped, lowest rank wins a slot (merge order ~ frequency order in the tokenizer's
+    // training data, so low ranks are the pieces seen most often); tokens of 2..8 bytes only (key = the bytes)
+    H.hot_slots.assign(K_HOT, PieceSlot{0, 0, 0});
+    {
+        std::vector<int64_t> order((size_t)n_vocab);
+        for (int64_t v = 0; v < n_vocab; ++v) order[(size_t)v] = v;
+        std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return ranks[x] < ranks[y]; });
+        for (int64_t v : order) {
+            const uint32_t len = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
+            if (len < 2 || len > 8) continue;
+            const uint64_t key = piece_key_host(token_bytes + token_offsets[v], len);
+            PieceSlot& hs = H.hot_slots[hot_index(key, len)];
+            if (hs.len == 0) { hs.key = key; hs.rank = (uint32_t)ranks[v]; hs.len = len; }
+        }
     }
 
     // pair table: every split of every token whose halves are both "parts" the merge loop can

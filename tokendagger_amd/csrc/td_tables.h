@@ -26,6 +26,7 @@ struct HostTables {
     std::vector<int32_t> byte_id;
     std::vector<int32_t> byte_pair;
     std::vector<PieceSlot> piece_slots;
+    std::vector<PieceSlot> hot_slots;
     std::vector<uint64_t> pair_slots;
     std::vector<uint32_t> tok_off;
     std::vector<uint8_t> tok_bytes;
