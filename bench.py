@@ -123,7 +123,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("TD_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -147,12 +148,12 @@ def main():
     tok.set_option(capi.TD_OPT_PROFILE, 1)
     stream = torch.cuda.current_stream(dev)
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
-    gathered = torch.zeros(2 * world, dtype=torch.int64, device=dev) if world > 1 else None
+    gathered = torch.zeros(2 * world, dtype=torch.int64, device=dev) if use_dist else None
 
     def step():
         tok.encode_device(d_text.data_ptr(), n, d_offs.data_ptr(), n_docs, d_tok.data_ptr(), cap, d_toff.data_ptr(),
                           stream.cuda_stream)
-        if world > 1:  # the path's only exchange: per-rank {docs, tokens} -> global offsets
+        if use_dist:  # the path's only exchange: per-rank {docs, tokens} -> global offsets
             counts[0] = n_docs
             counts[1:2] = d_toff[n_docs:n_docs + 1]
             dist.all_gather_into_tensor(gathered, counts)
@@ -162,20 +163,20 @@ def main():
     torch.cuda.synchronize(dev)
     tok.device_status(stream.cuda_stream)
     tok.profile_read()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     tok.device_status(stream.cuda_stream)
     sp_ms, en_ms, k_n = tok.profile_read()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -230,7 +231,11 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x, offs, ranks, special, pat)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        # global view from the gathered counts: every rank's document / token base (what a consumer of the sharded
+        # output needs); checked here so that a broken exchange cannot go unnoticed
+        tab = gathered.view(world, 2).cpu().numpy()
+        assert int(tab[rank, 0]) == n_docs and int(tab[rank, 1]) == n_tok, "all-gather returned foreign counts"
         dist.barrier()
         dist.destroy_process_group()
 
