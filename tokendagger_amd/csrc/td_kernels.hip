@@ -391,6 +391,48 @@ __global__ void td_split_slow(const EncodeArgs a) {
     }
 }
 
+// Everything the hot probe loop of td_encode_tiles leaves to a second, rolled loop: keys longer than 8 bytes (hashed +
+// verified against the token bytes), probe sequences longer than one slot, pieces longer than K_MAXSHORT (handed to
+// td_long_pieces), and the miss mark.  (An out-of-line call here cost +30 % kernel time: too many waves take it.)
+__device__ __forceinline__ void resolve_piece_cold(const EncodeArgs& a, const Tables& T, const uint8_t* s_txt, uint32_t* s_tok,
+                                                uint32_t* s_miss, const int32_t* s_byteid, uint32_t* s_haslong, int64_t wg0,
+                                                int i, uint32_t len) {
+    if (len > (uint32_t)K_MAXSHORT) {
+        if (len == 0xFFFFFFFFu) { raise(a, TD_E_SCRATCH, wg0 + i); return; }
+        const uint32_t idx = atomicAdd(a.long_count, 1u);
+        if (idx < a.long_cap) {
+            LongEntry le;
+            le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
+            a.long_list[idx] = le;
+            s_tok[i] = TOK_LONGREF | idx;
+            *s_haslong = 1;
+        } else {
+            raise(a, TD_E_SCRATCH, wg0 + i);
+        }
+        return;
+    }
+    const uint8_t* pb = s_txt + i;
+    if (len == 1) {
+        const int32_t id = s_byteid[pb[0]];
+        if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
+        s_tok[i] = (uint32_t)id;
+        return;
+    }
+    if (a.use_fastpath) {
+        auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
+        uint64_t key;
+        if (len <= 8) {
+            key = 0;
+            for (uint32_t q = 0; q < len; ++q) key |= (uint64_t)pb[q] << (8 * q);
+        } else {
+            key = hash_bytes(get, len);
+        }
+        const int32_t r = piece_lookup(T, key, len, get);
+        if (r != NO_RANK) { s_tok[i] = (uint32_t)r; return; }
+    }
+    atomicOr(&s_miss[i >> 5], 1u << (i & 31));
+}
+
 // ------------------------------------------------------------------ td_encode_tiles ---------
 // Token kernel: pieces (from the START bitmap) -> token ids, compacted per tile.
 //   whole-piece table probe, one lane per piece      (CoreBPE::encode fast path, tiktoken.cpp:209-215)
@@ -505,93 +547,75 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         }
         __syncthreads();
         if (a.stop_after == 31) continue;
-        // 3b: probe, piece k -> lane k mod 256; four pieces per lane at a time so that the table loads of a
-        //     batch are in flight together (the probes are latency-, not bandwidth-bound)
+        const long long ext_end = s_ext_end;
+        // 3b: probe, piece k -> lane k mod 256; four pieces per lane at a time so that the table loads of a batch are
+        //     in flight together.  Hot path = pieces of 2..8 bytes (key = the bytes): LDS hot table, else first slot
+        //     of the HBM table; everything else (longer keys, probe collisions, long pieces, 1-byte pieces) goes
+        //     through resolve_piece_cold, out of line.
         {
-            const long long ext_end = s_ext_end;
             constexpr int NB = 4;
             for (uint32_t k0 = tid; k0 < np_total; k0 += NB * K_THREADS) {
-                int pi[NB];
+                int pi[NB];          // piece start (tile position) still to be resolved in stage 3, -1 = done
+                uint32_t cold = 0;   // pieces of this batch left to the rolled loop below
                 uint32_t plen[NB];
                 uint64_t pkey[NB];
-                PieceSlot slot[NB];
                 uint32_t ph[NB];
-                bool probe[NB];
+                PieceSlot slot[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const uint32_t k = k0 + u * K_THREADS;
-                    probe[u] = false;
                     pi[u] = -1;
+                    plen[u] = 0;
                     if (k >= np_total) continue;
                     const int i = s_plist[k];
-                    uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
-                    if (ext_end && k == np_total - 1) {
-                        const long long l = ext_end - (wg0 + i);
-                        if (l > 0x7FFFFFFFll) { raise(a, TD_E_SCRATCH, wg0 + i); continue; }
-                        len = (uint32_t)l;
-                    }
+                    const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
                     pi[u] = i;
                     plen[u] = len;
-                    if (len > (uint32_t)K_MAXSHORT || len == 1 || !a.use_fastpath) continue;
-                    uint64_t key;
-                    if (len <= 8) {
-                        const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
-                        const uint32_t sh = (i & 3) * 8;
-                        const uint64_t lo64 = ((uint64_t)wp[1] << 32) | wp[0];
-                        const uint64_t hi64 = ((uint64_t)wp[2] << 32) | wp[1];
-                        const uint32_t klo = (uint32_t)(lo64 >> sh), khi = (uint32_t)(hi64 >> sh);
-                        key = ((uint64_t)khi << 32) | klo;
-                        if (len < 8) key &= (1ull << (8 * len)) - 1;
-                    } else {
-                        const uint8_t* pb = s_txt + i;
-                        key = hash_bytes([pb](uint32_t q) { return (uint32_t)pb[q]; }, len);
+                    if (len == 1) {  // single byte: direct table
+                        const int32_t id = s_byteid[s_txt[i]];
+                        if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
+                        s_tok[i] = (uint32_t)id;
+                        pi[u] = -1;
+                        continue;
                     }
-                    pkey[u] = key;
+                    if (len > 8 || !a.use_fastpath || (ext_end && k == np_total - 1)) { cold |= 1u << u; pi[u] = -1; continue; }
+                    const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
+                    const uint32_t sh = (i & 3) * 8;
+                    const uint64_t lo64 = ((uint64_t)wp[1] << 32) | wp[0];
+                    const uint64_t hi64 = ((uint64_t)wp[2] << 32) | wp[1];
+                    uint64_t key = ((uint64_t)(uint32_t)(hi64 >> sh) << 32) | (uint32_t)(lo64 >> sh);
+                    if (len < 8) key &= (1ull << (8 * len)) - 1;
                     const uint32_t hsh = hash_piece(key, len);
-                    if (len <= 8) {  // LDS-resident hot table first: no L2 round trip for the most frequent pieces
-                        const PieceSlot hs = s_hot[(hsh >> 9) & (K_HOT - 1)];
-                        if (hs.key == key && hs.len == len) { s_tok[i - K_HL] = hs.rank; pi[u] = -1; continue; }
-                    }
+                    const PieceSlot hs = s_hot[(hsh >> 9) & (K_HOT - 1)];
+                    if (hs.key == key && hs.len == len) { s_tok[i] = hs.rank; pi[u] = -1; continue; }
+                    pkey[u] = key;
                     ph[u] = hsh & T.piece_mask;
-                    probe[u] = true;
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u)
-                    if (probe[u]) slot[u] = T.piece_slots[ph[u]];
+                    if (pi[u] >= 0) slot[u] = T.piece_slots[ph[u]];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int i = pi[u];
                     if (i < 0) continue;
-                    const uint32_t len = plen[u];
-                    if (len > (uint32_t)K_MAXSHORT) {
-                        const uint32_t idx = atomicAdd(a.long_count, 1u);
-                        if (idx < a.long_cap) {
-                            LongEntry le;
-                            le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
-                            a.long_list[idx] = le;
-                            s_tok[i - K_HL] = TOK_LONGREF | idx;
-                            s_haslong = 1;
-                        } else {
-                            raise(a, TD_E_SCRATCH, wg0 + i);
+                    const PieceSlot s0 = slot[u];
+                    if (s0.key == pkey[u] && s0.len == plen[u]) { s_tok[i] = s0.rank; continue; }   // the common case
+                    if (s0.len == 0) { atomicOr(&s_miss[i >> 5], 1u << (i & 31)); continue; }      // empty slot: not a token
+                    cold |= 1u << u;                                                                 // occupied by another key
+                }
+                if (__any(cold != 0)) {
+                    while (cold) {
+                        const int u = __ffs(cold) - 1;
+                        cold &= cold - 1;
+                        const uint32_t k = k0 + u * K_THREADS;
+                        const int i = s_plist[k];
+                        uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
+                        if (ext_end && k == np_total - 1) {
+                            const long long l = ext_end - (wg0 + i);
+                            len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
                         }
-                        continue;
+                        resolve_piece_cold(a, T, s_txt, s_tok, s_miss, s_byteid, &s_haslong, wg0, i, len);
                     }
-                    const uint8_t* pb = s_txt + i;
-                    if (len == 1) {
-                        const int32_t id = s_byteid[pb[0]];
-                        if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
-                        s_tok[i - K_HL] = (uint32_t)id;
-                        continue;
-                    }
-                    if (probe[u]) {
-                        int32_t r;
-                        const PieceSlot s0 = slot[u];
-                        if (s0.len == 0) r = NO_RANK;                                               // empty slot: not a token
-                        else if (s0.key == pkey[u] && s0.len == len && len <= 8) r = (int32_t)s0.rank;  // the common case
-                        else r = piece_lookup(T, pkey[u], len, [pb](uint32_t q) { return (uint32_t)pb[q]; });
-                        if (r != NO_RANK) { s_tok[i - K_HL] = (uint32_t)r; continue; }
-                    }
-                    atomicOr(&s_miss[i >> 5], 1u << (i & 31));
                 }
             }
         }
