@@ -293,6 +293,14 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
             }
             int avail = 64;
             auto bytes = [&](int i) { return g.byte(base + i); };
+            if (p - base < 32) {  // the kernel's hot path: a 32-bit view cut out of the 64-bit window at the piece start
+                BitWin32 v;
+                const int off = (int)(p - base);
+                for (int k = 0; k < MK_COUNT; ++k) v.m[k] = (uint32_t)(w.m[k] >> off);
+                auto b32 = [&](int i) { return g.byte(p + i); };
+                const int r32 = scan_piece_p(WinP32(v, 32), b32);
+                if (r32 >= 0 && p + r32 != e) ++bad;
+            }
             const int r = scan_piece_bits(w, bytes, (int)(p - base), avail);
             ++checked;
             if (r < 0) { ++unres; if (e - base < 58 - 3) { /* short piece must resolve unless look-ahead is long */ } }

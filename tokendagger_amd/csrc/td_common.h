@@ -474,6 +474,35 @@ struct WinP {
     }
 };
 
+// 32-bit register window whose bit 0 is the piece start itself (o == 0): all run searches are single 32-bit
+// ctz operations.  The kernel cuts it out of its 64-bit window with one funnel shift per mask.
+struct BitWin32 {
+    uint32_t m[MK_COUNT];
+};
+TD_HD int td_ctz32(uint32_t x) { return x ? (int)__builtin_ctz(x) : 32; }
+struct WinP32 {
+    const BitWin32& w;
+    int o, lim;
+    uint32_t E;
+    TD_HD WinP32(const BitWin32& w_, int avail) : w(w_), o(0), lim(avail), E(w_.m[MK_D] & ~1u) {}
+    TD_HD bool bit(int k, int i) const { return (w.m[k] >> i) & 1u; }
+    TD_HD bool ebit(int i) const { return (E >> i) & 1u; }
+    TD_HD int run_end(int k, int from) const { return from >= 32 ? 32 : from + td_ctz32(~((w.m[k] & ~E) >> from)); }
+    TD_HD static uint32_t below(int n) { return n >= 32 ? ~0u : ((1u << n) - 1u); }
+    TD_HD int last_and(int k1, int k2, int lo, int hi) const {
+        const uint32_t m = w.m[k1] & w.m[k2] & below(hi) & ~below(lo);
+        return m ? 31 - (int)__builtin_clz(m) : -1;
+    }
+    TD_HD int last_set(int k, int lo, int hi) const {
+        const uint32_t m = w.m[k] & below(hi) & ~below(lo);
+        return m ? 31 - (int)__builtin_clz(m) : -1;
+    }
+    TD_HD int last_clear(int k, int lo, int hi) const {
+        const uint32_t m = ~w.m[k] & below(hi) & ~below(lo);
+        return m ? 31 - (int)__builtin_clz(m) : -1;
+    }
+};
+
 // Provider over a word-major mask array (word i>>6 of mask k at arr[(i>>6)*MK_COUNT + k]): no limit on run
 // length below `lim`.  Used for pieces / look-ahead that do not fit a 64-bit register window.
 struct ArrMaskP {

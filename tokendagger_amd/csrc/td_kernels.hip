@@ -317,20 +317,23 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                 int p = s;
                 for (;;) {
                     if (p >= tile_hi) { mark(p); break; }  // delimits the last owned piece
-                    if (p - base > 36) { base = p; load_bitwin(wv, s_mask, base); }
-                    if (p >= c1 && ((wv.m[MK_SYNC] >> (p - base)) & 1ull)) break;  // the lane owning p starts there
+                    int off = p - base;
+                    if (off >= 32) { base = p; off = 0; load_bitwin(wv, s_mask, base); }
+                    // 32-bit view of every mask with bit 0 = the piece start: one funnel shift each
+                    BitWin32 v;
+#pragma unroll
+                    for (int k = 0; k < MK_COUNT; ++k)
+                        v.m[k] = __funnelshift_r((uint32_t)wv.m[k], (uint32_t)(wv.m[k] >> 32), (uint32_t)off);
+                    if (p >= c1 && (v.m[MK_SYNC] & 1u)) break;  // the lane owning p starts there
                     if (p >= K_HL) mark(p);
+                    const int avail = (K_LIM - p < 32) ? (K_LIM - p) : 32;
                     int e = -1;
-                    for (int attempt = 0; attempt < 2; ++attempt) {  // second attempt: window re-based at the piece start
-                        const int avail = (K_LIM - base < 64) ? (K_LIM - base) : 64;
-                        const int r = scan_piece_bits(wv, [&](int q) { return (uint32_t)s_txt[base + q]; }, p - base, avail);
-                        if (r >= 0) { e = base + r; break; }
-                        if (p == base) break;
-                        base = p;
-                        load_bitwin(wv, s_mask, base);
+                    {
+                        const int r = scan_piece_p(WinP32(v, avail), [&](int q) { return (uint32_t)s_txt[p + q]; });
+                        if (r >= 0) e = p + r;
                     }
                     if (e < 0) {
-                        e = scan_piece_lds(s_mask, s_txt, p);  // longer than a register window: mask words in LDS
+                        e = scan_piece_lds(s_mask, s_txt, p);  // piece or look-ahead beyond 32 bytes: mask words in LDS
                         if (e < 0) { if (p >= K_HL) defer(wg0 + p, 0); break; }
                     }
                     p = e;
