@@ -147,6 +147,28 @@ def test_full_size_properties(tok):
     assert (np.diff(toff) > 0).all()
 
 
+def test_malformed_utf8_is_handled_like_the_oracle(tok):
+    # The reference assumes valid UTF-8 (PCRE2_NO_UTF_CHECK); this repo defines malformed input (oracle/td_oracle.c
+    # char_at) and the device must agree with that definition and never hang or crash.
+    O = H.port_tokenizer()
+    rng = np.random.default_rng(12)
+    docs = []
+    for i in range(300):
+        n = int(rng.integers(1, 400))
+        kind = i % 3
+        if kind == 0:
+            b = rng.integers(0, 256, size=n, dtype=np.uint8)
+        elif kind == 1:
+            b = rng.choice(np.frombuffer(b"a \n\xc3\xa9\xe4\xb8\xad\xf0\x9f\x98\x80\x80\xbf\xc0\xff'", dtype=np.uint8), size=n)
+        else:
+            s = H.random_unicode_string(random.Random(i), 80).encode("utf-8")
+            b = np.frombuffer(s, dtype=np.uint8).copy()
+            b[rng.integers(0, len(b), size=max(1, len(b) // 10))] = rng.integers(0x80, 0x100, size=max(1, len(b) // 10))
+        docs.append(b.tobytes())
+    text, offs = H.pack_docs(docs)
+    _check_batch(tok, O, text, offs)
+
+
 def test_error_unknown_byte():
     from tokendagger_amd import capi
     pat, _, _ = H.llama4()

@@ -182,7 +182,7 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
 // piece starts.  One workgroup per 4 KiB tile (+64 B left / 192 B right halo), persistent grid.
 #ifndef TD_SPLIT_MIN_WAVES
-#define TD_SPLIT_MIN_WAVES 4
+#define TD_SPLIT_MIN_WAVES 5
 #endif
 __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
@@ -252,10 +252,26 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                 fhi = (uint32_t)s_lut[t8.y & 0x7F] | ((uint32_t)s_lut[(t8.y >> 8) & 0x7F] << 8) |
                       ((uint32_t)s_lut[(t8.y >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.y >> 24] << 24);
             } else {
+                // non-ASCII: one table walk per CHARACTER (lead byte); its continuation bytes inherit the class.
+                // Continuation bytes whose lead is in the previous item, strays and document boundaries take the
+                // general per-byte route (feature_at).
                 flo = fhi = 0;
+                uint32_t cur = 0;
+                int remaining = 0;  // continuation bytes the current lead still claims
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t b = ((k < 4 ? t8.x : t8.y) >> (8 * (k & 3))) & 0xFF;
-                    const uint32_t f = (b < 0x80) ? (uint32_t)s_lut[b] : feature_at(T, src, it * 8 + k);
+                    const int pos = it * 8 + k;
+                    uint32_t f;
+                    if (b < 0x80) { f = s_lut[b]; remaining = 0; }
+                    else if ((b & 0xC0) == 0x80) {
+                        if (remaining > 0 && !src.doc(pos)) { f = cur | FB_C; --remaining; }
+                        else { f = feature_at(T, src, pos); remaining = 0; }
+                    } else {
+                        remaining = (int)utf8_declared_len(b) - 1;
+                        if (pos >= src.lo && pos < src.hi) cur = feature_of_class(classify_at(T, src, pos) & CLS_MASK);
+                        else cur = FB_X;
+                        f = cur;
+                    }
                     if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4));
                 }
             }
