@@ -246,33 +246,72 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         for (int it = tid; it < K_WIN / 8; it += K_THREADS) {
             const uint2 t8 = reinterpret_cast<const uint2*>(s_txt)[it];
             uint32_t flo, fhi;
+            // state handed to the next lane: class features of my last character and how many continuation bytes it
+            // still claims (0x100 = "unknown": this item held continuation bytes only)
+            uint32_t st_out = 0;
+            int lead_conts = 0;  // continuation bytes at the start of my item (they belong to the previous lane's char)
             if (!((t8.x | t8.y) & 0x80808080u)) {
                 flo = (uint32_t)s_lut[t8.x & 0x7F] | ((uint32_t)s_lut[(t8.x >> 8) & 0x7F] << 8) |
                       ((uint32_t)s_lut[(t8.x >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.x >> 24] << 24);
                 fhi = (uint32_t)s_lut[t8.y & 0x7F] | ((uint32_t)s_lut[(t8.y >> 8) & 0x7F] << 8) |
                       ((uint32_t)s_lut[(t8.y >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.y >> 24] << 24);
             } else {
-                // non-ASCII: one table walk per CHARACTER (lead byte); its continuation bytes inherit the class.
-                // Continuation bytes whose lead is in the previous item, strays and document boundaries take the
-                // general per-byte route (feature_at).
+                // non-ASCII: one iteration and one table walk per CHARACTER.  Well-formed sequences (the lead's
+                // continuation bytes all present, no document start inside) are decoded inline from a 16-byte register
+                // window; anything else takes the general per-byte route (feature_at).
                 flo = fhi = 0;
                 uint32_t cur = 0;
-                int remaining = 0;  // continuation bytes the current lead still claims
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t b = ((k < 4 ? t8.x : t8.y) >> (8 * (k & 3))) & 0xFF;
+                int remaining = 0;  // continuation bytes my last lead still claims beyond this item
+                bool seen_start = false;
+                const uint2 t8n = (it + 1 < K_WIN / 8) ? reinterpret_cast<const uint2*>(s_txt)[it + 1] : make_uint2(0, 0);
+                const uint64_t lo8 = ((uint64_t)t8.y << 32) | t8.x, hi8 = ((uint64_t)t8n.y << 32) | t8n.x;
+                const uint32_t docb = (uint32_t)reinterpret_cast<const uint8_t*>(s_doc)[it] |
+                                      ((it + 1 < K_WIN / 8) ? (uint32_t)reinterpret_cast<const uint8_t*>(s_doc)[it + 1] << 8 : 0u);
+                auto put = [&](int k, uint32_t f) { if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4)); };
+                int k = 0;
+                // continuation bytes at the very start belong to the previous lane's character (resolved below)
+                while (k < 8 && (((uint32_t)(lo8 >> (8 * k)) & 0xC0u) == 0x80u) && !((docb >> k) & 1u)) ++k;
+                lead_conts = k;
+                while (k < 8) {
+                    const uint32_t b = (uint32_t)(lo8 >> (8 * k)) & 0xFFu;
                     const int pos = it * 8 + k;
-                    uint32_t f;
-                    if (b < 0x80) { f = s_lut[b]; remaining = 0; }
-                    else if ((b & 0xC0) == 0x80) {
-                        if (remaining > 0 && !src.doc(pos)) { f = cur | FB_C; --remaining; }
-                        else { f = feature_at(T, src, pos); remaining = 0; }
-                    } else {
-                        remaining = (int)utf8_declared_len(b) - 1;
-                        if (pos >= src.lo && pos < src.hi) cur = feature_of_class(classify_at(T, src, pos) & CLS_MASK);
-                        else cur = FB_X;
-                        f = cur;
+                    seen_start = true;
+                    if (b < 0x80) { cur = s_lut[b]; put(k, cur); remaining = 0; ++k; continue; }
+                    const int need = (int)utf8_declared_len(b) - 1;
+                    // bytes k+1 .. k+3 of the 16-byte window
+                    const int shb = 8 * (k + 1);
+                    const uint32_t nxt = (uint32_t)((shb < 64) ? ((lo8 >> shb) | (hi8 << (64 - shb))) : hi8);
+                    const uint32_t c1 = nxt & 0xFF, c2 = (nxt >> 8) & 0xFF, c3 = (nxt >> 16) & 0xFF;
+                    const bool ok = need > 0 && pos + need < (int)src.hi && pos >= (int)src.lo && !((docb >> (k + 1)) & ((1u << need) - 1u)) &&
+                                    (c1 & 0xC0) == 0x80 && (need < 2 || (c2 & 0xC0) == 0x80) && (need < 3 || (c3 & 0xC0) == 0x80);
+                    if (!ok) {  // invalid lead, truncated sequence, stray continuation byte, document boundary inside
+                        const uint32_t f = feature_at(T, src, pos);
+                        put(k, f);
+                        cur = f & ~(uint32_t)FB_C;
+                        remaining = 0;
+                        ++k;
+                        continue;
                     }
-                    if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4));
+                    uint32_t cp = (need == 1) ? ((b & 0x1F) << 6) | (c1 & 0x3F)
+                                : (need == 2) ? ((b & 0x0F) << 12) | ((c1 & 0x3F) << 6) | (c2 & 0x3F)
+                                              : ((b & 0x07) << 18) | ((c1 & 0x3F) << 12) | ((c2 & 0x3F) << 6) | (c3 & 0x3F);
+                    cur = feature_of_class(class_of_cp(T, cp));
+                    put(k, cur);
+                    for (int q = 1; q <= need && k + q < 8; ++q) put(k + q, cur | FB_C);
+                    remaining = (k + need >= 8) ? (k + need - 7) : 0;
+                    k += need + 1;
+                }
+                st_out = seen_start ? (cur | ((uint32_t)remaining << 9)) : 0x100u;
+            }
+            {   // continuation bytes at the start of the item: the previous lane's last character claims them
+                const uint32_t st_in = __shfl_up(st_out, 1);
+                if (lead_conts) {
+                    const bool known = lane != 0 && !(st_in & 0x100u);
+                    const int claim = (int)(st_in >> 9);
+                    for (int k = 0; k < lead_conts; ++k) {
+                        const uint32_t f = (known && k < claim) ? ((st_in & 0xFFu) | FB_C) : feature_at(T, src, it * 8 + k);
+                        if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4));
+                    }
                 }
             }
             // feature byte of the byte in front of my 8 (for the sync predicate)
