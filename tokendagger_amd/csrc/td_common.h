@@ -79,7 +79,7 @@ struct Tables {
     const int32_t* byte_id;       // [256]    id of the 1-byte token, or pseudo id (>= pseudo_base) if absent
     const int32_t* byte_pair;     // [65536]  rank of the 2-byte token (b0<<8|b1) or NO_RANK
     const PieceSlot* piece_slots; // open addressing, linear probing
-    const uint64_t* pair_slots;   // (left<<42 | right<<21 | rank), PAIR_EMPTY if empty
+    const uint64_t* pair_slots;   // cuckoo table: (left<<42 | right<<21 | rank), PAIR_EMPTY if empty
     const PieceSlot* hot_slots;   // [K_HOT] direct-mapped copy of the lowest-rank tokens of <= 8 bytes (staged in LDS)
     const uint32_t* tok_off;      // [max_id+2] byte offsets of token id's bytes (decode + long-key verify)
     const uint8_t* tok_bytes;
@@ -124,16 +124,26 @@ TD_HD uint64_t hash_bytes(const Get& get, uint32_t len) {
 
 TD_HD uint32_t hot_index(uint64_t key, uint32_t len) { return (hash_piece(key, len) >> 9) & (K_HOT - 1); }
 
-// (left id, right id) -> rank of the concatenation, NO_RANK if it is not a token.
-TD_HD int32_t pair_lookup(const Tables& T, uint32_t left, uint32_t right) {
+// (left id, right id) -> rank of the concatenation, NO_RANK if it is not a token.  The pair table is a CUCKOO table
+// (two hash functions, one entry per slot): a lookup is exactly two independent 8-byte loads and no loop, so the
+// loads of several lookups can be in flight together (the merge rounds are bound by this latency).
+TD_HD uint32_t hash_pair2(uint32_t left, uint32_t right) {
+    uint32_t h = (left ^ 0x68E31DA4u) * 0xB5297A4Du + (right ^ 0x1B56C4E9u) * 0x68E31DA5u;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    return h;
+}
+TD_HD int32_t pair_match(uint64_t e1, uint64_t e2, uint32_t left, uint32_t right) {
     const uint64_t key = ((uint64_t)left << ID_BITS) | right;
-    uint32_t h = hash_pair(left, right) & T.pair_mask;
-    for (;;) {
-        const uint64_t e = T.pair_slots[h];
-        if (e == PAIR_EMPTY) return NO_RANK;
-        if ((e >> ID_BITS) == key) return (int32_t)(e & ((1u << ID_BITS) - 1));
-        h = (h + 1) & T.pair_mask;
-    }
+    if ((e1 >> ID_BITS) == key) return (int32_t)(e1 & ((1u << ID_BITS) - 1));
+    if ((e2 >> ID_BITS) == key) return (int32_t)(e2 & ((1u << ID_BITS) - 1));
+    return NO_RANK;  // (an empty slot is all ones and matches no key: ids are < 2^21)
+}
+TD_HD int32_t pair_lookup(const Tables& T, uint32_t left, uint32_t right) {
+    const uint64_t e1 = T.pair_slots[hash_pair(left, right) & T.pair_mask];
+    const uint64_t e2 = T.pair_slots[hash_pair2(left, right) & T.pair_mask];
+    return pair_match(e1, e2, left, right);
 }
 
 // piece bytes -> rank, NO_RANK if the piece is not a token.  `get(i)` returns byte i of the piece.

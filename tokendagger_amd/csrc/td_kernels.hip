@@ -491,6 +491,28 @@ __device__ __forceinline__ void resolve_piece_cold(const EncodeArgs& a, const Ta
     atomicOr(&s_miss[i >> 5], 1u << (i & 31));
 }
 
+// Segmented inclusive min-scan across the wavefront with DPP (no LDS round trips): lane l ends up with the minimum
+// of x over lanes [max(ps, 0) .. l] where ps is the first lane of l's segment.  Rows of 16 lanes are scanned with
+// row_shr 1/2/4/8, then row_bcast15 (rows 1 and 3) and row_bcast31 (rows 2 and 3) carry the row totals across.
+__device__ __forceinline__ uint32_t seg_min_scan_dpp(uint32_t x, int lane, int ps) {
+    constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118, ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143;
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_SHR1, 0xF, 0xF, false);
+    if (lane - 1 >= ps) x = t < x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_SHR2, 0xF, 0xF, false);
+    if (lane - 2 >= ps) x = t < x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_SHR4, 0xF, 0xF, false);
+    if (lane - 4 >= ps) x = t < x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_SHR8, 0xF, 0xF, false);
+    if (lane - 8 >= ps) x = t < x ? t : x;
+    const int row0 = lane & ~15;  // first lane of my row
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_BCAST15, 0xA, 0xF, false);
+    if ((lane & 16) && ps < row0) x = t < x ? t : x;            // rows 1 and 3 take the total of rows 0 and 2
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_BCAST31, 0xC, 0xF, false);
+    if (lane >= 32 && ps < 32) x = t < x ? t : x;               // rows 2 and 3 take the total of rows 0-1
+    return x;
+}
+
 // ------------------------------------------------------------------ td_encode_tiles ---------
 // Token kernel: pieces (from the START bitmap) -> token ids, compacted per tile.
 //   whole-piece table probe, one lane per piece      (CoreBPE::encode fast path, tiktoken.cpp:209-215)
@@ -720,13 +742,8 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                 if (active && lane + 1 < pe) rank = T.byte_pair[(b << 8) | bn];
                 for (;;) {
                     const uint32_t key = (alive && rank != NO_RANK) ? (((uint32_t)rank << 6) | (uint32_t)lane) : 0xFFFFFFFFu;
-                    uint32_t m = key;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {  // segmented inclusive min over [ps, lane]
-                        const uint32_t t = __shfl_up(m, d);
-                        if (lane - d >= ps) m = t < m ? t : m;
-                    }
-                    m = __shfl(m, (pe - 1) & 63);  // lowest-rank, leftmost pair of my piece
+                    uint32_t m = seg_min_scan_dpp(key, lane, ps);  // segmented inclusive min over [ps, lane]
+                    m = __shfl(m, (pe - 1) & 63);                  // lowest-rank, leftmost pair of my piece
                     const bool has = active && m != 0xFFFFFFFFu;
                     if (!__any(has)) break;
                     const uint64_t A = __ballot(alive);

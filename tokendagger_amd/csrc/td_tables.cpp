@@ -212,14 +212,29 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
         }
     }
     H.n_pairs = pairs.size();
-    const uint32_t qcap = pow2_at_least((uint64_t)pairs.size() * 2 + 2);
-    H.pair_mask = qcap - 1;
-    H.pair_slots.assign(qcap, PAIR_EMPTY);
-    for (auto& pr : pairs) {
-        const uint32_t l = (uint32_t)(pr.first >> ID_BITS), r = (uint32_t)(pr.first & ((1u << ID_BITS) - 1));
-        uint32_t h = hash_pair(l, r) & H.pair_mask;
-        while (H.pair_slots[h] != PAIR_EMPTY) h = (h + 1) & H.pair_mask;
-        H.pair_slots[h] = (pr.first << ID_BITS) | pr.second;
+    // cuckoo insertion (2 hash functions, random-walk eviction); grow the table if a walk does not terminate
+    for (uint32_t qcap = pow2_at_least((uint64_t)pairs.size() * 2 + 2);; qcap <<= 1) {
+        H.pair_mask = qcap - 1;
+        H.pair_slots.assign(qcap, PAIR_EMPTY);
+        bool ok = true;
+        uint32_t rng = 0x9E3779B9u;
+        for (auto& pr : pairs) {
+            uint64_t cur = (pr.first << ID_BITS) | pr.second;
+            bool placed = false;
+            uint32_t h = 0;
+            for (int kick = 0; kick < 1000; ++kick) {
+                const uint32_t l = (uint32_t)(cur >> (2 * ID_BITS)), r = (uint32_t)((cur >> ID_BITS) & ((1u << ID_BITS) - 1));
+                const uint32_t h1 = hash_pair(l, r) & H.pair_mask, h2 = hash_pair2(l, r) & H.pair_mask;
+                if (H.pair_slots[h1] == PAIR_EMPTY) { H.pair_slots[h1] = cur; placed = true; break; }
+                if (H.pair_slots[h2] == PAIR_EMPTY) { H.pair_slots[h2] = cur; placed = true; break; }
+                rng = rng * 1664525u + 1013904223u;
+                h = (kick == 0) ? ((rng >> 16) & 1 ? h1 : h2) : (h == h1 ? h2 : h1);  // evict from the other seat
+                std::swap(cur, H.pair_slots[h]);
+            }
+            if (!placed) { ok = false; break; }
+        }
+        if (ok) break;
+        if (qcap >= (1u << 28)) { err = "pair table construction failed"; return TD_E_VOCAB; }
     }
 
     // Is the whole-piece fast path redundant (encode == encode_ordinary on every input)?
