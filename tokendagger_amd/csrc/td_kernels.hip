@@ -538,9 +538,10 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
     __shared__ uint32_t s_wave[8];
     __shared__ long long s_ext_end;                // global end of the tile's last piece when it leaves the window (else 0)
     __shared__ uint32_t s_haslong;
+    __shared__ uint32_t s_segctr;                  // phase 4: next 256-byte segment to merge
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     const Tables& T = *a.Tp;
     s_byteid[tid] = T.byte_id[tid];
     for (int q = tid; q < K_HOT; q += K_THREADS) s_hot[q] = T.hot_slots[q];
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
             const uint4 none = make_uint4(TOK_NONE, TOK_NONE, TOK_NONE, TOK_NONE);
             for (int v = tid; v < (K_TILE + K_MAXSHORT) / 4; v += K_THREADS) reinterpret_cast<uint4*>(s_tok)[v] = none;
         }
-        if (tid == 0) { s_ext_end = 0; s_haslong = 0; }
+        if (tid == 0) { s_ext_end = 0; s_haslong = 0; s_segctr = 0; }
         __syncthreads();
         if (a.stop_after == 30) continue;
 
@@ -705,14 +706,22 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         // ---- phase 4: byte-pair merge of the missed pieces: a wavefront per 64-byte window of pieces, one lane per
         //      byte.  (Measured alternative, round 1: one missed piece per LANE with ranks in L2 — 2.6x slower on
         //      the mixed-script corpus, 1.5x on code: the serial per-lane rank scans are not latency-hidden.)
-        {
-            const int seg_lo = K_HL + wave * (K_TILE / 4);
-            const int seg_hi = (seg_lo + K_TILE / 4 < tile_hi) ? seg_lo + K_TILE / 4 : tile_hi;
+        for (;;) {
+            // the tile is cut into 256-byte segments that the four wavefronts take from a shared counter (merge work
+            // is very uneven across a tile: static quarters left three wavefronts waiting at the barrier)
+            constexpr int SEG = 256;
+            int sg = 0;
+            if (lane == 0) sg = (int)atomicAdd(&s_segctr, 1u);
+            sg = __builtin_amdgcn_readfirstlane(sg);
+            if (sg >= K_TILE / SEG) break;
+            const int seg_lo = K_HL + sg * SEG;
+            if (seg_lo >= tile_hi) break;
+            const int seg_hi = (seg_lo + SEG < tile_hi) ? seg_lo + SEG : tile_hi;
             int pos = seg_lo;
             const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);  // lanes <= mine
-            {   // nothing missed in this wavefront's quarter of the tile (the common case on plain text): skip it
+            {   // nothing missed in this segment (the common case on plain text): skip it
                 const int wlo = seg_lo >> 5;
-                const uint32_t mw = (lane < (K_TILE / 4) / 32) ? s_miss[wlo + lane] : 0u;
+                const uint32_t mw = (lane < SEG / 32) ? s_miss[wlo + lane] : 0u;
                 if (!__any(mw != 0)) pos = seg_hi;
             }
             while (pos < seg_hi) {
