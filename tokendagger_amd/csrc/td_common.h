@@ -72,6 +72,12 @@ struct PieceSlot {  // 16 B; len == 0 marks an empty slot
     uint32_t len;
 };
 
+struct Piece16Slot {  // 24 B: tokens of 9..16 bytes, exact key in two words (no verification against tok_bytes needed)
+    uint64_t k0;      // bytes 0..7
+    uint64_t k1;      // bytes 8..len-1, little-endian, zero padded
+    uint64_t rl;      // rank | len << 32; 0 marks an empty slot
+};
+
 struct Tables {
     const uint8_t* ascii_cls;     // [128]
     const uint16_t* ucls1;        // [4352]   code point >> 8 -> block
@@ -80,6 +86,7 @@ struct Tables {
     const int32_t* byte_pair;     // [65536]  rank of the 2-byte token (b0<<8|b1) or NO_RANK
     const PieceSlot* piece_slots; // open addressing, linear probing
     const uint64_t* pair_slots;   // cuckoo table: (left<<42 | right<<21 | rank), PAIR_EMPTY if empty
+    const Piece16Slot* piece16_slots;  // open addressing, linear probing (tokens of 9..16 bytes; they are also in piece_slots)
     const PieceSlot* hot_slots;   // [K_HOT] direct-mapped copy of the lowest-rank tokens of <= 8 bytes (staged in LDS)
     const uint32_t* tok_off;      // [max_id+2] byte offsets of token id's bytes (decode + long-key verify)
     const uint8_t* tok_bytes;
@@ -88,7 +95,7 @@ struct Tables {
     int32_t max_id;               // largest real id
     int32_t pseudo_base;          // ids >= pseudo_base stand for single bytes that are not tokens
     uint32_t max_token_len;
-    uint32_t pad_;
+    uint32_t piece16_mask;
 };
 
 // ------------------------------------------------------------------ hashing -----------------
@@ -122,6 +129,9 @@ TD_HD uint64_t hash_bytes(const Get& get, uint32_t len) {
     return k ^ (k >> 31);
 }
 
+TD_HD uint32_t hash_piece16(uint64_t k0, uint64_t k1, uint32_t len) {
+    return hash_piece(k0 ^ ((k1 << 29) | (k1 >> 35)) ^ (k1 * 0x9E3779B97F4A7C15ull), len);
+}
 TD_HD uint32_t hot_index(uint64_t key, uint32_t len) { return (hash_piece(key, len) >> 9) & (K_HOT - 1); }
 
 // (left id, right id) -> rank of the concatenation, NO_RANK if it is not a token.  The pair table is a CUCKOO table

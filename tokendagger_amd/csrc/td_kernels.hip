@@ -639,9 +639,9 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                 int pi[NB];          // piece start (tile position) still to be resolved in stage 3, -1 = done
                 uint32_t cold = 0;   // pieces of this batch left to the rolled loop below
                 uint32_t plen[NB];
-                uint64_t pkey[NB];
+                uint64_t pkey[NB], pkey1[NB];
                 uint32_t ph[NB];
-                PieceSlot slot[NB];
+                uint64_t sl0[NB], sl1[NB], sl2[NB];  // probed slot: {key, rank|len<<32, -} or {k0, k1, rank|len<<32}
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const uint32_t k = k0 + u * K_THREADS;
@@ -659,30 +659,53 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                         pi[u] = -1;
                         continue;
                     }
-                    if (len > 8 || !a.use_fastpath || (ext_end && k == np_total - 1)) { cold |= 1u << u; pi[u] = -1; continue; }
+                    if (len > 16 || !a.use_fastpath || (ext_end && k == np_total - 1)) { cold |= 1u << u; pi[u] = -1; continue; }
+                    // up to 16 key bytes, read unaligned from LDS: five dwords, funnel-shifted
                     const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
                     const uint32_t sh = (i & 3) * 8;
-                    const uint64_t lo64 = ((uint64_t)wp[1] << 32) | wp[0];
-                    const uint64_t hi64 = ((uint64_t)wp[2] << 32) | wp[1];
-                    uint64_t key = ((uint64_t)(uint32_t)(hi64 >> sh) << 32) | (uint32_t)(lo64 >> sh);
-                    if (len < 8) key &= (1ull << (8 * len)) - 1;
-                    const uint32_t hsh = hash_piece(key, len);
-                    const PieceSlot hs = s_hot[(hsh >> 9) & (K_HOT - 1)];
-                    if (hs.key == key && hs.len == len) { s_tok[i] = hs.rank; pi[u] = -1; continue; }
-                    pkey[u] = key;
-                    ph[u] = hsh & T.piece_mask;
+                    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                    uint64_t key = ((uint64_t)__funnelshift_r(w1, w2, sh) << 32) | __funnelshift_r(w0, w1, sh);
+                    if (len <= 8) {
+                        if (len < 8) key &= (1ull << (8 * len)) - 1;
+                        const uint32_t hsh = hash_piece(key, len);
+                        const PieceSlot hs = s_hot[(hsh >> 9) & (K_HOT - 1)];  // LDS hot table first: no L2 round trip
+                        if (hs.key == key && hs.len == len) { s_tok[i] = hs.rank; pi[u] = -1; continue; }
+                        pkey[u] = key;
+                        pkey1[u] = 0;
+                        ph[u] = hsh & T.piece_mask;
+                    } else {
+                        const uint32_t w3 = wp[3], w4 = wp[4];
+                        uint64_t key1 = ((uint64_t)__funnelshift_r(w3, w4, sh) << 32) | __funnelshift_r(w2, w3, sh);
+                        if (len < 16) key1 &= (1ull << (8 * (len - 8))) - 1;
+                        pkey[u] = key;
+                        pkey1[u] = key1;
+                        ph[u] = hash_piece16(key, key1, len) & T.piece16_mask;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u)
-                    if (pi[u] >= 0) slot[u] = T.piece_slots[ph[u]];
+                    if (pi[u] >= 0) {
+                        if (plen[u] <= 8) {
+                            const PieceSlot* sp = T.piece_slots + ph[u];
+                            sl0[u] = sp->key;
+                            sl1[u] = (uint64_t)sp->rank | ((uint64_t)sp->len << 32);
+                            sl2[u] = 0;
+                        } else {
+                            const Piece16Slot* sp = T.piece16_slots + ph[u];
+                            sl0[u] = sp->k0; sl1[u] = sp->rl; sl2[u] = sp->k1;
+                        }
+                    }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int i = pi[u];
                     if (i < 0) continue;
-                    const PieceSlot s0 = slot[u];
-                    if (s0.key == pkey[u] && s0.len == plen[u]) { s_tok[i] = s0.rank; continue; }   // the common case
-                    if (s0.len == 0) { atomicOr(&s_miss[i >> 5], 1u << (i & 31)); continue; }      // empty slot: not a token
-                    cold |= 1u << u;                                                                 // occupied by another key
+                    const uint64_t want = (uint64_t)plen[u] << 32;
+                    if (sl0[u] == pkey[u] && sl2[u] == pkey1[u] && (sl1[u] & 0xFFFFFFFF00000000ull) == want) {  // the common case
+                        s_tok[i] = (uint32_t)sl1[u];
+                        continue;
+                    }
+                    if ((sl1[u] >> 32) == 0) { atomicOr(&s_miss[i >> 5], 1u << (i & 31)); continue; }  // empty slot: not a token
+                    cold |= 1u << u;                                                                    // occupied by another key
                 }
                 if (__any(cold != 0)) {
                     while (cold) {

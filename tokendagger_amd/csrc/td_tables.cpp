@@ -40,6 +40,8 @@ Tables HostTables::view() const {
     T.byte_pair = byte_pair.data();
     T.piece_slots = piece_slots.data();
     T.hot_slots = hot_slots.data();
+    T.piece16_slots = piece16_slots.data();
+    T.piece16_mask = piece16_mask;
     T.pair_slots = pair_slots.data();
     T.tok_off = tok_off.data();
     T.tok_bytes = tok_bytes.data();
@@ -172,6 +174,29 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
         }
         if (len == 1) H.byte_id[p[0]] = ranks[v];
         if (len == 2) H.byte_pair[((uint32_t)p[0] << 8) | p[1]] = ranks[v];
+    }
+
+    // exact-key table for tokens of 9..16 bytes (the hot probe loop handles them without the hash + verify route)
+    {
+        uint64_t n16 = 0;
+        for (int64_t v = 0; v < n_vocab; ++v) {
+            const int64_t len = token_offsets[v + 1] - token_offsets[v];
+            if (len >= 9 && len <= 16) ++n16;
+        }
+        const uint32_t cap16 = pow2_at_least(n16 * 2 + 2);
+        H.piece16_mask = cap16 - 1;
+        H.piece16_slots.assign(cap16, Piece16Slot{0, 0, 0});
+        for (int64_t v = 0; v < n_vocab; ++v) {
+            const uint32_t len = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
+            if (len < 9 || len > 16) continue;
+            const uint8_t* p = token_bytes + token_offsets[v];
+            uint64_t k0 = 0, k1 = 0;
+            for (uint32_t i = 0; i < 8; ++i) k0 |= (uint64_t)p[i] << (8 * i);
+            for (uint32_t i = 8; i < len; ++i) k1 |= (uint64_t)p[i] << (8 * (i - 8));
+            uint32_t h = hash_piece16(k0, k1, len) & H.piece16_mask;
+            while (H.piece16_slots[h].rl != 0) h = (h + 1) & H.piece16_mask;
+            H.piece16_slots[h] = Piece16Slot{k0, k1, (uint64_t)(uint32_t)ranks[v] | ((uint64_t)len << 32)};
+        }
     }
 
     // hot-piece table: direct-mapped, lowest rank wins a slot (merge order ~ frequency order in the tokenizer's
