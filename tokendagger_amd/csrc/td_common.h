@@ -64,7 +64,10 @@ constexpr uint32_t TOK_NONE = 0xFFFFFFFFu;    // empty slot in the byte-indexed 
 constexpr uint32_t TOK_LONGREF = 0x80000000u; // | index into the long-piece list
 constexpr int ID_BITS = 21;                   // ids / ranks must be < 2^21 (pair slots pack 2 ids + rank in 64 bit)
 constexpr uint64_t PAIR_EMPTY = ~0ull;
-constexpr int K_HOT = 512;                    // slots of the LDS-resident hot-piece table (BPE rank ~ frequency rank)
+#ifndef TD_K_HOT
+#define TD_K_HOT 512
+#endif
+constexpr int K_HOT = TD_K_HOT;                    // slots of the LDS-resident hot-piece table (BPE rank ~ frequency rank)
 
 struct PieceSlot {  // 16 B; len == 0 marks an empty slot
     uint64_t key;   // len <= 8: the bytes, little-endian, zero padded; len > 8: hash_bytes()
@@ -741,7 +744,10 @@ TD_HD uint64_t sync_word(uint64_t U, uint64_t W, uint64_t X, uint64_t S, uint64_
 
 // ------------------------------------------------------------------ tile geometry -----------
 // One workgroup of td_encode_tiles handles one tile of text at a time.
-constexpr int K_THREADS = 256;                 // 4 wavefronts
+#ifndef TD_K_THREADS
+#define TD_K_THREADS 256
+#endif
+constexpr int K_THREADS = TD_K_THREADS;        // 4 wavefronts
 constexpr int K_CHUNK = 16;                    // text bytes whose boundaries one lane is responsible for
 constexpr int K_TILE = K_THREADS * K_CHUNK;    // 4096 text bytes per tile
 constexpr int K_HL = 64;                       // left halo (sync-point back-search)

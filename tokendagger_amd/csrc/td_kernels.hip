@@ -82,6 +82,38 @@ __device__ __noinline__ uint32_t feature_at(const Tables& T, const LdsSrc& src, 
     return feature_of_class(c & CLS_MASK) | ((c & F_CONT) ? (uint32_t)FB_C : 0u);
 }
 
+// The table descriptor lives in device memory (EncodeArgs::Tp).  Read through the pointer, its fields are ordinary
+// global loads the compiler may not hoist: every `T.piece_mask` inside a loop was a vector load + s_waitcnt vmcnt(0)
+// (a full L2 round trip that also drains the loads in flight), every table access a dependent pointer load.  So each
+// kernel copies the descriptor once into wave-uniform registers (SGPRs) at entry.
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <class P>
+__device__ __forceinline__ P* uni_ptr(P* p) {
+    const uint64_t v = (uint64_t)p;
+    return (P*)(((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v));
+}
+__device__ __forceinline__ Tables uniform_tables(const Tables* p) {
+    Tables t;
+    t.ascii_cls = uni_ptr(p->ascii_cls);
+    t.ucls1 = uni_ptr(p->ucls1);
+    t.ucls2 = uni_ptr(p->ucls2);
+    t.byte_id = uni_ptr(p->byte_id);
+    t.byte_pair = uni_ptr(p->byte_pair);
+    t.piece_slots = uni_ptr(p->piece_slots);
+    t.pair_slots = uni_ptr(p->pair_slots);
+    t.piece16_slots = uni_ptr(p->piece16_slots);
+    t.hot_slots = uni_ptr(p->hot_slots);
+    t.tok_off = uni_ptr(p->tok_off);
+    t.tok_bytes = uni_ptr(p->tok_bytes);
+    t.piece_mask = uni32(p->piece_mask);
+    t.pair_mask = uni32(p->pair_mask);
+    t.max_id = (int32_t)uni32((uint32_t)p->max_id);
+    t.pseudo_base = (int32_t)uni32((uint32_t)p->pseudo_base);
+    t.max_token_len = uni32(p->max_token_len);
+    t.piece16_mask = uni32(p->piece16_mask);
+    return t;
+}
+
 __device__ __forceinline__ void raise(const EncodeArgs& a, int code, int64_t pos) {
     if (atomicCAS(a.err, 0, code) == 0) *a.err_pos = pos;
 }
@@ -184,6 +216,16 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 #ifndef TD_SPLIT_MIN_WAVES
 #define TD_SPLIT_MIN_WAVES 5
 #endif
+// software prefetch of the next tile's side inputs (tuning switches; defaults = what measured fastest)
+#ifndef TD_PF_DOCBITS
+#define TD_PF_DOCBITS 0
+#endif
+#ifndef TD_PF_START
+#define TD_PF_START 1
+#endif
+#ifndef TD_PF_DOC
+#define TD_PF_DOC 0
+#endif
 __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
     __shared__ __attribute__((aligned(16))) uint64_t s_mask[(K_MWORDS + 1) * MK_COUNT];  // class masks, word-major
@@ -193,15 +235,23 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const Tables& T = *a.Tp;
-    if (tid < 128) s_lut[tid] = (uint8_t)feature_of_class(T.ascii_cls[tid]);
+    const Tables T = uniform_tables(a.Tp);
+    for (int q = tid; q < 128; q += K_THREADS) s_lut[q] = (uint8_t)feature_of_class(T.ascii_cls[q]);
 
     static_assert(K_WIN / 16 <= 2 * K_THREADS, "two prefetch registers per lane cover the window");
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
+    uint32_t pfd = 0;  // document-start bits of window word `tid` (K_WIN / 32 <= K_THREADS)
+    static_assert(K_WIN / 32 <= K_THREADS, "one prefetched document word per lane covers the window");
+    const int64_t nwords = (a.n + 31) >> 5;
+    auto load_docword = [&](int64_t wg0_) -> uint32_t {
+        const int64_t gw = (wg0_ >> 5) + tid;
+        return (tid < K_WIN / 32 && gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
+    };
     if ((int)blockIdx.x < a.n_tiles) {
         const int64_t w0 = (int64_t)blockIdx.x * K_TILE - K_HL;
         pf0 = load_text16(a, w0 + (int64_t)tid * 16);
         if (tid < K_WIN / 16 - K_THREADS) pf1 = load_text16(a, w0 + (int64_t)(K_THREADS + tid) * 16);
+        if (TD_PF_DOCBITS) pfd = load_docword(w0);
     }
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
@@ -213,24 +263,21 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         //      iteration ago (registers pf0/pf1), so its HBM latency is hidden behind the previous tile -----------
         reinterpret_cast<uint4*>(s_txt)[tid] = pf0;
         if (tid < K_WIN / 16 - K_THREADS) reinterpret_cast<uint4*>(s_txt)[K_THREADS + tid] = pf1;
+        if (tid < K_WIN / 32) {
+            uint32_t dw = TD_PF_DOCBITS ? pfd : load_docword(wg0);
+            const int64_t g = wg0 + (int64_t)tid * 32;  // bytes past the end of the text: "end of subject" sentinels
+            if (g + 32 > a.n) dw |= (g >= a.n) ? 0xFFFFFFFFu : ~((1u << (int)(a.n - g)) - 1u);
+            s_doc[tid] = dw;
+        }
         {
             const int64_t nwg0 = wg0 + (int64_t)gridDim.x * K_TILE;  // next tile of this workgroup
             if (tile + (int)gridDim.x < a.n_tiles) {
                 pf0 = load_text16(a, nwg0 + (int64_t)tid * 16);
                 if (tid < K_WIN / 16 - K_THREADS) pf1 = load_text16(a, nwg0 + (int64_t)(K_THREADS + tid) * 16);
+                if (TD_PF_DOCBITS) pfd = load_docword(nwg0);
             }
         }
-        {
-            const int64_t nwords = (a.n + 31) >> 5;
-            for (int w = tid; w < K_WIN / 32; w += K_THREADS) {
-                const int64_t gw = (wg0 >> 5) + w;
-                uint32_t dw = (gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
-                const int64_t g = wg0 + (int64_t)w * 32;  // bytes past the end of the text: "end of subject" sentinels
-                if (g + 32 > a.n) dw |= (g >= a.n) ? 0xFFFFFFFFu : ~((1u << (int)(a.n - g)) - 1u);
-                s_doc[w] = dw;
-            }
-            for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
-        }
+        for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
         __syncthreads();
 
         // ---- phase 1: class masks.  Every lane takes 8 text bytes: feature byte per byte (ASCII: 128-B LUT in LDS;
@@ -415,7 +462,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
 // missing START bits in, until it lands on a provable sync point — from there on the fast kernel's bits are
 // right.  Exact, slow per byte, and proportional to the length of the offending piece.
 __global__ void td_split_slow(const EncodeArgs a) {
-    const Tables& T = *a.Tp;
+    const Tables T = uniform_tables(a.Tp);
     const uint32_t nslow = *a.slow_count < a.slow_cap ? *a.slow_count : a.slow_cap;
     GlobAcc G;
     G.T = &T; G.s.text = a.text; G.s.docbits = a.docbits; G.s.lo = 0; G.s.hi = a.n; G.n = a.n; G.lim = a.n + 4;
@@ -542,15 +589,29 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const Tables& T = *a.Tp;
-    s_byteid[tid] = T.byte_id[tid];
+    const Tables T = uniform_tables(a.Tp);
+    for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
     for (int q = tid; q < K_HOT; q += K_THREADS) s_hot[q] = T.hot_slots[q];
 
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
+    uint32_t pfs = 0;  // START bits of window word `tid`
+#if TD_PF_DOC
+    uint32_t pf_fd = 0xFFFFFFFFu;  // first document that starts in the tile (td_mark_docs), 0xFFFFFFFF = none
+#endif
+    static_assert(K_BWIN / 32 + 3 <= K_THREADS, "one prefetched START word per lane covers the window");
+    const int64_t nwords = (a.n + 31) >> 5;
+    auto load_startword = [&](int64_t wg0_) -> uint32_t {
+        const int64_t gw = (wg0_ >> 5) + tid;
+        return (tid < K_BWIN / 32 + 3 && gw < nwords) ? a.startbits[gw] : 0u;
+    };
     if ((int)blockIdx.x < a.n_tiles) {
         const int64_t w0 = (int64_t)blockIdx.x * K_TILE;
         pf0 = load_text16(a, w0 + (int64_t)tid * 16);
         if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, w0 + (int64_t)(K_THREADS + tid) * 16);
+        if (TD_PF_START) pfs = load_startword(w0);
+#if TD_PF_DOC
+        pf_fd = a.tile_first_doc[blockIdx.x];
+#endif
     }
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
@@ -563,24 +624,28 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         //      requested one iteration ago (pf0/pf1) -----------------------------------------------------------
         reinterpret_cast<uint4*>(s_txt)[tid] = pf0;
         if (tid < (K_BWIN + 16) / 16 - K_THREADS) reinterpret_cast<uint4*>(s_txt)[K_THREADS + tid] = pf1;
+        if (tid < K_BWIN / 32 + 3) {
+            uint32_t sw = TD_PF_START ? pfs : load_startword(wg0);
+            const int64_t g = wg0 + (int64_t)tid * 32;
+            if (a.n >= g && a.n < g + 32) sw |= 1u << (int)(a.n - g);  // the end of the text delimits the last piece
+            s_start[tid] = sw;
+            s_miss[tid] = 0;
+        }
         {
             const int64_t nwg0 = wg0 + (int64_t)gridDim.x * K_TILE;
             if (tile + (int)gridDim.x < a.n_tiles) {
                 pf0 = load_text16(a, nwg0 + (int64_t)tid * 16);
                 if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, nwg0 + (int64_t)(K_THREADS + tid) * 16);
+                if (TD_PF_START) pfs = load_startword(nwg0);
             }
         }
-        {
-            const int64_t nwords = (a.n + 31) >> 5;
-            for (int w = tid; w < K_BWIN / 32 + 3; w += K_THREADS) {
-                const int64_t gw = (wg0 >> 5) + w;
-                uint32_t sw = (gw < nwords) ? a.startbits[gw] : 0u;
-                const int64_t g = wg0 + (int64_t)w * 32;
-                if (a.n >= g && a.n < g + 32) sw |= 1u << (int)(a.n - g);  // the end of the text delimits the last piece
-                s_start[w] = sw;
-                s_miss[w] = 0;
-            }
-        }
+        // offsets of the documents that start in this tile (consumed by phase 5): requested now, next tile's first
+        // document index one iteration ahead
+#if TD_PF_DOC
+        const int64_t fd = (int64_t)pf_fd;
+        const int64_t my_doc_off = (fd + tid < a.n_docs) ? a.doc_offsets[fd + tid] : INT64_MAX;
+        if (tile + (int)gridDim.x < a.n_tiles) pf_fd = a.tile_first_doc[tile + gridDim.x];
+#endif
         {
             const uint4 none = make_uint4(TOK_NONE, TOK_NONE, TOK_NONE, TOK_NONE);
             for (int v = tid; v < (K_TILE + K_MAXSHORT) / 4; v += K_THREADS) reinterpret_cast<uint4*>(s_tok)[v] = none;
@@ -682,6 +747,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                         ph[u] = hash_piece16(key, key1, len) & T.piece16_mask;
                     }
                 }
+                if (a.stop_after == 32) continue;
 #pragma unroll
                 for (int u = 0; u < NB; ++u)
                     if (pi[u] >= 0) {
@@ -707,6 +773,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                     if ((sl1[u] >> 32) == 0) { atomicOr(&s_miss[i >> 5], 1u << (i & 31)); continue; }  // empty slot: not a token
                     cold |= 1u << u;                                                                    // occupied by another key
                 }
+                if (a.stop_after == 33) continue;
                 if (__any(cold != 0)) {
                     while (cold) {
                         const int u = __ffs(cold) - 1;
@@ -840,8 +907,15 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
             // token slot of every document that starts in this tile (documents are consecutive from the
             // tile's first one, recorded by td_mark_docs; empty documents share a position)
             const int64_t tile_end_g = tile_g0 + (tile_hi - K_HL);
-            for (int64_t d = (int64_t)a.tile_first_doc[tile] + tid; d < a.n_docs; d += K_THREADS) {
+#if !TD_PF_DOC
+            const int64_t fd = (int64_t)a.tile_first_doc[tile];
+#endif
+            for (int64_t d = fd + tid; d < a.n_docs; d += K_THREADS) {
+#if TD_PF_DOC
+                const int64_t p = (d == fd + tid) ? my_doc_off : a.doc_offsets[d];
+#else
                 const int64_t p = a.doc_offsets[d];
+#endif
                 if (p >= tile_end_g) break;
                 const int lp = (int)(p - tile_g0);
                 a.doc_slot[d] = s_off[lp >> 4] + __popc((uint32_t)s_valid[lp >> 4] & ((1u << (lp & 15)) - 1u));
@@ -952,7 +1026,7 @@ __device__ __forceinline__ void lp_do_piece(const EncodeArgs& a, const Tables& T
 
 __global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
     __shared__ uint32_t s_parts[4][2 * LP_MEDIUM];  // per wavefront: ids | ranks
-    const Tables& T = *a.Tp;
+    const Tables T = uniform_tables(a.Tp);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nlong = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
     const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -1253,13 +1327,14 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
 // scan, then every token copies its bytes from the rank -> bytes store.  Ids are validated on the
 // host before launch (td_api.cpp), the device check is a backstop.
 __global__ void td_decode_len(const DecodeArgs a) {
+    const Tables T = uniform_tables(a.Tp);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t id = a.tokens[i];
         int64_t len = 0;
-        if (id < 0 || id > a.Tp->max_id) {
+        if (id < 0 || id > T.max_id) {
             if (atomicCAS(a.err, 0, TD_E_BAD_TOKEN) == 0) *a.err_pos = i;
         } else {
-            len = (int64_t)a.Tp->tok_off[id + 1] - a.Tp->tok_off[id];
+            len = (int64_t)T.tok_off[id + 1] - T.tok_off[id];
         }
         a.byte_off[i + 1] = len;
     }
@@ -1287,10 +1362,11 @@ __global__ __launch_bounds__(1024) void td_decode_scan(const DecodeArgs a) {
     }
 }
 __global__ void td_decode_copy(const DecodeArgs a) {
+    const Tables T = uniform_tables(a.Tp);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t id = a.tokens[i];
-        if (id < 0 || id > a.Tp->max_id) continue;
-        const uint8_t* src = a.Tp->tok_bytes + a.Tp->tok_off[id];
+        if (id < 0 || id > T.max_id) continue;
+        const uint8_t* src = T.tok_bytes + T.tok_off[id];
         const int64_t o = a.byte_off[i], len = a.byte_off[i + 1] - o;
         for (int64_t k = 0; k < len; ++k)
             if (o + k < a.out_cap) a.out[o + k] = src[k];
