@@ -102,6 +102,18 @@ def test_tile_boundary_sweep(tok):
     _check_batch(tok, O, text, offs)
 
 
+def test_one_token_per_byte_across_tiles(tok):
+    # every byte its own token (" \x01" is two pieces-bytes, two ids) for whole tiles, with the pieces straddling
+    # the tile edges: a tile then owns MORE tokens than it has bytes (its last piece ends in the next tile)
+    O = H.port_tokenizer()
+    docs = [b"a" * k + b" \x01" * 9000 for k in range(3)]
+    docs.append(b" \x01" * 3000 + b"\x02" * 70 + b" \x01" * 3000)      # with a long piece (marker slot) inside
+    docs.append((b" \x7f" * 2040 + b" " + b"\x01\x02\x03" * 20) * 3)   # 61-byte unmergeable pieces over the edge
+    text, offs = H.pack_docs(docs)
+    _check_batch(tok, O, text, offs)
+    _check_batch(tok, O, text, np.asarray([0, len(text)], dtype=np.int64))
+
+
 def test_unaligned_text_pointer_and_empty_docs(tok):
     O = H.port_tokenizer()
     x, o = td_corpus.mixed(300000, seed=9)

@@ -100,7 +100,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->docbits, (size_t)((n + 31) / 32 + 2) * 4))) return rc;
     if ((rc = ensure(t, t->startbits, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
     if ((rc = ensure(t, t->slow_list, (size_t)(n_tiles * 8 + 64) * 8))) return rc;
-    if ((rc = ensure(t, t->stage, (size_t)std::max<int64_t>(n_tiles, 1) * K_TILE * 4))) return rc;
+    if ((rc = ensure(t, t->stage, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;

@@ -755,6 +755,8 @@ constexpr int K_HR = 192;                      // right halo (piece overrun / lo
 constexpr int K_WIN = K_HL + K_TILE + K_HR;    // bytes staged in LDS per tile
 constexpr int K_LIM = K_WIN - 4;               // the scanner may read window positions < K_LIM
 constexpr int K_MAXSHORT = 64;                 // pieces up to this many bytes merge inside one wavefront
+constexpr int K_STAGE = K_TILE + K_MAXSHORT;   // staging slots per tile: a tile owns the tokens of the pieces that START in it,
+                                               // and its last piece may end up to K_MAXSHORT - 1 bytes into the next tile
 
 // One lane's share of the boundary scan of a tile (phase 2 of td_encode_tiles; the CPU twin runs the
 // same code lane by lane).  Window coordinates: index i <-> global byte wg0 + i; the tile owns

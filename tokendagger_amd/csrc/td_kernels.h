@@ -26,7 +26,7 @@ struct EncodeArgs {
     int64_t* slow_list;         // [slow_cap] positions handed from td_split_tiles to td_split_slow: (byte << 1) | kind
     uint32_t slow_cap;
     uint32_t* slow_count;
-    uint32_t* stage;            // [n_tiles*K_TILE] per-tile compacted slots (token ids / long markers)
+    uint32_t* stage;            // [n_tiles*K_STAGE] per-tile compacted slots (token ids / long markers)
     uint32_t* tile_count;       // [n_tiles] slots in the tile
     uint32_t* tile_extra;       // [n_tiles] sum(ntok-1) over the tile's long pieces
     int64_t* tile_base;         // [n_tiles+1] exclusive scan of count+extra

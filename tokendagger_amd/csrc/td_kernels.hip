@@ -586,6 +586,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
     __shared__ long long s_ext_end;                // global end of the tile's last piece when it leaves the window (else 0)
     __shared__ uint32_t s_haslong;
     __shared__ uint32_t s_segctr;                  // phase 4: next 256-byte segment to merge
+    __shared__ uint32_t s_tailcnt;                 // phase 5: tokens in the slots past the tile end
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -870,7 +871,9 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         __syncthreads();
         if (a.stop_after == 4) continue;
 
-        // ---- phase 5: compact the byte-indexed token array into the tile's staging area -----
+        // ---- phase 5: compact the byte-indexed token array (in place, in LDS: a token never moves to a higher
+        //      index, and every lane has read its slots before the scan's barriers), then stream the dense prefix to
+        //      the tile's staging area with 16-byte stores -------------------------------------------------------
         {
             uint32_t vals[K_CHUNK];
 #pragma unroll
@@ -881,27 +884,32 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
             uint32_t vmask = 0;
 #pragma unroll
             for (int k = 0; k < K_CHUNK; ++k) vmask |= (vals[k] != TOK_NONE) ? (1u << k) : 0u;
-            uint32_t cnt = __popc(vmask);
-            // tokens of the tile's last piece may sit past the tile end (slots K_TILE .. K_TILE+63):
-            // they follow everything else in byte order, so the last lane appends them
-            uint32_t tail = 0;
-            if (tid == K_THREADS - 1)
-                for (int k = 0; k < K_MAXSHORT; ++k) tail += (s_tok[K_TILE + k] != TOK_NONE) ? 1u : 0u;
-            cnt += tail;
+            const uint32_t cnt = __popc(vmask);
+            // tokens of the tile's last piece may sit past the tile end (slots K_TILE .. K_TILE+63): they follow
+            // everything else in byte order; the first wavefront carries them, one slot per lane
+            static_assert(K_MAXSHORT == 64, "one tail slot per lane of a wavefront");
+            uint32_t tv = TOK_NONE;
+            uint64_t tb = 0;
+            if (tid < 64) {
+                tv = s_tok[K_TILE + tid];
+                tb = __ballot(tv != TOK_NONE);
+                if (tid == 0) s_tailcnt = (uint32_t)__popcll((unsigned long long)tb);
+            }
             uint32_t total;
             const uint32_t off = block_excl_scan(cnt, s_wave, total);
+            const uint32_t total_regular = total;
+            total += s_tailcnt;
             s_off[tid] = off;
             s_valid[tid] = (uint16_t)vmask;
-            uint32_t* dst = a.stage + (size_t)tile * K_TILE + off;
-            uint32_t k2 = 0;
+            uint32_t k2 = off;
 #pragma unroll
             for (int k = 0; k < K_CHUNK; ++k)
-                if (vals[k] != TOK_NONE) dst[k2++] = vals[k];
-            if (tail)
-                for (int k = 0; k < K_MAXSHORT; ++k) {
-                    const uint32_t v = s_tok[K_TILE + k];
-                    if (v != TOK_NONE) dst[k2++] = v;
-                }
+                if (vals[k] != TOK_NONE) s_tok[k2++] = vals[k];
+            if (tid < 64 && tv != TOK_NONE)
+                s_tok[total_regular + (uint32_t)__popcll((unsigned long long)(tb & ((1ull << tid) - 1ull)))] = tv;
+            __syncthreads();
+            uint4* dst4 = reinterpret_cast<uint4*>(a.stage + (size_t)tile * K_STAGE);
+            for (uint32_t v = tid; v * 4 < total; v += K_THREADS) dst4[v] = reinterpret_cast<const uint4*>(s_tok)[v];
             if (tid == 0) a.tile_count[tile] = total | (s_haslong ? 0x80000000u : 0u);
             __syncthreads();
             // token slot of every document that starts in this tile (documents are consecutive from the
@@ -1181,7 +1189,8 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
 // few KB: many small independent copies in flight beat few large ones); tiles that contain long-piece markers
 // are left to a second, workgroup-wide pass that expands them.
 __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
-    __shared__ uint32_t s_off[K_TILE];
+    constexpr int K_PCH = (K_STAGE + K_THREADS - 1) / K_THREADS;  // staging slots per lane in pass 2
+    __shared__ uint32_t s_off[K_THREADS * K_PCH];
     __shared__ uint32_t s_wave[8];
     __shared__ uint32_t s_mark[64];
     __shared__ uint32_t s_nmark;
@@ -1194,7 +1203,7 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         if (tc >> 31) continue;
         const uint32_t cnt = tc;
         const int64_t base = a.tile_base[tile];
-        const uint32_t* src = a.stage + (size_t)tile * K_TILE;
+        const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
         if (base + cnt <= a.out_cap)
             for (uint32_t i = lane; i < cnt; i += 64) a.out_tokens[base + i] = (int32_t)src[i];
         const int64_t g_lo = (int64_t)tile * K_TILE;
@@ -1214,12 +1223,12 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         if (!(tc >> 31)) continue;  // uniform per workgroup
         const uint32_t cnt = tc & 0x7FFFFFFFu;
         const int64_t base = a.tile_base[tile];
-        const uint32_t* src = a.stage + (size_t)tile * K_TILE;
-        uint32_t sz[K_CHUNK];
+        const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
+        uint32_t sz[K_PCH];
         uint32_t mine = 0;
         if (tid == 0) s_nmark = 0;
-        for (int k = 0; k < K_CHUNK; ++k) {
-            const uint32_t i = tid * K_CHUNK + k;
+        for (int k = 0; k < K_PCH; ++k) {
+            const uint32_t i = tid * K_PCH + k;
             uint32_t sl = 0;
             if (i < cnt) {
                 const uint32_t v = src[i];
@@ -1230,8 +1239,8 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         }
         uint32_t tot;
         uint32_t run = block_excl_scan(mine, s_wave, tot);
-        for (int k = 0; k < K_CHUNK; ++k) {
-            s_off[tid * K_CHUNK + k] = run;
+        for (int k = 0; k < K_PCH; ++k) {
+            s_off[tid * K_PCH + k] = run;
             run += sz[k];
         }
         __syncthreads();
