@@ -130,6 +130,41 @@ int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum
 int64_t td_special_count(const td_tokenizer* t);
 int td_special_get(const td_tokenizer* t, int64_t i, const char** str, int64_t* len, int32_t* id);
 
+/* Vocabulary accessors (host tables, no launch): the bytes of one token id (tiktoken decode_single_token_bytes;
+ * TD_E_BAD_TOKEN if the id is not in the vocabulary) and the id of one whole token (tiktoken encode_single_token:
+ * regular tokens first, then special tokens; TD_E_UNKNOWN_BYTE if the bytes are not a token). */
+int td_token_bytes(const td_tokenizer* t, int32_t id, const uint8_t** bytes, int64_t* len);
+int td_single_token(const td_tokenizer* t, const uint8_t* bytes, int64_t len, int32_t* id);
+
+/* ---- vocabulary files (host only; no GPU needed) ------------------------------------------------------------
+ * Replaces the reference's loaders, which live in its demo and in Python: LoadBPEFile / LoadTokenizer
+ * (src/main.cpp:70-137), load_bpe_vocab / load_special_tokens / load_mistral_config (tests/throughput_test.py:
+ * 106-180) and Tokenizer._load_vocab_file / _load_special_tokens_file (tokendagger/wrapper.py:116-134).
+ * A td_vocab accumulates regular tokens, special tokens and (tekken only) the split pattern; every loader appends.
+ * All return TD_OK, TD_E_INVALID (bad argument) or TD_E_VOCAB (unreadable / malformed file: td_vocab_error). */
+typedef struct td_vocab td_vocab;
+int td_vocab_create(td_vocab** out);
+void td_vocab_destroy(td_vocab* v);
+const char* td_vocab_error(const td_vocab* v);
+/* tiktoken ".model": lines of "<base64 token bytes> <rank>" */
+int td_vocab_load_tiktoken(td_vocab* v, const char* path);
+/* Hugging Face tokenizer_config.json: added_tokens_decoder {"<id>": {"content": "..."}} -> special tokens;
+ * also_mergeable != 0 additionally enters them as regular tokens, as the reference's tests do
+ * (tests/throughput_test.py:211-213). */
+int td_vocab_load_hf_special(td_vocab* v, const char* path, int also_mergeable);
+/* Mistral tekken.json: config.pattern + the first default_vocab_size - default_num_special_tokens entries of
+ * "vocab", id = index + default_num_special_tokens */
+int td_vocab_load_tekken(td_vocab* v, const char* path);
+/* the reference wrapper's JSON files; either path may be NULL */
+int td_vocab_load_json(td_vocab* v, const char* vocab_json_path, const char* special_json_path);
+int td_vocab_set_pattern(td_vocab* v, const char* pat_str);
+const char* td_vocab_pattern(const td_vocab* v); /* "" if none was set / loaded */
+/* flat views (valid until the next load / destroy): which = 0 regular, 1 special */
+int td_vocab_arrays(const td_vocab* v, int which, const uint8_t** bytes, const int64_t** offsets, const int32_t** ranks,
+                    int64_t* n);
+/* td_create over a loaded vocabulary (pattern = td_vocab_pattern) */
+int td_create_from_vocab(const td_vocab* v, int device, td_tokenizer** out);
+
 #ifdef __cplusplus
 }
 #endif

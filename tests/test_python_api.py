@@ -89,3 +89,56 @@ def test_attributes_and_errors(enc):
     assert t.encode("ab") == [2] and t.encode("ba") == [1, 0]
     with pytest.raises(tokendagger.TokenDaggerError):
         t.encode("abc")
+
+
+def test_from_files_matches_in_memory_construction(enc, tmp_path):
+    """C++ loader path (Tokenizer.from_files / load_tokenizer) builds the same tokenizer as Encoding(...)."""
+    import base64
+    import json
+    import tokendagger as tiktoken
+    pat, mr, sp = H.llama4()
+    with open(tmp_path / "tokenizer.model", "w") as f:
+        for b, r in mr.items():
+            if r < 200000:
+                f.write(base64.b64encode(b).decode() + " " + str(r) + "\n")
+    (tmp_path / "tokenizer_config.json").write_text(json.dumps(
+        {"added_tokens_decoder": {str(i): {"content": s} for s, i in sp.items()}}))
+    t = tiktoken.Tokenizer.from_files("llama4-files", pat_str=pat, tiktoken_model=tmp_path / "tokenizer.model",
+                                      hf_config=tmp_path / "tokenizer_config.json", specials_mergeable=True)
+    assert t.pattern == pat and t.max_token_value == enc.max_token_value and t.n_vocab == enc.n_vocab
+    assert t.special_tokens_set == enc.special_tokens_set
+    for s in ["Hello, world!", "def f(x):\n    return x**2  # 中文 😀", "<|begin_of_text|>hi<|eot|>", " " * 70 + "end"]:
+        assert t.encode(s) == enc.encode(s)
+        assert t.encode(s, allowed_special="all") == enc.encode(s, allowed_special="all")
+        assert t.decode(t.encode(s)) == s
+    assert tiktoken.load_tiktoken_bpe(tmp_path / "tokenizer.model") == {b: r for b, r in mr.items() if r < 200000}
+    # the reference wrapper's JSON formats through load_tokenizer (wrapper.py:333-355)
+    small = [{"rank": r, "token_bytes": list(b), "token_string": ""} for b, r in mr.items() if r < 3000]
+    (tmp_path / "vocab.json").write_text(json.dumps(small))
+    (tmp_path / "special.json").write_text(json.dumps({"<|x|>": 5000}))
+    lt = tiktoken.load_tokenizer("small", tmp_path / "vocab.json", pat, tmp_path / "special.json")
+    ref_small = tiktoken.Encoding("small", pat_str=pat, mergeable_ranks={bytes(e["token_bytes"]): e["rank"] for e in small},
+                                  special_tokens={"<|x|>": 5000})
+    for s in ["the quick brown fox", "a<|x|>b"]:
+        assert lt.encode(s, allowed_special="all") == ref_small.encode(s, allowed_special="all")
+    with pytest.raises(FileNotFoundError):
+        tiktoken.load_tokenizer("none", tmp_path / "missing.json", pat)
+    with pytest.raises(tiktoken.TokenDaggerError):
+        tiktoken.Tokenizer.from_files("bad", pat_str="[a-z]+", tiktoken_model=tmp_path / "tokenizer.model")
+
+
+def test_single_token_accessors(enc):
+    pat, mr, special = H.llama4()
+    assert enc.encode_single_token("hello") == mr[b"hello"] and enc.encode_single_token(b" the") == mr[b" the"]
+    assert enc.encode_single_token("<|begin_of_text|>") == special["<|begin_of_text|>"]
+    for bad in ["hello world, this is not one token", b"\xff\xfe\xfd\xfc\xfb\xfa"]:
+        with pytest.raises(KeyError):
+            enc.encode_single_token(bad)
+    assert enc.decode_single_token_bytes(mr[b"hello"]) == b"hello"
+    assert enc.decode_tokens_bytes([19873, 24, 3817, 13]) == [b"Hello", b",", b" world", b"!"]
+    with pytest.raises(KeyError):
+        enc.decode_single_token_bytes(enc.n_vocab + 5)
+    tbv = enc.token_byte_values()
+    assert len(tbv) == len(set(mr.values()) - set(special.values())) and tbv == sorted(tbv) and b"hello" in tbv
+    with pytest.raises(KeyError):
+        enc.eot_token  # Llama-4 names its end token differently: same behaviour as a tiktoken Encoding without "<|endoftext|>"

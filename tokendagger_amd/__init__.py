@@ -12,7 +12,7 @@ Importing the tokenizer classes without them raises ImportError — there is no 
 """
 __version__ = "0.1.0"
 
-__all__ = ["Tokenizer", "TokenDaggerError", "load_tokenizer", "create_tokenizer", "Encoding", "llama4_scout", "core"]
+__all__ = ["Tokenizer", "TokenDaggerError", "load_tokenizer", "create_tokenizer", "Encoding", "llama4_scout", "load_tiktoken_bpe", "core"]
 
 
 def __getattr__(name):  # lazy: keep `import tokendagger_amd.vocab_io` usable before the extension is built
@@ -28,6 +28,7 @@ def __getattr__(name):  # lazy: keep `import tokendagger_amd.vocab_io` usable be
         g = globals()
         g.update(Tokenizer=wrapper.Tokenizer, TokenDaggerError=wrapper.TokenDaggerError,
                  load_tokenizer=wrapper.load_tokenizer, create_tokenizer=wrapper.create_tokenizer,
-                 Encoding=wrapper.Encoding, llama4_scout=wrapper.llama4_scout, core=core)
+                 Encoding=wrapper.Encoding, llama4_scout=wrapper.llama4_scout,
+                 load_tiktoken_bpe=wrapper.load_tiktoken_bpe, core=core)
         return g[name]
     raise AttributeError(f"module 'tokendagger_amd' has no attribute {name!r}")

@@ -27,6 +27,9 @@ EXPORTS = [
     "td_create", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",
     "td_device_status", "td_decode_bytes", "td_encode_with_special", "td_info", "td_set_option",
     "td_special_count", "td_special_get", "td_profile_read",
+    "td_vocab_create", "td_vocab_destroy", "td_vocab_error", "td_vocab_load_tiktoken", "td_vocab_load_hf_special",
+    "td_vocab_load_tekken", "td_vocab_load_json", "td_vocab_set_pattern", "td_vocab_pattern", "td_vocab_arrays",
+    "td_create_from_vocab", "td_token_bytes", "td_single_token",
 ]
 
 
@@ -100,6 +103,28 @@ def load_library():
     lib.td_special_count.argtypes = [vp]
     lib.td_special_get.restype = i32
     lib.td_special_get.argtypes = [vp, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
+    lib.td_token_bytes.restype = i32
+    lib.td_token_bytes.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    lib.td_single_token.restype = i32
+    lib.td_single_token.argtypes = [vp, vp, i64, ctypes.POINTER(ctypes.c_int32)]
+    lib.td_vocab_create.restype = i32
+    lib.td_vocab_create.argtypes = [ctypes.POINTER(vp)]
+    lib.td_vocab_destroy.argtypes = [vp]
+    lib.td_vocab_error.restype = ctypes.c_char_p
+    lib.td_vocab_error.argtypes = [vp]
+    for fn in ("td_vocab_load_tiktoken", "td_vocab_load_tekken", "td_vocab_set_pattern"):
+        getattr(lib, fn).restype = i32
+        getattr(lib, fn).argtypes = [vp, ctypes.c_char_p]
+    lib.td_vocab_load_hf_special.restype = i32
+    lib.td_vocab_load_hf_special.argtypes = [vp, ctypes.c_char_p, i32]
+    lib.td_vocab_load_json.restype = i32
+    lib.td_vocab_load_json.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+    lib.td_vocab_pattern.restype = ctypes.c_char_p
+    lib.td_vocab_pattern.argtypes = [vp]
+    lib.td_vocab_arrays.restype = i32
+    lib.td_vocab_arrays.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    lib.td_create_from_vocab.restype = i32
+    lib.td_create_from_vocab.argtypes = [vp, i32, ctypes.POINTER(vp)]
     _lib = lib
     return lib
 
@@ -119,8 +144,105 @@ def _as_u8(data) -> np.ndarray:
     return np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(0, dtype=np.uint8)
 
 
+class Vocab:
+    """A `td_vocab`: vocabulary files read by the C++ loaders (tiktoken .model, HF tokenizer_config.json,
+    tekken.json, the reference wrapper's JSON files).  Host only: works without a GPU."""
+
+    def __init__(self):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        if self._lib.td_vocab_create(ctypes.byref(h)) != TD_OK:
+            raise TokenDaggerHipError(1, "td_vocab_create failed")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.td_vocab_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc: int):
+        if rc != TD_OK:
+            raise TokenDaggerHipError(rc, self._lib.td_vocab_error(self._h).decode("utf-8", "replace"))
+        return self
+
+    @staticmethod
+    def _p(path) -> bytes:
+        import os
+        return os.fsencode(str(path))
+
+    def load_tiktoken(self, path):
+        return self._check(self._lib.td_vocab_load_tiktoken(self._h, self._p(path)))
+
+    def load_hf_special(self, path, also_mergeable: bool = False):
+        return self._check(self._lib.td_vocab_load_hf_special(self._h, self._p(path), int(also_mergeable)))
+
+    def load_tekken(self, path):
+        return self._check(self._lib.td_vocab_load_tekken(self._h, self._p(path)))
+
+    def load_json(self, vocab_path=None, special_path=None):
+        return self._check(self._lib.td_vocab_load_json(self._h, self._p(vocab_path) if vocab_path else None,
+                                                        self._p(special_path) if special_path else None))
+
+    def set_pattern(self, pat_str: str):
+        return self._check(self._lib.td_vocab_set_pattern(self._h, pat_str.encode("utf-8")))
+
+    @property
+    def pattern(self) -> str:
+        return self._lib.td_vocab_pattern(self._h).decode("utf-8")
+
+    def arrays(self, special: bool = False):
+        """-> (bytes uint8[total], offsets int64[n+1], ranks int32[n]) copies of the loaded tokens."""
+        b, o, r = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        n = ctypes.c_int64(0)
+        self._check(self._lib.td_vocab_arrays(self._h, int(special), ctypes.byref(b), ctypes.byref(o), ctypes.byref(r),
+                                              ctypes.byref(n)))
+        cnt = n.value
+        offs = np.ctypeslib.as_array(ctypes.cast(o, ctypes.POINTER(ctypes.c_int64)), shape=(cnt + 1,)).copy()
+        ranks = (np.ctypeslib.as_array(ctypes.cast(r, ctypes.POINTER(ctypes.c_int32)), shape=(cnt,)).copy()
+                 if cnt else np.zeros(0, dtype=np.int32))
+        total = int(offs[-1])
+        blob = (np.ctypeslib.as_array(ctypes.cast(b, ctypes.POINTER(ctypes.c_uint8)), shape=(total,)).copy()
+                if total else np.zeros(0, dtype=np.uint8))
+        return blob, offs, ranks
+
+    def __len__(self) -> int:
+        n = ctypes.c_int64(0)
+        self._lib.td_vocab_arrays(self._h, 0, None, None, None, ctypes.byref(n))
+        return n.value
+
+    def mergeable_ranks(self) -> dict[bytes, int]:
+        blob, offs, ranks = self.arrays(False)
+        raw = blob.tobytes()
+        return {raw[offs[i]:offs[i + 1]]: int(ranks[i]) for i in range(len(ranks))}
+
+    def special_tokens(self) -> dict[str, int]:
+        blob, offs, ranks = self.arrays(True)
+        raw = blob.tobytes()
+        return {raw[offs[i]:offs[i + 1]].decode("utf-8"): int(ranks[i]) for i in range(len(ranks))}
+
+
+def load_tiktoken_bpe(path) -> dict[bytes, int]:
+    """tiktoken.load.load_tiktoken_bpe for a local file, through the C++ loader."""
+    return Vocab().load_tiktoken(path).mergeable_ranks()
+
+
 class HipTokenizer:
     """Owns one `td_tokenizer` handle (device tables + workspace on one GPU)."""
+
+    @classmethod
+    def from_vocab(cls, vocab: Vocab, device: int = -1) -> "HipTokenizer":
+        """td_create_from_vocab: no Python-side token objects at all."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        self._h = None
+        h = ctypes.c_void_p()
+        rc = self._lib.td_create_from_vocab(vocab._h, device, ctypes.byref(h))
+        if rc != TD_OK:
+            raise TokenDaggerHipError(rc, self._lib.td_last_error(None).decode("utf-8", "replace"))
+        self._h = h
+        return self
 
     def __init__(self, pat_str: str, mergeable_ranks: dict[bytes, int], special_tokens: dict[str, int] | None = None,
                  device: int = -1):

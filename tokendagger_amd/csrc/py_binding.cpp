@@ -70,6 +70,46 @@ public:
         if (rc != TD_OK) throw TiktokenError(td_last_error(nullptr));
         for (const auto& it : special) special_ids_[it.token_string] = it.rank;
     }
+    // Vocabulary files read by the C++ loaders (td_vocab_*): no Python-side VocabItem objects at all.  Empty paths
+    // are skipped; `pattern` overrides the pattern a tekken file carries.
+    struct FromFiles {};
+    CoreBPE(FromFiles, const std::string& pattern, const std::string& tiktoken_model, const std::string& hf_config,
+            bool specials_mergeable, const std::string& tekken, const std::string& vocab_json, const std::string& special_json,
+            int device) {
+        td_vocab* v = nullptr;
+        if (td_vocab_create(&v) != TD_OK) throw TiktokenError("td_vocab_create failed");
+        int rc = TD_OK;
+        std::string err;
+        {
+            py::gil_scoped_release rel;
+            if (rc == TD_OK && !tekken.empty()) rc = td_vocab_load_tekken(v, tekken.c_str());
+            if (rc == TD_OK && !tiktoken_model.empty()) rc = td_vocab_load_tiktoken(v, tiktoken_model.c_str());
+            if (rc == TD_OK && !hf_config.empty()) rc = td_vocab_load_hf_special(v, hf_config.c_str(), specials_mergeable ? 1 : 0);
+            if (rc == TD_OK && (!vocab_json.empty() || !special_json.empty()))
+                rc = td_vocab_load_json(v, vocab_json.empty() ? nullptr : vocab_json.c_str(),
+                                        special_json.empty() ? nullptr : special_json.c_str());
+            if (rc == TD_OK && !pattern.empty()) rc = td_vocab_set_pattern(v, pattern.c_str());
+            if (rc != TD_OK) err = td_vocab_error(v);
+            if (rc == TD_OK) {
+                rc = td_create_from_vocab(v, device, &h_);
+                if (rc != TD_OK) err = td_last_error(nullptr);
+            }
+        }
+        if (rc == TD_OK) {
+            pattern_ = td_vocab_pattern(v);
+            const uint8_t* b;
+            const int64_t* o;
+            const int32_t* r;
+            int64_t n;
+            td_vocab_arrays(v, 1, &b, &o, &r, &n);
+            for (int64_t i = 0; i < n; ++i) special_ids_[std::string((const char*)b + o[i], (size_t)(o[i + 1] - o[i]))] = r[i];
+        }
+        td_vocab_destroy(v);
+        if (rc != TD_OK) throw TiktokenError(err);
+    }
+    std::string pattern() const { return pattern_; }
+    std::map<std::string, int32_t> special_map() const { return special_ids_; }
+
     ~CoreBPE() { td_destroy(h_); }
     CoreBPE(const CoreBPE&) = delete;
     CoreBPE& operator=(const CoreBPE&) = delete;
@@ -217,12 +257,24 @@ public:
         return py::bytes(out);
     }
 
+    py::object token_bytes(int id) const {  // None if the id is not in the vocabulary
+        const uint8_t* p = nullptr;
+        int64_t n = 0;
+        if (td_token_bytes(h_, id, &p, &n) != TD_OK) return py::none();
+        return py::bytes((const char*)p, (size_t)n);
+    }
+    py::object single_token(const std::string& bytes) const {  // None if the bytes are not one token
+        int32_t id = 0;
+        if (bytes.empty() || td_single_token(h_, (const uint8_t*)bytes.data(), (int64_t)bytes.size(), &id) != TD_OK) return py::none();
+        return py::int_(id);
+    }
     int64_t info(int what) const { return td_info(h_, what); }
     uintptr_t handle() const { return (uintptr_t)h_; }
 
 private:
     td_tokenizer* h_ = nullptr;
     std::map<std::string, int32_t> special_ids_;
+    std::string pattern_;
 };
 
 }  // namespace
@@ -241,6 +293,18 @@ PYBIND11_MODULE(_tokendagger_core, m) {
     py::class_<CoreBPE>(m, "CoreBPE")
         .def(py::init<const std::string&, const std::vector<VocabItem>&, const std::vector<VocabItem>&, int>(),
              py::arg("pattern"), py::arg("vocab"), py::arg("special_vocab"), py::arg("device") = -1)
+        .def_static(
+            "from_files",
+            [](const std::string& pattern, const std::string& tiktoken_model, const std::string& hf_config, bool specials_mergeable,
+               const std::string& tekken, const std::string& vocab_json, const std::string& special_json, int device) {
+                return new CoreBPE(CoreBPE::FromFiles{}, pattern, tiktoken_model, hf_config, specials_mergeable, tekken, vocab_json,
+                                   special_json, device);
+            },
+            py::arg("pattern") = "", py::arg("tiktoken_model") = "", py::arg("hf_config") = "", py::arg("specials_mergeable") = false,
+            py::arg("tekken") = "", py::arg("vocab_json") = "", py::arg("special_json") = "", py::arg("device") = -1,
+            py::return_value_policy::take_ownership)
+        .def("pattern", &CoreBPE::pattern)
+        .def("special_map", &CoreBPE::special_map)
         .def("encode_ordinary", [](CoreBPE& self, const std::string& text) { return self.encode_mode(text, TD_MODE_ORDINARY); },
              py::arg("text"))
         .def("encode", &CoreBPE::encode, py::arg("text"), py::arg("allowed_special"))
@@ -250,6 +314,8 @@ PYBIND11_MODULE(_tokendagger_core, m) {
         .def("encode_batch", &CoreBPE::encode_batch, py::arg("texts"), py::arg("mode") = TD_MODE_ENCODE)
         .def("encode_batch_numpy", &CoreBPE::encode_batch_numpy, py::arg("text"), py::arg("offsets"), py::arg("mode") = TD_MODE_ENCODE)
         .def("decode_to_bytes", &CoreBPE::decode_to_bytes, py::arg("tokens"))
+        .def("token_bytes", &CoreBPE::token_bytes, py::arg("id"))
+        .def("single_token", [](const CoreBPE& self, py::bytes b) { return self.single_token(std::string(b)); }, py::arg("token_bytes"))
         .def("info", &CoreBPE::info, py::arg("what"))
         .def("handle", &CoreBPE::handle);
 }

@@ -12,6 +12,7 @@
 #include "../../include/tokendagger_hip.h"
 #include "td_kernels.h"
 #include "td_tables.h"
+#include "td_vocab.h"
 
 using namespace td;
 
@@ -566,6 +567,98 @@ int td_special_get(const td_tokenizer* t, int64_t i, const char** str, int64_t* 
     if (len) *len = (int64_t)t->H.special_strs[(size_t)i].size();
     if (id) *id = t->H.special_ids[(size_t)i];
     return TD_OK;
+}
+
+int td_token_bytes(const td_tokenizer* t, int32_t id, const uint8_t** bytes, int64_t* len) {
+    if (!t) return TD_E_INVALID;
+    const HostTables& H = t->H;
+    if (id < 0 || id > H.max_id || H.tok_off[(size_t)id + 1] == H.tok_off[(size_t)id]) return TD_E_BAD_TOKEN;
+    if (bytes) *bytes = H.tok_bytes.data() + H.tok_off[(size_t)id];
+    if (len) *len = (int64_t)H.tok_off[(size_t)id + 1] - (int64_t)H.tok_off[(size_t)id];
+    return TD_OK;
+}
+
+int td_single_token(const td_tokenizer* t, const uint8_t* bytes, int64_t len, int32_t* id) {
+    if (!t || !bytes || len <= 0 || !id) return TD_E_INVALID;
+    const HostTables& H = t->H;
+    const Tables hv = H.view();
+    int32_t r = NO_RANK;
+    if (len == 1) {
+        r = H.byte_id[bytes[0]];
+        if (r >= H.pseudo_base) r = NO_RANK;
+    } else if (len <= (int64_t)H.max_token_len) {
+        r = piece_lookup(hv, piece_key_host(bytes, (uint32_t)len), (uint32_t)len, [bytes](uint32_t i) { return (uint32_t)bytes[i]; });
+    }
+    if (r == NO_RANK)
+        for (size_t i = 0; i < H.special_ids.size(); ++i)
+            if ((int64_t)H.special_strs[i].size() == len && memcmp(H.special_strs[i].data(), bytes, (size_t)len) == 0) { r = H.special_ids[i]; break; }
+    if (r == NO_RANK) return TD_E_UNKNOWN_BYTE;
+    *id = r;
+    return TD_OK;
+}
+
+// ---- vocabulary files ------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct td_vocab {
+    td::VocabData d;
+};
+
+extern "C" {
+
+int td_vocab_create(td_vocab** out) {
+    if (!out) return TD_E_INVALID;
+    *out = new td_vocab;
+    return TD_OK;
+}
+void td_vocab_destroy(td_vocab* v) { delete v; }
+const char* td_vocab_error(const td_vocab* v) { return v ? v->d.err.c_str() : "null td_vocab"; }
+
+int td_vocab_load_tiktoken(td_vocab* v, const char* path) {
+    if (!v || !path) return TD_E_INVALID;
+    return load_tiktoken_model(path, v->d) ? TD_OK : TD_E_VOCAB;
+}
+int td_vocab_load_hf_special(td_vocab* v, const char* path, int also_mergeable) {
+    if (!v || !path) return TD_E_INVALID;
+    return load_hf_added_tokens(path, v->d, also_mergeable != 0) ? TD_OK : TD_E_VOCAB;
+}
+int td_vocab_load_tekken(td_vocab* v, const char* path) {
+    if (!v || !path) return TD_E_INVALID;
+    return load_tekken_json(path, v->d) ? TD_OK : TD_E_VOCAB;
+}
+int td_vocab_load_json(td_vocab* v, const char* vocab_json_path, const char* special_json_path) {
+    if (!v || (!vocab_json_path && !special_json_path)) return TD_E_INVALID;
+    return load_wrapper_json(vocab_json_path ? vocab_json_path : "", special_json_path ? special_json_path : "", v->d) ? TD_OK
+                                                                                                                      : TD_E_VOCAB;
+}
+int td_vocab_set_pattern(td_vocab* v, const char* pat_str) {
+    if (!v || !pat_str) return TD_E_INVALID;
+    v->d.pattern = pat_str;
+    return TD_OK;
+}
+const char* td_vocab_pattern(const td_vocab* v) { return v ? v->d.pattern.c_str() : ""; }
+
+int td_vocab_arrays(const td_vocab* v, int which, const uint8_t** bytes, const int64_t** offsets, const int32_t** ranks,
+                    int64_t* n) {
+    if (!v || (which != 0 && which != 1)) return TD_E_INVALID;
+    const td::TokenList& l = which ? v->d.special : v->d.regular;
+    static const uint8_t none = 0;
+    if (bytes) *bytes = l.bytes.empty() ? &none : l.bytes.data();
+    if (offsets) *offsets = l.offsets.data();
+    if (ranks) *ranks = l.ranks.data();
+    if (n) *n = l.size();
+    return TD_OK;
+}
+
+int td_create_from_vocab(const td_vocab* v, int device, td_tokenizer** out) {
+    if (!v || !out) return TD_E_INVALID;
+    const uint8_t *b = nullptr, *sb = nullptr;
+    const int64_t *o = nullptr, *so = nullptr;
+    const int32_t *r = nullptr, *sr = nullptr;
+    int64_t n = 0, ns = 0;
+    td_vocab_arrays(v, 0, &b, &o, &r, &n);
+    td_vocab_arrays(v, 1, &sb, &so, &sr, &ns);
+    return td_create(v->d.pattern.c_str(), n, b, o, r, ns, sb, so, sr, device, out);
 }
 
 }  // extern "C"

@@ -87,6 +87,31 @@ class Tokenizer:
         except Exception as e:
             raise TokenDaggerError(f"Failed to initialize CoreBPE: {e}")
 
+    @classmethod
+    def from_files(cls, name: str, *, pat_str: str | None = None, tiktoken_model: str | Path | None = None,
+                   hf_config: str | Path | None = None, specials_mergeable: bool = False,
+                   tekken: str | Path | None = None, vocab_file: str | Path | None = None,
+                   special_tokens_file: str | Path | None = None, device: int = -1) -> "Tokenizer":
+        """Build a tokenizer straight from vocabulary files with the C++ loaders (no per-token Python objects):
+        a tiktoken ``.model`` (+ optional Hugging Face ``tokenizer_config.json`` for the special tokens, which
+        ``specials_mergeable`` also enters as ordinary tokens the way the reference's benchmarks do), a Mistral
+        ``tekken.json`` (carries its own pattern), or the reference wrapper's JSON files."""
+        for p in (tiktoken_model, hf_config, tekken, vocab_file, special_tokens_file):
+            if p is not None and not Path(p).exists():
+                raise FileNotFoundError(f"Vocabulary file not found: {p}")
+        s = lambda p: "" if p is None else str(p)
+        self = cls.__new__(cls)
+        self.name = name
+        try:
+            self._core_bpe = _core.CoreBPE.from_files(pat_str or "", s(tiktoken_model), s(hf_config), specials_mergeable,
+                                                      s(tekken), s(vocab_file), s(special_tokens_file), device)
+        except Exception as e:
+            raise TokenDaggerError(f"Failed to initialize CoreBPE: {e}")
+        self.pattern = self._core_bpe.pattern()
+        self._special_tokens = dict(self._core_bpe.special_map())
+        self.max_token_value = int(self._core_bpe.info(3))
+        return self
+
     @staticmethod
     def _read_json(path, what):
         p = Path(path)
@@ -203,10 +228,38 @@ class Tokenizer:
         return [self.decode(t, errors=errors) for t in tokens]
 
     def decode_single_token_bytes(self, token: int) -> bytes:
-        return self.decode_bytes([token])
+        """tiktoken semantics: KeyError for an id that is not in the vocabulary (host table lookup, no launch)."""
+        b = self._core_bpe.token_bytes(int(token))
+        if b is None:
+            raise KeyError(token)
+        return b
 
     def decode_tokens_bytes(self, tokens: Sequence[int]) -> list[bytes]:
-        return [self.decode_bytes([t]) for t in tokens]
+        return [self.decode_single_token_bytes(t) for t in tokens]
+
+    def encode_single_token(self, text_or_bytes: str | bytes) -> int:
+        """tiktoken semantics: the id of exactly one token (ordinary or special), KeyError otherwise."""
+        data = text_or_bytes.encode("utf-8") if isinstance(text_or_bytes, str) else bytes(text_or_bytes)
+        tid = self._core_bpe.single_token(data)
+        if tid is None:
+            raise KeyError(text_or_bytes)
+        return tid
+
+    def token_byte_values(self) -> list[bytes]:
+        """Byte strings of all ordinary tokens, sorted (tiktoken.Encoding.token_byte_values)."""
+        special = set(self._special_tokens.values())
+        out = []
+        for t in range(self.max_token_value + 1):
+            if t in special:
+                continue
+            b = self._core_bpe.token_bytes(t)
+            if b is not None:
+                out.append(b)
+        return sorted(out)
+
+    @property
+    def eot_token(self) -> int:
+        return self._special_tokens["<|endoftext|>"]
 
     # ------------------------------------------------------------------ utilities --------------
     def special_tokens(self) -> list[str]:
@@ -228,7 +281,14 @@ class Tokenizer:
 
 
 def load_tokenizer(name: str, vocab_file: str | Path, pattern: str, special_tokens_file: str | Path | None = None) -> Tokenizer:
-    return Tokenizer(name=name, pattern=pattern, vocab_file=vocab_file, special_tokens_file=special_tokens_file)
+    """Reference: wrapper.py:333-355.  The JSON files are read by the C++ loader (td_vocab_load_json)."""
+    return Tokenizer.from_files(name, pat_str=pattern, vocab_file=vocab_file, special_tokens_file=special_tokens_file)
+
+
+def load_tiktoken_bpe(path: str | Path) -> dict[bytes, int]:
+    """``tiktoken.load.load_tiktoken_bpe`` for a local ``.model`` / ``.tiktoken`` file (C++ loader)."""
+    from . import capi
+    return capi.load_tiktoken_bpe(path)
 
 
 def create_tokenizer(name: str, pattern: str, vocab: list[dict], special_tokens: dict[str, int] | None = None) -> Tokenizer:
