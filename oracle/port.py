@@ -35,14 +35,20 @@ def _lib():
     lib.tdo_decode.restype = ctypes.c_int64
     lib.tdo_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
     lib.tdo_class_of_cp.argtypes = [ctypes.c_uint32]
+    lib.tdo_split_variant.restype = ctypes.c_int64
+    lib.tdo_split_variant.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
+    lib.tdo_set_variant.argtypes = [ctypes.c_void_p, ctypes.c_int]
     return lib
 
 
-def split(data: bytes) -> np.ndarray:
-    """Piece END offsets of the Llama-4 pre-tokenizer over `data`."""
+VARIANT_LLAMA4, VARIANT_TEKKEN = 0, 1
+
+
+def split(data: bytes, variant: int = VARIANT_LLAMA4) -> np.ndarray:
+    """Piece END offsets of the pre-tokenizer (Llama-4 pattern, or its tekken variant) over `data`."""
     lib = _lib()
     out = np.empty(max(len(data), 1), dtype=np.int64)
-    n = lib.tdo_split(data, len(data), out.ctypes.data, out.size)
+    n = lib.tdo_split_variant(data, len(data), out.ctypes.data, out.size, variant)
     if n < 0:
         raise OracleError(lib.tdo_last_error().decode())
     return out[:n].copy()
@@ -55,7 +61,7 @@ def class_of_cp(cp: int) -> int:
 class OracleTokenizer:
     """CPU restatement of CoreBPE for the Llama-4 split pattern (see td_oracle.c header)."""
 
-    def __init__(self, mergeable_ranks: dict[bytes, int]):
+    def __init__(self, mergeable_ranks: dict[bytes, int], variant: int = VARIANT_LLAMA4):
         self._lib = _lib()
         items = list(mergeable_ranks.items())
         ranks = np.asarray([r for _, r in items], dtype=np.int32)
@@ -63,6 +69,7 @@ class OracleTokenizer:
         np.cumsum([len(b) for b, _ in items], out=offs[1:])
         blob = np.frombuffer(b"".join(b for b, _ in items) or b"\0", dtype=np.uint8).copy()
         self._h = self._lib.tdo_create(len(items), blob.ctypes.data, offs.ctypes.data, ranks.ctypes.data)
+        self._lib.tdo_set_variant(self._h, variant)
 
     def __del__(self):
         if getattr(self, "_h", None):

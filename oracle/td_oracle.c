@@ -98,7 +98,11 @@ static int64_t contraction(const uint8_t* s, int64_t e, int64_t n) {
 }
 
 /* End of the piece that starts at pos (pos < n), subject end n. */
-static int64_t next_piece_llama4(const uint8_t* s, int64_t pos, int64_t n) {
+/* variant 0: the Llama-4 / o200k pattern (src/main.cpp:114).  variant 1: the Mistral tekken pattern (tekken.json
+ * config.pattern, read by tests/throughput_test.py:118): the same alternatives without the contraction suffix and with
+ * \p{N} in place of \p{N}{1,3}. */
+static int64_t next_piece_llama4(const uint8_t* s, int64_t pos, int64_t n, int variant) {
+    const int contr = variant == 0, nmax = variant == 0 ? 3 : 1;
     int l0;
     int c0 = char_at(s, pos, n, &l0, NULL);
 
@@ -128,19 +132,19 @@ static int64_t next_piece_llama4(const uint8_t* s, int64_t pos, int64_t n) {
                 } else {
                     continue;
                 }
-                return contraction(s, e, n);
+                return contr ? contraction(s, e, n) : e;
             } else {
                 if (q == st) continue; /* U+ */
                 int64_t e = q;
                 while (e < n) { c = char_at(s, e, n, &l, NULL); if (!is_W(c)) break; e += l; }
-                return contraction(s, e, n);
+                return contr ? contraction(s, e, n) : e;
             }
         }
     }
     /* alternative 3: \p{N}{1,3} */
     if (c0 == C_NUM) {
         int64_t e = pos + l0;
-        for (int k = 1; k < 3 && e < n; ++k) {
+        for (int k = 1; k < nmax && e < n; ++k) {
             int l, c = char_at(s, e, n, &l, NULL);
             if (c != C_NUM) break;
             e += l;
@@ -192,6 +196,7 @@ typedef struct {
     int32_t* slots;     /* index into vocab or -1 */
     int32_t max_rank;
     int64_t* by_rank;   /* rank -> vocab index or -1 (decode) */
+    int variant;        /* split pattern: 0 Llama-4 / o200k, 1 tekken */
 } tdo_t;
 
 static uint64_t fnv(const uint8_t* p, int64_t n) {
@@ -247,10 +252,13 @@ void tdo_destroy(void* h) {
 /* ---------------------------------------------------------------- split -------------------- */
 
 /* piece END offsets of text[0,n); returns count (cap >= n is always enough) */
-int64_t tdo_split(const uint8_t* text, int64_t n, int64_t* ends, int64_t cap) {
+int64_t tdo_split_variant(const uint8_t* text, int64_t n, int64_t* ends, int64_t cap, int variant);
+int64_t tdo_split(const uint8_t* text, int64_t n, int64_t* ends, int64_t cap) { return tdo_split_variant(text, n, ends, cap, 0); }
+void tdo_set_variant(void* h, int variant) { ((tdo_t*)h)->variant = variant; }
+int64_t tdo_split_variant(const uint8_t* text, int64_t n, int64_t* ends, int64_t cap, int variant) {
     int64_t pos = 0, k = 0;
     while (pos < n) {
-        int64_t e = next_piece_llama4(text, pos, n);
+        int64_t e = next_piece_llama4(text, pos, n, variant);
         if (k >= cap) { snprintf(g_err, sizeof g_err, "split capacity"); return -2; }
         ends[k++] = e;
         pos = e;
@@ -310,7 +318,7 @@ int64_t tdo_encode(void* h, const uint8_t* text, int64_t n, int32_t* out, int64_
     const tdo_t* t = (const tdo_t*)h;
     int64_t pos = 0, k = 0;
     while (pos < n) {
-        int64_t e = next_piece_llama4(text, pos, n);
+        int64_t e = next_piece_llama4(text, pos, n, t->variant);
         const uint8_t* piece = text + pos;
         int64_t len = e - pos;
         int32_t r = (len == 1 || !ordinary) ? lookup(t, piece, len) : INT_MAX;

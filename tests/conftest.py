@@ -17,3 +17,11 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(ROOT / "tests" / "golden" / "llama4_golden.npz", allow_pickle=True)
+
+
+@pytest.fixture(scope="session")
+def tekken_golden():
+    """Compiled-reference outputs for the Mistral tekken split pattern over the Llama-4 vocabulary, on the documents
+    of llama4_golden.npz (tools/make_golden.py tekken)."""
+    import numpy as np
+    return np.load(ROOT / "tests" / "golden" / "tekken_style_golden.npz", allow_pickle=True)

@@ -45,6 +45,30 @@ def port_tokenizer():
     return port.OracleTokenizer(mr)
 
 
+# "tekken-style" configuration: the Mistral tekken split pattern over the Llama-4 vocabulary.  The real tekken.json
+# vocabulary is absent from the reference checkout (.MISSING_LARGE_BLOBS), so the pattern family is pinned
+# on this labelled surrogate.
+TEKKEN_PAT = vocab_io.TEKKEN_PAT_STR
+
+
+@functools.lru_cache(maxsize=None)
+def ref_tokenizer_tekken():
+    from oracle import ref
+    if not ref.available():
+        subprocess.check_call([str(ROOT / "oracle" / "build_ref.sh")])
+    _, mr, special = llama4()
+    return ref.RefTokenizer(TEKKEN_PAT, mr, special)
+
+
+@functools.lru_cache(maxsize=None)
+def port_tokenizer_tekken():
+    from oracle import port
+    if not port.available():
+        subprocess.check_call([str(ROOT / "oracle" / "build_oracle.sh")])
+    _, mr, _ = llama4()
+    return port.OracleTokenizer(mr, port.VARIANT_TEKKEN)
+
+
 def pack_docs(docs: list[bytes]):
     offs = np.zeros(len(docs) + 1, dtype=np.int64)
     np.cumsum([len(d) for d in docs], out=offs[1:])
@@ -188,6 +212,12 @@ class Twin:
 def twin_llama4():
     pat, mr, special = llama4()
     return Twin(pat, mr, special)
+
+
+@functools.lru_cache(maxsize=None)
+def twin_tekken():
+    _, mr, special = llama4()
+    return Twin(TEKKEN_PAT, mr, special)
 
 
 # ----------------------------------------------------------------------------- inputs -------

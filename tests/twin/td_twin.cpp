@@ -37,9 +37,10 @@ struct GAcc {
     const uint8_t* cls;
     const uint8_t* text;
     int64_t n, lim;
+    uint32_t pv;  // PV_* pattern variant
     uint32_t cf(int64_t i) const { return i >= n ? (uint32_t)F_DOC : cls[i]; }
     uint32_t byte(int64_t i) const { return i < n ? text[i] : 0u; }
-    int64_t scan(int64_t pos) const { return scan_piece(*this, pos); }
+    int64_t scan(int64_t pos) const { return scan_piece(*this, pos, pv); }
 };
 
 struct WAcc {  // one tile window
@@ -90,6 +91,7 @@ void twin_destroy(void* h) { delete (Twin*)h; }
 
 int64_t twin_info(void* h, int what) {
     Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
     switch (what) {
         case 1: return (int64_t)t->H.n_pairs;
         case 2: return t->H.merge_closed;
@@ -103,6 +105,7 @@ int64_t twin_info(void* h, int what) {
 // per-byte class + F_CONT + F_DOC exactly as phase 1 of the kernel defines them
 void twin_classify(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, uint8_t* out) {
     Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
     std::vector<uint8_t> cls;
     classify_all(t->H.view(), text, n, offs, n_docs, cls);
     if (n) memcpy(out, cls.data(), (size_t)n);
@@ -111,14 +114,15 @@ void twin_classify(void* h, const uint8_t* text, int64_t n, const int64_t* offs,
 // piece starts by serial scanning from every document start (flags[i] = 1 where a piece starts)
 int twin_split_serial(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, uint8_t* flags) {
     Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
     std::vector<uint8_t> cls;
     classify_all(t->H.view(), text, n, offs, n_docs, cls);
     memset(flags, 0, (size_t)n);
-    GAcc g{cls.data(), text, n, n + 4};
+    GAcc g{cls.data(), text, n, n + 4, T.pat_flags};
     int64_t p = 0;
     while (p < n) {
         flags[p] = 1;
-        int64_t e = scan_piece(g, p);
+        int64_t e = scan_piece(g, p, T.pat_flags);
         if (e <= p) return -1;
         p = e;
     }
@@ -131,11 +135,12 @@ int twin_split_serial(void* h, const uint8_t* text, int64_t n, const int64_t* of
 int twin_split_tiled(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, uint8_t* flags,
                      int64_t* ext_ends /* [n] or NULL: global end for ext pieces, else 0 */, int64_t* stats) {
     Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
     std::vector<uint8_t> cls;
     classify_all(t->H.view(), text, n, offs, n_docs, cls);
     memset(flags, 0, (size_t)n);
     if (ext_ends) memset(ext_ends, 0, sizeof(int64_t) * (size_t)n);
-    GAcc g{cls.data(), text, n, n + 4};
+    GAcc g{cls.data(), text, n, n + 4, T.pat_flags};
     const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
     std::vector<uint8_t> wcls(K_WIN), wtxt(K_WIN);
     for (int64_t tile = 0; tile < n_tiles; ++tile) {
@@ -153,7 +158,7 @@ int twin_split_tiled(void* h, const uint8_t* text, int64_t n, const int64_t* off
         WAcc w{wcls.data(), wtxt.data(), K_LIM, -1, 0};
         // lanes run sequentially here; they only communicate through F_START marks, which no lane reads
         // for its decisions (is_sync / scan_piece ignore F_START), so the order does not matter.
-        for (int tid = 0; tid < K_THREADS; ++tid) scan_lane(w, g, tid, tile_hi, wg0);
+        for (int tid = 0; tid < K_THREADS; ++tid) scan_lane(w, g, tid, tile_hi, wg0, T.pat_flags);
         for (int i = K_HL; i < tile_hi; ++i)
             if (wcls[i] & F_START) flags[wg0 + i] = 1;
         if (w.ext_start >= 0) {
@@ -175,11 +180,12 @@ int twin_split_tiled(void* h, const uint8_t* text, int64_t n, const int64_t* off
 int64_t twin_sync_violations(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs,
                              int64_t* n_sync) {
     Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
     std::vector<uint8_t> cls;
     classify_all(t->H.view(), text, n, offs, n_docs, cls);
     std::vector<uint8_t> flags((size_t)n + 1, 0);
-    GAcc g{cls.data(), text, n, n + 4};
-    for (int64_t p = 0; p < n;) { flags[(size_t)p] = 1; p = scan_piece(g, p); }
+    GAcc g{cls.data(), text, n, n + 4, T.pat_flags};
+    for (int64_t p = 0; p < n;) { flags[(size_t)p] = 1; p = scan_piece(g, p, T.pat_flags); }
     int64_t bad = 0, ns = 0;
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t vp = i > 0 ? cls[(size_t)i - 1] : 0u;
@@ -232,13 +238,14 @@ int64_t twin_encode(void* h, const uint8_t* text, int64_t n, const int64_t* offs
 int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, int64_t* n_unres,
                         int64_t* n_checked) {
     Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
     std::vector<uint8_t> cls;
     classify_all(t->H.view(), text, n, offs, n_docs, cls);
-    GAcc g{cls.data(), text, n, n + 4};
+    GAcc g{cls.data(), text, n, n + 4, T.pat_flags};
     int64_t bad = 0, unres = 0, checked = 0;
     const int backs[4] = {0, 3, 17, 40};
     for (int64_t p = 0; p < n;) {
-        const int64_t e = scan_piece(g, p);
+        const int64_t e = scan_piece(g, p, T.pat_flags);
         for (int bi = 0; bi < 4; ++bi) {
             const int64_t base = p - backs[bi];
             if (base < 0) continue;
@@ -298,10 +305,10 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
                 const int off = (int)(p - base);
                 for (int k = 0; k < MK_COUNT; ++k) v.m[k] = (uint32_t)(w.m[k] >> off);
                 auto b32 = [&](int i) { return g.byte(p + i); };
-                const int r32 = scan_piece_p(WinP32(v, 32), b32);
+                const int r32 = scan_piece_p(WinP32(v, 32), b32, T.pat_flags);
                 if (r32 >= 0 && p + r32 != e) ++bad;
             }
-            const int r = scan_piece_bits(w, bytes, (int)(p - base), avail);
+            const int r = scan_piece_bits(w, bytes, (int)(p - base), avail, T.pat_flags);
             ++checked;
             if (r < 0) { ++unres; if (e - base < 58 - 3) { /* short piece must resolve unless look-ahead is long */ } }
             else if (base + r != e) ++bad;
@@ -316,9 +323,10 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
 // ArrMaskP (mask words in an array, unlimited run length) vs byte scanner on every true piece start of the text.
 int64_t twin_arrmask_check(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, int64_t* n_checked) {
     Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
     std::vector<uint8_t> cls;
     classify_all(t->H.view(), text, n, offs, n_docs, cls);
-    GAcc g{cls.data(), text, n, n + 4};
+    GAcc g{cls.data(), text, n, n + 4, T.pat_flags};
     const int64_t nw = (n + 4 + 63) / 64 + 1;
     std::vector<uint64_t> arr((size_t)nw * MK_COUNT, 0);
     for (int64_t i = 0; i < nw * 64; ++i) {
@@ -330,10 +338,10 @@ int64_t twin_arrmask_check(void* h, const uint8_t* text, int64_t n, const int64_
     int64_t bad = 0, checked = 0;
     auto bytes = [&](int i) { return g.byte(i); };
     for (int64_t p = 0; p < n;) {
-        const int64_t e = scan_piece(g, p);
+        const int64_t e = scan_piece(g, p, T.pat_flags);
         if (n + 4 < 0x7FFFFFFF) {
             ArrMaskP mp(arr.data(), (int)p, (int)(n + 4));
-            const int r = scan_piece_p(mp, bytes);
+            const int r = scan_piece_p(mp, bytes, T.pat_flags);
             ++checked;
             if (r != (int)e) ++bad;
         }

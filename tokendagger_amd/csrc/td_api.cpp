@@ -257,6 +257,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     d.pseudo_base = H.pseudo_base;
     d.max_token_len = H.max_token_len;
     d.piece16_mask = H.piece16_mask;
+    d.pat_flags = hv.pat_flags;
     if ((rc = upload(t, H.ascii_cls.data(), H.ascii_cls.size(), &d.ascii_cls))) return fail(rc);
     if ((rc = upload(t, hv.ucls1, (size_t)4352, &d.ucls1))) return fail(rc);
     {
@@ -490,7 +491,7 @@ int td_encode_with_special(td_tokenizer* t, const uint8_t* text, int64_t n_bytes
             const Tables hv = t->H.view();
             HostAcc A{&hv, seg_text.data(), s_lo, s_hi, s_hi + 4};
             int64_t p = s_lo, last = s_lo;
-            while (p < s_hi) { last = p; p = scan_piece(A, p); }
+            while (p < s_hi) { last = p; p = scan_piece(A, p, hv.pat_flags); }
             // ids of that piece == the tail of the batch result that starts at its first byte; count them
             // by re-deriving the piece's merge on the host tables (metadata, not the id path)
             std::vector<int32_t> tmp;

@@ -99,7 +99,13 @@ struct Tables {
     int32_t pseudo_base;          // ids >= pseudo_base stand for single bytes that are not tokens
     uint32_t max_token_len;
     uint32_t piece16_mask;
+    uint32_t pat_flags;           // PV_* bits: which member of the split-pattern family the scanners implement
 };
+
+// The split patterns the scanners implement are one family: the Llama-4 / o200k pattern (reference src/main.cpp:114)
+// and its Mistral "tekken" sibling (tekken.json config.pattern, reference tests/throughput_test.py:118), which drops the
+// (?i:'s|'t|'re|'ve|'m|'ll|'d)? suffix of the two letter alternatives and matches \p{N} instead of \p{N}{1,3}.
+enum : uint32_t { PV_NO_CONTRACTION = 1, PV_SINGLE_DIGIT = 2 };
 
 // ------------------------------------------------------------------ hashing -----------------
 TD_HD uint32_t hash_piece(uint64_t key, uint32_t len) {
@@ -290,7 +296,7 @@ TD_HD typename A::pos_t scan_contraction(const A& a, typename A::pos_t e) {
 
 // alternatives 1 (U* W+) and 2 (U+ W*) from `st` (== pos, or the byte after the 1-char prefix)
 template <class A>
-TD_HD typename A::pos_t scan_letters(const A& a, typename A::pos_t pos, typename A::pos_t st, int alt) {
+TD_HD typename A::pos_t scan_letters(const A& a, typename A::pos_t pos, typename A::pos_t st, int alt, uint32_t pv) {
     using P = typename A::pos_t;
     P q = st, lastw_end = 0;
     uint32_t c = 255;
@@ -308,7 +314,7 @@ TD_HD typename A::pos_t scan_letters(const A& a, typename A::pos_t pos, typename
     const bool w_follows = !eos && in_set(M_W, c);
     if (alt == 1) {
         if (w_follows) e = q;
-        else if (lastw_end) return scan_contraction(a, lastw_end);  // greedy U* gives back to its last W-class char
+        else if (lastw_end) return (pv & PV_NO_CONTRACTION) ? lastw_end : scan_contraction(a, lastw_end);  // greedy U* gives back to its last W-class char
         else return 0;
     } else {
         if (q == st) return 0;
@@ -322,12 +328,12 @@ TD_HD typename A::pos_t scan_letters(const A& a, typename A::pos_t pos, typename
             ++e;
         }
     }
-    return scan_contraction(a, e);
+    return (pv & PV_NO_CONTRACTION) ? e : scan_contraction(a, e);
 }
 
-// End of the piece that starts at `pos` (a character start, pos < lim).
+// End of the piece that starts at `pos` (a character start, pos < lim).  pv: PV_* pattern variant bits.
 template <class A>
-TD_HD typename A::pos_t scan_piece(const A& a, typename A::pos_t pos) {
+TD_HD typename A::pos_t scan_piece(const A& a, typename A::pos_t pos, uint32_t pv = 0) {
     using P = typename A::pos_t;
     const uint32_t c0 = a.cf(pos) & CLS_MASK;
     P p1 = pos + 1;  // end of the first character
@@ -345,19 +351,20 @@ TD_HD typename A::pos_t scan_piece(const A& a, typename A::pos_t pos) {
         if (l0 || l1) {
             for (int alt = 1; alt <= 2; ++alt) {
                 if (l1) {
-                    const P r = scan_letters(a, pos, p1, alt);
+                    const P r = scan_letters(a, pos, p1, alt, pv);
                     if (r != 0) return r;
                 }
                 if (l0) {
-                    const P r = scan_letters(a, pos, pos, alt);
+                    const P r = scan_letters(a, pos, pos, alt, pv);
                     if (r != 0) return r;
                 }
             }
         }
     }
-    if (c0 == C_NUM) {  // \p{N}{1,3}
+    if (c0 == C_NUM) {  // \p{N}{1,3}  (tekken: \p{N})
         P e = p1;
-        for (int k = 1; k < 3; ++k) {
+        const int nmax = (pv & PV_SINGLE_DIGIT) ? 1 : 3;
+        for (int k = 1; k < nmax; ++k) {
             if (e >= a.lim) return -1;
             const uint32_t v = a.cf(e);
             if ((v & F_DOC) || (v & CLS_MASK) != C_NUM) break;
@@ -600,7 +607,7 @@ TD_HD int scan_contraction_p(const P& p, const B& bytes, int e) {
 
 // End of the piece starting at p.o, in the provider's coordinates, or -1 (needs positions >= p.lim).
 template <class P, class B>
-TD_HD int scan_piece_p(const P& p, const B& bytes) {
+TD_HD int scan_piece_p(const P& p, const B& bytes, uint32_t pv = 0) {
     const int o = p.o, lim = p.lim;
     const bool u0 = p.bit(MK_U, o), w0 = p.bit(MK_W, o), x0 = p.bit(MK_X, o), s0 = p.bit(MK_S, o), n0 = p.bit(MK_N, o);
     const bool cr0 = p.bit(MK_CR, o);
@@ -637,12 +644,13 @@ TD_HD int scan_piece_p(const P& p, const B& bytes) {
                 if (e1) break;  // alt 1 with the earlier candidate wins over everything that follows
             }
             const int e = e1 ? e1 : e2;
-            if (e) return scan_contraction_p(p, bytes, e);
+            if (e) return (pv & PV_NO_CONTRACTION) ? e : scan_contraction_p(p, bytes, e);
         }
     }
-    if (n0) {  // \p{N}{1,3}
+    if (n0) {  // \p{N}{1,3}  (tekken: \p{N})
         int e = p1;
-        for (int k = 1; k < 3; ++k) {
+        const int nmax = (pv & PV_SINGLE_DIGIT) ? 1 : 3;
+        for (int k = 1; k < nmax; ++k) {
             if (e >= lim) return -1;
             if (!p.bit(MK_N, e) || p.ebit(e)) break;
             ++e;
@@ -678,9 +686,9 @@ TD_HD int scan_piece_p(const P& p, const B& bytes) {
 
 // register-window form (the fast path of td_split_tiles)
 template <class B>
-TD_HD int scan_piece_bits(const BitWin& w, const B& bytes, int o, int avail) {
+TD_HD int scan_piece_bits(const BitWin& w, const B& bytes, int o, int avail, uint32_t pv = 0) {
     const WinP p(w, o, avail);
-    return scan_piece_p(p, bytes);
+    return scan_piece_p(p, bytes, pv);
 }
 
 // Feature byte: the class-set memberships of one byte, one bit each (what phase 1 of the kernel keeps per byte;
@@ -768,7 +776,7 @@ constexpr int K_STAGE = K_TILE + K_MAXSHORT;   // staging slots per tile: a tile
 //   every lane scans piece by piece until it lands on a provable sync point at/after its chunk end
 //   (the lane owning that chunk started there) or leaves the tile.
 template <class W, class G>
-TD_HD void scan_lane(W& w, const G& g, int tid, int tile_hi, int64_t wg0) {
+TD_HD void scan_lane(W& w, const G& g, int tid, int tile_hi, int64_t wg0, uint32_t pv = 0) {
     const int c0 = K_HL + tid * K_CHUNK, c1 = c0 + K_CHUNK;
     int s = -1;
     if (tid == 0) {
@@ -794,7 +802,7 @@ TD_HD void scan_lane(W& w, const G& g, int tid, int tile_hi, int64_t wg0) {
         if (p >= tile_hi) { w.mark(p); break; }                       // delimits the last owned piece
         if (p >= c1 && is_sync(w.cf(p - 1), w.cf(p))) break;           // the lane owning p starts there
         if (p >= K_HL) w.mark(p);
-        int e = scan_piece(w, p);
+        int e = scan_piece(w, p, pv);
         if (e < 0) {
             const int64_t ge = g.scan(wg0 + p);
             if (ge - wg0 > (int64_t)K_LIM) {                           // piece leaves the window: one per tile at most

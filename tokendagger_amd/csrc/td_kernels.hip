@@ -71,7 +71,7 @@ struct GlobAcc {
         return v;
     }
     __device__ __forceinline__ uint32_t byte(int64_t i) const { return i < n ? s.text[i] : 0u; }
-    __device__ __noinline__ int64_t scan(int64_t pos) const { return scan_piece(*this, pos); }
+    __device__ __noinline__ int64_t scan(int64_t pos) const { return scan_piece(*this, pos, T->pat_flags); }
 };
 
 // feature byte of a non-ASCII byte of the LDS window (out of line: the UTF-8 / 2-stage-table walk is only needed for
@@ -111,6 +111,7 @@ __device__ __forceinline__ Tables uniform_tables(const Tables* p) {
     t.pseudo_base = (int32_t)uni32((uint32_t)p->pseudo_base);
     t.max_token_len = uni32(p->max_token_len);
     t.piece16_mask = uni32(p->piece16_mask);
+    t.pat_flags = uni32(p->pat_flags);
     return t;
 }
 
@@ -179,9 +180,9 @@ __device__ __forceinline__ uint64_t bits64(const uint32_t* arr, int pos) {
 
 // pieces / look-ahead longer than a 64-byte register window: the same matcher on the mask words in LDS (cold path,
 // kept out of line so that the hot loop stays small)
-__device__ __noinline__ int scan_piece_lds(const uint64_t* s_mask, const uint8_t* s_txt, int p) {
+__device__ __noinline__ int scan_piece_lds(const uint64_t* s_mask, const uint8_t* s_txt, int p, uint32_t pv) {
     const ArrMaskP mp(s_mask, p, K_LIM);
-    return scan_piece_p(mp, [s_txt](int q) { return (uint32_t)s_txt[q]; });
+    return scan_piece_p(mp, [s_txt](int q) { return (uint32_t)s_txt[q]; }, pv);
 }
 
 // the 64-byte mask window that starts at window byte `base`
@@ -431,11 +432,11 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     const int avail = (K_LIM - p < 32) ? (K_LIM - p) : 32;
                     int e = -1;
                     {
-                        const int r = scan_piece_p(WinP32(v, avail), [&](int q) { return (uint32_t)s_txt[p + q]; });
+                        const int r = scan_piece_p(WinP32(v, avail), [&](int q) { return (uint32_t)s_txt[p + q]; }, T.pat_flags);
                         if (r >= 0) e = p + r;
                     }
                     if (e < 0) {
-                        e = scan_piece_lds(s_mask, s_txt, p);  // piece or look-ahead beyond 32 bytes: mask words in LDS
+                        e = scan_piece_lds(s_mask, s_txt, p, T.pat_flags);  // piece or look-ahead beyond 32 bytes: mask words in LDS
                         if (e < 0) { if (p >= K_HL) defer(wg0 + p, 0); break; }
                     }
                     p = e;

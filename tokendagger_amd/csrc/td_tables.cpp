@@ -14,12 +14,23 @@ static const char kO200k[] =
     "|[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]+[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?"
     "|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n/]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
 
+// Mistral "tekken" (tekken.json config.pattern): the same seven alternatives without the contraction suffix and
+// with single-digit number pieces.
+static const char kTekken[] =
+    "[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]*[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]+"
+    "|[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]+[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]*"
+    "|\\p{N}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n/]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+
 const char* o200k_pattern() { return kO200k; }
+const char* tekken_pattern() { return kTekken; }
 
 PatternKind classify_pattern(const std::string& pat) {
     if (pat == kO200k) return PATTERN_O200K;
+    if (pat == kTekken) return PATTERN_TEKKEN;
     return PATTERN_UNSUPPORTED;
 }
+
+uint32_t pattern_flags(PatternKind k) { return k == PATTERN_TEKKEN ? (PV_NO_CONTRACTION | PV_SINGLE_DIGIT) : 0u; }
 
 uint64_t piece_key_host(const uint8_t* p, uint32_t len) {
     if (len <= 8) {
@@ -42,6 +53,7 @@ Tables HostTables::view() const {
     T.hot_slots = hot_slots.data();
     T.piece16_slots = piece16_slots.data();
     T.piece16_mask = piece16_mask;
+    T.pat_flags = pattern_flags(pattern_kind);
     T.pair_slots = pair_slots.data();
     T.tok_off = tok_off.data();
     T.tok_bytes = tok_bytes.data();
@@ -91,7 +103,8 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
     H.pattern = pattern ? pattern : "";
     H.pattern_kind = classify_pattern(H.pattern);
     if (H.pattern_kind == PATTERN_UNSUPPORTED) {
-        err = "split pattern is not supported by the device pre-tokenizer (supported: the o200k/Llama-4 pattern); "
+        err = "split pattern is not supported by the device pre-tokenizer (supported: the o200k/Llama-4 pattern and the "
+              "Mistral tekken pattern); "
               "there is no CPU regex fallback";
         return TD_E_PATTERN;
     }

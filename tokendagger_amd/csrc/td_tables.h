@@ -15,7 +15,10 @@ namespace td {
 enum PatternKind : int {
     PATTERN_UNSUPPORTED = -1,
     PATTERN_O200K = 0,  // the Llama-4 / o200k_base split pattern (reference src/main.cpp:114)
+    PATTERN_TEKKEN = 1, // Mistral tekken.json config.pattern (reference tests/throughput_test.py:118)
 };
+uint32_t pattern_flags(PatternKind k);  // PV_* bits for the scanners
+const char* tekken_pattern();
 PatternKind classify_pattern(const std::string& pat);
 const char* o200k_pattern();
 

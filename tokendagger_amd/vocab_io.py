@@ -29,6 +29,14 @@ LLAMA4_PAT_STR = (
     r"|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+"
 )
 
+# Mistral tekken.json config.pattern (reference loads it from the file: tests/throughput_test.py:118): the Llama-4
+# pattern without the contraction suffix and with single-digit number pieces.
+TEKKEN_PAT_STR = (
+    r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+"
+    r"|[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*"
+    r"|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+)
+
 
 def save_tdv(path, name: str, pat_str: str, mergeable_ranks: dict[bytes, int],
              special_tokens: dict[str, int]) -> None:

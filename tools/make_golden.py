@@ -73,5 +73,30 @@ def main():
           f"{out.stat().st_size} bytes on disk")
 
 
+def tekken_style():
+    """Second fixture: the SAME input documents through the compiled reference with the Mistral tekken split pattern
+    (Llama-4 vocabulary: the tekken.json vocabulary is absent from the reference checkout) -> tekken_style_golden.npz
+    {enc, enc_offsets, piece_ends, piece_offsets}; inputs are llama4_golden.npz's text/offsets."""
+    g = np.load(ROOT / "tests" / "golden" / "llama4_golden.npz", allow_pickle=True)
+    text, offs = g["text"].tobytes(), g["offsets"]
+    R = H.ref_tokenizer_tekken()
+    enc, enc_offs, pe, pe_offs = [], [0], [], [0]
+    for d in range(len(offs) - 1):
+        doc = text[offs[d]:offs[d + 1]]
+        e = R.encode(doc)
+        assert np.array_equal(e, R.encode_ordinary(doc))
+        enc.append(e); enc_offs.append(enc_offs[-1] + len(e))
+        p = R.split(doc) if len(doc) else np.zeros(0, np.int64)
+        pe.append(p); pe_offs.append(pe_offs[-1] + len(p))
+    out = ROOT / "tests" / "golden" / "tekken_style_golden.npz"
+    np.savez_compressed(out, pattern=np.asarray(H.TEKKEN_PAT), enc=np.concatenate(enc).astype(np.int32),
+                        enc_offsets=np.asarray(enc_offs, dtype=np.int64), piece_ends=np.concatenate(pe).astype(np.int64),
+                        piece_offsets=np.asarray(pe_offs, dtype=np.int64))
+    print(f"wrote {out}: {len(offs) - 1} docs, {enc_offs[-1]} tokens, {out.stat().st_size} bytes on disk")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "tekken":
+        tekken_style()
+    else:
+        main()
