@@ -78,7 +78,7 @@ def cpu_baseline(x: np.ndarray, offs: np.ndarray, ranks: dict, special: dict, pa
         import subprocess
         if not port.available():
             subprocess.check_call([str(ROOT / "oracle" / "build_oracle.sh")], stdout=subprocess.DEVNULL)
-        O = port.OracleTokenizer(ranks)
+        O = port.OracleTokenizer(ranks, port.VARIANT_TEKKEN if pat == vocab_io_tekken() else port.VARIANT_LLAMA4)
         sample_docs = max(1, int(np.searchsorted(offs, 8 << 20)))
         s_offs = offs[:sample_docs + 1]
         s_bytes = int(s_offs[-1])
@@ -93,6 +93,11 @@ def cpu_baseline(x: np.ndarray, offs: np.ndarray, ranks: dict, special: dict, pa
                   f"CoreBPE::encode per document on {used} std::threads, best of 2",
         "cpu_model": _cpu_model(),
     }
+
+
+def vocab_io_tekken() -> str:
+    from tokendagger_amd import vocab_io
+    return vocab_io.TEKKEN_PAT_STR
 
 
 def _cpu_model() -> str:
@@ -112,6 +117,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--corpus", default="english", choices=["english", "mixed", "code"])
     ap.add_argument("--size-mb", type=int, default=256, help="MiB of text per GPU")
+    ap.add_argument("--pattern", default="llama4", choices=["llama4", "tekken"],
+                    help="split pattern; 'tekken' = the Mistral tekken pattern over the Llama-4 vocabulary, the labelled "
+                         "surrogate for BASELINE config 4 (tekken.json is absent from the reference checkout)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     a = ap.parse_args()
@@ -134,6 +142,8 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     name, pat, ranks, special = vocab_io.load_tdv(vocab_io.default_vocab_path())
+    if a.pattern == "tekken":
+        pat = vocab_io.TEKKEN_PAT_STR
     tok = capi.HipTokenizer(pat, ranks, special, device=dev.index)
 
     n = a.size_mb << 20
@@ -190,7 +200,7 @@ def main():
             import subprocess
             if not port.available():
                 subprocess.check_call([str(ROOT / "oracle" / "build_oracle.sh")], stdout=subprocess.DEVNULL)
-            O = port.OracleTokenizer(ranks)
+            O = port.OracleTokenizer(ranks, port.VARIANT_TEKKEN if a.pattern == "tekken" else port.VARIANT_LLAMA4)
             k = max(1, int(np.searchsorted(offs, 1 << 20)))
             et, eo = O.encode_batch(x[:offs[k]].tobytes(), offs[:k + 1])
             got_off = d_toff[:k + 1].cpu().numpy()
@@ -217,7 +227,8 @@ def main():
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": f"synthetic (seeded td_corpus.{a.corpus}, 32 MiB generator block tiled)",
-            "config": {"workload": f"Llama-4-Scout vocab, {a.size_mb} MiB synthetic {a.corpus} text per GPU, "
+            "config": {"workload": f"Llama-4-Scout vocab{' + tekken split pattern' if a.pattern == 'tekken' else ''}, "
+                                   f"{a.size_mb} MiB synthetic {a.corpus} text per GPU, "
                                    f"{n_docs} documents, CoreBPE::encode semantics, input resident in HBM",
                        "bytes_per_gpu": n, "tokens_per_gpu": n_tok, "docs_per_gpu": n_docs,
                        "parallelism": f"dp{world} (documents sharded, RCCL all-gather of counts)" if world > 1 else "single GPU",

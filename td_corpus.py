@@ -186,10 +186,10 @@ _CODE_LINES = [
     "// {id} {id} {id} {id}", "# TODO: {id} the {id} before {id}", "    {id} = {{\"{id}\": {num}, \"{id}\": [{num}, {num}]}}",
     "#include <{id}/{id}.h>", "import {id}.{id} as {id}", "    printf(\"%d %s\\n\", {id}, {id}->{id});",
     "const {id} = async ({id}) => {{ await {id}.{id}(); }};", "\t\t{id} += {id} * {num};", "",
-    "/* ==================================================================== */",
     "    x = 0x{num}ULL << {num};  // {id}", "template <class {id}> struct {id} : public {id}<{id}> {{",
     "    self.{id}_{id}_{id} = {id}_{id}  # {id}", "        \"{id}\": \"{id} {id} {id}\",",
 ]
+_CODE_RULER = "/* ==================================================================== */"
 _IDS = ("i j k n x y tmp value result index count data buffer node left right parent key item list map size length "
         "offset start end pos token tokens text encode decode rank piece merge lookup table hash vocab special regex "
         "tokenizer_config mergeable_ranks get_thread_local_match_data find_next_special_token byte_pair_encode").split()
@@ -204,6 +204,8 @@ def code(n_bytes: int, seed: int = 0):
         lines = []
         for _ in range(nlines):
             tpl = _CODE_LINES[int(rng.integers(0, len(_CODE_LINES)))]
+            if rng.random() < 1.0 / 800:  # comment rulers: the pieces longer than 64 bytes of real source files
+                tpl = _CODE_RULER       # (99.74 % of the bytes are in pieces <= 64 B)
             n_id, n_num = tpl.count("{id}"), tpl.count("{num}")
             ids = [_IDS[int(i)] for i in rng.integers(0, len(_IDS), size=n_id)]
             nums = [str(int(rng.integers(0, 10 ** int(rng.integers(1, 7))))) for _ in range(n_num)]
