@@ -124,6 +124,13 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line.  Native libraries write there too (RCCL prints its version banner and its
+    # warnings to stdout), so file descriptor 1 is pointed at stderr for the whole run and the JSON line goes out
+    # through a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from tokendagger_amd import capi, vocab_io
 
@@ -241,7 +248,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x, offs, ranks, special, pat)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         # global view from the gathered counts: every rank's document / token base (what a consumer of the sharded
         # output needs); checked here so that a broken exchange cannot go unnoticed
