@@ -91,7 +91,6 @@ void twin_destroy(void* h) { delete (Twin*)h; }
 
 int64_t twin_info(void* h, int what) {
     Twin* t = (Twin*)h;
-    const Tables T = t->H.view();
     switch (what) {
         case 1: return (int64_t)t->H.n_pairs;
         case 2: return t->H.merge_closed;
@@ -105,7 +104,6 @@ int64_t twin_info(void* h, int what) {
 // per-byte class + F_CONT + F_DOC exactly as phase 1 of the kernel defines them
 void twin_classify(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, uint8_t* out) {
     Twin* t = (Twin*)h;
-    const Tables T = t->H.view();
     std::vector<uint8_t> cls;
     classify_all(t->H.view(), text, n, offs, n_docs, cls);
     if (n) memcpy(out, cls.data(), (size_t)n);

@@ -64,10 +64,6 @@ constexpr uint32_t TOK_NONE = 0xFFFFFFFFu;    // empty slot in the byte-indexed 
 constexpr uint32_t TOK_LONGREF = 0x80000000u; // | index into the long-piece list
 constexpr int ID_BITS = 21;                   // ids / ranks must be < 2^21 (pair slots pack 2 ids + rank in 64 bit)
 constexpr uint64_t PAIR_EMPTY = ~0ull;
-#ifndef TD_K_HOT
-#define TD_K_HOT 512
-#endif
-constexpr int K_HOT = TD_K_HOT;                    // slots of the LDS-resident hot-piece table (BPE rank ~ frequency rank)
 
 struct PieceSlot {  // 16 B; len == 0 marks an empty slot
     uint64_t key;   // len <= 8: the bytes, little-endian, zero padded; len > 8: hash_bytes()
@@ -90,7 +86,6 @@ struct Tables {
     const PieceSlot* piece_slots; // open addressing, linear probing
     const uint64_t* pair_slots;   // cuckoo table: (left<<42 | right<<21 | rank), PAIR_EMPTY if empty
     const Piece16Slot* piece16_slots;  // open addressing, linear probing (tokens of 9..16 bytes; they are also in piece_slots)
-    const PieceSlot* hot_slots;   // [K_HOT] direct-mapped copy of the lowest-rank tokens of <= 8 bytes (staged in LDS)
     const uint32_t* tok_off;      // [max_id+2] byte offsets of token id's bytes (decode + long-key verify)
     const uint8_t* tok_bytes;
     uint32_t piece_mask;
@@ -141,7 +136,6 @@ TD_HD uint64_t hash_bytes(const Get& get, uint32_t len) {
 TD_HD uint32_t hash_piece16(uint64_t k0, uint64_t k1, uint32_t len) {
     return hash_piece(k0 ^ ((k1 << 29) | (k1 >> 35)) ^ (k1 * 0x9E3779B97F4A7C15ull), len);
 }
-TD_HD uint32_t hot_index(uint64_t key, uint32_t len) { return (hash_piece(key, len) >> 9) & (K_HOT - 1); }
 
 // (left id, right id) -> rank of the concatenation, NO_RANK if it is not a token.  The pair table is a CUCKOO table
 // (two hash functions, one entry per slot): a lookup is exactly two independent 8-byte loads and no loop, so the

@@ -102,7 +102,6 @@ __device__ __forceinline__ Tables uniform_tables(const Tables* p) {
     t.piece_slots = uni_ptr(p->piece_slots);
     t.pair_slots = uni_ptr(p->pair_slots);
     t.piece16_slots = uni_ptr(p->piece16_slots);
-    t.hot_slots = uni_ptr(p->hot_slots);
     t.tok_off = uni_ptr(p->tok_off);
     t.tok_bytes = uni_ptr(p->tok_bytes);
     t.piece_mask = uni32(p->piece_mask);
@@ -194,20 +193,21 @@ __device__ __forceinline__ void load_bitwin(BitWin& w, const uint64_t* s_mask, i
     for (int k = 0; k < MK_COUNT; ++k) w.m[k] = sh ? (lo[k] >> sh) | (hi[k] << (64 - sh)) : lo[k];
 }
 
-// 16 text bytes at global offset g (zero outside [0, n)); one coalesced 16 B/lane load when the base is aligned
-__device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
-    uint4 x = make_uint4(0, 0, 0, 0);
-    if (g >= 0 && g + 16 <= a.n && a.text_aligned) {
-        x = *reinterpret_cast<const uint4*>(a.text + g);
-    } else if (g + 16 > 0 && g < a.n) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        for (int k = 0; k < 16; ++k) {
-            const int64_t gg = g + k;
-            if (gg >= 0 && gg < a.n) w[k >> 2] |= (uint32_t)a.text[gg] << ((k & 3) * 8);
-        }
-        x = make_uint4(w[0], w[1], w[2], w[3]);
+// 16 text bytes at global offset g (zero outside [0, n)); one coalesced 16 B/lane load when the base is aligned.
+// The byte-wise edge path (first / last window of the text, unaligned text pointer) is out of line: inlined, its
+// sixteen address computations were carried (and spilled) through every call site.
+__device__ __noinline__ uint4 load_text16_edge(const uint8_t* text, int64_t n, int64_t g) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 16; ++k) {
+        const int64_t gg = g + k;
+        if (gg >= 0 && gg < n) w[k >> 2] |= (uint32_t)text[gg] << ((k & 3) * 8);
     }
-    return x;
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
+    if (g >= 0 && g + 16 <= a.n && a.text_aligned) return *reinterpret_cast<const uint4*>(a.text + g);
+    if (g + 16 > 0 && g < a.n) return load_text16_edge(a.text, a.n, g);
+    return make_uint4(0, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------ td_split_tiles ----------
@@ -570,7 +570,11 @@ __device__ __forceinline__ uint32_t seg_min_scan_dpp(uint32_t x, int lane, int p
 constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per tile by this kernel
 
 #ifndef TD_TILES_MIN_WAVES
-#define TD_TILES_MIN_WAVES 4
+#define TD_TILES_MIN_WAVES 5
+#endif
+#ifndef TD_PROBE_NB
+#define TD_PROBE_NB 1  // whole-piece probes a lane keeps in flight (more cost registers: 4 in flight at 4 waves/SIMD
+                       // measured 17 % slower than 1 at 5 waves/SIMD)
 #endif
 __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_BWIN + 16];
@@ -581,7 +585,6 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
     // phase 5 reuses the (then dead) piece list: token slots before each lane's chunk / which of its 16 slots hold a token
     uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_plist);
     uint16_t* const s_valid = s_plist + 2 * K_THREADS;
-    __shared__ __attribute__((aligned(16))) PieceSlot s_hot[K_HOT];        // lowest-rank short tokens, direct-mapped
     __shared__ int32_t s_byteid[256];
     __shared__ uint32_t s_wave[8];
     __shared__ long long s_ext_end;                // global end of the tile's last piece when it leaves the window (else 0)
@@ -593,7 +596,6 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
     const int lane = tid & 63;
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
-    for (int q = tid; q < K_HOT; q += K_THREADS) s_hot[q] = T.hot_slots[q];
 
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
     uint32_t pfs = 0;  // START bits of window word `tid`
@@ -696,12 +698,13 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         __syncthreads();
         if (a.stop_after == 31) continue;
         const long long ext_end = s_ext_end;
-        // 3b: probe, piece k -> lane k mod 256; four pieces per lane at a time so that the table loads of a batch are
-        //     in flight together.  Hot path = pieces of 2..8 bytes (key = the bytes): LDS hot table, else first slot
-        //     of the HBM table; everything else (longer keys, probe collisions, long pieces, 1-byte pieces) goes
-        //     through resolve_piece_cold, out of line.
+        // 3b: probe, piece k -> lane k mod 256, TD_PROBE_NB pieces per lane at a time.  Hot path = pieces of 2..16
+        //     bytes (key = the bytes): first slot of the HBM table for their length class; single bytes index the
+        //     256-entry LDS table; everything else (probe collisions, keys over 16 bytes, long pieces) goes through
+        //     resolve_piece_cold in a second, rolled loop.  (An LDS copy of the 512 lowest-rank tokens in front of the
+        //     HBM probe measured no faster: its 8 KB cost the fifth wavefront per SIMD.)
         {
-            constexpr int NB = 4;
+            constexpr int NB = TD_PROBE_NB;
             for (uint32_t k0 = tid; k0 < np_total; k0 += NB * K_THREADS) {
                 int pi[NB];          // piece start (tile position) still to be resolved in stage 3, -1 = done
                 uint32_t cold = 0;   // pieces of this batch left to the rolled loop below
@@ -735,8 +738,6 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                     if (len <= 8) {
                         if (len < 8) key &= (1ull << (8 * len)) - 1;
                         const uint32_t hsh = hash_piece(key, len);
-                        const PieceSlot hs = s_hot[(hsh >> 9) & (K_HOT - 1)];  // LDS hot table first: no L2 round trip
-                        if (hs.key == key && hs.len == len) { s_tok[i] = hs.rank; pi[u] = -1; continue; }
                         pkey[u] = key;
                         pkey1[u] = 0;
                         ph[u] = hsh & T.piece_mask;

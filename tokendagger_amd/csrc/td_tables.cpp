@@ -50,7 +50,6 @@ Tables HostTables::view() const {
     T.byte_id = byte_id.data();
     T.byte_pair = byte_pair.data();
     T.piece_slots = piece_slots.data();
-    T.hot_slots = hot_slots.data();
     T.piece16_slots = piece16_slots.data();
     T.piece16_mask = piece16_mask;
     T.pat_flags = pattern_flags(pattern_kind);
@@ -209,22 +208,6 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
             uint32_t h = hash_piece16(k0, k1, len) & H.piece16_mask;
             while (H.piece16_slots[h].rl != 0) h = (h + 1) & H.piece16_mask;
             H.piece16_slots[h] = Piece16Slot{k0, k1, (uint64_t)(uint32_t)ranks[v] | ((uint64_t)len << 32)};
-        }
-    }
-
-    // hot-piece table: direct-mapped, lowest rank wins a slot (merge order ~ frequency order in the tokenizer's
-    // training data, so low ranks are the pieces seen most often); tokens of 2..8 bytes only (key = the bytes)
-    H.hot_slots.assign(K_HOT, PieceSlot{0, 0, 0});
-    {
-        std::vector<int64_t> order((size_t)n_vocab);
-        for (int64_t v = 0; v < n_vocab; ++v) order[(size_t)v] = v;
-        std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return ranks[x] < ranks[y]; });
-        for (int64_t v : order) {
-            const uint32_t len = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
-            if (len < 2 || len > 8) continue;
-            const uint64_t key = piece_key_host(token_bytes + token_offsets[v], len);
-            PieceSlot& hs = H.hot_slots[hot_index(key, len)];
-            if (hs.len == 0) { hs.key = key; hs.rank = (uint32_t)ranks[v]; hs.len = len; }
         }
     }
 

@@ -29,7 +29,6 @@ struct HostTables {
     std::vector<int32_t> byte_id;
     std::vector<int32_t> byte_pair;
     std::vector<PieceSlot> piece_slots;
-    std::vector<PieceSlot> hot_slots;
     std::vector<Piece16Slot> piece16_slots;
     uint32_t piece16_mask = 0;
     std::vector<uint64_t> pair_slots;
