@@ -76,7 +76,11 @@ struct GlobAcc {
 
 // feature byte of a non-ASCII byte of the LDS window (out of line: the UTF-8 / 2-stage-table walk is only needed for
 // non-ASCII text and must not be replicated into the hot ASCII path)
-__device__ __noinline__ uint32_t feature_at(const Tables& T, const LdsSrc& src, int idx) {
+// (the window description travels by value: a struct passed by reference to an out-of-line function has to live in
+// scratch memory, and the per-tile store of it was 0.5 GB of HBM writes per launch)
+__device__ __noinline__ uint32_t feature_at_v(const Tables& T, const uint8_t* txt, const uint32_t* docw, int lo, int hi, int idx) {
+    LdsSrc src;
+    src.txt = txt; src.docw = docw; src.lo = lo; src.hi = hi;
     if (idx < src.lo || idx >= src.hi) return FB_X;
     const uint32_t c = classify_at(T, src, idx);
     return feature_of_class(c & CLS_MASK) | ((c & F_CONT) ? (uint32_t)FB_C : 0u);
@@ -215,7 +219,7 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
 // piece starts.  One workgroup per 4 KiB tile (+64 B left / 192 B right halo), persistent grid.
 #ifndef TD_SPLIT_MIN_WAVES
-#define TD_SPLIT_MIN_WAVES 5
+#define TD_SPLIT_MIN_WAVES 6
 #endif
 // software prefetch of the next tile's side inputs (tuning switches; defaults = what measured fastest)
 #ifndef TD_PF_DOCBITS
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     const bool ok = need > 0 && pos + need < (int)src.hi && pos >= (int)src.lo && !((docb >> (k + 1)) & ((1u << need) - 1u)) &&
                                     (c1 & 0xC0) == 0x80 && (need < 2 || (c2 & 0xC0) == 0x80) && (need < 3 || (c3 & 0xC0) == 0x80);
                     if (!ok) {  // invalid lead, truncated sequence, stray continuation byte, document boundary inside
-                        const uint32_t f = feature_at(T, src, pos);
+                        const uint32_t f = feature_at_v(T, s_txt, s_doc, (int)src.lo, (int)src.hi, pos);
                         put(k, f);
                         cur = f & ~(uint32_t)FB_C;
                         remaining = 0;
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     const bool known = lane != 0 && !(st_in & 0x100u);
                     const int claim = (int)(st_in >> 9);
                     for (int k = 0; k < lead_conts; ++k) {
-                        const uint32_t f = (known && k < claim) ? ((st_in & 0xFFu) | FB_C) : feature_at(T, src, it * 8 + k);
+                        const uint32_t f = (known && k < claim) ? ((st_in & 0xFFu) | FB_C) : feature_at_v(T, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 + k);
                         if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4));
                     }
                 }
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                 pf = 0;
                 if (it > 0) {
                     const uint32_t pb = s_txt[it * 8 - 1];
-                    pf = (pb < 0x80) ? (uint32_t)s_lut[pb] : feature_at(T, src, it * 8 - 1);
+                    pf = (pb < 0x80) ? (uint32_t)s_lut[pb] : feature_at_v(T, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 - 1);
                 }
             }
             const uint64_t P = transpose8x8(((uint64_t)fhi << 32) | flo);  // byte k = bit plane of feature bit k
@@ -1206,8 +1210,22 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         const uint32_t cnt = tc;
         const int64_t base = a.tile_base[tile];
         const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
-        if (base + cnt <= a.out_cap)
-            for (uint32_t i = lane; i < cnt; i += 64) a.out_tokens[base + i] = (int32_t)src[i];
+        if (base + cnt <= a.out_cap) {
+            // 16-byte stores to the (arbitrarily placed) destination: single ids up to its next 16-byte boundary, then
+            // four ids per lane (the staging side is read with dword-aligned 16-byte loads)
+            int32_t* dst = a.out_tokens + base;
+            uint32_t head = (uint32_t)((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2;
+            if (head > cnt) head = cnt;
+            if ((uint32_t)lane < head) dst[lane] = (int32_t)src[lane];
+            const uint32_t nv = (cnt - head) >> 2;
+            for (uint32_t v = lane; v < nv; v += 64) {
+                uint4 x;
+                __builtin_memcpy(&x, src + head + 4 * v, 16);
+                *reinterpret_cast<uint4*>(dst + head + 4 * v) = x;
+            }
+            const uint32_t done = head + 4 * nv;
+            if (done + (uint32_t)lane < cnt) dst[done + lane] = (int32_t)src[done + lane];
+        }
         const int64_t g_lo = (int64_t)tile * K_TILE;
         const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
         for (int64_t d = (int64_t)a.tile_first_doc[tile] + lane; d < a.n_docs; d += 64) {
