@@ -114,6 +114,26 @@ def test_one_token_per_byte_across_tiles(tok):
     _check_batch(tok, O, text, np.asarray([0, len(text)], dtype=np.int64))
 
 
+def test_long_piece_length_sweep(tok):
+    # every piece length around the hand-over points of td_long_pieces (64 | 128 | 255/256 | 1024) and beyond:
+    # character runs, random letters (many merges), CJK sentences (3-byte characters), mixed-case identifiers
+    O = H.port_tokenizer()
+    rng = random.Random(8)
+    cjk = "的一是不了人我在有他这为之大来以个中上们到说国和地也子时道出而要于就下得可你年生自会那后能对着事其里所去行过家十用发天如然作方成者多日都三小军二无同么经法当起与好看学进种将还分此心前面又定见只主没公从"
+    docs = []
+    for L in list(range(60, 140)) + list(range(250, 262)) + [300, 511, 1020, 1024, 1025, 1500, 5000]:
+        docs.append(("=" * L + "\n").encode())
+        docs.append(("x" + " " * L + "y").encode())
+        docs.append(("".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(L)) + " ").encode())
+        docs.append(("".join(rng.choice("abcXYZ") for _ in range(L)) + ".").encode())
+        if L <= 1500:
+            docs.append(("".join(rng.choice(cjk) for _ in range((L + 2) // 3)) + "。").encode("utf-8"))
+    text, offs = H.pack_docs(docs)
+    _check_batch(tok, O, text, offs)
+    _check_batch(tok, O, text, offs, mode=1)
+    assert tok.info(7) > 300
+
+
 def test_unaligned_text_pointer_and_empty_docs(tok):
     O = H.port_tokenizer()
     x, o = td_corpus.mixed(300000, seed=9)

@@ -1038,21 +1038,134 @@ __device__ __forceinline__ void lp_do_piece(const EncodeArgs& a, const Tables& T
     }
 }
 
+// Pieces of 65..LP_TINY bytes (the bulk of the long pieces: comment rulers, CJK sentences): eight lanes per piece,
+// eight pieces per wavefront, parts as a doubly linked list in LDS — a merge touches a handful of entries instead of
+// shifting the tail, so a round is: strided min over the rank array (dead parts carry NO_RANK), 3-step shuffle reduce,
+// relink, two pair-table probes (one lane each).  The rounds are bound by the probe latency; pieces in flight per
+// wavefront are what buys throughput.
+constexpr int LP_TINY = 128;      // eight lanes per piece up to here
+constexpr int LP_LINKED = 255;    // sixteen lanes per piece up to here (links are bytes)
+constexpr uint32_t LP_END = 255;  // "no neighbour" in the link arrays
+template <int G>
+__device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Tables& T, uint32_t j, volatile uint32_t* id,
+                                                   volatile uint32_t* rk, volatile uint8_t* nx, volatile uint8_t* pv, int grp, int gl) {
+    const int64_t gs = a.long_list[j].gs;
+    const uint32_t len = a.long_list[j].len;
+    const uint8_t* p = a.text + gs;
+    int32_t whole = NO_RANK;
+    if (a.use_fastpath && len <= T.max_token_len) {  // whole-piece table first (CoreBPE::encode, tiktoken.cpp:209-215)
+        if (gl == 0) {
+            auto get = [p](uint32_t k) { return (uint32_t)p[k]; };
+            whole = piece_lookup(T, hash_bytes(get, len), len, get);
+        }
+        whole = __shfl(whole, 0, G);
+    }
+    uint32_t m = len;
+    if (whole != NO_RANK) {
+        m = 1;
+        if (gl == 0) { id[0] = (uint32_t)whole; nx[0] = (uint8_t)LP_END; }
+    } else {
+        for (uint32_t q = gl; q < len; q += G) {
+            const uint32_t b = p[q];
+            id[q] = (uint32_t)T.byte_id[b];
+            rk[q] = (q + 1 < len) ? (uint32_t)T.byte_pair[(b << 8) | p[q + 1]] : (uint32_t)NO_RANK;
+            nx[q] = (uint8_t)((q + 1 < len) ? q + 1 : LP_END);
+            pv[q] = (uint8_t)(q ? q - 1 : LP_END);
+        }
+        for (;;) {
+            uint32_t best = 0xFFFFFFFFu;
+            for (uint32_t q = gl; q < len; q += G) {
+                const uint32_t r = rk[q];
+                if (r != (uint32_t)NO_RANK) {
+                    const uint32_t key = (r << 8) | q;  // ties go left, like the reference's strict '<' scan
+                    best = key < best ? key : best;
+                }
+            }
+#pragma unroll
+            for (int d = G / 2; d >= 1; d >>= 1) {
+                const uint32_t o = __shfl_xor(best, d, G);
+                best = o < best ? o : best;
+            }
+            if (best == 0xFFFFFFFFu) break;
+            const uint32_t w = best & 255u, r = best >> 8;
+            const uint32_t nxt = nx[w];     // the part that is absorbed
+            const uint32_t nn = nx[nxt];    // the part after it
+            const uint32_t pw = pv[w];
+            const uint32_t id_nn = (nn != LP_END) ? id[nn] : 0u;
+            const uint32_t id_pw = (pw != LP_END) ? id[pw] : 0u;
+            --m;
+            if (gl == 0) {
+                id[w] = r;
+                rk[nxt] = (uint32_t)NO_RANK;
+                id[nxt] = TOK_NONE;
+                nx[w] = (uint8_t)nn;
+                if (nn != LP_END) pv[nn] = (uint8_t)w;
+                rk[w] = (nn != LP_END) ? (uint32_t)pair_lookup(T, r, id_nn) : (uint32_t)NO_RANK;
+            } else if (gl == 1 && pw != LP_END) {
+                rk[pw] = (uint32_t)pair_lookup(T, id_pw, r);
+            }
+        }
+    }
+    unsigned long long off = 0;
+    if (gl == 0) off = atomicAdd(a.pool_used, (unsigned long long)m);
+    off = __shfl(off, 0, G);
+    if (off + m > a.pool_cap) {
+        if (gl == 0) raise(a, TD_E_SCRATCH, gs);
+        return;
+    }
+    // surviving parts in position order: eight positions at a time, rank inside the group's byte of the ballot
+    uint32_t run = 0;
+    const uint32_t span = (m == 1 && whole != NO_RANK) ? 1u : len;
+    for (uint32_t q0 = 0; q0 < span; q0 += G) {
+        const uint32_t q = q0 + gl;
+        const uint32_t v = (q < span) ? id[q] : TOK_NONE;
+        const bool alive = v != TOK_NONE;
+        const uint32_t bits = (uint32_t)(__ballot(alive) >> (grp * G)) & ((1u << G) - 1u);
+        if (alive) {
+            if ((int32_t)v >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gs);
+            a.pool[off + run + __popc(bits & ((1u << gl) - 1u))] = v;
+        }
+        run += __popc(bits);
+    }
+    if (gl == 0) {
+        a.long_list[j].ntok = m;
+        a.long_list[j].pool_off = off;
+        if (m > 1) atomicAdd(&a.tile_extra[gs / K_TILE], m - 1);
+    }
+}
+
+constexpr int LP_WAVE_WORDS = 8 * (2 * LP_TINY + 2 * LP_TINY / 4);  // LDS words per wavefront: 8 pieces x (ids, ranks, links)
+static_assert(LP_WAVE_WORDS >= 2 * LP_MEDIUM, "the wavefront-per-piece pass reuses the same LDS");
 __global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
-    __shared__ uint32_t s_parts[4][2 * LP_MEDIUM];  // per wavefront: ids | ranks
+    __shared__ uint32_t s_parts[4][LP_WAVE_WORDS];  // per wavefront: ids | ranks (| links)
     const Tables T = uniform_tables(a.Tp);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nlong = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
     const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + wv;
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
 
-    // pass 1: pieces <= 256 B, a 16-lane group each
+    // pass 0: pieces <= 128 B, an 8-lane group each (linked parts)
+    {
+        const int grp = lane >> 3, gl = lane & 7;
+        volatile uint32_t* id = &s_parts[wv][grp * (LP_WAVE_WORDS / 8)];
+        volatile uint32_t* rk = id + LP_TINY;
+        volatile uint8_t* nx = reinterpret_cast<volatile uint8_t*>(rk + LP_TINY);
+        volatile uint8_t* pv = nx + LP_TINY;
+        for (uint32_t j = wave_global * 8 + grp; j < nlong; j += nwaves * 8)
+            if (a.long_list[j].len <= LP_TINY) lp_do_piece_linked<8>(a, T, j, id, rk, nx, pv, grp, gl);
+    }
+    // pass 1: pieces <= 255 B, a 16-lane group each (linked parts); 256 B: the dense variant
     {
         const int grp = lane >> 4, gl = lane & 15;
-        volatile uint32_t* id = &s_parts[wv][grp * 2 * LP_SMALL];
+        volatile uint32_t* id = &s_parts[wv][grp * (LP_WAVE_WORDS / 4)];
         volatile uint32_t* rk = id + LP_SMALL;
-        for (uint32_t j = wave_global * 4 + grp; j < nlong; j += nwaves * 4)
-            if (a.long_list[j].len <= LP_SMALL) lp_do_piece<16>(a, T, j, id, rk, gl);
+        volatile uint8_t* nx = reinterpret_cast<volatile uint8_t*>(rk + LP_SMALL);
+        volatile uint8_t* pv = nx + LP_SMALL;
+        for (uint32_t j = wave_global * 4 + grp; j < nlong; j += nwaves * 4) {
+            const uint32_t len = a.long_list[j].len;
+            if (len > LP_TINY && len <= LP_LINKED) lp_do_piece_linked<16>(a, T, j, id, rk, nx, pv, grp, gl);
+            else if (len == LP_SMALL) lp_do_piece<16>(a, T, j, id, rk, gl);
+        }
     }
     // pass 2: pieces <= 1024 B, a wavefront each
     {
