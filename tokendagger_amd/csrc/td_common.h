@@ -752,7 +752,10 @@ TD_HD uint64_t sync_word(uint64_t U, uint64_t W, uint64_t X, uint64_t S, uint64_
 constexpr int K_THREADS = TD_K_THREADS;        // 4 wavefronts
 constexpr int K_CHUNK = 16;                    // text bytes whose boundaries one lane is responsible for
 constexpr int K_TILE = K_THREADS * K_CHUNK;    // 4096 text bytes per tile
-constexpr int K_HL = 64;                       // left halo (sync-point back-search)
+#ifndef TD_K_HL
+#define TD_K_HL 128
+#endif
+constexpr int K_HL = TD_K_HL;                  // left halo (sync-point back-search)
 constexpr int K_HR = 192;                      // right halo (piece overrun / look-ahead)
 constexpr int K_WIN = K_HL + K_TILE + K_HR;    // bytes staged in LDS per tile
 constexpr int K_LIM = K_WIN - 4;               // the scanner may read window positions < K_LIM

@@ -217,7 +217,7 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 // ------------------------------------------------------------------ td_split_tiles ----------
 // Pre-tokenizer: the regex split of the reference (CoreBPE::split_text, tiktoken.cpp:70-128) as a
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
-// piece starts.  One workgroup per 4 KiB tile (+64 B left / 192 B right halo), persistent grid.
+// piece starts.  One workgroup per 4 KiB tile (+128 B left / 192 B right halo), persistent grid.
 #ifndef TD_SPLIT_MIN_WAVES
 #define TD_SPLIT_MIN_WAVES 6
 #endif
@@ -406,11 +406,17 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                 else raise(a, TD_E_SCRATCH, g);
             };
             if (tid == 0) {
-                // last provable sync point at or before the tile start (window bytes 4..64)
-                const uint64_t w0 = s_mask[0 * MK_COUNT + MK_SYNC] & ~0xFull;
-                if (s_mask[1 * MK_COUNT + MK_SYNC] & 1ull) s = 64;
-                else if (w0) s = td_top64(w0) - 1;
-                else defer(tile_g0, 1);
+                // last provable sync point at or before the tile start (window bytes 4..K_HL)
+                static_assert(K_HL % 64 == 0 && K_HL >= 64, "left halo = whole mask words");
+                if (s_mask[(K_HL / 64) * MK_COUNT + MK_SYNC] & 1ull) s = K_HL;
+                else {
+                    for (int w = K_HL / 64 - 1; w >= 0 && s < 0; --w) {
+                        uint64_t m = s_mask[w * MK_COUNT + MK_SYNC];
+                        if (w == 0) m &= ~0xFull;
+                        if (m) s = w * 64 + td_top64(m) - 1;
+                    }
+                    if (s < 0) defer(tile_g0, 1);
+                }
             } else if (c0 < tile_hi) {
                 uint32_t sy = (uint32_t)(s_mask[(c0 >> 6) * MK_COUNT + MK_SYNC] >> (c0 & 63)) & 0xFFFFu;
                 if (c1 > tile_hi) sy &= (1u << (tile_hi - c0)) - 1u;
