@@ -221,16 +221,6 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 #ifndef TD_SPLIT_MIN_WAVES
 #define TD_SPLIT_MIN_WAVES 6
 #endif
-// software prefetch of the next tile's side inputs (tuning switches; defaults = what measured fastest)
-#ifndef TD_PF_DOCBITS
-#define TD_PF_DOCBITS 0
-#endif
-#ifndef TD_PF_START
-#define TD_PF_START 1
-#endif
-#ifndef TD_PF_DOC
-#define TD_PF_DOC 0
-#endif
 __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
     __shared__ __attribute__((aligned(16))) uint64_t s_mask[(K_MWORDS + 1) * MK_COUNT];  // class masks, word-major
@@ -245,8 +235,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
 
     static_assert(K_WIN / 16 <= 2 * K_THREADS, "two prefetch registers per lane cover the window");
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
-    uint32_t pfd = 0;  // document-start bits of window word `tid` (K_WIN / 32 <= K_THREADS)
-    static_assert(K_WIN / 32 <= K_THREADS, "one prefetched document word per lane covers the window");
+    static_assert(K_WIN / 32 <= K_THREADS, "one document word per lane covers the window");
     const int64_t nwords = (a.n + 31) >> 5;
     auto load_docword = [&](int64_t wg0_) -> uint32_t {
         const int64_t gw = (wg0_ >> 5) + tid;
@@ -256,7 +245,6 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         const int64_t w0 = (int64_t)blockIdx.x * K_TILE - K_HL;
         pf0 = load_text16(a, w0 + (int64_t)tid * 16);
         if (tid < K_WIN / 16 - K_THREADS) pf1 = load_text16(a, w0 + (int64_t)(K_THREADS + tid) * 16);
-        if (TD_PF_DOCBITS) pfd = load_docword(w0);
     }
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
@@ -269,7 +257,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         reinterpret_cast<uint4*>(s_txt)[tid] = pf0;
         if (tid < K_WIN / 16 - K_THREADS) reinterpret_cast<uint4*>(s_txt)[K_THREADS + tid] = pf1;
         if (tid < K_WIN / 32) {
-            uint32_t dw = TD_PF_DOCBITS ? pfd : load_docword(wg0);
+            uint32_t dw = load_docword(wg0);
             const int64_t g = wg0 + (int64_t)tid * 32;  // bytes past the end of the text: "end of subject" sentinels
             if (g + 32 > a.n) dw |= (g >= a.n) ? 0xFFFFFFFFu : ~((1u << (int)(a.n - g)) - 1u);
             s_doc[tid] = dw;
@@ -279,7 +267,6 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
             if (tile + (int)gridDim.x < a.n_tiles) {
                 pf0 = load_text16(a, nwg0 + (int64_t)tid * 16);
                 if (tid < K_WIN / 16 - K_THREADS) pf1 = load_text16(a, nwg0 + (int64_t)(K_THREADS + tid) * 16);
-                if (TD_PF_DOCBITS) pfd = load_docword(nwg0);
             }
         }
         for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
@@ -609,9 +596,6 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
 
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
     uint32_t pfs = 0;  // START bits of window word `tid`
-#if TD_PF_DOC
-    uint32_t pf_fd = 0xFFFFFFFFu;  // first document that starts in the tile (td_mark_docs), 0xFFFFFFFF = none
-#endif
     static_assert(K_BWIN / 32 + 3 <= K_THREADS, "one prefetched START word per lane covers the window");
     const int64_t nwords = (a.n + 31) >> 5;
     auto load_startword = [&](int64_t wg0_) -> uint32_t {
@@ -622,10 +606,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         const int64_t w0 = (int64_t)blockIdx.x * K_TILE;
         pf0 = load_text16(a, w0 + (int64_t)tid * 16);
         if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, w0 + (int64_t)(K_THREADS + tid) * 16);
-        if (TD_PF_START) pfs = load_startword(w0);
-#if TD_PF_DOC
-        pf_fd = a.tile_first_doc[blockIdx.x];
-#endif
+        pfs = load_startword(w0);
     }
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
@@ -639,7 +620,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         reinterpret_cast<uint4*>(s_txt)[tid] = pf0;
         if (tid < (K_BWIN + 16) / 16 - K_THREADS) reinterpret_cast<uint4*>(s_txt)[K_THREADS + tid] = pf1;
         if (tid < K_BWIN / 32 + 3) {
-            uint32_t sw = TD_PF_START ? pfs : load_startword(wg0);
+            uint32_t sw = pfs;
             const int64_t g = wg0 + (int64_t)tid * 32;
             if (a.n >= g && a.n < g + 32) sw |= 1u << (int)(a.n - g);  // the end of the text delimits the last piece
             s_start[tid] = sw;
@@ -650,16 +631,9 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
             if (tile + (int)gridDim.x < a.n_tiles) {
                 pf0 = load_text16(a, nwg0 + (int64_t)tid * 16);
                 if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, nwg0 + (int64_t)(K_THREADS + tid) * 16);
-                if (TD_PF_START) pfs = load_startword(nwg0);
+                pfs = load_startword(nwg0);
             }
         }
-        // offsets of the documents that start in this tile (consumed by phase 5): requested now, next tile's first
-        // document index one iteration ahead
-#if TD_PF_DOC
-        const int64_t fd = (int64_t)pf_fd;
-        const int64_t my_doc_off = (fd + tid < a.n_docs) ? a.doc_offsets[fd + tid] : INT64_MAX;
-        if (tile + (int)gridDim.x < a.n_tiles) pf_fd = a.tile_first_doc[tile + gridDim.x];
-#endif
         {
             const uint4 none = make_uint4(TOK_NONE, TOK_NONE, TOK_NONE, TOK_NONE);
             for (int v = tid; v < (K_TILE + K_MAXSHORT) / 4; v += K_THREADS) reinterpret_cast<uint4*>(s_tok)[v] = none;
@@ -927,15 +901,9 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
             // token slot of every document that starts in this tile (documents are consecutive from the
             // tile's first one, recorded by td_mark_docs; empty documents share a position)
             const int64_t tile_end_g = tile_g0 + (tile_hi - K_HL);
-#if !TD_PF_DOC
             const int64_t fd = (int64_t)a.tile_first_doc[tile];
-#endif
             for (int64_t d = fd + tid; d < a.n_docs; d += K_THREADS) {
-#if TD_PF_DOC
-                const int64_t p = (d == fd + tid) ? my_doc_off : a.doc_offsets[d];
-#else
                 const int64_t p = a.doc_offsets[d];
-#endif
                 if (p >= tile_end_g) break;
                 const int lp = (int)(p - tile_g0);
                 a.doc_slot[d] = s_off[lp >> 4] + __popc((uint32_t)s_valid[lp >> 4] & ((1u << (lp & 15)) - 1u));
