@@ -179,6 +179,41 @@ def test_full_size_properties(tok):
     assert (np.diff(toff) > 0).all()
 
 
+def test_big_host_batch_composition_capacity_and_threads(tok):
+    """One 104 MiB host batch == its three parts encoded separately (ids and offsets, empty documents at the seams);
+    the capacity protocol at that size; one handle shared by several host threads."""
+    x, o = td_corpus.mixed(24 << 20, seed=3)
+    y, p = td_corpus.code(40 << 20, seed=4)
+    z, q = td_corpus.english(40 << 20, seed=5)
+    empty = np.zeros(3, dtype=np.int64)
+    text = np.concatenate([x, y, z])
+    offs = np.concatenate([o, o[-1] + empty, o[-1] + p[1:], o[-1] + p[-1] + empty, o[-1] + p[-1] + q[1:]]).astype(np.int64)
+    assert len(text) >= (100 << 20)
+    toks, toffs = tok.encode_batch(text, offs)
+    parts = [tok.encode_batch(a, b) for a, b in ((x, o), (y, p), (z, q))]
+    want = np.concatenate([t for t, _ in parts])
+    assert np.array_equal(toks, want)
+    base, k = 0, 0
+    for (t, to), nd in zip(parts, (len(o) - 1, len(p) - 1, len(q) - 1)):
+        assert np.array_equal(toffs[k:k + nd + 1], to + base)
+        base += len(t)
+        k += nd + 3  # the three empty documents that follow
+    assert toffs[-1] == len(want) and (np.diff(toffs) >= 0).all()
+    from tokendagger_amd import capi
+    with pytest.raises(capi.TokenDaggerHipError) as e:
+        tok.encode_batch(text, offs, capacity=1000)
+    assert e.value.code == 5 and str(len(want)) in str(e.value)
+    # one handle, several host threads (the reference shares one CoreBPE between the threads of encode_batch)
+    import threading
+    res = {}
+    def work(i, a, b):
+        res[i] = tok.encode_batch(a, b)
+    th = [threading.Thread(target=work, args=(i, a, b)) for i, (a, b) in enumerate(((x, o), (text, offs), (z, q), (y, p)))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert np.array_equal(res[1][0], want) and np.array_equal(res[0][0], parts[0][0]) and np.array_equal(res[3][0], parts[1][0])
+
+
 def test_malformed_utf8_is_handled_like_the_oracle(tok):
     # The reference assumes valid UTF-8 (PCRE2_NO_UTF_CHECK); this repo defines malformed input (oracle/td_oracle.c
     # char_at) and the device must agree with that definition and never hang or crash.
