@@ -139,11 +139,11 @@ int twin_split_tiled(void* h, const uint8_t* text, int64_t n, const int64_t* off
     memset(flags, 0, (size_t)n);
     if (ext_ends) memset(ext_ends, 0, sizeof(int64_t) * (size_t)n);
     GAcc g{cls.data(), text, n, n + 4, T.pat_flags};
-    const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
+    const int64_t n_tiles = (n + KS_TILE - 1) / KS_TILE;
     std::vector<uint8_t> wcls(K_WIN), wtxt(K_WIN);
     for (int64_t tile = 0; tile < n_tiles; ++tile) {
-        const int64_t tile_g0 = tile * K_TILE, wg0 = tile_g0 - K_HL;
-        const int tile_hi = K_HL + (int)((n - tile_g0 < K_TILE) ? (n - tile_g0) : K_TILE);
+        const int64_t tile_g0 = tile * KS_TILE, wg0 = tile_g0 - K_HL;
+        const int tile_hi = K_HL + (int)((n - tile_g0 < KS_TILE) ? (n - tile_g0) : KS_TILE);
         for (int i = 0; i < K_WIN; ++i) {
             const int64_t gi = wg0 + i;
             if (gi < 0) { wcls[i] = C_OTHER; wtxt[i] = 0; }

@@ -192,21 +192,31 @@ public:
         const int64_t nbytes = offsets.size() ? offsets.data()[n_docs] : 0;
         if (nbytes > (int64_t)text.size()) throw TiktokenError("offsets exceed the text buffer");
         py::array_t<int64_t> toffs(n_docs + 1);
-        std::vector<int32_t> out((size_t)(nbytes / 3 + 16));
+        // the ids land in the numpy array itself (no intermediate vector: at corpus scale that copy costs as much as
+        // the tokenization); the array is shrunk in place afterwards
+        py::array_t<int32_t> toks(nbytes / 3 + 16);
         int64_t n = 0;
         int rc;
         {
+            int32_t* outp = toks.mutable_data();
+            int64_t cap = (int64_t)toks.size();
+            const uint8_t* tp = text.data();
+            const int64_t* op = offsets.data();
+            int64_t* top = toffs.mutable_data();
             py::gil_scoped_release rel;
-            rc = td_encode_batch(h_, text.data(), offsets.data(), n_docs, mode, out.data(), (int64_t)out.size(), toffs.mutable_data(), &n);
-            if (rc == TD_E_CAPACITY && n > (int64_t)out.size()) {
-                out.resize((size_t)n);
-                rc = td_encode_batch(h_, text.data(), offsets.data(), n_docs, mode, out.data(), (int64_t)out.size(),
-                                     toffs.mutable_data(), &n);
-            }
+            rc = td_encode_batch(h_, tp, op, n_docs, mode, outp, cap, top, &n);
+        }
+        if (rc == TD_E_CAPACITY && n > (int64_t)toks.size()) {
+            toks = py::array_t<int32_t>(n);
+            int32_t* outp = toks.mutable_data();
+            const uint8_t* tp = text.data();
+            const int64_t* op = offsets.data();
+            int64_t* top = toffs.mutable_data();
+            py::gil_scoped_release rel;
+            rc = td_encode_batch(h_, tp, op, n_docs, mode, outp, n, top, &n);
         }
         if (rc != TD_OK) fail();
-        py::array_t<int32_t> toks(n);
-        if (n) memcpy(toks.mutable_data(), out.data(), (size_t)n * 4);
+        if (n != (int64_t)toks.size()) toks.resize({(py::ssize_t)n}, false);
         return py::make_tuple(toks, toffs);
     }
 

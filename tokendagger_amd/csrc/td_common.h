@@ -757,7 +757,15 @@ constexpr int K_TILE = K_THREADS * K_CHUNK;    // 4096 text bytes per tile
 #endif
 constexpr int K_HL = TD_K_HL;                  // left halo (sync-point back-search)
 constexpr int K_HR = 192;                      // right halo (piece overrun / look-ahead)
-constexpr int K_WIN = K_HL + K_TILE + K_HR;    // bytes staged in LDS per tile
+// The pre-tokenizer (td_split_tiles / td_split_slow, and the CPU twin's scan_lane) has its own geometry: a lane owns
+// KS_CHUNK = 32 bytes.  Its scan loop runs as long as the busiest lane of the wavefront (pieces per chunk + 1); with
+// 16-byte chunks that was 5.8 wavefront-iterations per KiB of English for 3.3 pieces per lane, with 32 it is 4.7.
+#ifndef TD_KS_CHUNK
+#define TD_KS_CHUNK 32
+#endif
+constexpr int KS_CHUNK = TD_KS_CHUNK;
+constexpr int KS_TILE = K_THREADS * KS_CHUNK;  // text bytes per pre-tokenizer tile
+constexpr int K_WIN = K_HL + KS_TILE + K_HR;   // bytes the pre-tokenizer stages in LDS per tile
 constexpr int K_LIM = K_WIN - 4;               // the scanner may read window positions < K_LIM
 constexpr int K_MAXSHORT = 64;                 // pieces up to this many bytes merge inside one wavefront
 constexpr int K_STAGE = K_TILE + K_MAXSHORT;   // staging slots per tile: a tile owns the tokens of the pieces that START in it,
@@ -774,7 +782,7 @@ constexpr int K_STAGE = K_TILE + K_MAXSHORT;   // staging slots per tile: a tile
 //   (the lane owning that chunk started there) or leaves the tile.
 template <class W, class G>
 TD_HD void scan_lane(W& w, const G& g, int tid, int tile_hi, int64_t wg0, uint32_t pv = 0) {
-    const int c0 = K_HL + tid * K_CHUNK, c1 = c0 + K_CHUNK;
+    const int c0 = K_HL + tid * KS_CHUNK, c1 = c0 + KS_CHUNK;
     int s = -1;
     if (tid == 0) {
         for (int i = c0; i >= 4; --i)

@@ -43,7 +43,8 @@ struct EncodeArgs {
     int64_t* out_offsets;       // [n_docs+1] token offset of each document; [n_docs] = total
     int* err;                   // err[0] = first TD_E_* raised on device (0 = ok)
     long long* err_pos;         // byte offset it refers to
-    int n_tiles;
+    int n_tiles;                // token-kernel tiles (K_TILE bytes)
+    int n_stiles;               // pre-tokenizer tiles (KS_TILE bytes)
     int use_fastpath;           // whole-piece lookup before the merge loop (CoreBPE::encode) or not
     int text_aligned;           // text pointer is 16-byte aligned
     int stop_after;             // debug/ablation: leave the tile loop after phase N (0 = run everything)

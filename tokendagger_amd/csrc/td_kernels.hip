@@ -219,7 +219,7 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
 // piece starts.  One workgroup per 4 KiB tile (+128 B left / 192 B right halo), persistent grid.
 #ifndef TD_SPLIT_MIN_WAVES
-#define TD_SPLIT_MIN_WAVES 6
+#define TD_SPLIT_MIN_WAVES 5
 #endif
 __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
@@ -233,42 +233,36 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 128; q += K_THREADS) s_lut[q] = (uint8_t)feature_of_class(T.ascii_cls[q]);
 
-    static_assert(K_WIN / 16 <= 2 * K_THREADS, "two prefetch registers per lane cover the window");
-    uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
-    static_assert(K_WIN / 32 <= K_THREADS, "one document word per lane covers the window");
+    constexpr int NPF = (K_WIN / 16 + K_THREADS - 1) / K_THREADS;  // 16-byte prefetch registers per lane for one window
+    uint4 pf[NPF];
     const int64_t nwords = (a.n + 31) >> 5;
-    auto load_docword = [&](int64_t wg0_) -> uint32_t {
-        const int64_t gw = (wg0_ >> 5) + tid;
-        return (tid < K_WIN / 32 && gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
+    auto load_window = [&](int64_t w0) {
+#pragma unroll
+        for (int q = 0; q < NPF; ++q)
+            if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = load_text16(a, w0 + (int64_t)(q * K_THREADS + tid) * 16);
     };
-    if ((int)blockIdx.x < a.n_tiles) {
-        const int64_t w0 = (int64_t)blockIdx.x * K_TILE - K_HL;
-        pf0 = load_text16(a, w0 + (int64_t)tid * 16);
-        if (tid < K_WIN / 16 - K_THREADS) pf1 = load_text16(a, w0 + (int64_t)(K_THREADS + tid) * 16);
-    }
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const int64_t tile_g0 = (int64_t)tile * K_TILE;
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) pf[q] = make_uint4(0, 0, 0, 0);
+    if ((int)blockIdx.x < a.n_stiles) load_window((int64_t)blockIdx.x * KS_TILE - K_HL);
+    for (int tile = blockIdx.x; tile < a.n_stiles; tile += gridDim.x) {
+        const int64_t tile_g0 = (int64_t)tile * KS_TILE;
         const int64_t wg0 = tile_g0 - K_HL;  // global offset of window index 0 (multiple of 64)
-        const int tile_hi = K_HL + (int)((a.n - tile_g0 < K_TILE) ? (a.n - tile_g0) : K_TILE);
-        const int c0 = K_HL + tid * K_CHUNK, c1 = c0 + K_CHUNK;
+        const int tile_hi = K_HL + (int)((a.n - tile_g0 < KS_TILE) ? (a.n - tile_g0) : KS_TILE);
+        const int c0 = K_HL + tid * KS_CHUNK, c1 = c0 + KS_CHUNK;
 
         // ---- phase 0: stage the text window and the document bits.  The text of this tile was requested one
-        //      iteration ago (registers pf0/pf1), so its HBM latency is hidden behind the previous tile -----------
-        reinterpret_cast<uint4*>(s_txt)[tid] = pf0;
-        if (tid < K_WIN / 16 - K_THREADS) reinterpret_cast<uint4*>(s_txt)[K_THREADS + tid] = pf1;
-        if (tid < K_WIN / 32) {
-            uint32_t dw = load_docword(wg0);
-            const int64_t g = wg0 + (int64_t)tid * 32;  // bytes past the end of the text: "end of subject" sentinels
+        //      iteration ago (registers pf[]), so its HBM latency is hidden behind the previous tile --------------
+#pragma unroll
+        for (int q = 0; q < NPF; ++q)
+            if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) reinterpret_cast<uint4*>(s_txt)[q * K_THREADS + tid] = pf[q];
+        for (int w = tid; w < K_WIN / 32; w += K_THREADS) {
+            const int64_t gw = (wg0 >> 5) + w;
+            uint32_t dw = (gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
+            const int64_t g = wg0 + (int64_t)w * 32;  // bytes past the end of the text: "end of subject" sentinels
             if (g + 32 > a.n) dw |= (g >= a.n) ? 0xFFFFFFFFu : ~((1u << (int)(a.n - g)) - 1u);
-            s_doc[tid] = dw;
+            s_doc[w] = dw;
         }
-        {
-            const int64_t nwg0 = wg0 + (int64_t)gridDim.x * K_TILE;  // next tile of this workgroup
-            if (tile + (int)gridDim.x < a.n_tiles) {
-                pf0 = load_text16(a, nwg0 + (int64_t)tid * 16);
-                if (tid < K_WIN / 16 - K_THREADS) pf1 = load_text16(a, nwg0 + (int64_t)(K_THREADS + tid) * 16);
-            }
-        }
+        if (tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);  // next tile of this workgroup
         for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
         __syncthreads();
 
@@ -405,7 +399,8 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     if (s < 0) defer(tile_g0, 1);
                 }
             } else if (c0 < tile_hi) {
-                uint32_t sy = (uint32_t)(s_mask[(c0 >> 6) * MK_COUNT + MK_SYNC] >> (c0 & 63)) & 0xFFFFu;
+                static_assert(KS_CHUNK == 16 || KS_CHUNK == 32, "a lane's sync bits come out of one 64-bit mask word");
+                uint32_t sy = (uint32_t)(s_mask[(c0 >> 6) * MK_COUNT + MK_SYNC] >> (c0 & 63)) & (uint32_t)((1ull << KS_CHUNK) - 1ull);
                 if (c1 > tile_hi) sy &= (1u << (tile_hi - c0)) - 1u;
                 if (sy) s = c0 + __ffs(sy) - 1;
             }
@@ -442,7 +437,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         }
         __syncthreads();
         // ---- publish the tile's own START bits (tile-aligned words: no other workgroup writes them) ----
-        if (tid < K_TILE / 32) {
+        if (tid < KS_TILE / 32) {
             const int64_t g = tile_g0 + (int64_t)tid * 32;
             if (g < a.n) {
                 uint32_t v = s_start[K_HL / 32 + tid];
@@ -467,8 +462,8 @@ __global__ void td_split_slow(const EncodeArgs a) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nslow; j += gridDim.x * blockDim.x) {
         const int64_t ent = a.slow_list[j];
         const int64_t g = ent >> 1;
-        const int64_t tile_g0 = g - (g % K_TILE);
-        const int64_t tile_end = (tile_g0 + K_TILE < a.n) ? tile_g0 + K_TILE : a.n;
+        const int64_t tile_g0 = g - (g % KS_TILE);
+        const int64_t tile_end = (tile_g0 + KS_TILE < a.n) ? tile_g0 + KS_TILE : a.n;
         int64_t p;
         if (ent & 1) {  // no sync point in the tile's left halo: walk back to one, then forward to the tile
             p = 0;
@@ -482,7 +477,7 @@ __global__ void td_split_slow(const EncodeArgs a) {
             // stop where a lane of the fast kernel STARTED: the first provable sync point of a 16-byte chunk other
             // than the tile's first chunk (lane 0 starts from the left halo, never inside its own chunk)
             if (p != g && is_sync(G.cf(p - 1), G.cf(p))) {
-                const int64_t cs = p - ((p - tile_g0) % K_CHUNK);
+                const int64_t cs = p - ((p - tile_g0) % KS_CHUNK);
                 bool first = cs != tile_g0;
                 for (int64_t q = cs; first && q < p; ++q)
                     if (is_sync(G.cf(q - 1), G.cf(q))) first = false;
@@ -1422,7 +1417,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(td_mark_docs, dim3(blocks), dim3(256), 0, stream, a.doc_offsets, nd, a.n, a.docbits, a.tile_first_doc);
     }
-    const int sblocks = a.n_tiles < split_grid_blocks() ? a.n_tiles : split_grid_blocks();
+    const int sblocks = a.n_stiles < split_grid_blocks() ? a.n_stiles : split_grid_blocks();
     const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
     if (ev0) (void)hipEventRecord(ev0, stream);
     hipLaunchKernelGGL(td_split_tiles, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
