@@ -101,7 +101,9 @@ static int64_t contraction(const uint8_t* s, int64_t e, int64_t n) {
 /* variant 0: the Llama-4 / o200k pattern (src/main.cpp:114).  variant 1: the Mistral tekken pattern (tekken.json
  * config.pattern, read by tests/throughput_test.py:118): the same alternatives without the contraction suffix and with
  * \p{N} in place of \p{N}{1,3}. */
+static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n);
 static int64_t next_piece_llama4(const uint8_t* s, int64_t pos, int64_t n, int variant) {
+    if (variant == 2) return next_piece_cl100k(s, pos, n);
     const int contr = variant == 0, nmax = variant == 0 ? 3 : 1;
     int l0;
     int c0 = char_at(s, pos, n, &l0, NULL);
@@ -182,6 +184,67 @@ static int64_t next_piece_llama4(const uint8_t* s, int64_t pos, int64_t n, int v
     }
     /* unreachable for this pattern (every character is covered); keep the reference's
      * no-progress rule (tiktoken.cpp:120-122) as a guard */
+    return pos + l0;
+}
+
+/* variant 2: cl100k_base / Llama-3 (tiktoken's pat_str; the reference accepts any pattern, wrapper.py:39):
+ *   (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
+ * \p{L} has no marks here: a combining mark is [^\s\p{L}\p{N}]. */
+static int is_L2(int c) { return c == C_UP || c == C_LW || c == C_LB; }
+static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n) {
+    int l0;
+    int c0 = char_at(s, pos, n, &l0, NULL);
+    /* alternative 1: the contraction on its own */
+    if (s[pos] == '\'') {
+        int64_t e = contraction(s, pos, n);
+        if (e != pos) return e;
+    }
+    /* alternative 2: optional prefix (tried taken first), then letters */
+    for (int with_prefix = 1; with_prefix >= 0; --with_prefix) {
+        if (with_prefix && (c0 == C_CRLF || is_L2(c0) || c0 == C_NUM)) continue;
+        int64_t st = with_prefix ? pos + l0 : pos, e = st;
+        int l, c;
+        while (e < n) { c = char_at(s, e, n, &l, NULL); if (!is_L2(c)) break; e += l; }
+        if (e > st) return e;
+    }
+    /* alternative 3: \p{N}{1,3} */
+    if (c0 == C_NUM) {
+        int64_t e = pos + l0;
+        for (int k = 1; k < 3 && e < n; ++k) {
+            int l, c = char_at(s, e, n, &l, NULL);
+            if (c != C_NUM) break;
+            e += l;
+        }
+        return e;
+    }
+    /* alternative 4:  ?[^\s\p{L}\p{N}]+[\r\n]* */
+    for (int with_space = 1; with_space >= 0; --with_space) {
+        if (with_space && c0 != C_SP) continue;
+        int64_t st = with_space ? pos + 1 : pos, e = st;
+        int l, c;
+        while (e < n) { c = char_at(s, e, n, &l, NULL); if (is_S(c) || is_L2(c) || c == C_NUM) break; e += l; }
+        if (e == st) continue;
+        while (e < n && (s[e] == '\r' || s[e] == '\n')) ++e;
+        return e;
+    }
+    /* alternatives 5-7: as in the Llama-4 pattern */
+    {
+        int64_t q = pos, last_crlf_end = -1, last_char = pos;
+        int l, c;
+        while (q < n) {
+            c = char_at(s, q, n, &l, NULL);
+            if (!is_S(c)) break;
+            if (c == C_CRLF) last_crlf_end = q + l;
+            last_char = q;
+            q += l;
+        }
+        if (q > pos) {
+            if (last_crlf_end >= 0) return last_crlf_end;
+            if (q == n) return q;
+            if (last_char > pos) return last_char;
+            return q;
+        }
+    }
     return pos + l0;
 }
 

@@ -25,3 +25,11 @@ def tekken_golden():
     of llama4_golden.npz (tools/make_golden.py tekken)."""
     import numpy as np
     return np.load(ROOT / "tests" / "golden" / "tekken_style_golden.npz", allow_pickle=True)
+
+
+@pytest.fixture(scope="session")
+def cl100k_golden():
+    """Compiled-reference outputs for the cl100k_base / Llama-3 split pattern over the Llama-4 vocabulary, on the
+    documents of llama4_golden.npz (tools/make_golden.py cl100k)."""
+    import numpy as np
+    return np.load(ROOT / "tests" / "golden" / "cl100k_style_golden.npz", allow_pickle=True)

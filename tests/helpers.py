@@ -69,6 +69,27 @@ def port_tokenizer_tekken():
     return port.OracleTokenizer(mr, port.VARIANT_TEKKEN)
 
 
+CL100K_PAT = vocab_io.CL100K_PAT_STR
+
+
+@functools.lru_cache(maxsize=None)
+def ref_tokenizer_cl100k():
+    from oracle import ref
+    if not ref.available():
+        subprocess.check_call([str(ROOT / "oracle" / "build_ref.sh")])
+    _, mr, special = llama4()
+    return ref.RefTokenizer(CL100K_PAT, mr, special)
+
+
+@functools.lru_cache(maxsize=None)
+def port_tokenizer_cl100k():
+    from oracle import port
+    if not port.available():
+        subprocess.check_call([str(ROOT / "oracle" / "build_oracle.sh")])
+    _, mr, _ = llama4()
+    return port.OracleTokenizer(mr, port.VARIANT_CL100K)
+
+
 def pack_docs(docs: list[bytes]):
     offs = np.zeros(len(docs) + 1, dtype=np.int64)
     np.cumsum([len(d) for d in docs], out=offs[1:])
@@ -218,6 +239,12 @@ def twin_llama4():
 def twin_tekken():
     _, mr, special = llama4()
     return Twin(TEKKEN_PAT, mr, special)
+
+
+@functools.lru_cache(maxsize=None)
+def twin_cl100k():
+    _, mr, special = llama4()
+    return Twin(CL100K_PAT, mr, special)
 
 
 # ----------------------------------------------------------------------------- inputs -------

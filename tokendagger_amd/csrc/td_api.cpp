@@ -161,6 +161,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.err_pos = &ctl->err_pos;
     a.n_tiles = (int)n_tiles;
     a.n_stiles = (int)((n + KS_TILE - 1) / KS_TILE);
+    a.pat_flags = pattern_flags(t->H.pattern_kind);
     // encode_ordinary has no whole-piece fast path (tiktoken.cpp:156-167); when every token is
     // reproduced by the merge loop the fast path cannot change the result and stays on.
     a.use_fastpath = (mode == TD_MODE_ENCODE) || t->H.merge_closed;

@@ -100,7 +100,12 @@ struct Tables {
 // The split patterns the scanners implement are one family: the Llama-4 / o200k pattern (reference src/main.cpp:114)
 // and its Mistral "tekken" sibling (tekken.json config.pattern, reference tests/throughput_test.py:118), which drops the
 // (?i:'s|'t|'re|'ve|'m|'ll|'d)? suffix of the two letter alternatives and matches \p{N} instead of \p{N}{1,3}.
-enum : uint32_t { PV_NO_CONTRACTION = 1, PV_SINGLE_DIGIT = 2 };
+// Third member: the cl100k_base / Llama-3 pattern
+//   (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
+// : the contraction is an alternative of its own in front (not a suffix), letters are plain \p{L}+ (no case structure;
+// marks are punctuation) and '/' does not extend a punctuation piece.  The last two are class REMAPS done when the
+// tables are built (C_MK -> C_OTHER, C_SLASH -> C_OTHER), so only the first two reach the scanners as flags.
+enum : uint32_t { PV_NO_CONTRACTION = 1, PV_SINGLE_DIGIT = 2, PV_LEADING_CONTRACTION = 4, PV_PLAIN_LETTERS = 8 };
 
 // ------------------------------------------------------------------ hashing -----------------
 TD_HD uint32_t hash_piece(uint64_t key, uint32_t len) {
@@ -264,11 +269,12 @@ TD_HD bool is_sync(uint32_t vp, uint32_t v) {
 // alternative does not match" (helpers only), or -1 when the answer depends on bytes at/after lim.
 
 template <class A>
-TD_HD typename A::pos_t scan_contraction(const A& a, typename A::pos_t e) {
+TD_HD typename A::pos_t scan_contraction(const A& a, typename A::pos_t e, bool leading = false) {
     // (?i:'s|'t|'re|'ve|'m|'ll|'d)?  — caseless under UTF+UCP, so U+017F also matches the s.
+    // leading: the apostrophe is the piece start itself (cl100k's first alternative), where a document may begin.
     if (e + 3 > a.lim) return -1;
     uint32_t v = a.cf(e);
-    if ((v & F_DOC) || (v & CLS_MASK) != C_APOS) return e;
+    if (((v & F_DOC) && !leading) || (v & CLS_MASK) != C_APOS) return e;
     v = a.cf(e + 1);
     if (v & F_DOC) return e;
     const uint32_t b1 = a.byte(e + 1);
@@ -336,12 +342,27 @@ TD_HD typename A::pos_t scan_piece(const A& a, typename A::pos_t pos, uint32_t p
         if (!(a.cf(p1) & F_CONT)) break;
         ++p1;
     }
+    if ((pv & PV_LEADING_CONTRACTION) && c0 == C_APOS) {
+        const P r = scan_contraction(a, pos, true);
+        if (r < 0) return -1;
+        if (r != pos) return r;
+    }
     if (c0 != C_CRLF && c0 != C_NUM) {
         const bool prefixable = in_set(M_P, c0);
         // only worth trying when a letter-class char is at pos or right after the prefix char
         const uint32_t v1 = a.cf(p1);
         const bool l0 = in_set(M_U | M_W, c0);
         const bool l1 = prefixable && !(v1 & F_DOC) && in_set(M_U | M_W, v1 & CLS_MASK);
+        if ((pv & PV_PLAIN_LETTERS) && (l0 || l1)) {  // [^\r\n\p{L}\p{N}]?\p{L}+
+            P e = l1 ? p1 : pos;
+            for (;;) {
+                if (e >= a.lim) return -1;
+                const uint32_t v = a.cf(e);
+                if ((e > pos && (v & F_DOC)) || !in_set(M_U | M_W, v & CLS_MASK)) break;
+                ++e;
+            }
+            return e;
+        }
         if (l0 || l1) {
             for (int alt = 1; alt <= 2; ++alt) {
                 if (l1) {
@@ -484,6 +505,7 @@ struct WinP {
     TD_HD bool bit(int k, int i) const { return (w.m[k] >> i) & 1ull; }
     TD_HD bool ebit(int i) const { return (E >> i) & 1ull; }
     TD_HD int run_end(int k, int from) const { return td_run_end(w.m[k] & ~E, from); }
+    TD_HD int run_end2(int k1, int k2, int from) const { return td_run_end((w.m[k1] | w.m[k2]) & ~E, from); }
     TD_HD int last_and(int k1, int k2, int lo, int hi) const {  // highest i in [lo,hi) with both bits set, -1 if none
         const uint64_t m = w.m[k1] & w.m[k2] & td_bits_below(hi) & ~td_bits_below(lo);
         return m ? td_top64(m) - 1 : -1;
@@ -512,6 +534,9 @@ struct WinP32 {
     TD_HD bool bit(int k, int i) const { return (w.m[k] >> i) & 1u; }
     TD_HD bool ebit(int i) const { return (E >> i) & 1u; }
     TD_HD int run_end(int k, int from) const { return from >= 32 ? 32 : from + td_ctz32(~((w.m[k] & ~E) >> from)); }
+    TD_HD int run_end2(int k1, int k2, int from) const {
+        return from >= 32 ? 32 : from + td_ctz32(~(((w.m[k1] | w.m[k2]) & ~E) >> from));
+    }
     TD_HD static uint32_t below(int n) { return n >= 32 ? ~0u : ((1u << n) - 1u); }
     TD_HD int last_and(int k1, int k2, int lo, int hi) const {
         const uint32_t m = w.m[k1] & w.m[k2] & below(hi) & ~below(lo);
@@ -553,6 +578,17 @@ struct ArrMaskP {
         }
         return i;
     }
+    TD_HD int run_end2(int k1, int k2, int from) const {
+        int i = from;
+        while (i < lim) {
+            const int wi = i >> 6, sh = i & 63;
+            const uint64_t m = ((word(k1, wi) | word(k2, wi)) & ~eword(wi)) >> sh;
+            const int t = td_ctz64(~m);
+            if (t < 64 - sh) return i + t;
+            i += 64 - sh;
+        }
+        return i;
+    }
     template <class F>
     TD_HD int last_where(const F& f, int lo, int hi) const {  // highest i in [lo,hi) whose bit in f(word index) is set
         if (hi <= lo) return -1;
@@ -578,9 +614,9 @@ struct ArrMaskP {
 
 // (?i:'s|'t|'re|'ve|'m|'ll|'d)? on masks; `bytes(i)` returns the raw byte at position i.
 template <class P, class B>
-TD_HD int scan_contraction_p(const P& p, const B& bytes, int e) {
+TD_HD int scan_contraction_p(const P& p, const B& bytes, int e, bool leading = false) {
     if (e + 3 > p.lim) return -1;
-    if (!p.bit(MK_A, e) || p.bit(MK_D, e)) return e;
+    if (!p.bit(MK_A, e) || (p.bit(MK_D, e) && !leading)) return e;
     if (p.bit(MK_D, e + 1)) return e;
     const uint32_t b1 = bytes(e + 1);
     const bool d2 = p.bit(MK_D, e + 2);
@@ -608,10 +644,19 @@ TD_HD int scan_piece_p(const P& p, const B& bytes, uint32_t pv = 0) {
     int p1 = o + 1;  // end of the first character
     while (p1 < lim && p.bit(MK_C, p1)) ++p1;
     if (p1 >= lim) return -1;
+    if ((pv & PV_LEADING_CONTRACTION) && p.bit(MK_A, o)) {
+        const int r = scan_contraction_p(p, bytes, o, true);
+        if (r < 0) return -1;
+        if (r != o) return r;
+    }
     if (!cr0 && !n0) {
         const bool prefixable = x0 || s0;  // [^\r\n\p{L}\p{N}] = X or non-CR/LF whitespace
         const bool l0 = u0 || w0;
         const bool l1 = prefixable && !p.ebit(p1) && (p.bit(MK_U, p1) || p.bit(MK_W, p1));
+        if ((pv & PV_PLAIN_LETTERS) && (l0 || l1)) {  // [^\r\n\p{L}\p{N}]?\p{L}+
+            const int e = p.run_end2(MK_U, MK_W, l1 ? p1 : o);
+            return e >= lim ? -1 : e;
+        }
         if (l0 || l1) {
             // candidates in backtracking order: alt1 from p1, alt1 from o, alt2 from p1, alt2 from o
             int e1 = 0, e2 = 0;  // first successful alt-1 / alt-2 end (0 = none)

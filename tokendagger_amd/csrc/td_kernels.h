@@ -45,6 +45,7 @@ struct EncodeArgs {
     long long* err_pos;         // byte offset it refers to
     int n_tiles;                // token-kernel tiles (K_TILE bytes)
     int n_stiles;               // pre-tokenizer tiles (KS_TILE bytes)
+    uint32_t pat_flags;         // PV_* scanner flags of the split pattern (selects the td_split_tiles instantiation)
     int use_fastpath;           // whole-piece lookup before the merge loop (CoreBPE::encode) or not
     int text_aligned;           // text pointer is 16-byte aligned
     int stop_after;             // debug/ablation: leave the tile loop after phase N (0 = run everything)

@@ -183,9 +183,10 @@ __device__ __forceinline__ uint64_t bits64(const uint32_t* arr, int pos) {
 
 // pieces / look-ahead longer than a 64-byte register window: the same matcher on the mask words in LDS (cold path,
 // kept out of line so that the hot loop stays small)
-__device__ __noinline__ int scan_piece_lds(const uint64_t* s_mask, const uint8_t* s_txt, int p, uint32_t pv) {
+template <uint32_t PV>
+__device__ __noinline__ int scan_piece_lds(const uint64_t* s_mask, const uint8_t* s_txt, int p) {
     const ArrMaskP mp(s_mask, p, K_LIM);
-    return scan_piece_p(mp, [s_txt](int q) { return (uint32_t)s_txt[q]; }, pv);
+    return scan_piece_p(mp, [s_txt](int q) { return (uint32_t)s_txt[q]; }, PV);
 }
 
 // the 64-byte mask window that starts at window byte `base`
@@ -221,6 +222,9 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 #ifndef TD_SPLIT_MIN_WAVES
 #define TD_SPLIT_MIN_WAVES 5
 #endif
+// PV = the pattern's scanner flags as a compile-time constant: one instantiation per member of the pattern family, so
+// the hot scan loop of the Llama-4 pattern carries no trace of the others (as run-time flags they cost 5 % of it).
+template <uint32_t PV>
 __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
     __shared__ __attribute__((aligned(16))) uint64_t s_mask[(K_MWORDS + 1) * MK_COUNT];  // class masks, word-major
@@ -424,11 +428,11 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     const int avail = (K_LIM - p < 32) ? (K_LIM - p) : 32;
                     int e = -1;
                     {
-                        const int r = scan_piece_p(WinP32(v, avail), [&](int q) { return (uint32_t)s_txt[p + q]; }, T.pat_flags);
+                        const int r = scan_piece_p(WinP32(v, avail), [&](int q) { return (uint32_t)s_txt[p + q]; }, PV);
                         if (r >= 0) e = p + r;
                     }
                     if (e < 0) {
-                        e = scan_piece_lds(s_mask, s_txt, p, T.pat_flags);  // piece or look-ahead beyond 32 bytes: mask words in LDS
+                        e = scan_piece_lds<PV>(s_mask, s_txt, p);  // piece or look-ahead beyond 32 bytes: mask words in LDS
                         if (e < 0) { if (p >= K_HL) defer(wg0 + p, 0); break; }
                     }
                     p = e;
@@ -1402,7 +1406,7 @@ int encode_grid_blocks() {
     return g_blocks_encode;
 }
 static int split_grid_blocks() {
-    if (!g_blocks_split) g_blocks_split = resident_blocks((const void*)td_split_tiles, 3);
+    if (!g_blocks_split) g_blocks_split = resident_blocks((const void*)td_split_tiles<0u>, 3);
     const char* e = getenv("TD_SPLIT_BLOCKS_PER_CU");
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_split;
@@ -1420,7 +1424,14 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
     const int sblocks = a.n_stiles < split_grid_blocks() ? a.n_stiles : split_grid_blocks();
     const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
     if (ev0) (void)hipEventRecord(ev0, stream);
-    hipLaunchKernelGGL(td_split_tiles, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
+    constexpr uint32_t PV_TEKKEN = PV_NO_CONTRACTION | PV_SINGLE_DIGIT;
+    constexpr uint32_t PV_CL100K = PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS;
+    switch (a.pat_flags) {
+        case 0u: hipLaunchKernelGGL(td_split_tiles<0u>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
+        case PV_TEKKEN: hipLaunchKernelGGL(td_split_tiles<PV_TEKKEN>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
+        case PV_CL100K: hipLaunchKernelGGL(td_split_tiles<PV_CL100K>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
     hipLaunchKernelGGL(td_split_slow, dim3(64), dim3(64), 0, stream, a);
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (a.stop_after != 2 && a.stop_after != 11 && a.stop_after != 12) {

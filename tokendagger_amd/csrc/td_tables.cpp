@@ -21,16 +21,28 @@ static const char kTekken[] =
     "|[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]+[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]*"
     "|\\p{N}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n/]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
 
+// cl100k_base / Llama-3: the classic form and tiktoken's later possessive spelling of the same language.
+static const char kCl100k[] =
+    "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+static const char kCl100kPossessive[] =
+    "'(?i:[sdmt]|ll|ve|re)|[^\\r\\n\\p{L}\\p{N}]?+\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]++[\\r\\n]*|\\s*[\\r\\n]|\\s+(?!\\S)|\\s+";
+
 const char* o200k_pattern() { return kO200k; }
 const char* tekken_pattern() { return kTekken; }
+const char* cl100k_pattern() { return kCl100k; }
 
 PatternKind classify_pattern(const std::string& pat) {
     if (pat == kO200k) return PATTERN_O200K;
     if (pat == kTekken) return PATTERN_TEKKEN;
+    if (pat == kCl100k || pat == kCl100kPossessive) return PATTERN_CL100K;
     return PATTERN_UNSUPPORTED;
 }
 
-uint32_t pattern_flags(PatternKind k) { return k == PATTERN_TEKKEN ? (PV_NO_CONTRACTION | PV_SINGLE_DIGIT) : 0u; }
+uint32_t pattern_flags(PatternKind k) {
+    if (k == PATTERN_TEKKEN) return PV_NO_CONTRACTION | PV_SINGLE_DIGIT;
+    if (k == PATTERN_CL100K) return PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS;
+    return 0u;
+}
 
 uint64_t piece_key_host(const uint8_t* p, uint32_t len) {
     if (len <= 8) {
@@ -46,7 +58,7 @@ Tables HostTables::view() const {
     memset(&T, 0, sizeof T);
     T.ascii_cls = ascii_cls.data();
     T.ucls1 = td_ucls_stage1;
-    T.ucls2 = td_ucls_stage2;
+    T.ucls2 = ucls2_remap.empty() ? td_ucls_stage2 : ucls2_remap.data();
     T.byte_id = byte_id.data();
     T.byte_pair = byte_pair.data();
     T.piece_slots = piece_slots.data();
@@ -102,16 +114,23 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
     H.pattern = pattern ? pattern : "";
     H.pattern_kind = classify_pattern(H.pattern);
     if (H.pattern_kind == PATTERN_UNSUPPORTED) {
-        err = "split pattern is not supported by the device pre-tokenizer (supported: the o200k/Llama-4 pattern and the "
-              "Mistral tekken pattern); "
+        err = "split pattern is not supported by the device pre-tokenizer (supported: the o200k/Llama-4 pattern, the "
+              "Mistral tekken pattern and the cl100k_base/Llama-3 pattern); "
               "there is no CPU regex fallback";
         return TD_E_PATTERN;
     }
     if (n_vocab <= 0) { err = "empty vocabulary"; return TD_E_VOCAB; }
 
-    // ASCII classes straight from the Unicode table
+    // Class tables: the probed Unicode table; cl100k reads marks as punctuation and gives '/' no trailer role, which is
+    // a remap of two class ids (the scanners never see the difference)
+    if (H.pattern_kind == PATTERN_CL100K) {
+        H.ucls2_remap.assign(td_ucls_stage2, td_ucls_stage2 + sizeof td_ucls_stage2);
+        for (auto& c : H.ucls2_remap)
+            if (c == C_MK || c == C_SLASH) c = C_OTHER;
+    }
+    const uint8_t* stage2 = H.ucls2_remap.empty() ? td_ucls_stage2 : H.ucls2_remap.data();
     H.ascii_cls.resize(128);
-    for (uint32_t c = 0; c < 128; ++c) H.ascii_cls[c] = td_ucls_stage2[(uint32_t)td_ucls_stage1[0] * 256u + c];
+    for (uint32_t c = 0; c < 128; ++c) H.ascii_cls[c] = stage2[(uint32_t)td_ucls_stage1[0] * 256u + c];
 
     int32_t max_rank = -1;
     uint32_t max_len = 0;

@@ -16,7 +16,9 @@ enum PatternKind : int {
     PATTERN_UNSUPPORTED = -1,
     PATTERN_O200K = 0,  // the Llama-4 / o200k_base split pattern (reference src/main.cpp:114)
     PATTERN_TEKKEN = 1, // Mistral tekken.json config.pattern (reference tests/throughput_test.py:118)
+    PATTERN_CL100K = 2, // cl100k_base / Llama-3 (tiktoken's pat_str; any pattern is legal input to the reference: wrapper.py:39)
 };
+const char* cl100k_pattern();
 uint32_t pattern_flags(PatternKind k);  // PV_* bits for the scanners
 const char* tekken_pattern();
 PatternKind classify_pattern(const std::string& pat);
@@ -26,6 +28,7 @@ struct HostTables {
     PatternKind pattern_kind = PATTERN_UNSUPPORTED;
     std::string pattern;
     std::vector<uint8_t> ascii_cls;
+    std::vector<uint8_t> ucls2_remap;  // stage-2 class table with the pattern's class remaps applied (empty: the static one)
     std::vector<int32_t> byte_id;
     std::vector<int32_t> byte_pair;
     std::vector<PieceSlot> piece_slots;

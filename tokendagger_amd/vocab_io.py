@@ -29,6 +29,15 @@ LLAMA4_PAT_STR = (
     r"|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+"
 )
 
+# cl100k_base (GPT-4) / Llama-3 split pattern
+CL100K_PAT_STR = (
+    r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+)
+# tiktoken's later spelling of the same language (possessive quantifiers)
+CL100K_PAT_STR_POSSESSIVE = (
+    r"'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]++[\r\n]*|\s*[\r\n]|\s+(?!\S)|\s+"
+)
+
 # Mistral tekken.json config.pattern (reference loads it from the file: tests/throughput_test.py:118): the Llama-4
 # pattern without the contraction suffix and with single-digit number pieces.
 TEKKEN_PAT_STR = (
