@@ -78,7 +78,10 @@ struct GlobAcc {
 // non-ASCII text and must not be replicated into the hot ASCII path)
 // (the window description travels by value: a struct passed by reference to an out-of-line function has to live in
 // scratch memory, and the per-tile store of it was 0.5 GB of HBM writes per launch)
-__device__ __noinline__ uint32_t feature_at_v(const Tables& T, const uint8_t* txt, const uint32_t* docw, int lo, int hi, int idx) {
+__device__ __noinline__ uint32_t feature_at_v(const uint8_t* ascii_cls, const uint16_t* ucls1, const uint8_t* ucls2, const uint8_t* txt,
+                                              const uint32_t* docw, int lo, int hi, int idx) {
+    Tables T;  // only the class tables are read here
+    T.ascii_cls = ascii_cls; T.ucls1 = ucls1; T.ucls2 = ucls2;
     LdsSrc src;
     src.txt = txt; src.docw = docw; src.lo = lo; src.hi = hi;
     if (idx < src.lo || idx >= src.hi) return FB_X;
@@ -220,7 +223,7 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
 // piece starts.  One workgroup per 4 KiB tile (+128 B left / 192 B right halo), persistent grid.
 #ifndef TD_SPLIT_MIN_WAVES
-#define TD_SPLIT_MIN_WAVES 5
+#define TD_SPLIT_MIN_WAVES 6
 #endif
 // PV = the pattern's scanner flags as a compile-time constant: one instantiation per member of the pattern family, so
 // the hot scan loop of the Llama-4 pattern carries no trace of the others (as run-time flags they cost 5 % of it).
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     const bool ok = need > 0 && pos + need < (int)src.hi && pos >= (int)src.lo && !((docb >> (k + 1)) & ((1u << need) - 1u)) &&
                                     (c1 & 0xC0) == 0x80 && (need < 2 || (c2 & 0xC0) == 0x80) && (need < 3 || (c3 & 0xC0) == 0x80);
                     if (!ok) {  // invalid lead, truncated sequence, stray continuation byte, document boundary inside
-                        const uint32_t f = feature_at_v(T, s_txt, s_doc, (int)src.lo, (int)src.hi, pos);
+                        const uint32_t f = feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, pos);
                         put(k, f);
                         cur = f & ~(uint32_t)FB_C;
                         remaining = 0;
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     const bool known = lane != 0 && !(st_in & 0x100u);
                     const int claim = (int)(st_in >> 9);
                     for (int k = 0; k < lead_conts; ++k) {
-                        const uint32_t f = (known && k < claim) ? ((st_in & 0xFFu) | FB_C) : feature_at_v(T, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 + k);
+                        const uint32_t f = (known && k < claim) ? ((st_in & 0xFFu) | FB_C) : feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 + k);
                         if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4));
                     }
                 }
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                 pf = 0;
                 if (it > 0) {
                     const uint32_t pb = s_txt[it * 8 - 1];
-                    pf = (pb < 0x80) ? (uint32_t)s_lut[pb] : feature_at_v(T, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 - 1);
+                    pf = (pb < 0x80) ? (uint32_t)s_lut[pb] : feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 - 1);
                 }
             }
             const uint64_t P = transpose8x8(((uint64_t)fhi << 32) | flo);  // byte k = bit plane of feature bit k
