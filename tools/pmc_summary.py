@@ -12,6 +12,8 @@ for pdir in sorted(glob.glob(os.path.join(root, "*"))):
     for f in glob.glob(os.path.join(pdir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("void "):  # templated kernels carry their return type
+                k = k[5:]
             if not k.startswith("td::"):
                 continue
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
