@@ -5,7 +5,7 @@ set -u
 out="$1"; stops="${2:-0}"; corpus="${3:-english}"
 cd /tmp && export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"
-mkdir -p "$R/gpurun_out/$out"
+rm -rf "$R/gpurun_out/$out"; mkdir -p "$R/gpurun_out/$out"   # never mix the CSVs of two runs
 run() { # name, counters...
   name="$1"; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/gpurun_out/$out/$name" -- python "$R/tools/gpu_ablate.py" "$corpus" 256 "$stops" > "$R/gpurun_out/$out/$name.log" 2>&1

@@ -5,7 +5,7 @@ set -u
 out="$1"; corpus="${2:-english}"; mb="${3:-256}"
 cd /tmp && export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"
-mkdir -p "$R/gpurun_out/$out"
+rm -rf "$R/gpurun_out/$out"; mkdir -p "$R/gpurun_out/$out"   # never mix the CSVs of two runs
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$R/gpurun_out/$out/$c" -- python "$R/tools/gpu_ablate.py" $corpus $mb 0 > "$R/gpurun_out/$out/$c.log" 2>&1
 done
