@@ -45,7 +45,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, slow_list, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc;
+    DevBuf docbits, startbits, slow_list, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -93,6 +93,8 @@ struct Ctl {  // small control block in device memory
     uint32_t long_count;   // --- from here on: reset before every call
     uint32_t slow_count;
     unsigned long long pool_used;
+    uint32_t scan_done;
+    uint32_t pad2;
 };
 
 int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
@@ -107,6 +109,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
     if ((rc = ensure(t, t->doc_slot, (size_t)(n_docs + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_first_doc, (size_t)(n_tiles + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->chunk_pref, (size_t)(n_tiles / 4096 + 2) * 8))) return rc;
     if ((rc = ensure(t, t->long_list, (size_t)(n / (K_MAXSHORT + 1) + n_tiles + 16) * sizeof(LongEntry)))) return rc;
     const int64_t pool_bytes = t->pool_bytes_opt > 0 ? t->pool_bytes_opt : std::max<int64_t>(64ll << 20, 2 * n);
     if ((rc = ensure(t, t->pool, (size_t)pool_bytes))) return rc;
@@ -154,6 +157,10 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.pool = (uint32_t*)t->pool.p;
     a.pool_cap = t->pool.cap / 4;
     a.pool_used = &ctl->pool_used;
+    a.scan_done = &ctl->scan_done;
+    a.chunk_pref = (int64_t*)t->chunk_pref.p;
+    a.ctl_reset = &ctl->long_count;  // keep a sticky error (err / err_pos) but reset the per-call counters
+    a.ctl_reset_words = (uint32_t)((sizeof(Ctl) - offsetof(Ctl, long_count)) / 4);
     a.out_tokens = (int32_t*)d_out;
     a.out_cap = d_out ? out_cap : 0;
     a.out_offsets = (int64_t*)d_out_offs;
@@ -167,11 +174,6 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.use_fastpath = (mode == TD_MODE_ENCODE) || t->H.merge_closed;
     a.text_aligned = (((uintptr_t)d_text) & 15) == 0;
     a.stop_after = t->stop_after;
-    HIP_TRY(t, hipMemsetAsync(t->docbits.p, 0, (size_t)((n + 31) / 32 + 2) * 4, stream));
-    HIP_TRY(t, hipMemsetAsync(t->tile_extra.p, 0, (size_t)(n_tiles + 1) * 4, stream));
-    HIP_TRY(t, hipMemsetAsync(t->tile_first_doc.p, 0xFF, (size_t)(n_tiles + 1) * 4, stream));
-    // keep a sticky error (err / err_pos) but reset the per-call counters
-    HIP_TRY(t, hipMemsetAsync(&ctl->long_count, 0, sizeof(Ctl) - offsetof(Ctl, long_count), stream));
     td_tokenizer::Ev3 ev{{nullptr, nullptr, nullptr}};
     if (t->profile) {
         if (!t->ev_free.empty()) { ev = t->ev_free.back(); t->ev_free.pop_back(); }
@@ -291,7 +293,7 @@ void td_destroy(td_tokenizer* t) {
     for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
     for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
-                      &t->pool, &t->ctl, &t->tile_first_doc, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
+                      &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                       &t->dec_off, &t->dec_out};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);

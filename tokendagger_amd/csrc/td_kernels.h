@@ -38,6 +38,9 @@ struct EncodeArgs {
     uint32_t* pool;             // long-piece scratch + token store
     uint64_t pool_cap;          // in u32
     unsigned long long* pool_used;
+    uint32_t* scan_done;        // chunks of td_scan_tiles finished (the last one scans the chunk totals)
+    int64_t* chunk_pref;        // [n_tiles/4096 + 2] token base of every 4096-tile chunk (exclusive scan of the chunk totals)
+    uint32_t* ctl_reset; uint32_t ctl_reset_words;  // per-call counters td_prepare clears
     int32_t* out_tokens;        // [out_cap]
     int64_t out_cap;
     int64_t* out_offsets;       // [n_docs+1] token offset of each document; [n_docs] = total

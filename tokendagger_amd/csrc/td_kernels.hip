@@ -173,6 +173,19 @@ __global__ void td_mark_docs(const int64_t* doc_offsets, int64_t n_docs, int64_t
     }
 }
 
+// ------------------------------------------------------------------ td_prepare --------------
+__global__ void td_prepare(const EncodeArgs a) {
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    const int64_t words = (a.n + 31) / 32 + 2;
+    uint4* d4 = reinterpret_cast<uint4*>(a.docbits);  // (hipMalloc alignment; the buffer is padded past `words`)
+    for (int64_t i = gid; i < (words + 3) / 4; i += gsz) d4[i] = make_uint4(0, 0, 0, 0);
+    for (int64_t i = gid; i <= a.n_tiles; i += gsz) {
+        a.tile_extra[i] = 0;
+        a.tile_first_doc[i] = 0xFFFFFFFFu;
+    }
+    if (gid < a.ctl_reset_words) a.ctl_reset[gid] = 0;
+}
+
 // ------------------------------------------------------------------ shared helpers ----------
 constexpr int K_MWORDS = K_WIN / 64;  // 64-byte mask words per window
 
@@ -1231,16 +1244,18 @@ __global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
 }
 
 // ------------------------------------------------------------------ td_scan_tiles -----------
-// Device-wide exclusive scan of the per-tile token counts (n_tiles = N/4096: 65 536 entries for 256 MiB).
-// One 1024-thread workgroup walks the array in coalesced 4096-entry chunks (16 B per lane), wavefront shuffle
-// scans + one LDS hop per chunk, running carry across chunks.
+// Device-wide exclusive scan of the per-tile token counts (n_tiles = N/4096: 65 536 entries for 256 MiB), two levels
+// in one launch: every 1024-thread workgroup scans one chunk of 4096 tiles (16 B per lane, wavefront shuffle scans + one
+// LDS hop) and publishes the chunk total; the workgroup that finishes last scans the chunk totals (chunk_pref).  A
+// tile's token base is tile_base[tile] + chunk_pref[tile / 4096].
+constexpr int K_SCAN_CHUNK = 4096;
 __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
     __shared__ unsigned long long s_wsum[16];
-    __shared__ unsigned long long s_carry;
+    __shared__ uint32_t s_last;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < a.n_tiles; c0 += 4096) {
+    const int nchunks = (a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK;
+    {
+        const int c0 = blockIdx.x * K_SCAN_CHUNK;
         const int e0 = c0 + tid * 4;
         uint32_t v[4] = {0, 0, 0, 0};
         if (e0 + 4 <= a.n_tiles) {
@@ -1261,21 +1276,43 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
         }
         if (lane == 63) s_wsum[wv] = x;
         __syncthreads();
-        unsigned long long woff = s_carry;
+        unsigned long long woff = 0;
         for (int w = 0; w < wv; ++w) woff += s_wsum[w];
-        unsigned long long run = woff + x - mine;  // exclusive prefix of my first element
+        unsigned long long run = woff + x - mine;  // exclusive prefix of my first element inside the chunk
         for (int k = 0; k < 4; ++k) {
             if (e0 + k < a.n_tiles) a.tile_base[e0 + k] = (int64_t)run;
             run += v[k];
         }
-        __syncthreads();
-        if (tid == 1023) s_carry = run;  // inclusive total through this chunk
+        if (tid == 1023) {
+            a.chunk_pref[blockIdx.x] = (int64_t)run;  // chunk total for now; the last workgroup turns it into a prefix
+            __threadfence();
+            s_last = (atomicAdd(a.scan_done, 1u) == (uint32_t)nchunks - 1u) ? 1u : 0u;
+        }
         __syncthreads();
     }
-    if (tid == 0) {
-        const int64_t total = (int64_t)s_carry;
-        a.tile_base[a.n_tiles] = total;
-        if (total > a.out_cap) raise(a, TD_E_CAPACITY, total);
+    if (!s_last) return;
+    __threadfence();
+    // exclusive scan of the chunk totals (at most a few hundred), one wavefront
+    if (wv == 0) {
+        unsigned long long carry = 0;
+        for (int c0 = 0; c0 < nchunks; c0 += 64) {
+            const int c = c0 + lane;
+            const unsigned long long tot = (c < nchunks) ? (unsigned long long)a.chunk_pref[c] : 0ull;
+            unsigned long long x = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned long long t = __shfl_up(x, d);
+                if (lane >= d) x += t;
+            }
+            if (c < nchunks) a.chunk_pref[c] = (int64_t)(carry + x - tot);
+            carry += __shfl(x, 63);
+        }
+        if (lane == 0) {
+            const int64_t total = (int64_t)carry;
+            a.chunk_pref[nchunks] = total;
+            a.tile_base[a.n_tiles] = total;
+            if (total > a.out_cap) raise(a, TD_E_CAPACITY, total);
+        }
     }
 }
 
@@ -1292,12 +1329,13 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t total = a.tile_base[a.n_tiles];
     const int nwaves = gridDim.x * (K_THREADS / 64);
+    auto base_of = [&](int tile) { return a.tile_base[tile] + a.chunk_pref[tile / K_SCAN_CHUNK]; };
     // pass 1: plain tiles
     for (int tile = blockIdx.x * (K_THREADS / 64) + wv; tile < a.n_tiles; tile += nwaves) {
         const uint32_t tc = a.tile_count[tile];
         if (tc >> 31) continue;
         const uint32_t cnt = tc;
-        const int64_t base = a.tile_base[tile];
+        const int64_t base = base_of(tile);
         const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
         if (base + cnt <= a.out_cap) {
             // 16-byte stores to the (arbitrarily placed) destination: single ids up to its next 16-byte boundary, then
@@ -1331,7 +1369,7 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         const uint32_t tc = a.tile_count[tile];
         if (!(tc >> 31)) continue;  // uniform per workgroup
         const uint32_t cnt = tc & 0x7FFFFFFFu;
-        const int64_t base = a.tile_base[tile];
+        const int64_t base = base_of(tile);
         const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
         uint32_t sz[K_PCH];
         uint32_t mine = 0;
@@ -1417,6 +1455,14 @@ static int split_grid_blocks() {
 
 hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2) {
     if (a.n_tiles <= 0) return hipSuccess;
+    {   // one launch clears what was seven memsets: document bits, per-tile long-piece counts, first-document
+        // indices (0xFFFFFFFF = none) and the per-call counters
+        const int64_t words = (a.n + 31) / 32 + 2;
+        int pb = (int)((words / 4 + 255) / 256);
+        if (pb > 2048) pb = 2048;
+        if (pb < 1) pb = 1;
+        hipLaunchKernelGGL(td_prepare, dim3(pb), dim3(256), 0, stream, a);
+    }
     {
         const int64_t nd = a.n_docs;
         int blocks = (int)((nd + 255) / 256);
@@ -1441,7 +1487,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
         hipLaunchKernelGGL(td_encode_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
         if (ev2) (void)hipEventRecord(ev2, stream);
         hipLaunchKernelGGL(td_long_pieces, dim3(256 * 5), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(td_scan_tiles, dim3(1), dim3(1024), 0, stream, a);
+        hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
         hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
     } else if (ev2) (void)hipEventRecord(ev2, stream);
     return hipGetLastError();
