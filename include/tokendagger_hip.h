@@ -130,6 +130,13 @@ int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum
 int64_t td_special_count(const td_tokenizer* t);
 int td_special_get(const td_tokenizer* t, int64_t i, const char** str, int64_t* len, int32_t* id);
 
+/* Device-resident decode: d_tokens int32[n_tokens] -> d_out bytes (capacity out_capacity), total byte count to
+ * *d_n_bytes (device int64, may be NULL).  Asynchronous on hip_stream; an id outside the vocabulary (TD_E_BAD_TOKEN,
+ * position = its index) or a too small d_out (TD_E_CAPACITY, position = bytes needed) surface through
+ * td_device_status.  Same semantics as td_decode_bytes / CoreBPE::decode_bytes (tiktoken.cpp:236-255). */
+int td_decode_device(td_tokenizer* t, const void* d_tokens, int64_t n_tokens, void* d_out, int64_t out_capacity,
+                     void* d_n_bytes, void* hip_stream);
+
 /* Vocabulary accessors (host tables, no launch): the bytes of one token id (tiktoken decode_single_token_bytes;
  * TD_E_BAD_TOKEN if the id is not in the vocabulary) and the id of one whole token (tiktoken encode_single_token:
  * regular tokens first, then special tokens; TD_E_UNKNOWN_BYTE if the bytes are not a token). */

@@ -263,3 +263,32 @@ def test_decode(tok, golden):
         tok.decode_bytes([5, 99999999])
     assert e.value.code == 8
     assert tok.decode_bytes([]) == b""
+
+
+def test_decode_device_resident_and_errors(tok, golden):
+    import torch
+    from tokendagger_amd import capi
+    # whole golden batch: decode(encode(text)) == text, through the device-resident entry point
+    text = golden["text"]
+    ids = torch.from_numpy(golden["enc"].astype(np.int32)).cuda()
+    out = torch.zeros(len(text) + 32, dtype=torch.uint8, device="cuda")
+    nb = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    tok.decode_device(ids.data_ptr(), len(ids), out.data_ptr(), len(out), nb.data_ptr(), s)
+    tok.device_status(s)
+    assert int(nb.item()) == len(text) and np.array_equal(out[:len(text)].cpu().numpy(), text)
+    # chunk seams of the two-level scan: exactly 4096, 4097, 8191 ... ids
+    for k in (1, 4095, 4096, 4097, 8191, 8192, 12289):
+        part = golden["enc"][:k]
+        assert tok.decode_bytes(part) == H.port_tokenizer().decode_bytes(part)
+    # capacity and bad ids
+    tok.decode_device(ids.data_ptr(), len(ids), out.data_ptr(), 100, nb.data_ptr(), s)
+    with pytest.raises(capi.TokenDaggerHipError) as e:
+        tok.device_status(s)
+    assert e.value.code == 5 and int(nb.item()) == len(text)
+    with pytest.raises(capi.TokenDaggerHipError) as e:
+        tok.decode_bytes([5, 99999999, 7])
+    assert e.value.code == 8 and "99999999" in str(e.value)
+    with pytest.raises(capi.TokenDaggerHipError) as e:
+        tok.decode_bytes([5, -3])
+    assert e.value.code == 8

@@ -201,6 +201,9 @@ int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) 
             case TD_E_CAPACITY:
                 t->err = "output capacity too small: " + std::to_string(c.err_pos) + " tokens needed";
                 break;
+            case TD_E_BAD_TOKEN:
+                t->err = "Invalid token for decoding at index " + std::to_string(c.err_pos);
+                break;
             case TD_E_SCRATCH:
                 t->err = "long-piece scratch exhausted near byte offset " + std::to_string(c.err_pos) + " (raise TD_OPT_LONG_POOL_BYTES)";
                 break;
@@ -360,6 +363,45 @@ int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_off
     return TD_OK;
 }
 
+static int decode_args(td_tokenizer* t, const void* d_tokens, int64_t n_tokens, void* d_out, int64_t out_cap, void* d_n_bytes,
+                       hipStream_t stream, DecodeArgs& a) {
+    int rc;
+    const int64_t npref = ((n_tokens / 4096 + 4) + 1) & ~1ll;  // even: the offsets behind it stay 16-byte aligned
+    if ((rc = ensure(t, t->dec_off, (size_t)(n_tokens + 4) * 4 + (size_t)npref * 8))) return rc;
+    memset(&a, 0, sizeof a);
+    a.Tp = t->dTp;
+    a.tokens = (const int32_t*)d_tokens;
+    a.n = n_tokens;
+    a.chunk_pref = (int64_t*)t->dec_off.p;                       // 8-byte aligned part first
+    a.local_off = (uint32_t*)(a.chunk_pref + npref);
+    a.out = (uint8_t*)d_out;
+    a.out_cap = out_cap;
+    a.n_bytes = (int64_t*)d_n_bytes;
+    Ctl* ctl = (Ctl*)t->ctl.p;
+    a.scan_done = &ctl->scan_done;
+    a.err = &ctl->err;
+    a.err_pos = &ctl->err_pos;
+    HIP_TRY(t, hipMemsetAsync(&ctl->scan_done, 0, 4, stream));
+    return TD_OK;
+}
+
+int td_decode_device(td_tokenizer* t, const void* d_tokens, int64_t n_tokens, void* d_out, int64_t out_capacity, void* d_n_bytes,
+                     void* hip_stream) {
+    if (!t || n_tokens < 0 || (n_tokens > 0 && (!d_tokens || !d_out)) || out_capacity < 0) return TD_E_INVALID;
+    std::lock_guard<std::mutex> g(t->mu);
+    HIP_TRY(t, hipSetDevice(t->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (n_tokens == 0) {
+        if (d_n_bytes) HIP_TRY(t, hipMemsetAsync(d_n_bytes, 0, 8, s));
+        return TD_OK;
+    }
+    DecodeArgs a;
+    int rc = decode_args(t, d_tokens, n_tokens, d_out, out_capacity, d_n_bytes, s, a);
+    if (rc) return rc;
+    HIP_TRY(t, launch_decode(a, s, 3));
+    return TD_OK;
+}
+
 int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, uint8_t* out, int64_t out_capacity,
                     int64_t* n_bytes) {
     if (!t || n_tokens < 0 || (n_tokens > 0 && !tokens)) return TD_E_INVALID;
@@ -367,36 +409,26 @@ int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, ui
     if (n_bytes) *n_bytes = 0;
     if (n_tokens == 0) return TD_OK;
     HIP_TRY(t, hipSetDevice(t->device));
-    // size first (host table; ids are validated here so the device never sees a bad id)
-    const HostTables& H = t->H;
+    int rc;
+    if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4 + 16))) return rc;
+    HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
+    // lengths and offsets first: the byte total sizes the device buffer of the gather
+    DecodeArgs a;
+    if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, nullptr, a))) return rc;
+    HIP_TRY(t, launch_decode(a, nullptr, 1));
+    int64_t err_pos = 0;
+    rc = device_status_locked(t, nullptr, &err_pos);
+    if (rc == TD_E_BAD_TOKEN && err_pos >= 0 && err_pos < n_tokens)
+        t->err = "Invalid token for decoding: " + std::to_string(tokens[err_pos]);  // reference: tiktoken.cpp:249
+    if (rc) return rc;
     int64_t total = 0;
-    for (int64_t i = 0; i < n_tokens; ++i) {
-        const int32_t id = tokens[i];
-        if (id < 0 || id > H.max_id || H.tok_off[id + 1] == H.tok_off[id]) {
-            t->err = "Invalid token for decoding: " + std::to_string(id);
-            return TD_E_BAD_TOKEN;
-        }
-        total += H.tok_off[id + 1] - H.tok_off[id];
-    }
+    HIP_TRY(t, hipMemcpy(&total, a.chunk_pref + (n_tokens + 4095) / 4096, 8, hipMemcpyDeviceToHost));
     if (n_bytes) *n_bytes = total;
     if (total > out_capacity) { t->err = "decode capacity too small"; return TD_E_CAPACITY; }
-    int rc;
-    if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4))) return rc;
-    if ((rc = ensure(t, t->dec_off, (size_t)(n_tokens + 2) * 8))) return rc;
     if ((rc = ensure(t, t->dec_out, (size_t)total + 16))) return rc;
-    HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
-    DecodeArgs a;
-    memset(&a, 0, sizeof a);
-    a.Tp = t->dTp;
-    a.tokens = (const int32_t*)t->dec_tokens.p;
-    a.n = n_tokens;
-    a.byte_off = (int64_t*)t->dec_off.p;
     a.out = (uint8_t*)t->dec_out.p;
     a.out_cap = total;
-    Ctl* ctl = (Ctl*)t->ctl.p;
-    a.err = &ctl->err;
-    a.err_pos = &ctl->err_pos;
-    HIP_TRY(t, launch_decode(a, nullptr));
+    HIP_TRY(t, launch_decode(a, nullptr, 2));
     rc = device_status_locked(t, nullptr, nullptr);
     if (rc) return rc;
     if (total > 0) HIP_TRY(t, hipMemcpy(out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost));

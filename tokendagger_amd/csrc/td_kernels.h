@@ -58,9 +58,12 @@ struct DecodeArgs {
     const Tables* Tp;
     const int32_t* tokens;      // [n]
     int64_t n;
-    int64_t* byte_off;          // [n+1] scratch: exclusive scan of token byte lengths
+    uint32_t* local_off;        // [n] scratch: byte offset of token i inside its 4096-token chunk
+    int64_t* chunk_pref;        // [n/4096 + 2] scratch: byte base of every chunk; [nchunks] = total bytes
+    uint32_t* scan_done;        // zeroed by the caller's stream before the launch
     uint8_t* out;               // [out_cap]
     int64_t out_cap;
+    int64_t* n_bytes;           // device: total decoded bytes (may be null)
     int* err;
     long long* err_pos;
 };
@@ -69,7 +72,8 @@ struct DecodeArgs {
 // ev0/ev1 (optional): recorded right before / after the fused tile kernel
 hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                          hipEvent_t ev2 = nullptr);  // ev0 | td_split_tiles | ev1 | td_encode_tiles | ev2
-hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
+// phases: 1 = lengths + offsets (td_decode_len), 2 = gather (td_decode_copy), 3 = both
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, int phases = 3);
 int encode_grid_blocks();  // persistent grid size used by the fused kernel
 
 }  // namespace td

@@ -1494,63 +1494,163 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
 }
 
 // ------------------------------------------------------------------ decode ------------------
-// ids -> bytes (CoreBPE::decode_bytes, tiktoken.cpp:236-255): per-token byte lengths, exclusive
-// scan, then every token copies its bytes from the rank -> bytes store.  Ids are validated on the
-// host before launch (td_api.cpp), the device check is a backstop.
-__global__ void td_decode_len(const DecodeArgs a) {
+// ids -> bytes (CoreBPE::decode_bytes, tiktoken.cpp:236-255).  td_decode_len: byte length of every token (rank ->
+// bytes store), exclusive scan inside chunks of 4096 tokens; td_decode_chunks: exclusive scan of the chunk totals.
+// td_decode_copy: one lane per token copies its bytes to chunk base + local
+// offset.  An id outside the vocabulary raises TD_E_BAD_TOKEN with its index (the reference throws "Invalid token for
+// decoding", tiktoken.cpp:249).
+constexpr int K_DEC_CHUNK = 4096;
+__global__ __launch_bounds__(1024) void td_decode_len(const DecodeArgs a) {
+    __shared__ unsigned long long s_wsum[16];
     const Tables T = uniform_tables(a.Tp);
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t id = a.tokens[i];
-        int64_t len = 0;
-        if (id < 0 || id > T.max_id) {
-            if (atomicCAS(a.err, 0, TD_E_BAD_TOKEN) == 0) *a.err_pos = i;
-        } else {
-            len = (int64_t)T.tok_off[id + 1] - T.tok_off[id];
-        }
-        a.byte_off[i + 1] = len;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t e0 = (int64_t)blockIdx.x * K_DEC_CHUNK + tid * 4;
+    uint32_t v[4] = {0, 0, 0, 0};
+    int32_t ids[4] = {-1, -1, -1, -1};
+    if (e0 + 4 <= a.n && (((uintptr_t)a.tokens) & 15) == 0) {
+        const int4 q = *reinterpret_cast<const int4*>(a.tokens + e0);
+        ids[0] = q.x; ids[1] = q.y; ids[2] = q.z; ids[3] = q.w;
+    } else {
+        for (int k = 0; k < 4; ++k)
+            if (e0 + k < a.n) ids[k] = a.tokens[e0 + k];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.byte_off[0] = 0;
-}
-__global__ __launch_bounds__(1024) void td_decode_scan(const DecodeArgs a) {
-    __shared__ unsigned long long s_part[1024];
-    const int tid = threadIdx.x;
-    const int64_t per = (a.n + 1023) / 1024;
-    const int64_t lo = tid * per, hi = (lo + per < a.n) ? lo + per : a.n;
-    unsigned long long sum = 0;
-    for (int64_t i = lo; i < hi; ++i) sum += (unsigned long long)a.byte_off[i + 1];
-    s_part[tid] = sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = e0 + k;
+        if (i >= a.n) break;
+        const int32_t id = ids[k];
+        uint32_t len = 0;
+        if (id >= 0 && id <= T.max_id) len = T.tok_off[id + 1] - T.tok_off[id];
+        if (len == 0 && atomicCAS(a.err, 0, TD_E_BAD_TOKEN) == 0) *a.err_pos = i;  // (no token is empty)
+        v[k] = len;
+    }
+    const unsigned long long mine = (unsigned long long)v[0] + v[1] + v[2] + v[3];
+    unsigned long long x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl_up(x, d);
+        if (lane >= d) x += t;
+    }
+    if (lane == 63) s_wsum[wv] = x;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const unsigned long long t = (tid >= d) ? s_part[tid - d] : 0;
+    unsigned long long woff = 0;
+    for (int w = 0; w < wv; ++w) woff += s_wsum[w];
+    unsigned long long run = woff + x - mine;
+    uint32_t lo4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lo4[k] = (uint32_t)run;
+        run += v[k];
+    }
+    if (e0 + 4 <= a.n) *reinterpret_cast<uint4*>(a.local_off + e0) = make_uint4(lo4[0], lo4[1], lo4[2], lo4[3]);  // (16-byte aligned: e0 % 4 == 0)
+    else
+        for (int k = 0; k < 4; ++k)
+            if (e0 + k < a.n) a.local_off[e0 + k] = lo4[k];
+    if (tid == 1023) a.chunk_pref[blockIdx.x] = (int64_t)run;  // chunk total; td_decode_chunks turns it into a prefix
+}
+// exclusive scan of the chunk totals (13 k chunks for 55 M ids: a launch of its own — a "last workgroup" scheme would
+// serialise one atomic per chunk on a single address)
+__global__ __launch_bounds__(1024) void td_decode_chunks(const DecodeArgs a) {
+    __shared__ unsigned long long s_wsum[16];
+    __shared__ unsigned long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t nchunks = (a.n + K_DEC_CHUNK - 1) / K_DEC_CHUNK;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < nchunks; c0 += 1024) {
+        const int64_t c = c0 + tid;
+        const unsigned long long tot = (c < nchunks) ? (unsigned long long)a.chunk_pref[c] : 0ull;
+        unsigned long long y = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(y, d);
+            if (lane >= d) y += t;
+        }
+        if (lane == 63) s_wsum[wv] = y;
         __syncthreads();
-        s_part[tid] += t;
+        unsigned long long woff = s_carry;
+        for (int w = 0; w < wv; ++w) woff += s_wsum[w];
+        if (c < nchunks) a.chunk_pref[c] = (int64_t)(woff + y - tot);
+        __syncthreads();
+        if (tid == 1023) s_carry = woff + y;
         __syncthreads();
     }
-    unsigned long long run = s_part[tid] - sum;
-    for (int64_t i = lo; i < hi; ++i) {
-        run += (unsigned long long)a.byte_off[i + 1];
-        a.byte_off[i + 1] = (int64_t)run;
+    if (tid == 0) {
+        const unsigned long long total = s_carry;
+        a.chunk_pref[nchunks] = (int64_t)total;
+        if (a.n_bytes) *a.n_bytes = (int64_t)total;
+        if ((int64_t)total > a.out_cap && atomicCAS(a.err, 0, TD_E_CAPACITY) == 0) *a.err_pos = (long long)total;
     }
 }
-__global__ void td_decode_copy(const DecodeArgs a) {
+// One workgroup per chunk of 4096 tokens; the chunk's bytes are contiguous in the output.  Lanes copy their tokens'
+// bytes (byte loads from the 1.4 MB rank -> bytes store, L2-resident) into an LDS window, the workgroup streams the
+// window out with 16-byte stores; chunks whose bytes exceed the window take several passes.
+constexpr int K_DEC_WIN = 32768;
+__global__ __launch_bounds__(1024) void td_decode_copy(const DecodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[K_DEC_WIN];
     const Tables T = uniform_tables(a.Tp);
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t id = a.tokens[i];
-        if (id < 0 || id > T.max_id) continue;
-        const uint8_t* src = T.tok_bytes + T.tok_off[id];
-        const int64_t o = a.byte_off[i], len = a.byte_off[i + 1] - o;
-        for (int64_t k = 0; k < len; ++k)
-            if (o + k < a.out_cap) a.out[o + k] = src[k];
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    const int64_t cbase = a.chunk_pref[c], cend = a.chunk_pref[c + 1];
+    if (cend > a.out_cap) return;  // capacity error already raised by td_decode_len
+    const int64_t e0 = c * K_DEC_CHUNK + tid * 4;
+    uint32_t so[4], lo[4], ln[4];
+    int32_t ids[4] = {-1, -1, -1, -1};
+    if (e0 + 4 <= a.n && (((uintptr_t)a.tokens) & 15) == 0) {
+        const int4 q = *reinterpret_cast<const int4*>(a.tokens + e0);
+        const uint4 l = *reinterpret_cast<const uint4*>(a.local_off + e0);
+        ids[0] = q.x; ids[1] = q.y; ids[2] = q.z; ids[3] = q.w;
+        lo[0] = l.x; lo[1] = l.y; lo[2] = l.z; lo[3] = l.w;
+    } else {
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = 0;
+            if (e0 + k < a.n) { ids[k] = a.tokens[e0 + k]; lo[k] = a.local_off[e0 + k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        so[k] = 0; ln[k] = 0;
+        if (ids[k] >= 0 && ids[k] <= T.max_id) {
+            so[k] = T.tok_off[ids[k]];
+            ln[k] = T.tok_off[ids[k] + 1] - so[k];
+        }
+    }
+    const uint32_t cbytes = (uint32_t)(cend - cbase);
+    constexpr uint32_t WIN = K_DEC_WIN - 16;  // the window is shifted so that LDS and global addresses agree mod 16
+    for (uint32_t w0 = 0; w0 < cbytes; w0 += WIN) {
+        const uint32_t wn = (cbytes - w0 < WIN) ? cbytes - w0 : WIN;
+        uint8_t* dst = a.out + cbase + w0;
+        const uint32_t shift = (uint32_t)(uintptr_t)dst & 15u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // the part of token k inside [w0, w0 + wn)
+            const uint32_t b = lo[k] > w0 ? lo[k] : w0;
+            const uint32_t e = (lo[k] + ln[k] < w0 + wn) ? lo[k] + ln[k] : w0 + wn;
+            const uint8_t* src = T.tok_bytes + so[k];
+            for (uint32_t q = b; q < e; ++q) s_out[q - w0 + shift] = src[q - lo[k]];
+        }
+        __syncthreads();
+        uint32_t head = (16u - shift) & 15u;
+        if (head > wn) head = wn;
+        if ((uint32_t)tid < head) dst[tid] = s_out[shift + tid];
+        const uint32_t nv = (wn - head) >> 4;
+        for (uint32_t v = tid; v < nv; v += 1024)
+            *reinterpret_cast<uint4*>(dst + head + 16 * v) = *reinterpret_cast<const uint4*>(s_out + shift + head + 16 * v);
+        const uint32_t done = head + 16 * nv;
+        if (done + (uint32_t)tid < wn) dst[done + tid] = s_out[shift + done + tid];
+        __syncthreads();
     }
 }
 
-hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, int phases) {
     if (a.n <= 0) return hipSuccess;
-    int blocks = (int)((a.n + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(td_decode_len, dim3(blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(td_decode_scan, dim3(1), dim3(1024), 0, stream, a);
-    hipLaunchKernelGGL(td_decode_copy, dim3(blocks), dim3(256), 0, stream, a);
+    const int64_t nchunks = (a.n + K_DEC_CHUNK - 1) / K_DEC_CHUNK;
+    if (nchunks > 0x7FFFFFF0ll) return hipErrorInvalidValue;
+    if (phases & 1) {
+        hipLaunchKernelGGL(td_decode_len, dim3((unsigned)nchunks), dim3(1024), 0, stream, a);
+        hipLaunchKernelGGL(td_decode_chunks, dim3(1), dim3(1024), 0, stream, a);
+    }
+    if (phases & 2) hipLaunchKernelGGL(td_decode_copy, dim3((unsigned)nchunks), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }
 
