@@ -130,6 +130,12 @@ int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum
 int64_t td_special_count(const td_tokenizer* t);
 int td_special_get(const td_tokenizer* t, int64_t i, const char** str, int64_t* len, int32_t* id);
 
+/* Batch decode (replaces the thread pool of Tokenizer.decode_batch, tokendagger/wrapper.py:237-256): the ids of all
+ * documents concatenated + tok_offsets[n_docs+1] -> the bytes of all documents concatenated + out_offsets[n_docs+1],
+ * one device pass.  *n_bytes = total bytes (also on TD_E_CAPACITY). */
+int td_decode_batch(td_tokenizer* t, const int32_t* tokens, const int64_t* tok_offsets, int64_t n_docs, uint8_t* out,
+                    int64_t out_capacity, int64_t* out_offsets, int64_t* n_bytes);
+
 /* Device-resident decode: d_tokens int32[n_tokens] -> d_out bytes (capacity out_capacity), total byte count to
  * *d_n_bytes (device int64, may be NULL).  Asynchronous on hip_stream; an id outside the vocabulary (TD_E_BAD_TOKEN,
  * position = its index) or a too small d_out (TD_E_CAPACITY, position = bytes needed) surface through

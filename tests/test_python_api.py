@@ -142,3 +142,23 @@ def test_single_token_accessors(enc):
     assert len(tbv) == len(set(mr.values()) - set(special.values())) and tbv == sorted(tbv) and b"hello" in tbv
     with pytest.raises(KeyError):
         enc.eot_token  # Llama-4 names its end token differently: same behaviour as a tiktoken Encoding without "<|endoftext|>"
+
+
+def test_decode_batch_one_pass(enc):
+    docs = ["Hello, world!", "", "中文 😀\n", "x" * 5000, "the quick brown fox " * 300, ""]
+    ids = enc.encode_batch(docs)
+    assert enc.decode_batch(ids) == docs
+    assert enc.decode_bytes_batch(ids) == [d.encode("utf-8") for d in docs]
+    assert enc.decode_batch([]) == [] and enc.decode_batch([[]]) == [""]
+    import tokendagger as tiktoken
+    with pytest.raises(tiktoken.TokenDaggerError) as e:
+        enc.decode_batch([[1, 2], [3, 10 ** 8]])
+    assert "Invalid token for decoding: 100000000" in str(e.value)
+    # through the C ABI with numpy arrays
+    from tokendagger_amd import capi
+    pat, mr, special = H.llama4()
+    tok = capi.HipTokenizer(pat, mr, special, device=0)
+    flat = np.asarray([t for d in ids for t in d], dtype=np.int32)
+    offs = np.cumsum([0] + [len(d) for d in ids]).astype(np.int64)
+    blob, boffs = tok.decode_batch(flat, offs)
+    assert [blob[boffs[i]:boffs[i + 1]] for i in range(len(docs))] == [d.encode("utf-8") for d in docs]

@@ -29,7 +29,7 @@ EXPORTS = [
     "td_special_count", "td_special_get", "td_profile_read",
     "td_vocab_create", "td_vocab_destroy", "td_vocab_error", "td_vocab_load_tiktoken", "td_vocab_load_hf_special",
     "td_vocab_load_tekken", "td_vocab_load_json", "td_vocab_set_pattern", "td_vocab_pattern", "td_vocab_arrays",
-    "td_create_from_vocab", "td_token_bytes", "td_single_token", "td_decode_device",
+    "td_create_from_vocab", "td_token_bytes", "td_single_token", "td_decode_device", "td_decode_batch",
 ]
 
 
@@ -103,6 +103,8 @@ def load_library():
     lib.td_special_count.argtypes = [vp]
     lib.td_special_get.restype = i32
     lib.td_special_get.argtypes = [vp, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
+    lib.td_decode_batch.restype = i32
+    lib.td_decode_batch.argtypes = [vp, vp, vp, i64, vp, i64, vp, ctypes.POINTER(i64)]
     lib.td_decode_device.restype = i32
     lib.td_decode_device.argtypes = [vp, vp, i64, vp, i64, vp, vp]
     lib.td_token_bytes.restype = i32
@@ -327,6 +329,25 @@ class HipTokenizer:
         return out[:nb.value].tobytes()
 
     # ---- device-buffer API (pointers are raw device addresses, e.g. torch_tensor.data_ptr()) --
+    def decode_batch(self, tokens, tok_offsets) -> tuple[bytes, np.ndarray]:
+        """ids of all documents concatenated + int64 offsets -> (all bytes concatenated, int64 byte offsets)."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        o = np.ascontiguousarray(tok_offsets, dtype=np.int64)
+        n_docs = len(o) - 1
+        out_offs = np.empty(n_docs + 1, dtype=np.int64)
+        cap = max(64, 8 * len(t))
+        nb = ctypes.c_int64(0)
+        for _ in range(2):
+            out = np.empty(cap, dtype=np.uint8)
+            rc = self._lib.td_decode_batch(self._h, t.ctypes.data if len(t) else None, o.ctypes.data, n_docs, out.ctypes.data, cap,
+                                           out_offs.ctypes.data, ctypes.byref(nb))
+            if rc == TD_E_CAPACITY and nb.value > cap:
+                cap = nb.value
+                continue
+            break
+        self._check(rc)
+        return out[:nb.value].tobytes(), out_offs
+
     def decode_device(self, d_tokens: int, n_tokens: int, d_out: int, out_capacity: int, d_n_bytes: int = 0, stream: int = 0):
         """Device pointers in, asynchronous on `stream`; check with device_status(stream)."""
         self._check(self._lib.td_decode_device(self._h, d_tokens, n_tokens, d_out, out_capacity, d_n_bytes or None, stream or None))

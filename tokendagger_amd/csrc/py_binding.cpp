@@ -267,6 +267,35 @@ public:
         return py::bytes(out);
     }
 
+    // list[list[int]] in, list[bytes] out through ONE device pass (td_decode_batch)
+    std::vector<py::bytes> decode_batch(const std::vector<std::vector<int>>& docs) {
+        std::vector<int64_t> offs(1, 0), boffs(docs.size() + 1);
+        size_t total = 0;
+        for (const auto& d : docs) total += d.size();
+        std::vector<int32_t> toks;
+        toks.reserve(total + 1);
+        for (const auto& d : docs) {
+            toks.insert(toks.end(), d.begin(), d.end());
+            offs.push_back((int64_t)toks.size());
+        }
+        std::string out(total * 8 + 64, '\0');
+        int64_t nb = 0;
+        int rc;
+        {
+            py::gil_scoped_release rel;
+            rc = td_decode_batch(h_, toks.data(), offs.data(), (int64_t)docs.size(), (uint8_t*)&out[0], (int64_t)out.size(), boffs.data(), &nb);
+            if (rc == TD_E_CAPACITY && nb > (int64_t)out.size()) {
+                out.resize((size_t)nb);
+                rc = td_decode_batch(h_, toks.data(), offs.data(), (int64_t)docs.size(), (uint8_t*)&out[0], (int64_t)out.size(), boffs.data(), &nb);
+            }
+        }
+        if (rc != TD_OK) fail();
+        std::vector<py::bytes> res;
+        res.reserve(docs.size());
+        for (size_t d = 0; d < docs.size(); ++d) res.emplace_back(out.data() + boffs[d], (size_t)(boffs[d + 1] - boffs[d]));
+        return res;
+    }
+
     py::object token_bytes(int id) const {  // None if the id is not in the vocabulary
         const uint8_t* p = nullptr;
         int64_t n = 0;
@@ -324,6 +353,7 @@ PYBIND11_MODULE(_tokendagger_core, m) {
         .def("encode_batch", &CoreBPE::encode_batch, py::arg("texts"), py::arg("mode") = TD_MODE_ENCODE)
         .def("encode_batch_numpy", &CoreBPE::encode_batch_numpy, py::arg("text"), py::arg("offsets"), py::arg("mode") = TD_MODE_ENCODE)
         .def("decode_to_bytes", &CoreBPE::decode_to_bytes, py::arg("tokens"))
+        .def("decode_batch", &CoreBPE::decode_batch, py::arg("docs"))
         .def("token_bytes", &CoreBPE::token_bytes, py::arg("id"))
         .def("single_token", [](const CoreBPE& self, py::bytes b) { return self.single_token(std::string(b)); }, py::arg("token_bytes"))
         .def("info", &CoreBPE::info, py::arg("what"))

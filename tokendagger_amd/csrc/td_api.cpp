@@ -435,6 +435,53 @@ int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, ui
     return TD_OK;
 }
 
+int td_decode_batch(td_tokenizer* t, const int32_t* tokens, const int64_t* tok_offsets, int64_t n_docs, uint8_t* out,
+                    int64_t out_capacity, int64_t* out_offsets, int64_t* n_bytes) {
+    if (!t || !tok_offsets || n_docs < 0 || !out_offsets) return TD_E_INVALID;
+    std::lock_guard<std::mutex> g(t->mu);
+    const int64_t n_tokens = tok_offsets[n_docs];
+    if (tok_offsets[0] != 0 || n_tokens < 0 || (n_tokens > 0 && !tokens)) { t->err = "tok_offsets must start at 0"; return TD_E_INVALID; }
+    for (int64_t d = 0; d < n_docs; ++d)
+        if (tok_offsets[d + 1] < tok_offsets[d]) { t->err = "tok_offsets must be non-decreasing"; return TD_E_INVALID; }
+    if (n_bytes) *n_bytes = 0;
+    if (n_tokens == 0) {
+        for (int64_t d = 0; d <= n_docs; ++d) out_offsets[d] = 0;
+        return TD_OK;
+    }
+    HIP_TRY(t, hipSetDevice(t->device));
+    int rc;
+    if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4 + 16))) return rc;
+    if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;
+    if ((rc = ensure(t, t->d_offsets, (size_t)(n_docs + 1) * 8))) return rc;
+    HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
+    HIP_TRY(t, hipMemcpy(t->h2d_offs.p, tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+    DecodeArgs a;
+    if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, nullptr, a))) return rc;
+    a.doc_tok_offsets = (const int64_t*)t->h2d_offs.p;
+    a.n_docs = n_docs;
+    a.doc_byte_offsets = (int64_t*)t->d_offsets.p;
+    HIP_TRY(t, launch_decode(a, nullptr, 1));
+    int64_t err_pos = 0;
+    rc = device_status_locked(t, nullptr, &err_pos);
+    if (rc == TD_E_BAD_TOKEN && err_pos >= 0 && err_pos < n_tokens) t->err = "Invalid token for decoding: " + std::to_string(tokens[err_pos]);
+    if (rc) return rc;
+    HIP_TRY(t, hipMemcpy(out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    const int64_t total = out_offsets[n_docs];
+    if (n_bytes) *n_bytes = total;
+    if (total > out_capacity) { t->err = "decode capacity too small"; return TD_E_CAPACITY; }
+    if ((rc = ensure(t, t->dec_out, (size_t)total + 16))) return rc;
+    a.out = (uint8_t*)t->dec_out.p;
+    a.out_cap = total;
+    HIP_TRY(t, launch_decode(a, nullptr, 2));
+    rc = device_status_locked(t, nullptr, nullptr);
+    if (rc) return rc;
+    if (total > 0) {
+        if (!out) return TD_E_INVALID;
+        HIP_TRY(t, hipMemcpy(out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost));
+    }
+    return TD_OK;
+}
+
 int td_encode_with_special(td_tokenizer* t, const uint8_t* text, int64_t n_bytes, const int32_t* allowed_ids,
                            int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity, int64_t* n_tokens,
                            int32_t* last_piece_token_len) {

@@ -64,6 +64,9 @@ struct DecodeArgs {
     uint8_t* out;               // [out_cap]
     int64_t out_cap;
     int64_t* n_bytes;           // device: total decoded bytes (may be null)
+    const int64_t* doc_tok_offsets;  // optional [n_docs+1]: token index where each document starts
+    int64_t n_docs;
+    int64_t* doc_byte_offsets;  // optional [n_docs+1]: filled with the byte offset of each document in `out`
     int* err;
     long long* err_pos;
 };
@@ -72,7 +75,7 @@ struct DecodeArgs {
 // ev0/ev1 (optional): recorded right before / after the fused tile kernel
 hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                          hipEvent_t ev2 = nullptr);  // ev0 | td_split_tiles | ev1 | td_encode_tiles | ev2
-// phases: 1 = lengths + offsets (td_decode_len), 2 = gather (td_decode_copy), 3 = both
+// phases: 1 = lengths + offsets (td_decode_len, td_decode_chunks, document byte offsets), 2 = gather (td_decode_copy), 3 = both
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, int phases = 3);
 int encode_grid_blocks();  // persistent grid size used by the fused kernel
 

@@ -1582,6 +1582,15 @@ __global__ __launch_bounds__(1024) void td_decode_chunks(const DecodeArgs a) {
         if ((int64_t)total > a.out_cap && atomicCAS(a.err, 0, TD_E_CAPACITY) == 0) *a.err_pos = (long long)total;
     }
 }
+// byte offset of every document start (decode_batch): token index -> chunk base + offset inside the chunk
+__global__ void td_decode_doc_offsets(const DecodeArgs a) {
+    const int64_t nchunks = (a.n + K_DEC_CHUNK - 1) / K_DEC_CHUNK;
+    for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d <= a.n_docs; d += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = a.doc_tok_offsets[d];
+        a.doc_byte_offsets[d] = (i >= a.n) ? a.chunk_pref[nchunks] : a.chunk_pref[i / K_DEC_CHUNK] + a.local_off[i];
+    }
+}
+
 // One workgroup per chunk of 4096 tokens; the chunk's bytes are contiguous in the output.  Lanes copy their tokens'
 // bytes (byte loads from the 1.4 MB rank -> bytes store, L2-resident) into an LDS window, the workgroup streams the
 // window out with 16-byte stores; chunks whose bytes exceed the window take several passes.
@@ -1649,6 +1658,11 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, int phases) {
     if (phases & 1) {
         hipLaunchKernelGGL(td_decode_len, dim3((unsigned)nchunks), dim3(1024), 0, stream, a);
         hipLaunchKernelGGL(td_decode_chunks, dim3(1), dim3(1024), 0, stream, a);
+        if (a.doc_byte_offsets && a.doc_tok_offsets) {
+            int blocks = (int)((a.n_docs + 256) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(td_decode_doc_offsets, dim3(blocks), dim3(256), 0, stream, a);
+        }
     }
     if (phases & 2) hipLaunchKernelGGL(td_decode_copy, dim3((unsigned)nchunks), dim3(1024), 0, stream, a);
     return hipGetLastError();

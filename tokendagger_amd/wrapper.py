@@ -225,7 +225,17 @@ class Tokenizer:
             raise TokenDaggerError(f"Decoding failed: {e}")
 
     def decode_batch(self, tokens: Sequence[Sequence[int]], *, num_threads: int = 8, errors: str = "replace") -> list[str]:
-        return [self.decode(t, errors=errors) for t in tokens]
+        """All documents in one device pass (reference: a thread pool of decode calls, wrapper.py:237-256)."""
+        try:
+            return [b.decode("utf-8", errors=errors) for b in self._core_bpe.decode_batch([list(t) for t in tokens])]
+        except Exception as e:
+            raise TokenDaggerError(f"Decoding failed: {e}")
+
+    def decode_bytes_batch(self, tokens: Sequence[Sequence[int]]) -> list[bytes]:
+        try:
+            return self._core_bpe.decode_batch([list(t) for t in tokens])
+        except Exception as e:
+            raise TokenDaggerError(f"Decoding failed: {e}")
 
     def decode_single_token_bytes(self, token: int) -> bytes:
         """tiktoken semantics: KeyError for an id that is not in the vocabulary (host table lookup, no launch)."""
