@@ -106,6 +106,13 @@ int td_encode_with_special(td_tokenizer* t, const uint8_t* text, int64_t n_bytes
                            int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity, int64_t* n_tokens,
                            int32_t* last_piece_token_len);
 
+/* The same over a batch of documents: every document is cut at its allowed special tokens (one pass, all literals at
+ * once), all ordinary segments of all documents go to the GPU as ONE batch, ids and per-document offsets come back
+ * stitched.  *n_tokens = ids needed (also on TD_E_CAPACITY). */
+int td_encode_batch_with_special(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
+                                 const int32_t* allowed_ids, int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity,
+                                 int64_t* out_offsets, int64_t* n_tokens);
+
 /* Introspection (tests, benchmarks). */
 #define TD_INFO_N_PAIRS 1        /* entries of the (id,id)->rank pair table */
 #define TD_INFO_MERGE_CLOSED 2   /* 1 if encode == encode_ordinary for every input with this vocab */

@@ -162,3 +162,16 @@ def test_decode_batch_one_pass(enc):
     offs = np.cumsum([0] + [len(d) for d in ids]).astype(np.int64)
     blob, boffs = tok.decode_batch(flat, offs)
     assert [blob[boffs[i]:boffs[i + 1]] for i in range(len(docs))] == [d.encode("utf-8") for d in docs]
+
+
+def test_encode_batch_with_allowed_special_is_one_batch(enc):
+    texts = ["<|begin_of_text|>Hello<|eot|>", "", "no specials here", "<|eot|><|eot|>x", "a<|not_a_token|>b",
+             "<|begin_of_text|>" * 50 + "tail", "edge <|e", "<|header_start|>user<|header_end|>\n\nHi<|eot|>" * 200]
+    got = enc.encode_batch(texts, allowed_special="all")
+    assert got == [enc.encode(t, allowed_special="all") for t in texts]
+    some = {"<|eot|>"}
+    assert enc.encode_batch(texts, allowed_special=some) == [enc.encode(t, allowed_special=some) for t in texts]
+    # a large document with every special allowed: one pass over the text, not one search per special
+    big = ("lorem ipsum dolor sit amet <tag> x < y " * 40000) + "<|eot|>"
+    ids = enc.encode(big, allowed_special="all")
+    assert ids[-1] == enc._special_tokens["<|eot|>"] and enc.decode(ids) == big

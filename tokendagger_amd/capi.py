@@ -29,7 +29,7 @@ EXPORTS = [
     "td_special_count", "td_special_get", "td_profile_read",
     "td_vocab_create", "td_vocab_destroy", "td_vocab_error", "td_vocab_load_tiktoken", "td_vocab_load_hf_special",
     "td_vocab_load_tekken", "td_vocab_load_json", "td_vocab_set_pattern", "td_vocab_pattern", "td_vocab_arrays",
-    "td_create_from_vocab", "td_token_bytes", "td_single_token", "td_decode_device", "td_decode_batch",
+    "td_create_from_vocab", "td_token_bytes", "td_single_token", "td_decode_device", "td_decode_batch", "td_encode_batch_with_special",
 ]
 
 
@@ -103,6 +103,8 @@ def load_library():
     lib.td_special_count.argtypes = [vp]
     lib.td_special_get.restype = i32
     lib.td_special_get.argtypes = [vp, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
+    lib.td_encode_batch_with_special.restype = i32
+    lib.td_encode_batch_with_special.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, vp, ctypes.POINTER(i64)]
     lib.td_decode_batch.restype = i32
     lib.td_decode_batch.argtypes = [vp, vp, vp, i64, vp, i64, vp, ctypes.POINTER(i64)]
     lib.td_decode_device.restype = i32
@@ -329,6 +331,28 @@ class HipTokenizer:
         return out[:nb.value].tobytes()
 
     # ---- device-buffer API (pointers are raw device addresses, e.g. torch_tensor.data_ptr()) --
+    def encode_batch_with_special(self, text, doc_offsets, allowed_ids):
+        """encode_batch with allowed special tokens (ids): -> (tokens int32[total], offsets int64[n_docs+1])"""
+        buf = _as_u8(text)
+        offs = np.ascontiguousarray(doc_offsets, dtype=np.int64)
+        ids = np.ascontiguousarray(sorted(allowed_ids), dtype=np.int32)
+        n_docs = len(offs) - 1
+        n = int(offs[-1]) if len(offs) else 0
+        cap = max(16, n // 3 + 16)
+        out_offs = np.empty(n_docs + 1, dtype=np.int64)
+        ntok = ctypes.c_int64(0)
+        for _ in range(2):
+            toks = np.empty(cap, dtype=np.int32)
+            rc = self._lib.td_encode_batch_with_special(self._h, buf.ctypes.data if n else None, offs.ctypes.data, n_docs,
+                                                        ids.ctypes.data if len(ids) else None, len(ids), toks.ctypes.data, cap,
+                                                        out_offs.ctypes.data, ctypes.byref(ntok))
+            if rc == TD_E_CAPACITY and ntok.value > cap:
+                cap = ntok.value
+                continue
+            break
+        self._check(rc)
+        return toks[:ntok.value], out_offs
+
     def decode_batch(self, tokens, tok_offsets) -> tuple[bytes, np.ndarray]:
         """ids of all documents concatenated + int64 offsets -> (all bytes concatenated, int64 byte offsets)."""
         t = np.ascontiguousarray(tokens, dtype=np.int32)

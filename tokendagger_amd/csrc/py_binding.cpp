@@ -267,6 +267,43 @@ public:
         return py::bytes(out);
     }
 
+    // list[str] + allowed special strings -> list[list[int]], all ordinary segments of all texts in ONE device batch
+    std::vector<std::vector<int>> encode_batch_special(const std::vector<std::string>& texts, const std::set<std::string>& allowed) {
+        std::vector<int32_t> ids;
+        for (const auto& s : allowed) {
+            auto it = special_ids_.find(s);
+            if (it == special_ids_.end()) throw TiktokenError("Special token '" + s + "' not found in special encoder");
+            ids.push_back(it->second);
+        }
+        std::vector<int64_t> offs(1, 0);
+        size_t total = 0;
+        for (const auto& s : texts) total += s.size();
+        std::vector<uint8_t> buf;
+        buf.reserve(total + 1);
+        for (const auto& s : texts) {
+            buf.insert(buf.end(), s.begin(), s.end());
+            offs.push_back((int64_t)buf.size());
+        }
+        std::vector<int32_t> out(total / 3 + 16);
+        std::vector<int64_t> toffs(texts.size() + 1);
+        int64_t n = 0;
+        int rc;
+        {
+            py::gil_scoped_release rel;
+            rc = td_encode_batch_with_special(h_, buf.data(), offs.data(), (int64_t)texts.size(), ids.data(), (int64_t)ids.size(), out.data(),
+                                              (int64_t)out.size(), toffs.data(), &n);
+            if (rc == TD_E_CAPACITY && n > (int64_t)out.size()) {
+                out.resize((size_t)n);
+                rc = td_encode_batch_with_special(h_, buf.data(), offs.data(), (int64_t)texts.size(), ids.data(), (int64_t)ids.size(), out.data(),
+                                                  (int64_t)out.size(), toffs.data(), &n);
+            }
+        }
+        if (rc != TD_OK) fail();
+        std::vector<std::vector<int>> res(texts.size());
+        for (size_t d = 0; d < texts.size(); ++d) res[d].assign(out.begin() + toffs[d], out.begin() + toffs[d + 1]);
+        return res;
+    }
+
     // list[list[int]] in, list[bytes] out through ONE device pass (td_decode_batch)
     std::vector<py::bytes> decode_batch(const std::vector<std::vector<int>>& docs) {
         std::vector<int64_t> offs(1, 0), boffs(docs.size() + 1);
@@ -354,6 +391,7 @@ PYBIND11_MODULE(_tokendagger_core, m) {
         .def("encode_batch_numpy", &CoreBPE::encode_batch_numpy, py::arg("text"), py::arg("offsets"), py::arg("mode") = TD_MODE_ENCODE)
         .def("decode_to_bytes", &CoreBPE::decode_to_bytes, py::arg("tokens"))
         .def("decode_batch", &CoreBPE::decode_batch, py::arg("docs"))
+        .def("encode_batch_special", &CoreBPE::encode_batch_special, py::arg("texts"), py::arg("allowed_special"))
         .def("token_bytes", &CoreBPE::token_bytes, py::arg("id"))
         .def("single_token", [](const CoreBPE& self, py::bytes b) { return self.single_token(std::string(b)); }, py::arg("token_bytes"))
         .def("info", &CoreBPE::info, py::arg("what"))

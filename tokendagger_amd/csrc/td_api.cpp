@@ -482,59 +482,141 @@ int td_decode_batch(td_tokenizer* t, const int32_t* tokens, const int64_t* tok_o
     return TD_OK;
 }
 
+}  // extern "C" (reopened below)
+
+namespace {
+// Allowed special tokens indexed by their first two bytes: one pass over the text finds, at every position, the
+// longest allowed special that starts there (tiktoken semantics: cut at the EARLIEST occurrence; longest on ties).
+struct SpecialIndex {
+    struct Ent { const std::string* s; int32_t id; };
+    bool first[256] = {};
+    std::vector<std::vector<Ent>> bucket;  // [65536] by (b0 << 8 | b1), longest first; 1-byte specials in `single`
+    std::vector<Ent> single[256];
+    SpecialIndex() : bucket(65536) {}
+    void add(const std::string* s, int32_t id) {
+        if (s->empty()) return;
+        const uint8_t b0 = (uint8_t)(*s)[0];
+        first[b0] = true;
+        if (s->size() == 1) single[b0].push_back({s, id});
+        else bucket[((size_t)b0 << 8) | (uint8_t)(*s)[1]].push_back({s, id});
+    }
+    void finish() {
+        for (auto& b : bucket)
+            std::sort(b.begin(), b.end(), [](const Ent& x, const Ent& y) { return x.s->size() > y.s->size(); });
+    }
+    // longest special starting at text[p] (p < hi), or nullptr
+    const Ent* match(const uint8_t* text, int64_t p, int64_t hi) const {
+        const uint8_t b0 = text[p];
+        if (!first[b0]) return nullptr;
+        if (p + 1 < hi)
+            for (const Ent& e : bucket[((size_t)b0 << 8) | text[p + 1]])
+                if (p + (int64_t)e.s->size() <= hi && memcmp(text + p, e.s->data(), e.s->size()) == 0) return &e;
+        return single[b0].empty() ? nullptr : &single[b0][0];
+    }
+};
+
+int build_special_index(td_tokenizer* t, const int32_t* allowed_ids, int64_t n_allowed, SpecialIndex& ix) {
+    std::lock_guard<std::mutex> g(t->mu);
+    for (int64_t k = 0; k < n_allowed; ++k) {
+        bool found = false;
+        for (size_t s = 0; s < t->H.special_ids.size(); ++s)
+            if (t->H.special_ids[s] == allowed_ids[k]) {
+                ix.add(&t->H.special_strs[s], allowed_ids[k]);
+                found = true;
+                break;
+            }
+        if (!found) {
+            t->err = "Special token id " + std::to_string(allowed_ids[k]) + " not found in special encoder";
+            return TD_E_SPECIAL;
+        }
+    }
+    ix.finish();
+    return TD_OK;
+}
+
+// text[lo, hi) -> ordinary segments appended to seg_text / seg_offs, the special id that follows each in seg_special
+// (-1 after the last segment of the document)
+void segment_document(const SpecialIndex& ix, const uint8_t* text, int64_t lo, int64_t hi, std::vector<uint8_t>& seg_text,
+                      std::vector<int64_t>& seg_offs, std::vector<int32_t>& seg_special) {
+    int64_t start = lo;
+    for (int64_t p = lo; p < hi;) {
+        const SpecialIndex::Ent* e = ix.match(text, p, hi);
+        if (!e) { ++p; continue; }
+        seg_text.insert(seg_text.end(), text + start, text + p);
+        seg_offs.push_back((int64_t)seg_text.size());
+        seg_special.push_back(e->id);
+        p += (int64_t)e->s->size();
+        start = p;
+    }
+    seg_text.insert(seg_text.end(), text + start, text + hi);
+    seg_offs.push_back((int64_t)seg_text.size());
+    seg_special.push_back(-1);
+}
+}  // namespace
+
+extern "C" int td_encode_batch_with_special(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
+                                            const int32_t* allowed_ids, int64_t n_allowed, int32_t* out_tokens,
+                                            int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
+    if (!t || !doc_offsets || n_docs < 0 || n_allowed < 0 || (n_allowed > 0 && !allowed_ids) || !out_offsets) return TD_E_INVALID;
+    for (int64_t d = 0; d < n_docs; ++d)
+        if (doc_offsets[d + 1] < doc_offsets[d] || doc_offsets[0] != 0) { t->err = "doc_offsets must start at 0 and be non-decreasing"; return TD_E_INVALID; }
+    SpecialIndex ix;
+    int rc = build_special_index(t, allowed_ids, n_allowed, ix);
+    if (rc) return rc;
+    std::vector<uint8_t> seg_text;
+    std::vector<int64_t> seg_offs{0}, doc_seg{0};
+    std::vector<int32_t> seg_special;
+    seg_text.reserve((size_t)doc_offsets[n_docs]);
+    for (int64_t d = 0; d < n_docs; ++d) {
+        segment_document(ix, text, doc_offsets[d], doc_offsets[d + 1], seg_text, seg_offs, seg_special);
+        doc_seg.push_back((int64_t)seg_special.size());
+    }
+    const int64_t nseg = (int64_t)seg_special.size();
+    std::vector<int32_t> toks((size_t)std::max<int64_t>((int64_t)seg_text.size(), 1));
+    std::vector<int64_t> toffs((size_t)nseg + 1);
+    int64_t ntok = 0;
+    rc = td_encode_batch(t, seg_text.data(), seg_offs.data(), nseg, TD_MODE_ENCODE, toks.data(), (int64_t)toks.size(), toffs.data(), &ntok);
+    if (rc) return rc;
+    int64_t n_special = 0;
+    for (int32_t v : seg_special) n_special += v >= 0;
+    const int64_t need = ntok + n_special;
+    if (n_tokens) *n_tokens = need;
+    // offsets first (they do not need the capacity), then the ids
+    int64_t k = 0;
+    for (int64_t d = 0; d < n_docs; ++d) {
+        out_offsets[d] = k;
+        for (int64_t sg = doc_seg[(size_t)d]; sg < doc_seg[(size_t)d + 1]; ++sg) k += toffs[(size_t)sg + 1] - toffs[(size_t)sg] + (seg_special[(size_t)sg] >= 0);
+    }
+    out_offsets[n_docs] = k;
+    if (need > out_capacity) { t->err = "output capacity too small: " + std::to_string(need) + " tokens needed"; return TD_E_CAPACITY; }
+    if (need > 0 && !out_tokens) return TD_E_INVALID;
+    k = 0;
+    for (int64_t sg = 0; sg < nseg; ++sg) {
+        const int64_t cnt = toffs[(size_t)sg + 1] - toffs[(size_t)sg];
+        if (cnt) memcpy(out_tokens + k, toks.data() + toffs[(size_t)sg], (size_t)cnt * 4);
+        k += cnt;
+        if (seg_special[(size_t)sg] >= 0) out_tokens[k++] = seg_special[(size_t)sg];
+    }
+    return TD_OK;
+}
+
+extern "C" {
 int td_encode_with_special(td_tokenizer* t, const uint8_t* text, int64_t n_bytes, const int32_t* allowed_ids,
                            int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity, int64_t* n_tokens,
                            int32_t* last_piece_token_len) {
     if (!t || n_bytes < 0 || n_allowed < 0 || (n_allowed > 0 && !allowed_ids)) return TD_E_INVALID;
     // 1. host: cut the text at the earliest occurrences of allowed special strings (tiktoken semantics;
     //    the reference's own loop, tiktoken.cpp:130-154,187-231, has iterator-invalidation UB)
-    std::vector<const std::string*> strs;
-    std::vector<int32_t> ids;
+    SpecialIndex ix;
     {
-        std::lock_guard<std::mutex> g(t->mu);
-        for (int64_t k = 0; k < n_allowed; ++k) {
-            bool found = false;
-            for (size_t s = 0; s < t->H.special_ids.size(); ++s)
-                if (t->H.special_ids[s] == allowed_ids[k]) {
-                    strs.push_back(&t->H.special_strs[s]);
-                    ids.push_back(allowed_ids[k]);
-                    found = true;
-                    break;
-                }
-            if (!found) {
-                t->err = "Special token id " + std::to_string(allowed_ids[k]) + " not found in special encoder";
-                return TD_E_SPECIAL;
-            }
-        }
+        const int rc0 = build_special_index(t, allowed_ids, n_allowed, ix);
+        if (rc0) return rc0;
     }
-    const char* base = (const char*)text;
-    std::vector<int64_t> next(strs.size(), -2);  // -2: not searched yet, -1: no further occurrence
     std::vector<uint8_t> seg_text;
     std::vector<int64_t> seg_offs{0};
     std::vector<int32_t> seg_special;  // special id following each segment, -1 for the last one
     seg_text.reserve((size_t)n_bytes);
-    int64_t start = 0;
-    for (;;) {
-        int64_t best = -1;
-        size_t best_k = 0;
-        for (size_t k = 0; k < strs.size(); ++k) {
-            if (strs[k]->empty()) continue;
-            if (next[k] != -1 && next[k] < start) {
-                const void* hit = (start <= n_bytes) ? memmem(base + start, (size_t)(n_bytes - start), strs[k]->data(), strs[k]->size()) : nullptr;
-                next[k] = hit ? (int64_t)((const char*)hit - base) : -1;
-            }
-            if (next[k] >= 0 && (best < 0 || next[k] < best || (next[k] == best && strs[k]->size() > strs[best_k]->size()))) {
-                best = next[k];
-                best_k = k;
-            }
-        }
-        const int64_t end = best >= 0 ? best : n_bytes;
-        seg_text.insert(seg_text.end(), text + start, text + end);
-        seg_offs.push_back((int64_t)seg_text.size());
-        if (best < 0) { seg_special.push_back(-1); break; }
-        seg_special.push_back(ids[best_k]);
-        start = end + (int64_t)strs[best_k]->size();
-    }
+    segment_document(ix, text, 0, n_bytes, seg_text, seg_offs, seg_special);
     // 2. device: all ordinary segments as one batch
     const int64_t nseg = (int64_t)seg_special.size();
     std::vector<int32_t> toks((size_t)std::max<int64_t>((int64_t)seg_text.size(), 1));

@@ -178,8 +178,8 @@ class Tokenizer:
         for t in texts:
             self._check_disallowed(t, disallowed)
         try:
-            if allowed:  # special-token segmentation is per text on the host; ordinary segments still run on the GPU
-                return [self._core_bpe.encode(t, allowed)[0] for t in texts]
+            if allowed:  # every text is cut at its allowed special tokens on the host; all ordinary segments of all
+                return self._core_bpe.encode_batch_special(texts, allowed)  # texts run on the GPU as one batch
             return self._core_bpe.encode_batch(texts, MODE_ENCODE)
         except Exception as e:
             raise TokenDaggerError(f"Encoding failed: {e}")
