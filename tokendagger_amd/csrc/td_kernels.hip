@@ -34,22 +34,6 @@ struct LdsSrc {
     __device__ __forceinline__ uint32_t byte(int64_t i) const { return txt[i]; }
     __device__ __forceinline__ bool doc(int64_t i) const { return (docw[i >> 5] >> (i & 31)) & 1u; }
 };
-// Byte-scanner view of the LDS window (fallback only: pieces / look-ahead longer than a 64-byte mask
-// window).  Classes are recomputed from the staged text; s_doc carries document starts and the
-// end-of-text sentinels.
-struct LdsAcc {
-    using pos_t = int;
-    const Tables* T;
-    LdsSrc src;
-    int lim;
-    __device__ __noinline__ uint32_t cf(int i) const {
-        const uint32_t d = src.doc(i) ? (uint32_t)F_DOC : 0u;
-        if (i >= src.hi) return F_DOC;
-        if (i < src.lo) return C_OTHER;
-        return classify_at(*T, src, i) | d;
-    }
-    __device__ __forceinline__ uint32_t byte(int i) const { return src.txt[i]; }
-};
 struct GlobSrc {
     const uint8_t* text;
     const uint32_t* docbits;
