@@ -18,7 +18,7 @@ _ALPHA = st.one_of(
     st.characters(min_codepoint=0x3000, max_codepoint=0x30FF),
     st.characters(min_codepoint=0x4E00, max_codepoint=0x4E7F),
     st.characters(min_codepoint=0x1F600, max_codepoint=0x1F64F),
-    st.sampled_from(["", "᠎", " ", "　", " ", "﻿", "\U000e0001"]),
+    st.sampled_from(["\u0085", "\u180e", "\u2028", "\u3000", "\u00a0", "\ufeff", "\U000e0001"]),
 )
 _TEXT = st.text(alphabet=_ALPHA, min_size=0, max_size=120)
 _RUN = st.builds(lambda t, k: t * k, st.text(alphabet=_ALPHA, min_size=1, max_size=6), st.integers(1, 900))
