@@ -175,3 +175,26 @@ def test_encode_batch_with_allowed_special_is_one_batch(enc):
     big = ("lorem ipsum dolor sit amet <tag> x < y " * 40000) + "<|eot|>"
     ids = enc.encode(big, allowed_special="all")
     assert ids[-1] == enc._special_tokens["<|eot|>"] and enc.decode(ids) == big
+
+
+def test_from_files_tekken_json(tmp_path):
+    """tekken.json through the C++ loader (pattern from the file, id = index + default_num_special_tokens) builds the
+    same tokenizer as Encoding(...) over the same entries."""
+    import base64
+    import json
+    import tokendagger as tiktoken
+    from tokendagger_amd import vocab_io
+    _, mr, _ = H.llama4()
+    by_rank = sorted(((r, b) for b, r in mr.items() if r < 30000), key=lambda x: x[0])
+    n_special = 1000
+    doc = {"config": {"pattern": vocab_io.TEKKEN_PAT_STR, "default_vocab_size": len(by_rank) + n_special,
+                      "default_num_special_tokens": n_special, "version": "v7-synthetic"},
+           "vocab": [{"rank": i, "token_bytes": base64.b64encode(b).decode(), "token_str": None} for i, (_, b) in enumerate(by_rank)] +
+                    [{"rank": 10 ** 6, "token_bytes": base64.b64encode(b"never loaded").decode(), "token_str": "x"}]}
+    (tmp_path / "tekken.json").write_text(json.dumps(doc))
+    t = tiktoken.Tokenizer.from_files("tekken-synthetic", tekken=tmp_path / "tekken.json")
+    ref = tiktoken.Encoding("same", pat_str=vocab_io.TEKKEN_PAT_STR, mergeable_ranks={b: i + n_special for i, (_, b) in enumerate(by_rank)})
+    assert t.pattern == vocab_io.TEKKEN_PAT_STR and t.max_token_value == ref.max_token_value
+    for s in ["Hello, world! It's 2024.", "def f(x):\n    return x**2  # 中文 😀", "12345 67", "  spaces   and\ttabs\n\n"]:
+        ids = t.encode(s)
+        assert ids == ref.encode(s) and min(ids) >= n_special and t.decode(ids) == s
