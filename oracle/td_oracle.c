@@ -102,8 +102,10 @@ static int64_t contraction(const uint8_t* s, int64_t e, int64_t n) {
  * config.pattern, read by tests/throughput_test.py:118): the same alternatives without the contraction suffix and with
  * \p{N} in place of \p{N}{1,3}. */
 static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n);
+static int64_t next_piece_gpt2(const uint8_t* s, int64_t pos, int64_t n);
 static int64_t next_piece_llama4(const uint8_t* s, int64_t pos, int64_t n, int variant) {
     if (variant == 2) return next_piece_cl100k(s, pos, n);
+    if (variant == 3) return next_piece_gpt2(s, pos, n);
     const int contr = variant == 0, nmax = variant == 0 ? 3 : 1;
     int l0;
     int c0 = char_at(s, pos, n, &l0, NULL);
@@ -243,6 +245,52 @@ static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n) {
             if (q == n) return q;
             if (last_char > pos) return last_char;
             return q;
+        }
+    }
+    return pos + l0;
+}
+
+/* variant 3: the GPT-2 pattern (r50k_base / p50k_base):
+ *   's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+
+ * case-sensitive contractions, the optional prefix is U+0020 only, digit runs are not cut, no trailer, no CR/LF rule. */
+static int64_t next_piece_gpt2(const uint8_t* s, int64_t pos, int64_t n) {
+    int l0;
+    int c0 = char_at(s, pos, n, &l0, NULL);
+    if (s[pos] == '\'' && pos + 1 < n) {
+        uint8_t a = s[pos + 1];
+        if (a == 's' || a == 't' || a == 'm' || a == 'd') return pos + 2;
+        if (pos + 2 < n) {
+            uint8_t b = s[pos + 2];
+            if ((a == 'r' && b == 'e') || (a == 'v' && b == 'e') || (a == 'l' && b == 'l')) return pos + 3;
+        }
+    }
+    for (int kind = 0; kind < 3; ++kind) {          /* letters, digits, other */
+        for (int with_space = 1; with_space >= 0; --with_space) {
+            if (with_space && c0 != C_SP) continue;
+            int64_t st = with_space ? pos + 1 : pos, e = st;
+            int l, c;
+            while (e < n) {
+                c = char_at(s, e, n, &l, NULL);
+                int ok = kind == 0 ? is_L2(c) : kind == 1 ? (c == C_NUM) : (!is_S(c) && !is_L2(c) && c != C_NUM);
+                if (!ok) break;
+                e += l;
+            }
+            if (e > st) return e;
+        }
+    }
+    {
+        int64_t q = pos, last_char = pos;
+        int l, c;
+        while (q < n) {
+            c = char_at(s, q, n, &l, NULL);
+            if (!is_S(c)) break;
+            last_char = q;
+            q += l;
+        }
+        if (q > pos) {
+            if (q == n) return q;                  /* \s+(?!\S) at the end of the subject */
+            if (last_char > pos) return last_char; /* \s+(?!\S) gives one character back */
+            return q;                              /* \s+ */
         }
     }
     return pos + l0;

@@ -33,3 +33,11 @@ def cl100k_golden():
     documents of llama4_golden.npz (tools/make_golden.py cl100k)."""
     import numpy as np
     return np.load(ROOT / "tests" / "golden" / "cl100k_style_golden.npz", allow_pickle=True)
+
+
+@pytest.fixture(scope="session")
+def gpt2_golden():
+    """Compiled-reference outputs for the GPT-2 (r50k_base / p50k_base) split pattern over the Llama-4 vocabulary, on
+    the documents of llama4_golden.npz (tools/make_golden.py gpt2)."""
+    import numpy as np
+    return np.load(ROOT / "tests" / "golden" / "gpt2_style_golden.npz", allow_pickle=True)

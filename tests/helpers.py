@@ -90,6 +90,27 @@ def port_tokenizer_cl100k():
     return port.OracleTokenizer(mr, port.VARIANT_CL100K)
 
 
+GPT2_PAT = vocab_io.GPT2_PAT_STR
+
+
+@functools.lru_cache(maxsize=None)
+def ref_tokenizer_gpt2():
+    from oracle import ref
+    if not ref.available():
+        subprocess.check_call([str(ROOT / "oracle" / "build_ref.sh")])
+    _, mr, special = llama4()
+    return ref.RefTokenizer(GPT2_PAT, mr, special)
+
+
+@functools.lru_cache(maxsize=None)
+def port_tokenizer_gpt2():
+    from oracle import port
+    if not port.available():
+        subprocess.check_call([str(ROOT / "oracle" / "build_oracle.sh")])
+    _, mr, _ = llama4()
+    return port.OracleTokenizer(mr, port.VARIANT_GPT2)
+
+
 def pack_docs(docs: list[bytes]):
     offs = np.zeros(len(docs) + 1, dtype=np.int64)
     np.cumsum([len(d) for d in docs], out=offs[1:])
@@ -245,6 +266,12 @@ def twin_tekken():
 def twin_cl100k():
     _, mr, special = llama4()
     return Twin(CL100K_PAT, mr, special)
+
+
+@functools.lru_cache(maxsize=None)
+def twin_gpt2():
+    _, mr, special = llama4()
+    return Twin(GPT2_PAT, mr, special)
 
 
 # ----------------------------------------------------------------------------- inputs -------

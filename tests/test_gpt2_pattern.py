@@ -1,0 +1,118 @@
+"""Fourth member of the split-pattern family: GPT-2 (r50k_base / p50k_base): case-sensitive contractions in front, the
+optional prefix is U+0020 only (also before digits), digit runs are not cut, no trailer, no CR/LF alternative.  Pinned like
+the others: compiled reference (PCRE2) -> golden vectors over the Llama-4 vocabulary; restatement, CPU twin, GPU."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import port, ref
+from tokendagger_amd import vocab_io
+
+
+def _docs(golden, step=1):
+    text, offs = golden["text"].tobytes(), golden["offsets"]
+    for d in range(0, len(offs) - 1, step):
+        yield d, text[offs[d]:offs[d + 1]]
+
+
+EDGE = ["don't", "'sup", "'S", "x'ſ", "''ll", "'", "a'", "éx", "́́", "a/\n/b", "A/\r\n", " 'tis", "\n'd", "'re'RE're",
+        "ʰʰ'm", "12'345", "中'文's", "_'t", " 's", "'ſſ"]
+
+
+def test_pattern_strings(gpt2_golden):
+    assert str(gpt2_golden["pattern"]) == H.GPT2_PAT == vocab_io.GPT2_PAT_STR
+
+
+def test_restatement_matches_golden_and_edges(golden, gpt2_golden):
+    O = H.port_tokenizer_gpt2()
+    enc, eo = gpt2_golden["enc"], gpt2_golden["enc_offsets"]
+    pe, po = gpt2_golden["piece_ends"], gpt2_golden["piece_offsets"]
+    differs = 0
+    for d, doc in _docs(golden):
+        assert np.array_equal(O.encode(doc), enc[eo[d]:eo[d + 1]]), golden["names"][d]
+        assert np.array_equal(port.split(doc, port.VARIANT_GPT2), pe[po[d]:po[d + 1]]), golden["names"][d]
+        differs += not np.array_equal(port.split(doc), pe[po[d]:po[d + 1]])
+    assert differs > 200
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_restatement_vs_compiled_reference_fuzz():
+    R, O = H.ref_tokenizer_gpt2(), H.port_tokenizer_gpt2()
+    rng = random.Random(13)
+    for i in range(4000):
+        s = (EDGE[i] if i < len(EDGE) else H.fuzz_string(rng) if i % 2 else H.random_unicode_string(rng)).encode("utf-8")
+        want = R.split(s)
+        assert np.array_equal(port.split(s, port.VARIANT_GPT2), want), repr(s)
+        assert np.array_equal(O.encode(s), R.encode(s)), repr(s)
+
+
+def test_twin_scanners_match_golden(golden, gpt2_golden):
+    tw = H.twin_gpt2()
+    text, offs = golden["text"].tobytes(), golden["offsets"]
+    pe, po = gpt2_golden["piece_ends"], gpt2_golden["piece_offsets"]
+    exp = []
+    for d in range(len(offs) - 1):
+        ends = pe[po[d]:po[d + 1]]
+        if len(ends):
+            starts = np.concatenate([[0], ends[:-1]])
+            if d % 9 == 0:
+                assert np.array_equal(tw.split_serial(text[offs[d]:offs[d + 1]]), starts), golden["names"][d]
+            exp.append(starts + offs[d])
+    got, _ = tw.split_tiled(text, offs)
+    assert np.array_equal(got, np.concatenate(exp))
+    bad, n = tw.sync_violations(text, offs)
+    assert bad == 0 and n > 100000
+    bad, unres, checked = tw.bits_check(text, offs)
+    assert bad == 0 and checked > 100000
+    bad, checked = tw.arrmask_check(text, offs)
+    assert bad == 0 and checked > 100000
+    toks, toffs = tw.encode_batch(text, offs)
+    assert np.array_equal(toffs, gpt2_golden["enc_offsets"]) and np.array_equal(toks, gpt2_golden["enc"])
+
+
+def test_twin_fuzz_vs_restatement():
+    tw, O = H.twin_gpt2(), H.port_tokenizer_gpt2()
+    rng = random.Random(78)
+    for it in range(12):
+        docs = [e.encode("utf-8") for e in EDGE] if it == 0 else []
+        for _ in range(rng.randint(1, 150)):
+            r = rng.random()
+            if r < 0.1:
+                docs.append((rng.choice(["a", " ", "=", "1", "\n", "A", "x'S", "'ll", "é", "/\n"]) * rng.randint(50, 6000)).encode())
+            else:
+                docs.append("".join(H.fuzz_string(rng) for _ in range(rng.randint(1, 30))).encode("utf-8"))
+        text, offs = H.pack_docs(docs)
+        toks, toffs = tw.encode_batch(text, offs)
+        etoks, eoffs = O.encode_batch(text, offs)
+        assert np.array_equal(toffs, eoffs) and np.array_equal(toks, etoks)
+        bad, _ = tw.sync_violations(text, offs)
+        assert bad == 0
+
+
+@pytest.mark.gpu
+def test_gpu_gpt2_style_parity(golden, gpt2_golden):
+    import td_corpus
+    from tokendagger_amd import capi
+    _, mr, special = H.llama4()
+    tok = capi.HipTokenizer(H.GPT2_PAT, mr, special, device=0)
+    text, offs = golden["text"], golden["offsets"]
+    for t in (tok,):
+        toks, toffs = t.encode_batch(text, offs)
+        assert np.array_equal(toffs, gpt2_golden["enc_offsets"]) and np.array_equal(toks, gpt2_golden["enc"])
+    O = H.port_tokenizer_gpt2()
+    rng = random.Random(22)
+    for it in range(6):
+        docs = ["".join(H.fuzz_string(rng) for _ in range(rng.randint(1, 40))).encode("utf-8") for _ in range(300)]
+        docs += [(rng.choice(["7", "it's ", "'re", "é ", "a/\n"]) * rng.randint(100, 5000)).encode() for _ in range(4)]
+        docs += [e.encode("utf-8") for e in EDGE]
+        t, o = H.pack_docs(docs)
+        toks, toffs = tok.encode_batch(t, o)
+        etoks, eoffs = O.encode_batch(t, o)
+        assert np.array_equal(toffs, eoffs) and np.array_equal(toks, etoks)
+    for gen in (td_corpus.mixed, td_corpus.code, td_corpus.english):
+        x, o = gen(2 << 20, seed=7)
+        toks, toffs = tok.encode_batch(x, o)
+        etoks, eoffs = O.encode_batch(x.tobytes(), o)
+        assert np.array_equal(toffs, eoffs) and np.array_equal(toks, etoks)

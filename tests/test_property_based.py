@@ -56,3 +56,9 @@ def test_tekken_pattern(docs):
 @given(_DOCS)
 def test_cl100k_pattern(docs):
     _check(H.twin_cl100k(), H.port_tokenizer_cl100k(), docs)
+
+
+@settings(**_CFG)
+@given(_DOCS)
+def test_gpt2_pattern(docs):
+    _check(H.twin_gpt2(), H.port_tokenizer_gpt2(), docs)

@@ -187,7 +187,7 @@ int64_t twin_sync_violations(void* h, const uint8_t* text, int64_t n, const int6
     int64_t bad = 0, ns = 0;
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t vp = i > 0 ? cls[(size_t)i - 1] : 0u;
-        if (is_sync(vp, cls[(size_t)i])) { ++ns; if (!flags[(size_t)i]) ++bad; }
+        if (is_sync(vp, cls[(size_t)i], T.pat_flags)) { ++ns; if (!flags[(size_t)i]) ++bad; }
     }
     if (n_sync) *n_sync = ns;
     return bad;
@@ -251,7 +251,7 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
             for (int k = 0; k < MK_COUNT; ++k) w.m[k] = 0;
             for (int i = 0; i < 64; ++i) {
                 const uint32_t v = g.cf(base + i), vp = (base + i > 0) ? g.cf(base + i - 1) : 0u;
-                const uint32_t bits = mask_bits_of(vp, v);
+                const uint32_t bits = mask_bits_of(vp, v, T.pat_flags);
                 for (int k = 0; k < MK_COUNT; ++k) w.m[k] |= (uint64_t)((bits >> k) & 1u) << i;
             }
             {   // the kernel derives SYNC with sync_word() from the other masks: must equal is_sync() per byte
@@ -259,7 +259,7 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
                 const uint32_t vprev = base > 0 ? g.cf(base - 1) : 0u;
                 const uint32_t pf = base > 0 ? (feature_of_class(vprev & CLS_MASK) | ((vprev & F_CONT) ? FB_C : 0u)) : 0u;
                 const uint64_t sy = sync_word(w.m[MK_U], w.m[MK_W], w.m[MK_X], w.m[MK_S], w.m[MK_N], w.m[MK_CR], SL,
-                                              w.m[MK_C], w.m[MK_D], w.m[MK_A], pf);
+                                              w.m[MK_C], w.m[MK_D], w.m[MK_A], pf, T.pat_flags);
                 if (sy != w.m[MK_SYNC]) ++bad;
                 // and the feature byte must reproduce the class-set masks
                 for (int i = 0; i < 64; ++i) {
@@ -288,7 +288,7 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
                     const uint32_t vprev = pos > 0 ? g.cf(pos - 1) : 0u;
                     const uint32_t pf = pos > 0 ? (feature_of_class(vprev & CLS_MASK) | ((vprev & F_CONT) ? FB_C : 0u)) : 0u;
                     const uint32_t D = (uint32_t)(w.m[MK_D] >> (8 * sl)) & 0xFF;
-                    const uint32_t sy = sync_byte(pU, pW, pX, pS, mN, pCR, pSL, pC, D, mA, pf);
+                    const uint32_t sy = sync_byte(pU, pW, pX, pS, mN, pCR, pSL, pC, D, mA, pf, T.pat_flags);
                     auto sl8 = [&](int k) { return (uint32_t)(w.m[k] >> (8 * sl)) & 0xFFu; };
                     if (pU != sl8(MK_U) || pW != sl8(MK_W) || pX != sl8(MK_X) || pS != sl8(MK_S) || mN != sl8(MK_N) ||
                         pCR != sl8(MK_CR) || (pCR | pSL) != sl8(MK_TR) || pC != sl8(MK_C) || mA != sl8(MK_A) ||
@@ -329,7 +329,7 @@ int64_t twin_arrmask_check(void* h, const uint8_t* text, int64_t n, const int64_
     std::vector<uint64_t> arr((size_t)nw * MK_COUNT, 0);
     for (int64_t i = 0; i < nw * 64; ++i) {
         const uint32_t v = g.cf(i), vp = i > 0 ? g.cf(i - 1) : 0u;
-        const uint32_t bits = mask_bits_of(vp, v);
+        const uint32_t bits = mask_bits_of(vp, v, T.pat_flags);
         for (int k = 0; k < MK_COUNT; ++k)
             if ((bits >> k) & 1u) arr[(size_t)(i >> 6) * MK_COUNT + k] |= 1ull << (i & 63);
     }

@@ -105,7 +105,12 @@ struct Tables {
 // : the contraction is an alternative of its own in front (not a suffix), letters are plain \p{L}+ (no case structure;
 // marks are punctuation) and '/' does not extend a punctuation piece.  The last two are class REMAPS done when the
 // tables are built (C_MK -> C_OTHER, C_SLASH -> C_OTHER), so only the first two reach the scanners as flags.
-enum : uint32_t { PV_NO_CONTRACTION = 1, PV_SINGLE_DIGIT = 2, PV_LEADING_CONTRACTION = 4, PV_PLAIN_LETTERS = 8 };
+// Fourth member: the GPT-2 pattern (r50k_base / p50k_base)
+//   's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+
+// : case-sensitive contractions in front, the optional prefix is U+0020 only (also before digits), digit runs are not
+// cut, no [\r\n/]* trailer and no \s*[\r\n]+ alternative.  It has a scanner of its own (scan_piece_gpt2*), selected
+// by PV_GPT2, and the same two class remaps as cl100k.
+enum : uint32_t { PV_NO_CONTRACTION = 1, PV_SINGLE_DIGIT = 2, PV_LEADING_CONTRACTION = 4, PV_PLAIN_LETTERS = 8, PV_GPT2 = 16 };
 
 // ------------------------------------------------------------------ hashing -----------------
 TD_HD uint32_t hash_piece(uint64_t key, uint32_t len) {
@@ -251,13 +256,14 @@ TD_HD uint32_t classify_at(const Tables& T, const S& s, int64_t i) {
 //   R4 a digit run starts or ends here (digits only occur in \p{N}{1,3} pieces);
 //   R5 punctuation other than ' follows a true letter (letters only occur in alternatives 1-2,
 //      which continue only with letter-class chars or a contraction).
-TD_HD bool is_sync(uint32_t vp, uint32_t v) {
+// (GPT-2 pattern: " 12" is one piece, so the START of a digit run proves nothing there; its end still does.)
+TD_HD bool is_sync(uint32_t vp, uint32_t v, uint32_t pv = 0) {
     if (v & F_CONT) return false;
     if (v & F_DOC) return true;
     const uint32_t c = v & CLS_MASK, p = vp & CLS_MASK;
     if ((c == C_SP || c == C_WS) && !in_set(M_S, p)) return true;
     if (p == C_CRLF && !in_set(M_S, c) && c != C_SLASH) return true;
-    if ((c == C_NUM) != (p == C_NUM)) return true;
+    if ((pv & PV_GPT2) ? (p == C_NUM && c != C_NUM) : ((c == C_NUM) != (p == C_NUM))) return true;
     if ((c == C_OTHER || c == C_SLASH) && in_set(M_L, p)) return true;
     return false;
 }
@@ -331,10 +337,71 @@ TD_HD typename A::pos_t scan_letters(const A& a, typename A::pos_t pos, typename
     return (pv & PV_NO_CONTRACTION) ? e : scan_contraction(a, e);
 }
 
+// The GPT-2 pattern (classes remapped: marks and '/' are C_OTHER).
+template <class A>
+TD_HD typename A::pos_t scan_piece_gpt2(const A& a, typename A::pos_t pos) {
+    using P = typename A::pos_t;
+    const uint32_t c0 = a.cf(pos) & CLS_MASK;
+    if (c0 == C_APOS) {  // 's|'t|'re|'ve|'m|'ll|'d  (case-sensitive)
+        if (pos + 3 > a.lim) return -1;
+        const uint32_t v1 = a.cf(pos + 1), v2 = a.cf(pos + 2);
+        if (!(v1 & F_DOC)) {
+            const uint32_t b1 = a.byte(pos + 1);
+            if (b1 == 's' || b1 == 't' || b1 == 'm' || b1 == 'd') return pos + 2;
+            if (!(v2 & F_DOC)) {
+                const uint32_t b2 = a.byte(pos + 2);
+                if ((b1 == 'r' && b2 == 'e') || (b1 == 'v' && b2 == 'e') || (b1 == 'l' && b2 == 'l')) return pos + 3;
+            }
+        }
+    }
+    //  ?\p{L}+ |  ?\p{N}+ |  ?[^\s\p{L}\p{N}]+ : the optional space is taken when a run of one of the three kinds follows
+    P st = pos;
+    uint32_t cls = c0;
+    if (c0 == C_SP) {
+        if (pos + 1 >= a.lim) return -1;
+        const uint32_t v1 = a.cf(pos + 1);
+        const uint32_t c1 = v1 & CLS_MASK;
+        if (!(v1 & F_DOC) && (in_set(M_U | M_W, c1) || c1 == C_NUM || in_set(M_X, c1))) { st = pos + 1; cls = c1; }
+    }
+    const uint32_t run_set = in_set(M_U | M_W, cls) ? (M_U | M_W) : (cls == C_NUM) ? (1u << C_NUM) : in_set(M_X, cls) ? M_X : 0u;
+    if (run_set) {
+        P e = st;
+        for (;;) {
+            if (e >= a.lim) return -1;
+            const uint32_t v = a.cf(e);
+            if ((e > pos && (v & F_DOC)) || !in_set(run_set, v & CLS_MASK)) break;
+            ++e;
+        }
+        return e;
+    }
+    // \s+(?!\S) | \s+ on the maximal whitespace run
+    {
+        P q = pos, last_lead = pos;
+        bool eos = false;
+        for (;;) {
+            if (q >= a.lim) return -1;
+            const uint32_t v = a.cf(q);
+            if (q > pos && (v & F_DOC)) { eos = true; break; }
+            if (!in_set(M_S, v & CLS_MASK)) break;
+            if (!(v & F_CONT)) last_lead = q;
+            ++q;
+        }
+        if (q == pos) {  // not reachable (every class is covered); mirrors the no-progress rule
+            P p1 = pos + 1;
+            while (p1 < a.lim && (a.cf(p1) & F_CONT)) ++p1;
+            return p1;
+        }
+        if (eos) return q;
+        if (last_lead > pos) return last_lead;
+        return q;
+    }
+}
+
 // End of the piece that starts at `pos` (a character start, pos < lim).  pv: PV_* pattern variant bits.
 template <class A>
 TD_HD typename A::pos_t scan_piece(const A& a, typename A::pos_t pos, uint32_t pv = 0) {
     using P = typename A::pos_t;
+    if (pv & PV_GPT2) return scan_piece_gpt2(a, pos);
     const uint32_t c0 = a.cf(pos) & CLS_MASK;
     P p1 = pos + 1;  // end of the first character
     for (;;) {
@@ -475,7 +542,7 @@ TD_HD uint64_t td_bits_below(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1u
 
 // Mask bits of one byte from its class+flag byte `v` and its predecessor's `vp` (the kernel turns these
 // into the 64-bit words with one wavefront ballot per mask; the CPU twin ORs them bit by bit).
-TD_HD uint32_t mask_bits_of(uint32_t vp, uint32_t v) {
+TD_HD uint32_t mask_bits_of(uint32_t vp, uint32_t v, uint32_t pv = 0) {
     const uint32_t c = v & CLS_MASK;
     uint32_t r = 0;
     r |= in_set(M_U, c) ? (1u << MK_U) : 0u;
@@ -489,7 +556,7 @@ TD_HD uint32_t mask_bits_of(uint32_t vp, uint32_t v) {
     r |= (v & F_DOC) ? (1u << MK_D) : 0u;
     r |= (c == C_APOS) ? (1u << MK_A) : 0u;
     r |= (c == C_SP) ? (1u << MK_SP) : 0u;
-    r |= is_sync(vp, v) ? (1u << MK_SYNC) : 0u;
+    r |= is_sync(vp, v, pv) ? (1u << MK_SYNC) : 0u;
     return r;
 }
 // Mask providers.  A provider answers bit / run questions about the class masks around one piece start `o`;
@@ -635,9 +702,45 @@ TD_HD int scan_contraction_p(const P& p, const B& bytes, int e, bool leading = f
     return e;
 }
 
+// The GPT-2 pattern on the masks.
+template <class P, class B>
+TD_HD int scan_piece_gpt2_p(const P& p, const B& bytes) {
+    const int o = p.o, lim = p.lim;
+    if (o + 3 > lim) return -1;
+    if (p.bit(MK_A, o) && !p.bit(MK_D, o + 1)) {  // 's|'t|'re|'ve|'m|'ll|'d  (case-sensitive)
+        const uint32_t b1 = bytes(o + 1);
+        if (b1 == 's' || b1 == 't' || b1 == 'm' || b1 == 'd') return o + 2;
+        if (!p.bit(MK_D, o + 2)) {
+            const uint32_t b2 = bytes(o + 2);
+            if ((b1 == 'r' && b2 == 'e') || (b1 == 'v' && b2 == 'e') || (b1 == 'l' && b2 == 'l')) return o + 3;
+        }
+    }
+    int st = o;
+    if (p.bit(MK_SP, o) && !p.ebit(o + 1) &&
+        (p.bit(MK_U, o + 1) || p.bit(MK_W, o + 1) || p.bit(MK_N, o + 1) || p.bit(MK_X, o + 1)))
+        st = o + 1;
+    int e = -1;
+    if (p.bit(MK_U, st) || p.bit(MK_W, st)) e = p.run_end2(MK_U, MK_W, st);
+    else if (p.bit(MK_N, st)) e = p.run_end(MK_N, st);
+    else if (p.bit(MK_X, st)) e = p.run_end(MK_X, st);
+    if (e >= 0) return e >= lim ? -1 : e;
+    if (p.bit(MK_S, o)) {  // \s+(?!\S) | \s+
+        const int q = p.run_end(MK_S, o);
+        if (q >= lim) return -1;
+        if (p.ebit(q)) return q;
+        const int last_lead = p.last_clear(MK_C, o, q);
+        if (last_lead > o) return last_lead;
+        return q;
+    }
+    int p1 = o + 1;
+    while (p1 < lim && p.bit(MK_C, p1)) ++p1;
+    return p1 >= lim ? -1 : p1;
+}
+
 // End of the piece starting at p.o, in the provider's coordinates, or -1 (needs positions >= p.lim).
 template <class P, class B>
 TD_HD int scan_piece_p(const P& p, const B& bytes, uint32_t pv = 0) {
+    if (pv & PV_GPT2) return scan_piece_gpt2_p(p, bytes);
     const int o = p.o, lim = p.lim;
     const bool u0 = p.bit(MK_U, o), w0 = p.bit(MK_W, o), x0 = p.bit(MK_X, o), s0 = p.bit(MK_S, o), n0 = p.bit(MK_N, o);
     const bool cr0 = p.bit(MK_CR, o);
@@ -766,26 +869,28 @@ TD_HD uint64_t transpose8x8(uint64_t x) {
 // 8-bit slice of the SYNC mask from the 8-bit slices of the class masks (same predicate as sync_word / is_sync);
 // `pf` = feature byte of the byte in front of the slice.
 TD_HD uint32_t sync_byte(uint32_t U, uint32_t W, uint32_t X, uint32_t S, uint32_t N, uint32_t CR, uint32_t SL,
-                         uint32_t C, uint32_t D, uint32_t A, uint32_t pf) {
+                         uint32_t C, uint32_t D, uint32_t A, uint32_t pf, uint32_t pv = 0) {
     const uint32_t L = (U | W) & ~X;
     const uint32_t pS = (S << 1) | ((pf & FB_S) ? 1u : 0u);
     const uint32_t pCR = (CR << 1) | ((pf & FB_CR) ? 1u : 0u);
     const uint32_t pN = (N << 1) | (fb_is_num(pf) ? 1u : 0u);
     const uint32_t pL = (L << 1) | (((pf & (FB_U | FB_W)) && !(pf & FB_X)) ? 1u : 0u);
-    const uint32_t sy = (S & ~CR & ~pS) | (pCR & ~S & ~SL) | (N ^ pN) | (X & ~(U | W) & ~A & pL);
+    const uint32_t num = (pv & PV_GPT2) ? (~N & pN) : (N ^ pN);
+    const uint32_t sy = (S & ~CR & ~pS) | (pCR & ~S & ~SL) | num | (X & ~(U | W) & ~A & pL);
     return ((sy & ~C) | D) & 0xFFu;
 }
 
 // SYNC mask word from the class mask words of the same 64 bytes; `pf` = feature byte of the byte just
 // before the word (0 if none).  Bit-for-bit the same predicate as is_sync().
 TD_HD uint64_t sync_word(uint64_t U, uint64_t W, uint64_t X, uint64_t S, uint64_t N, uint64_t CR, uint64_t SL,
-                         uint64_t C, uint64_t D, uint64_t A, uint32_t pf) {
+                         uint64_t C, uint64_t D, uint64_t A, uint32_t pf, uint32_t pv = 0) {
     const uint64_t L = (U | W) & ~X;
     const uint64_t pS = (S << 1) | ((pf & FB_S) ? 1ull : 0ull);
     const uint64_t pCR = (CR << 1) | ((pf & FB_CR) ? 1ull : 0ull);
     const uint64_t pN = (N << 1) | (fb_is_num(pf) ? 1ull : 0ull);
     const uint64_t pL = (L << 1) | (((pf & (FB_U | FB_W)) && !(pf & FB_X)) ? 1ull : 0ull);
-    uint64_t sy = (S & ~CR & ~pS) | (pCR & ~S & ~SL) | (N ^ pN) | (X & ~(U | W) & ~A & pL);
+    const uint64_t num = (pv & PV_GPT2) ? (~N & pN) : (N ^ pN);
+    uint64_t sy = (S & ~CR & ~pS) | (pCR & ~S & ~SL) | num | (X & ~(U | W) & ~A & pL);
     return (sy & ~C) | D;
 }
 
@@ -831,11 +936,11 @@ TD_HD void scan_lane(W& w, const G& g, int tid, int tile_hi, int64_t wg0, uint32
     int s = -1;
     if (tid == 0) {
         for (int i = c0; i >= 4; --i)
-            if (is_sync(w.cf(i - 1), w.cf(i))) { s = i; break; }
+            if (is_sync(w.cf(i - 1), w.cf(i), pv)) { s = i; break; }
         if (s < 0) {  // no sync point in the left halo: walk back through HBM (inside a giant piece)
             int64_t gs = 0;
             for (int64_t gi = wg0 + 3; gi > 0; --gi)
-                if (is_sync(g.cf(gi - 1), g.cf(gi))) { gs = gi; break; }
+                if (is_sync(g.cf(gi - 1), g.cf(gi), pv)) { gs = gi; break; }
             int64_t p = gs;
             const int64_t tile_g0 = wg0 + K_HL;
             while (p < tile_g0) p = g.scan(p);
@@ -844,13 +949,13 @@ TD_HD void scan_lane(W& w, const G& g, int tid, int tile_hi, int64_t wg0, uint32
     } else if (c0 < tile_hi) {
         const int cend = c1 < tile_hi ? c1 : tile_hi;
         for (int i = c0; i < cend; ++i)
-            if (is_sync(w.cf(i - 1), w.cf(i))) { s = i; break; }
+            if (is_sync(w.cf(i - 1), w.cf(i), pv)) { s = i; break; }
     }
     if (s < 0) return;
     int p = s;
     for (;;) {
         if (p >= tile_hi) { w.mark(p); break; }                       // delimits the last owned piece
-        if (p >= c1 && is_sync(w.cf(p - 1), w.cf(p))) break;           // the lane owning p starts there
+        if (p >= c1 && is_sync(w.cf(p - 1), w.cf(p), pv)) break;           // the lane owning p starts there
         if (p >= K_HL) w.mark(p);
         int e = scan_piece(w, p, pv);
         if (e < 0) {

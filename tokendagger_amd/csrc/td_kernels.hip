@@ -366,7 +366,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
             const uint32_t nraw = phi & 0xFF, mCR = (phi >> 8) & 0xFF, mSL = (phi >> 16) & 0xFF, mC = phi >> 24;
             const uint32_t mN = nraw & ~mX & ~mS, mA = nraw & mX, mSP = nraw & mS;
             const uint32_t mD = reinterpret_cast<const uint8_t*>(s_doc)[it];
-            const uint32_t mSY = sync_byte(mU, mW, mX, mS, mN, mCR, mSL, mC, mD, mA, pf);
+            const uint32_t mSY = sync_byte(mU, mW, mX, mS, mN, mCR, mSL, mC, mD, mA, pf, PV);
             static_assert(MK_U == 0 && MK_W == 1 && MK_X == 2 && MK_S == 3 && MK_N == 4 && MK_CR == 5 && MK_TR == 6 &&
                           MK_C == 7 && MK_D == 8 && MK_A == 9 && MK_SP == 10 && MK_SYNC == 11, "mask order");
             uint8_t* o = reinterpret_cast<uint8_t*>(s_mask + (it >> 3) * MK_COUNT) + (it & 7);
@@ -472,7 +472,7 @@ __global__ void td_split_slow(const EncodeArgs a) {
         if (ent & 1) {  // no sync point in the tile's left halo: walk back to one, then forward to the tile
             p = 0;
             for (int64_t gi = g; gi > 0; --gi)
-                if (is_sync(G.cf(gi - 1), G.cf(gi))) { p = gi; break; }
+                if (is_sync(G.cf(gi - 1), G.cf(gi), T.pat_flags)) { p = gi; break; }
             while (p < g) p = G.scan(p);
         } else {        // piece start known (and already marked), its end is not
             p = G.scan(g);
@@ -480,11 +480,11 @@ __global__ void td_split_slow(const EncodeArgs a) {
         while (p < tile_end) {
             // stop where a lane of the fast kernel STARTED: the first provable sync point of a 16-byte chunk other
             // than the tile's first chunk (lane 0 starts from the left halo, never inside its own chunk)
-            if (p != g && is_sync(G.cf(p - 1), G.cf(p))) {
+            if (p != g && is_sync(G.cf(p - 1), G.cf(p), T.pat_flags)) {
                 const int64_t cs = p - ((p - tile_g0) % KS_CHUNK);
                 bool first = cs != tile_g0;
                 for (int64_t q = cs; first && q < p; ++q)
-                    if (is_sync(G.cf(q - 1), G.cf(q))) first = false;
+                    if (is_sync(G.cf(q - 1), G.cf(q), T.pat_flags)) first = false;
                 if (first) break;
             }
             atomicOr(&a.startbits[p >> 5], 1u << (p & 31));
@@ -1460,6 +1460,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
     constexpr uint32_t PV_TEKKEN = PV_NO_CONTRACTION | PV_SINGLE_DIGIT;
     constexpr uint32_t PV_CL100K = PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS;
     switch (a.pat_flags) {
+        case PV_GPT2: hipLaunchKernelGGL(td_split_tiles<PV_GPT2>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
         case 0u: hipLaunchKernelGGL(td_split_tiles<0u>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
         case PV_TEKKEN: hipLaunchKernelGGL(td_split_tiles<PV_TEKKEN>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
         case PV_CL100K: hipLaunchKernelGGL(td_split_tiles<PV_CL100K>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;

@@ -38,6 +38,9 @@ CL100K_PAT_STR_POSSESSIVE = (
     r"'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]++[\r\n]*|\s*[\r\n]|\s+(?!\S)|\s+"
 )
 
+# GPT-2 (r50k_base / p50k_base) split pattern
+GPT2_PAT_STR = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
+
 # Mistral tekken.json config.pattern (reference loads it from the file: tests/throughput_test.py:118): the Llama-4
 # pattern without the contraction suffix and with single-digit number pieces.
 TEKKEN_PAT_STR = (

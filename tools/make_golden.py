@@ -115,8 +115,30 @@ def cl100k_style():
     print(f"wrote {out}: {len(offs) - 1} docs, {enc_offs[-1]} tokens, {out.stat().st_size} bytes on disk")
 
 
+def gpt2_style():
+    """Fourth fixture: the same documents through the compiled reference with the GPT-2 split pattern (Llama-4
+    vocabulary) -> gpt2_style_golden.npz."""
+    g = np.load(ROOT / "tests" / "golden" / "llama4_golden.npz", allow_pickle=True)
+    text, offs = g["text"].tobytes(), g["offsets"]
+    R = H.ref_tokenizer_gpt2()
+    enc, enc_offs, pe, pe_offs = [], [0], [], [0]
+    for d in range(len(offs) - 1):
+        doc = text[offs[d]:offs[d + 1]]
+        e = R.encode(doc)
+        enc.append(e); enc_offs.append(enc_offs[-1] + len(e))
+        p = R.split(doc) if len(doc) else np.zeros(0, np.int64)
+        pe.append(p); pe_offs.append(pe_offs[-1] + len(p))
+    out = ROOT / "tests" / "golden" / "gpt2_style_golden.npz"
+    np.savez_compressed(out, pattern=np.asarray(H.GPT2_PAT), enc=np.concatenate(enc).astype(np.int32),
+                        enc_offsets=np.asarray(enc_offs, dtype=np.int64), piece_ends=np.concatenate(pe).astype(np.int64),
+                        piece_offsets=np.asarray(pe_offs, dtype=np.int64))
+    print(f"wrote {out}: {len(offs) - 1} docs, {enc_offs[-1]} tokens, {out.stat().st_size} bytes on disk")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "cl100k":
+    if len(sys.argv) > 1 and sys.argv[1] == "gpt2":
+        gpt2_style()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cl100k":
         cl100k_style()
     elif len(sys.argv) > 1 and sys.argv[1] == "tekken":
         tekken_style()
