@@ -40,11 +40,15 @@ def test_restatement_matches_golden_and_edges(golden, gpt2_golden):
 @pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
 def test_restatement_vs_compiled_reference_fuzz():
     R, O = H.ref_tokenizer_gpt2(), H.port_tokenizer_gpt2()
+    _, mr, special = H.llama4()
+    R2 = ref.RefTokenizer(vocab_io.GPT2_PAT_STR_POSSESSIVE, mr, special)  # tiktoken's later spelling: same language
+    assert H.Twin(vocab_io.GPT2_PAT_STR_POSSESSIVE, {bytes([i]): i for i in range(256)}).info(3) == 255  # accepted as the same member
     rng = random.Random(13)
     for i in range(4000):
         s = (EDGE[i] if i < len(EDGE) else H.fuzz_string(rng) if i % 2 else H.random_unicode_string(rng)).encode("utf-8")
         want = R.split(s)
         assert np.array_equal(port.split(s, port.VARIANT_GPT2), want), repr(s)
+        assert np.array_equal(R2.split(s), want), repr(s)
         assert np.array_equal(O.encode(s), R.encode(s)), repr(s)
 
 

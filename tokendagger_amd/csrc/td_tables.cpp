@@ -30,6 +30,9 @@ static const char kCl100kPossessive[] =
 static const char kGpt2[] =
     "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
 
+static const char kGpt2Possessive[] =  // tiktoken's later spelling of the same language
+    "'(?:[sdmt]|ll|ve|re)| ?\\p{L}++| ?\\p{N}++| ?[^\\s\\p{L}\\p{N}]++|\\s++$|\\s+(?!\\S)|\\s";
+
 const char* o200k_pattern() { return kO200k; }
 const char* tekken_pattern() { return kTekken; }
 const char* cl100k_pattern() { return kCl100k; }
@@ -38,7 +41,7 @@ PatternKind classify_pattern(const std::string& pat) {
     if (pat == kO200k) return PATTERN_O200K;
     if (pat == kTekken) return PATTERN_TEKKEN;
     if (pat == kCl100k || pat == kCl100kPossessive) return PATTERN_CL100K;
-    if (pat == kGpt2) return PATTERN_GPT2;
+    if (pat == kGpt2 || pat == kGpt2Possessive) return PATTERN_GPT2;
     return PATTERN_UNSUPPORTED;
 }
 

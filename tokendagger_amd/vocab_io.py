@@ -41,6 +41,8 @@ CL100K_PAT_STR_POSSESSIVE = (
 # GPT-2 (r50k_base / p50k_base) split pattern
 GPT2_PAT_STR = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
 
+GPT2_PAT_STR_POSSESSIVE = r"'(?:[sdmt]|ll|ve|re)| ?\p{L}++| ?\p{N}++| ?[^\s\p{L}\p{N}]++|\s++$|\s+(?!\S)|\s"
+
 # Mistral tekken.json config.pattern (reference loads it from the file: tests/throughput_test.py:118): the Llama-4
 # pattern without the contraction suffix and with single-digit number pieces.
 TEKKEN_PAT_STR = (
