@@ -55,7 +55,14 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
 /* Replaces CoreBPE::~CoreBPE (tiktoken.hpp:69-73). */
 void td_destroy(td_tokenizer* t);
 
-/* Message of the last failure on this handle (t == NULL: last td_create failure of this thread). */
+/* Message of the calling thread's last failing call on this handle ("" if none; t == NULL: last td_create failure of
+ * this thread).  The pointer stays valid until the same thread's next failing call.
+ *
+ * Threads and streams: a handle may be shared by host threads; calls serialise on one internal lock.  All calls of a
+ * handle share ONE device workspace: work of a handle is ordered across streams by the library (a call on another
+ * stream than the previous call's waits, on the device, for that call's kernels), so asynchronous calls on different
+ * streams do not overlap each other — use one handle per stream for concurrency.  Every entry point leaves the
+ * caller's current HIP device as it found it. */
 const char* td_last_error(const td_tokenizer* t);
 
 /*
@@ -112,6 +119,17 @@ int td_encode_with_special(td_tokenizer* t, const uint8_t* text, int64_t n_bytes
 int td_encode_batch_with_special(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
                                  const int32_t* allowed_ids, int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity,
                                  int64_t* out_offsets, int64_t* n_tokens);
+
+/* The same two calls with the allowed set given as the special-token STRINGS themselves (concatenated UTF-8 bytes +
+ * n_allowed+1 offsets), which is how tiktoken's `allowed_special` names them: exactly the listed literals are cut
+ * out.  (With ids, every special string that carries a listed id is allowed — two strings may share one id.)
+ * A string that is not a special token fails with TD_E_SPECIAL, like tiktoken.cpp:178-180. */
+int td_encode_with_special_strs(td_tokenizer* t, const uint8_t* text, int64_t n_bytes, const uint8_t* allowed_bytes,
+                                const int64_t* allowed_offsets, int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity,
+                                int64_t* n_tokens, int32_t* last_piece_token_len);
+int td_encode_batch_with_special_strs(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
+                                      const uint8_t* allowed_bytes, const int64_t* allowed_offsets, int64_t n_allowed,
+                                      int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens);
 
 /* Introspection (tests, benchmarks). */
 #define TD_INFO_N_PAIRS 1        /* entries of the (id,id)->rank pair table */

@@ -224,3 +224,17 @@ def code(n_bytes: int, seed: int = 0):
     doc_offs = np.unique(np.asarray(doc_offs, dtype=np.int64))
     doc_offs[-1] = n_bytes
     return text, doc_offs
+
+
+def code_files(n_bytes: int = 0):
+    """BASELINE config 5's real input: the file set of the reference's tests/code_performance_benchmark.py (21 files,
+    2 146 667 bytes, one document per file; fixture tests/golden/code_corpus.npz made by tools/make_code_corpus.py),
+    repeated WHOLE floor(n_bytes / set size) times (at least once) — the result is a multiple of the set, not n_bytes.
+    -> (uint8[reps * set], int64 doc_offsets)"""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "tests" / "golden" / "code_corpus.npz", allow_pickle=False)
+    unit, uo = g["text"], g["offsets"].astype(np.int64)
+    reps = max(1, n_bytes // len(unit))
+    x = np.tile(unit, reps)
+    offs = np.concatenate([uo[:-1] + r * len(unit) for r in range(reps)] + [[reps * len(unit)]]).astype(np.int64)
+    return np.ascontiguousarray(x), offs

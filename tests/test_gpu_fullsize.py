@@ -1,0 +1,124 @@
+"""Full-size parity on the GPU (BASELINE configs 2 and 3 sizes, and beyond 2^31 bytes): EVERY document's ids and
+offsets against the compiled reference (oracle/_ref = the unmodified tiktoken.cpp, which travels to the GPU box as a
+prebuilt .so), not a sample.  The oracle is the checker only; the ids come from the C ABI (td_encode_device).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+import td_corpus
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tok():
+    from tokendagger_amd import capi
+    pat, mr, special = H.llama4()
+    t = capi.HipTokenizer(pat, mr, special, device=0)
+    yield t
+    t.close()
+
+
+def _tiled(kind: str, n: int, seed: int):
+    import bench
+    return bench.build_corpus(kind, n, seed)
+
+
+def _encode_device(tok, x, offs, cap_div=2):
+    import torch
+    n, n_docs = len(x), len(offs) - 1
+    d_text = torch.from_numpy(x).cuda()
+    d_offs = torch.from_numpy(offs).cuda()
+    cap = n // cap_div + 1024
+    d_tok = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_toff = torch.empty(n_docs + 1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    tok.encode_device(d_text.data_ptr(), n, d_offs.data_ptr(), n_docs, d_tok.data_ptr(), cap, d_toff.data_ptr(), s)
+    tok.device_status(s)
+    toff = d_toff.cpu().numpy()
+    total = int(toff[-1])
+    assert 0 < total <= cap
+    toks = d_tok[:total].cpu().numpy()
+    del d_text, d_offs, d_tok, d_toff
+    torch.cuda.empty_cache()
+    return toks, toff
+
+
+def _reference_all(x, offs):
+    """ids + offsets of every document from the compiled reference on all host threads."""
+    R = H.ref_tokenizer()
+    _, et, eo = R.encode_batch(x, offs, n_threads=os.cpu_count() or 1, want_tokens=True)
+    return et, eo
+
+
+def _assert_identical(got_t, got_o, want_t, want_o, offs):
+    if not np.array_equal(got_o, want_o):
+        d = int(np.nonzero(got_o != want_o)[0][0]) - 1
+        raise AssertionError(f"token offsets differ from document {max(d, 0)} on (bytes {offs[max(d, 0)]}..)")
+    if not np.array_equal(got_t, want_t):
+        i = int(np.nonzero(got_t != want_t)[0][0])
+        d = int(np.searchsorted(want_o, i, side="right")) - 1
+        raise AssertionError(f"ids differ at token {i}, document {d} (bytes {offs[d]}..{offs[d + 1]})")
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+@pytest.mark.parametrize("kind,mb", [("english", 256), ("mixed", 64), ("code", 64)])
+def test_every_document_matches_the_reference(tok, kind, mb):
+    """BASELINE config 2 (256 MiB English) id for id, plus the two harder corpora at a size the reference finishes in
+    seconds."""
+    x, offs = _tiled(kind, mb << 20, 1000)
+    toks, toff = _encode_device(tok, x, offs, cap_div=2 if kind == "english" else 1)
+    et, eo = _reference_all(x, offs)
+    _assert_identical(toks, toff, et, eo, offs)
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_1024_mib_corpus_matches_the_reference(tok):
+    """The corpus the headline metric is quoted on (BASELINE configs 3: 1024 MiB): all 1.7 M documents, id for id."""
+    x, offs = _tiled("english", 1024 << 20, 1000)
+    toks, toff = _encode_device(tok, x, offs)
+    et, eo = _reference_all(x, offs)
+    _assert_identical(toks, toff, et, eo, offs)
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_one_batch_above_2_31_bytes(tok):
+    """One td_encode_device call over more than 2^31 bytes (the reference's `int` positions stop there):
+    64-bit offsets everywhere.  2 GiB of tiled English followed by 96 MiB of mixed-script text and source code that
+    lie entirely above 2^31; every document that starts above 2^31 - 4 MiB is compared with the reference, the rest by
+    the periodicity of the tiled block + the reference on its first period."""
+    unit, uo = td_corpus.english(32 << 20, seed=0)
+    reps = 64
+    m, mo = td_corpus.mixed(48 << 20, seed=7)
+    c, co = td_corpus.code(48 << 20, seed=8)
+    x = np.concatenate([np.tile(unit, reps), m, c])
+    base_m = reps * len(unit)
+    base_c = base_m + len(m)
+    offs = np.concatenate([uo[:-1] + r * len(unit) for r in range(reps)] + [mo[:-1] + base_m, co + base_c]).astype(np.int64)
+    n = len(x)
+    assert n > (1 << 31) + (64 << 20) and offs[-1] == n
+    toks, toff = _encode_device(tok, x, offs)
+    assert (np.diff(toff) > 0).all() or (np.diff(offs)[np.diff(toff) == 0] == 0).all()
+    # (1) the tiled part: every repetition tokenizes like the first, and the first equals the reference
+    per = int(np.searchsorted(offs, len(unit)))
+    first = toks[toff[0]:toff[per]]
+    et, eo = _reference_all(x[:len(unit)], offs[:per + 1])
+    _assert_identical(first, toff[:per + 1], et, eo, offs)
+    for r in range(1, reps):
+        seg = toks[toff[r * per]:toff[(r + 1) * per]]
+        assert len(seg) == len(first) and np.array_equal(seg, first), f"repetition {r} differs"
+        assert np.array_equal(toff[r * per:(r + 1) * per + 1] - toff[r * per], toff[:per + 1]), f"offsets of repetition {r} differ"
+    # (2) everything from 4 MiB below 2^31 to the end (the seam and ~100 MiB above it), id for id
+    d0 = int(np.searchsorted(offs, (1 << 31) - (4 << 20)))
+    b0 = int(offs[d0])
+    et, eo = _reference_all(x[b0:], offs[d0:] - b0)
+    _assert_identical(toks[toff[d0]:], toff[d0:] - toff[d0], et, eo, offs[d0:])
+    # (3) decode(encode(.)) of the region above 2^31 gives the bytes back
+    da = int(np.searchsorted(offs, 1 << 31))
+    assert tok.decode_bytes(toks[toff[da]:]) == x[int(offs[da]):].tobytes()

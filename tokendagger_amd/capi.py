@@ -30,6 +30,7 @@ EXPORTS = [
     "td_vocab_create", "td_vocab_destroy", "td_vocab_error", "td_vocab_load_tiktoken", "td_vocab_load_hf_special",
     "td_vocab_load_tekken", "td_vocab_load_json", "td_vocab_set_pattern", "td_vocab_pattern", "td_vocab_arrays",
     "td_create_from_vocab", "td_token_bytes", "td_single_token", "td_decode_device", "td_decode_batch", "td_encode_batch_with_special",
+    "td_encode_with_special_strs", "td_encode_batch_with_special_strs",
 ]
 
 
@@ -105,6 +106,10 @@ def load_library():
     lib.td_special_get.argtypes = [vp, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
     lib.td_encode_batch_with_special.restype = i32
     lib.td_encode_batch_with_special.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, vp, ctypes.POINTER(i64)]
+    lib.td_encode_with_special_strs.restype = i32
+    lib.td_encode_with_special_strs.argtypes = [vp, vp, i64, vp, vp, i64, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
+    lib.td_encode_batch_with_special_strs.restype = i32
+    lib.td_encode_batch_with_special_strs.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, i64, vp, ctypes.POINTER(i64)]
     lib.td_decode_batch.restype = i32
     lib.td_decode_batch.argtypes = [vp, vp, vp, i64, vp, i64, vp, ctypes.POINTER(i64)]
     lib.td_decode_device.restype = i32
@@ -314,6 +319,45 @@ class HipTokenizer:
                                               ctypes.byref(ntok), ctypes.byref(last))
         self._check(rc)
         return toks[:ntok.value].copy(), last.value
+
+    @staticmethod
+    def _pack_strs(strs):
+        enc = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in strs]
+        offs = np.zeros(len(enc) + 1, dtype=np.int64)
+        if enc:
+            np.cumsum([len(b) for b in enc], out=offs[1:])
+        blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8).copy()
+        return blob, offs
+
+    def encode_with_special_strs(self, data, allowed) -> tuple[np.ndarray, int]:
+        """allowed: the special-token STRINGS that may be cut out (tiktoken's allowed_special)."""
+        buf = _as_u8(data)
+        ab, ao = self._pack_strs(list(allowed))
+        cap = len(buf) + 16
+        toks = np.empty(cap, dtype=np.int32)
+        ntok = ctypes.c_int64(0)
+        last = ctypes.c_int32(0)
+        rc = self._lib.td_encode_with_special_strs(self._h, buf.ctypes.data if len(buf) else None, len(buf), ab.ctypes.data,
+                                                   ao.ctypes.data, len(ao) - 1, toks.ctypes.data, cap, ctypes.byref(ntok),
+                                                   ctypes.byref(last))
+        self._check(rc)
+        return toks[:ntok.value].copy(), last.value
+
+    def encode_batch_with_special_strs(self, text, doc_offsets, allowed):
+        buf = _as_u8(text)
+        offs = np.ascontiguousarray(doc_offsets, dtype=np.int64)
+        ab, ao = self._pack_strs(list(allowed))
+        n_docs = len(offs) - 1
+        n = int(offs[-1]) if len(offs) else 0
+        cap = n + 16
+        out_offs = np.empty(n_docs + 1, dtype=np.int64)
+        toks = np.empty(cap, dtype=np.int32)
+        ntok = ctypes.c_int64(0)
+        rc = self._lib.td_encode_batch_with_special_strs(self._h, buf.ctypes.data if n else None, offs.ctypes.data, n_docs,
+                                                         ab.ctypes.data, ao.ctypes.data, len(ao) - 1, toks.ctypes.data, cap,
+                                                         out_offs.ctypes.data, ctypes.byref(ntok))
+        self._check(rc)
+        return toks[:ntok.value].copy(), out_offs
 
     def decode_bytes(self, tokens) -> bytes:
         t = np.ascontiguousarray(tokens, dtype=np.int32)

@@ -19,6 +19,7 @@
 
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -52,6 +53,25 @@ void pack(const std::vector<VocabItem>& v, bool use_string, std::vector<uint8_t>
     }
     if (bytes.empty()) bytes.push_back(0);
 }
+
+// allowed special strings -> concatenated bytes + offsets (td_encode_*_with_special_strs)
+void pack_allowed(const std::set<std::string>& allowed, std::vector<uint8_t>& bytes, std::vector<int64_t>& offs) {
+    offs.assign(1, 0);
+    for (const auto& s : allowed) {
+        bytes.insert(bytes.end(), s.begin(), s.end());
+        offs.push_back((int64_t)bytes.size());
+    }
+    if (bytes.empty()) bytes.push_back(0);
+}
+
+// uninitialised id buffer sized for the worst case (one id per input byte): no capacity miss, no second encode, and
+// only the pages that receive ids are ever touched
+struct IdBuf {
+    std::unique_ptr<int32_t[]> p;
+    int64_t cap;
+    explicit IdBuf(size_t n_bytes) : p(new int32_t[n_bytes + 16]), cap((int64_t)n_bytes + 16) {}
+    int32_t* data() { return p.get(); }
+};
 
 class CoreBPE {
 public:
@@ -118,39 +138,33 @@ public:
 
     // one document, host buffers
     std::vector<int> encode_mode(const std::string& text, int mode) {
-        std::vector<int32_t> out(text.size() / 3 + 16);
+        IdBuf out(text.size());
         int64_t offs[2] = {0, (int64_t)text.size()}, toffs[2], n = 0;
         int rc;
         {
             py::gil_scoped_release rel;
-            rc = td_encode_batch(h_, (const uint8_t*)text.data(), offs, 1, mode, out.data(), (int64_t)out.size(), toffs, &n);
-            if (rc == TD_E_CAPACITY && n > (int64_t)out.size()) {
-                out.resize((size_t)n);
-                rc = td_encode_batch(h_, (const uint8_t*)text.data(), offs, 1, mode, out.data(), (int64_t)out.size(), toffs, &n);
-            }
+            rc = td_encode_batch(h_, (const uint8_t*)text.data(), offs, 1, mode, out.data(), out.cap, toffs, &n);
         }
         if (rc != TD_OK) fail();
-        return std::vector<int>(out.begin(), out.begin() + n);
+        return std::vector<int>(out.data(), out.data() + n);
     }
 
     std::pair<std::vector<int>, int> encode(const std::string& text, const std::set<std::string>& allowed) {
-        std::vector<int32_t> ids;
-        for (const auto& s : allowed) {
-            auto it = special_ids_.find(s);
-            if (it == special_ids_.end()) throw TiktokenError("Special token '" + s + "' not found in special encoder");
-            ids.push_back(it->second);
-        }
-        std::vector<int32_t> out(text.size() + 16);
+        // the allowed set goes down as the strings themselves: two special strings may share an id
+        std::vector<uint8_t> ab;
+        std::vector<int64_t> ao;
+        pack_allowed(allowed, ab, ao);
+        IdBuf out(text.size());
         int64_t n = 0;
         int32_t last = 0;
         int rc;
         {
             py::gil_scoped_release rel;
-            rc = td_encode_with_special(h_, (const uint8_t*)text.data(), (int64_t)text.size(), ids.data(), (int64_t)ids.size(),
-                                        out.data(), (int64_t)out.size(), &n, &last);
+            rc = td_encode_with_special_strs(h_, (const uint8_t*)text.data(), (int64_t)text.size(), ab.data(), ao.data(),
+                                             (int64_t)allowed.size(), out.data(), out.cap, &n, &last);
         }
         if (rc != TD_OK) fail();
-        return {std::vector<int>(out.begin(), out.begin() + n), (int)last};
+        return {std::vector<int>(out.data(), out.data() + n), (int)last};
     }
 
     std::vector<unsigned char> decode_bytes(const std::vector<int>& tokens) {
@@ -231,22 +245,17 @@ public:
             buf.insert(buf.end(), s.begin(), s.end());
             offs.push_back((int64_t)buf.size());
         }
-        std::vector<int32_t> out(total / 3 + 16);
+        IdBuf out(total);
         std::vector<int64_t> toffs(texts.size() + 1);
         int64_t n = 0;
         int rc;
         {
             py::gil_scoped_release rel;
-            rc = td_encode_batch(h_, buf.data(), offs.data(), (int64_t)texts.size(), mode, out.data(), (int64_t)out.size(), toffs.data(), &n);
-            if (rc == TD_E_CAPACITY && n > (int64_t)out.size()) {
-                out.resize((size_t)n);
-                rc = td_encode_batch(h_, buf.data(), offs.data(), (int64_t)texts.size(), mode, out.data(), (int64_t)out.size(),
-                                     toffs.data(), &n);
-            }
+            rc = td_encode_batch(h_, buf.data(), offs.data(), (int64_t)texts.size(), mode, out.data(), out.cap, toffs.data(), &n);
         }
         if (rc != TD_OK) fail();
         std::vector<std::vector<int>> res(texts.size());
-        for (size_t d = 0; d < texts.size(); ++d) res[d].assign(out.begin() + toffs[d], out.begin() + toffs[d + 1]);
+        for (size_t d = 0; d < texts.size(); ++d) res[d].assign(out.data() + toffs[d], out.data() + toffs[d + 1]);
         return res;
     }
 
@@ -269,12 +278,9 @@ public:
 
     // list[str] + allowed special strings -> list[list[int]], all ordinary segments of all texts in ONE device batch
     std::vector<std::vector<int>> encode_batch_special(const std::vector<std::string>& texts, const std::set<std::string>& allowed) {
-        std::vector<int32_t> ids;
-        for (const auto& s : allowed) {
-            auto it = special_ids_.find(s);
-            if (it == special_ids_.end()) throw TiktokenError("Special token '" + s + "' not found in special encoder");
-            ids.push_back(it->second);
-        }
+        std::vector<uint8_t> ab;
+        std::vector<int64_t> ao;
+        pack_allowed(allowed, ab, ao);
         std::vector<int64_t> offs(1, 0);
         size_t total = 0;
         for (const auto& s : texts) total += s.size();
@@ -284,23 +290,18 @@ public:
             buf.insert(buf.end(), s.begin(), s.end());
             offs.push_back((int64_t)buf.size());
         }
-        std::vector<int32_t> out(total / 3 + 16);
+        IdBuf out(total);
         std::vector<int64_t> toffs(texts.size() + 1);
         int64_t n = 0;
         int rc;
         {
             py::gil_scoped_release rel;
-            rc = td_encode_batch_with_special(h_, buf.data(), offs.data(), (int64_t)texts.size(), ids.data(), (int64_t)ids.size(), out.data(),
-                                              (int64_t)out.size(), toffs.data(), &n);
-            if (rc == TD_E_CAPACITY && n > (int64_t)out.size()) {
-                out.resize((size_t)n);
-                rc = td_encode_batch_with_special(h_, buf.data(), offs.data(), (int64_t)texts.size(), ids.data(), (int64_t)ids.size(), out.data(),
-                                                  (int64_t)out.size(), toffs.data(), &n);
-            }
+            rc = td_encode_batch_with_special_strs(h_, buf.data(), offs.data(), (int64_t)texts.size(), ab.data(), ao.data(),
+                                                   (int64_t)allowed.size(), out.data(), out.cap, toffs.data(), &n);
         }
         if (rc != TD_OK) fail();
         std::vector<std::vector<int>> res(texts.size());
-        for (size_t d = 0; d < texts.size(); ++d) res[d].assign(out.begin() + toffs[d], out.begin() + toffs[d + 1]);
+        for (size_t d = 0; d < texts.size(); ++d) res[d].assign(out.data() + toffs[d], out.data() + toffs[d + 1]);
         return res;
     }
 

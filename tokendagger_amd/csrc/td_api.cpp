@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,26 @@ using namespace td;
 namespace {
 
 thread_local std::string g_create_err;
+// td_last_error(t) must not hand out a pointer into t->err, which another thread's call may be rewriting: every failing
+// call copies its message (under the handle's lock) into this thread's slot, and td_last_error reads the slot.
+thread_local std::string g_thread_err;
+thread_local const td_tokenizer* g_thread_err_owner = nullptr;
+
+// Entry points switch to the handle's device for their own duration only: the caller's current HIP device (torch's,
+// in a multi-GPU process) is what it was when the call returns, on every path, td_destroy from a finaliser included.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 #define HIP_TRY(t, expr)                                                                      \
     do {                                                                                      \
@@ -55,15 +76,20 @@ struct td_tokenizer {
     std::vector<Ev3> ev_pending, ev_free;
     int64_t last_long = 0;
     size_t ws_bytes = 0;
+    // One workspace per handle: work of this handle may be in flight on one stream at a time.  A call on another
+    // stream first waits (on the device, not the host) for the previous call's last kernel.
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+    std::vector<void*> graveyard;  // workspace buffers replaced by larger ones; freed at the next synchronisation point
 };
 
 namespace {
 
 int ensure(td_tokenizer* t, DevBuf& b, size_t bytes) {
     if (b.cap >= bytes && b.p) return TD_OK;
-    if (b.p) {
-        HIP_TRY(t, hipDeviceSynchronize());
-        HIP_TRY(t, hipFree(b.p));
+    if (b.p) {  // kernels of an earlier call may still read it: park it until the next synchronisation point
+        t->graveyard.push_back(b.p);
         t->ws_bytes -= b.cap;
         b.p = nullptr;
         b.cap = 0;
@@ -72,6 +98,43 @@ int ensure(td_tokenizer* t, DevBuf& b, size_t bytes) {
     HIP_TRY(t, hipMalloc(&b.p, want));
     b.cap = want;
     t->ws_bytes += want;
+    return TD_OK;
+}
+
+void bury(td_tokenizer* t) {  // caller has synchronised every stream this handle was used on
+    for (void* p : t->graveyard) (void)hipFree(p);
+    t->graveyard.clear();
+}
+
+// Runs f() with the handle locked and its device current; a failure's message is published to this thread's slot.
+template <class F>
+int locked(td_tokenizer* t, F&& f) {
+    std::lock_guard<std::mutex> g(t->mu);
+    DeviceGuard dg(t->device);
+    const int rc = f();
+    if (rc != TD_OK) {
+        g_thread_err = t->err;
+        g_thread_err_owner = t;
+    }
+    return rc;
+}
+int fail_unlocked(td_tokenizer* t, int rc, const std::string& msg) {  // argument errors found before taking the lock
+    g_thread_err = msg;
+    g_thread_err_owner = t;
+    return rc;
+}
+
+// Stream order across calls: the per-handle workspace and control block are reused by every call, so a call on a
+// stream other than the previous call's waits for that call's last kernel (device-side wait, no host stall).
+int order_before(td_tokenizer* t, hipStream_t stream) {
+    if (t->has_last && stream != t->last_stream) HIP_TRY(t, hipStreamWaitEvent(stream, t->last_done, 0));
+    return TD_OK;
+}
+int order_after(td_tokenizer* t, hipStream_t stream) {
+    if (!t->last_done) HIP_TRY(t, hipEventCreateWithFlags(&t->last_done, hipEventDisableTiming));
+    HIP_TRY(t, hipEventRecord(t->last_done, stream));
+    t->last_stream = stream;
+    t->has_last = true;
     return TD_OK;
 }
 
@@ -123,13 +186,13 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
         t->err = "td_encode_device: bad argument";
         return TD_E_INVALID;
     }
-    HIP_TRY(t, hipSetDevice(t->device));
+    int rc;
+    if ((rc = order_before(t, stream))) return rc;
     if (n == 0) {  // nothing but empty documents
         HIP_TRY(t, hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * 8, stream));
-        return TD_OK;
+        return order_after(t, stream);
     }
-    int rc = reserve_ws(t, n, n_docs);
-    if (rc) return rc;
+    if ((rc = reserve_ws(t, n, n_docs))) return rc;
     const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
     if (n_tiles > 0x7FFFFFF0ll) { t->err = "input too large"; return TD_E_INVALID; }
     EncodeArgs a;
@@ -181,12 +244,12 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
         t->ev_pending.push_back(ev);
     }
     HIP_TRY(t, launch_encode(a, stream, ev.e[0], ev.e[1], ev.e[2]));
-    return TD_OK;
+    return order_after(t, stream);
 }
 
 int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) {
-    HIP_TRY(t, hipSetDevice(t->device));
     HIP_TRY(t, hipStreamSynchronize(stream));
+    if (!t->has_last || t->last_stream == stream) bury(t);  // nothing of this handle is in flight any more
     if (!t->ctl.p) return TD_OK;
     Ctl c;
     HIP_TRY(t, hipMemcpy(&c, t->ctl.p, sizeof c, hipMemcpyDeviceToHost));
@@ -253,7 +316,11 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     }
     if (device >= ndev) { t->err = "device index out of range"; return fail(TD_E_INVALID); }
     t->device = device;
-    if (hipSetDevice(device) != hipSuccess) { t->err = "hipSetDevice failed"; return fail(TD_E_HIP); }
+    DeviceGuard dg(device);  // uploads go to the handle's device; the caller's current device is restored on return
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device) { t->err = "hipSetDevice failed"; return fail(TD_E_HIP); }
+    }
     const HostTables& H = t->H;
     const Tables hv = H.view();
     Tables d;
@@ -290,52 +357,67 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
 
 void td_destroy(td_tokenizer* t) {
     if (!t) return;
-    (void)hipSetDevice(t->device);
-    (void)hipDeviceSynchronize();
-    for (void* p : t->table_allocs) (void)hipFree(p);
-    for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
-    for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
-                      &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
-                      &t->dec_off, &t->dec_out};
-    for (DevBuf* b : bufs)
-        if (b->p) (void)hipFree(b->p);
+    {
+        DeviceGuard dg(t->device);  // reached from finalisers at arbitrary points: the caller's device must survive
+        (void)hipDeviceSynchronize();
+        bury(t);
+        for (void* p : t->table_allocs) (void)hipFree(p);
+        for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
+        for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
+        if (t->last_done) (void)hipEventDestroy(t->last_done);
+        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
+                          &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
+                          &t->dec_off, &t->dec_out};
+        for (DevBuf* b : bufs)
+            if (b->p) (void)hipFree(b->p);
+    }
+    if (g_thread_err_owner == t) g_thread_err_owner = nullptr;
     delete t;
 }
 
-const char* td_last_error(const td_tokenizer* t) { return t ? t->err.c_str() : g_create_err.c_str(); }
+const char* td_last_error(const td_tokenizer* t) {
+    if (!t) return g_create_err.c_str();
+    // this thread's copy of the message of ITS last failing call on the handle (never a pointer into storage that
+    // another thread's call may be rewriting)
+    return g_thread_err_owner == t ? g_thread_err.c_str() : "";
+}
 
 int td_reserve(td_tokenizer* t, int64_t max_bytes, int64_t max_docs) {
     if (!t || max_bytes < 0 || max_docs < 0) return TD_E_INVALID;
-    std::lock_guard<std::mutex> g(t->mu);
-    HIP_TRY(t, hipSetDevice(t->device));
-    return reserve_ws(t, std::max<int64_t>(max_bytes, 1), max_docs);
+    return locked(t, [&] { return reserve_ws(t, std::max<int64_t>(max_bytes, 1), max_docs); });
 }
 
 int td_encode_device(td_tokenizer* t, const void* d_text, int64_t n_bytes, const void* d_doc_offsets, int64_t n_docs,
                      int mode, void* d_out_tokens, int64_t out_capacity, void* d_out_offsets, void* hip_stream) {
     if (!t) return TD_E_INVALID;
-    std::lock_guard<std::mutex> g(t->mu);
-    return encode_device_locked(t, d_text, n_bytes, d_doc_offsets, n_docs, mode, d_out_tokens, out_capacity,
-                                d_out_offsets, (hipStream_t)hip_stream);
+    return locked(t, [&] {
+        return encode_device_locked(t, d_text, n_bytes, d_doc_offsets, n_docs, mode, d_out_tokens, out_capacity,
+                                    d_out_offsets, (hipStream_t)hip_stream);
+    });
 }
 
 int td_device_status(td_tokenizer* t, void* hip_stream, int64_t* err_pos) {
     if (!t) return TD_E_INVALID;
-    std::lock_guard<std::mutex> g(t->mu);
-    return device_status_locked(t, (hipStream_t)hip_stream, err_pos);
+    return locked(t, [&] { return device_status_locked(t, (hipStream_t)hip_stream, err_pos); });
 }
 
-int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
-                    int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
-    if (!t || !doc_offsets || n_docs < 0 || !out_offsets || out_capacity < 0) return TD_E_INVALID;
-    std::lock_guard<std::mutex> g(t->mu);
-    const int64_t n = doc_offsets[n_docs];
-    if (doc_offsets[0] != 0 || n < 0 || (n > 0 && !text)) { t->err = "doc_offsets must start at 0 and be non-decreasing"; return TD_E_INVALID; }
+}  // extern "C"
+
+namespace {
+
+int check_offsets(td_tokenizer* t, const char* what, const int64_t* offs, int64_t n_docs, const void* payload) {
+    if (offs[0] != 0) { t->err = std::string(what) + " must start at 0"; return TD_E_INVALID; }
     for (int64_t d = 0; d < n_docs; ++d)
-        if (doc_offsets[d + 1] < doc_offsets[d]) { t->err = "doc_offsets must be non-decreasing"; return TD_E_INVALID; }
-    HIP_TRY(t, hipSetDevice(t->device));
+        if (offs[d + 1] < offs[d]) { t->err = std::string(what) + " must be non-decreasing"; return TD_E_INVALID; }
+    if (offs[n_docs] > 0 && !payload) { t->err = "null buffer with non-empty documents"; return TD_E_INVALID; }
+    return TD_OK;
+}
+
+int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
+                        int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
     int rc;
+    if ((rc = check_offsets(t, "doc_offsets", doc_offsets, n_docs, text))) return rc;
+    const int64_t n = doc_offsets[n_docs];
     if ((rc = ensure(t, t->h2d_text, (size_t)n + 64))) return rc;
     if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;
     if ((rc = ensure(t, t->d_offsets, (size_t)(n_docs + 1) * 8))) return rc;
@@ -343,6 +425,7 @@ int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_off
     const int64_t dev_cap = std::max<int64_t>(n, 1);
     if ((rc = ensure(t, t->d_tokens, (size_t)dev_cap * 4))) return rc;
     hipStream_t s = nullptr;
+    if ((rc = order_before(t, s))) return rc;
     if (n > 0) HIP_TRY(t, hipMemcpyAsync(t->h2d_text.p, text, (size_t)n, hipMemcpyHostToDevice, s));
     HIP_TRY(t, hipMemcpyAsync(t->h2d_offs.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
     rc = encode_device_locked(t, t->h2d_text.p, n, t->h2d_offs.p, n_docs, mode, t->d_tokens.p, dev_cap, t->d_offsets.p, s);
@@ -357,14 +440,14 @@ int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_off
         return TD_E_CAPACITY;
     }
     if (total > 0) {
-        if (!out_tokens) return TD_E_INVALID;
+        if (!out_tokens) { t->err = "null out_tokens"; return TD_E_INVALID; }
         HIP_TRY(t, hipMemcpy(out_tokens, t->d_tokens.p, (size_t)total * 4, hipMemcpyDeviceToHost));
     }
     return TD_OK;
 }
 
-static int decode_args(td_tokenizer* t, const void* d_tokens, int64_t n_tokens, void* d_out, int64_t out_cap, void* d_n_bytes,
-                       hipStream_t stream, DecodeArgs& a) {
+int decode_args(td_tokenizer* t, const void* d_tokens, int64_t n_tokens, void* d_out, int64_t out_cap, void* d_n_bytes,
+                hipStream_t stream, DecodeArgs& a) {
     int rc;
     const int64_t npref = ((n_tokens / 4096 + 4) + 1) & ~1ll;  // even: the offsets behind it stay 16-byte aligned
     if ((rc = ensure(t, t->dec_off, (size_t)(n_tokens + 4) * 4 + (size_t)npref * 8))) return rc;
@@ -381,105 +464,121 @@ static int decode_args(td_tokenizer* t, const void* d_tokens, int64_t n_tokens, 
     a.scan_done = &ctl->scan_done;
     a.err = &ctl->err;
     a.err_pos = &ctl->err_pos;
+    if ((rc = order_before(t, stream))) return rc;
     HIP_TRY(t, hipMemsetAsync(&ctl->scan_done, 0, 4, stream));
     return TD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
+                    int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
+    if (!t || !doc_offsets || n_docs < 0 || !out_offsets || out_capacity < 0) return TD_E_INVALID;
+    return locked(t, [&] { return encode_batch_locked(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens); });
 }
 
 int td_decode_device(td_tokenizer* t, const void* d_tokens, int64_t n_tokens, void* d_out, int64_t out_capacity, void* d_n_bytes,
                      void* hip_stream) {
     if (!t || n_tokens < 0 || (n_tokens > 0 && (!d_tokens || !d_out)) || out_capacity < 0) return TD_E_INVALID;
-    std::lock_guard<std::mutex> g(t->mu);
-    HIP_TRY(t, hipSetDevice(t->device));
-    hipStream_t s = (hipStream_t)hip_stream;
-    if (n_tokens == 0) {
-        if (d_n_bytes) HIP_TRY(t, hipMemsetAsync(d_n_bytes, 0, 8, s));
-        return TD_OK;
-    }
-    DecodeArgs a;
-    int rc = decode_args(t, d_tokens, n_tokens, d_out, out_capacity, d_n_bytes, s, a);
-    if (rc) return rc;
-    HIP_TRY(t, launch_decode(a, s, 3));
-    return TD_OK;
+    return locked(t, [&] {
+        hipStream_t s = (hipStream_t)hip_stream;
+        if (n_tokens == 0) {
+            if (d_n_bytes) HIP_TRY(t, hipMemsetAsync(d_n_bytes, 0, 8, s));
+            return (int)TD_OK;
+        }
+        DecodeArgs a;
+        int rc = decode_args(t, d_tokens, n_tokens, d_out, out_capacity, d_n_bytes, s, a);
+        if (rc) return rc;
+        HIP_TRY(t, launch_decode(a, s, 3));
+        return order_after(t, s);
+    });
 }
 
 int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, uint8_t* out, int64_t out_capacity,
                     int64_t* n_bytes) {
     if (!t || n_tokens < 0 || (n_tokens > 0 && !tokens)) return TD_E_INVALID;
-    std::lock_guard<std::mutex> g(t->mu);
     if (n_bytes) *n_bytes = 0;
     if (n_tokens == 0) return TD_OK;
-    HIP_TRY(t, hipSetDevice(t->device));
-    int rc;
-    if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4 + 16))) return rc;
-    HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
-    // lengths and offsets first: the byte total sizes the device buffer of the gather
-    DecodeArgs a;
-    if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, nullptr, a))) return rc;
-    HIP_TRY(t, launch_decode(a, nullptr, 1));
-    int64_t err_pos = 0;
-    rc = device_status_locked(t, nullptr, &err_pos);
-    if (rc == TD_E_BAD_TOKEN && err_pos >= 0 && err_pos < n_tokens)
-        t->err = "Invalid token for decoding: " + std::to_string(tokens[err_pos]);  // reference: tiktoken.cpp:249
-    if (rc) return rc;
-    int64_t total = 0;
-    HIP_TRY(t, hipMemcpy(&total, a.chunk_pref + (n_tokens + 4095) / 4096, 8, hipMemcpyDeviceToHost));
-    if (n_bytes) *n_bytes = total;
-    if (total > out_capacity) { t->err = "decode capacity too small"; return TD_E_CAPACITY; }
-    if ((rc = ensure(t, t->dec_out, (size_t)total + 16))) return rc;
-    a.out = (uint8_t*)t->dec_out.p;
-    a.out_cap = total;
-    HIP_TRY(t, launch_decode(a, nullptr, 2));
-    rc = device_status_locked(t, nullptr, nullptr);
-    if (rc) return rc;
-    if (total > 0) HIP_TRY(t, hipMemcpy(out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost));
-    return TD_OK;
+    return locked(t, [&] {
+        int rc;
+        if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4 + 16))) return rc;
+        if ((rc = order_before(t, nullptr))) return rc;
+        HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
+        // lengths and offsets first: the byte total sizes the device buffer of the gather
+        DecodeArgs a;
+        if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, nullptr, a))) return rc;
+        HIP_TRY(t, launch_decode(a, nullptr, 1));
+        if ((rc = order_after(t, nullptr))) return rc;
+        int64_t err_pos = 0;
+        rc = device_status_locked(t, nullptr, &err_pos);
+        if (rc == TD_E_BAD_TOKEN && err_pos >= 0 && err_pos < n_tokens)
+            t->err = "Invalid token for decoding: " + std::to_string(tokens[err_pos]);  // reference: tiktoken.cpp:249
+        if (rc) return rc;
+        int64_t total = 0;
+        HIP_TRY(t, hipMemcpy(&total, a.chunk_pref + (n_tokens + 4095) / 4096, 8, hipMemcpyDeviceToHost));
+        if (n_bytes) *n_bytes = total;
+        if (total > out_capacity) { t->err = "decode capacity too small"; return (int)TD_E_CAPACITY; }
+        if (total > 0 && !out) { t->err = "null out"; return (int)TD_E_INVALID; }
+        if ((rc = ensure(t, t->dec_out, (size_t)total + 16))) return rc;
+        a.out = (uint8_t*)t->dec_out.p;
+        a.out_cap = total;
+        HIP_TRY(t, launch_decode(a, nullptr, 2));
+        if ((rc = order_after(t, nullptr))) return rc;
+        rc = device_status_locked(t, nullptr, nullptr);
+        if (rc) return rc;
+        if (total > 0) HIP_TRY(t, hipMemcpy(out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost));
+        return (int)TD_OK;
+    });
 }
 
 int td_decode_batch(td_tokenizer* t, const int32_t* tokens, const int64_t* tok_offsets, int64_t n_docs, uint8_t* out,
                     int64_t out_capacity, int64_t* out_offsets, int64_t* n_bytes) {
     if (!t || !tok_offsets || n_docs < 0 || !out_offsets) return TD_E_INVALID;
-    std::lock_guard<std::mutex> g(t->mu);
-    const int64_t n_tokens = tok_offsets[n_docs];
-    if (tok_offsets[0] != 0 || n_tokens < 0 || (n_tokens > 0 && !tokens)) { t->err = "tok_offsets must start at 0"; return TD_E_INVALID; }
-    for (int64_t d = 0; d < n_docs; ++d)
-        if (tok_offsets[d + 1] < tok_offsets[d]) { t->err = "tok_offsets must be non-decreasing"; return TD_E_INVALID; }
     if (n_bytes) *n_bytes = 0;
-    if (n_tokens == 0) {
-        for (int64_t d = 0; d <= n_docs; ++d) out_offsets[d] = 0;
-        return TD_OK;
-    }
-    HIP_TRY(t, hipSetDevice(t->device));
-    int rc;
-    if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4 + 16))) return rc;
-    if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;
-    if ((rc = ensure(t, t->d_offsets, (size_t)(n_docs + 1) * 8))) return rc;
-    HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
-    HIP_TRY(t, hipMemcpy(t->h2d_offs.p, tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
-    DecodeArgs a;
-    if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, nullptr, a))) return rc;
-    a.doc_tok_offsets = (const int64_t*)t->h2d_offs.p;
-    a.n_docs = n_docs;
-    a.doc_byte_offsets = (int64_t*)t->d_offsets.p;
-    HIP_TRY(t, launch_decode(a, nullptr, 1));
-    int64_t err_pos = 0;
-    rc = device_status_locked(t, nullptr, &err_pos);
-    if (rc == TD_E_BAD_TOKEN && err_pos >= 0 && err_pos < n_tokens) t->err = "Invalid token for decoding: " + std::to_string(tokens[err_pos]);
-    if (rc) return rc;
-    HIP_TRY(t, hipMemcpy(out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
-    const int64_t total = out_offsets[n_docs];
-    if (n_bytes) *n_bytes = total;
-    if (total > out_capacity) { t->err = "decode capacity too small"; return TD_E_CAPACITY; }
-    if ((rc = ensure(t, t->dec_out, (size_t)total + 16))) return rc;
-    a.out = (uint8_t*)t->dec_out.p;
-    a.out_cap = total;
-    HIP_TRY(t, launch_decode(a, nullptr, 2));
-    rc = device_status_locked(t, nullptr, nullptr);
-    if (rc) return rc;
-    if (total > 0) {
-        if (!out) return TD_E_INVALID;
-        HIP_TRY(t, hipMemcpy(out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost));
-    }
-    return TD_OK;
+    return locked(t, [&] {
+        int rc;
+        if ((rc = check_offsets(t, "tok_offsets", tok_offsets, n_docs, tokens))) return rc;
+        const int64_t n_tokens = tok_offsets[n_docs];
+        if (n_tokens == 0) {
+            for (int64_t d = 0; d <= n_docs; ++d) out_offsets[d] = 0;
+            return (int)TD_OK;
+        }
+        if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4 + 16))) return rc;
+        if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;
+        if ((rc = ensure(t, t->d_offsets, (size_t)(n_docs + 1) * 8))) return rc;
+        if ((rc = order_before(t, nullptr))) return rc;
+        HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
+        HIP_TRY(t, hipMemcpy(t->h2d_offs.p, tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+        DecodeArgs a;
+        if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, nullptr, a))) return rc;
+        a.doc_tok_offsets = (const int64_t*)t->h2d_offs.p;
+        a.n_docs = n_docs;
+        a.doc_byte_offsets = (int64_t*)t->d_offsets.p;
+        HIP_TRY(t, launch_decode(a, nullptr, 1));
+        if ((rc = order_after(t, nullptr))) return rc;
+        int64_t err_pos = 0;
+        rc = device_status_locked(t, nullptr, &err_pos);
+        if (rc == TD_E_BAD_TOKEN && err_pos >= 0 && err_pos < n_tokens) t->err = "Invalid token for decoding: " + std::to_string(tokens[err_pos]);
+        if (rc) return rc;
+        HIP_TRY(t, hipMemcpy(out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+        const int64_t total = out_offsets[n_docs];
+        if (n_bytes) *n_bytes = total;
+        if (total > out_capacity) { t->err = "decode capacity too small"; return (int)TD_E_CAPACITY; }
+        if ((rc = ensure(t, t->dec_out, (size_t)total + 16))) return rc;
+        a.out = (uint8_t*)t->dec_out.p;
+        a.out_cap = total;
+        HIP_TRY(t, launch_decode(a, nullptr, 2));
+        if ((rc = order_after(t, nullptr))) return rc;
+        rc = device_status_locked(t, nullptr, nullptr);
+        if (rc) return rc;
+        if (total > 0) {
+            if (!out) { t->err = "null out"; return (int)TD_E_INVALID; }
+            HIP_TRY(t, hipMemcpy(out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost));
+        }
+        return (int)TD_OK;
+    });
 }
 
 }  // extern "C" (reopened below)
@@ -492,9 +591,11 @@ struct SpecialIndex {
     bool first[256] = {};
     std::vector<std::vector<Ent>> bucket;  // [65536] by (b0 << 8 | b1), longest first; 1-byte specials in `single`
     std::vector<Ent> single[256];
+    size_t count = 0;
     SpecialIndex() : bucket(65536) {}
     void add(const std::string* s, int32_t id) {
         if (s->empty()) return;
+        ++count;
         const uint8_t b0 = (uint8_t)(*s)[0];
         first[b0] = true;
         if (s->size() == 1) single[b0].push_back({s, id});
@@ -515,73 +616,128 @@ struct SpecialIndex {
     }
 };
 
-int build_special_index(td_tokenizer* t, const int32_t* allowed_ids, int64_t n_allowed, SpecialIndex& ix) {
-    std::lock_guard<std::mutex> g(t->mu);
+// The allowed set arrives either as special-token STRINGS (exactly those literals are cut out, tiktoken's
+// allowed_special) or as ids (every special string that carries one of the ids — two strings may share an id).
+int build_special_index(td_tokenizer* t, const uint8_t* allowed_bytes, const int64_t* allowed_offsets, const int32_t* allowed_ids,
+                        int64_t n_allowed, SpecialIndex& ix) {
+    const HostTables& H = t->H;
     for (int64_t k = 0; k < n_allowed; ++k) {
         bool found = false;
-        for (size_t s = 0; s < t->H.special_ids.size(); ++s)
-            if (t->H.special_ids[s] == allowed_ids[k]) {
-                ix.add(&t->H.special_strs[s], allowed_ids[k]);
-                found = true;
-                break;
-            }
-        if (!found) {
-            t->err = "Special token id " + std::to_string(allowed_ids[k]) + " not found in special encoder";
-            return TD_E_SPECIAL;
+        if (allowed_offsets) {
+            const int64_t lo = allowed_offsets[k], hi = allowed_offsets[k + 1];
+            if (hi < lo) { t->err = "allowed_offsets must be non-decreasing"; return TD_E_INVALID; }
+            const std::string want((const char*)allowed_bytes + lo, (size_t)(hi - lo));
+            for (size_t s = 0; s < H.special_strs.size(); ++s)
+                if (H.special_strs[s] == want) { ix.add(&H.special_strs[s], H.special_ids[s]); found = true; break; }
+            if (!found) { t->err = "Special token '" + want + "' not found in special encoder"; return TD_E_SPECIAL; }  // tiktoken.cpp:178-180
+        } else {
+            for (size_t s = 0; s < H.special_ids.size(); ++s)
+                if (H.special_ids[s] == allowed_ids[k]) { ix.add(&H.special_strs[s], allowed_ids[k]); found = true; }
+            if (!found) { t->err = "Special token id " + std::to_string(allowed_ids[k]) + " not found in special encoder"; return TD_E_SPECIAL; }
         }
     }
     ix.finish();
     return TD_OK;
 }
 
-// text[lo, hi) -> ordinary segments appended to seg_text / seg_offs, the special id that follows each in seg_special
-// (-1 after the last segment of the document)
-void segment_document(const SpecialIndex& ix, const uint8_t* text, int64_t lo, int64_t hi, std::vector<uint8_t>& seg_text,
-                      std::vector<int64_t>& seg_offs, std::vector<int32_t>& seg_special) {
-    int64_t start = lo;
-    for (int64_t p = lo; p < hi;) {
-        const SpecialIndex::Ent* e = ix.match(text, p, hi);
-        if (!e) { ++p; continue; }
-        seg_text.insert(seg_text.end(), text + start, text + p);
-        seg_offs.push_back((int64_t)seg_text.size());
-        seg_special.push_back(e->id);
-        p += (int64_t)e->s->size();
-        start = p;
-    }
-    seg_text.insert(seg_text.end(), text + start, text + hi);
-    seg_offs.push_back((int64_t)seg_text.size());
-    seg_special.push_back(-1);
-}
-}  // namespace
+struct Segments {  // ordinary text between allowed special tokens, as one batch for the device
+    std::vector<int64_t> seg_offs{0};   // into the ORIGINAL text when `compact` is false, else into seg_text
+    std::vector<int64_t> seg_src;       // start of each segment in the original text
+    std::vector<int32_t> seg_special;   // special id that follows each segment, -1 after a document's last one
+    std::vector<int64_t> doc_seg{0};    // first segment of each document
+};
 
-extern "C" int td_encode_batch_with_special(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
-                                            const int32_t* allowed_ids, int64_t n_allowed, int32_t* out_tokens,
-                                            int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
-    if (!t || !doc_offsets || n_docs < 0 || n_allowed < 0 || (n_allowed > 0 && !allowed_ids) || !out_offsets) return TD_E_INVALID;
-    for (int64_t d = 0; d < n_docs; ++d)
-        if (doc_offsets[d + 1] < doc_offsets[d] || doc_offsets[0] != 0) { t->err = "doc_offsets must start at 0 and be non-decreasing"; return TD_E_INVALID; }
+// document text[lo, hi) -> (start, end) of its ordinary segments + the special id that follows each
+void segment_document(const SpecialIndex& ix, const uint8_t* text, int64_t lo, int64_t hi, std::vector<int64_t>& starts,
+                      std::vector<int64_t>& ends, std::vector<int32_t>& seg_special) {
+    int64_t start = lo;
+    if (ix.count)
+        for (int64_t p = lo; p < hi;) {
+            // memchr-speed skip to the next byte that can begin an allowed special
+            const SpecialIndex::Ent* e = ix.match(text, p, hi);
+            if (!e) { ++p; continue; }
+            starts.push_back(start); ends.push_back(p); seg_special.push_back(e->id);
+            p += (int64_t)e->s->size();
+            start = p;
+        }
+    starts.push_back(start); ends.push_back(hi); seg_special.push_back(-1);
+}
+
+// Shared body of the two *_with_special entry points (handle locked by the caller).
+int encode_special_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
+                          const uint8_t* allowed_bytes, const int64_t* allowed_offsets, const int32_t* allowed_ids, int64_t n_allowed,
+                          int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens,
+                          int64_t* last_seg_lo, int64_t* last_seg_hi) {
+    int rc;
+    if ((rc = check_offsets(t, "doc_offsets", doc_offsets, n_docs, text))) return rc;
     SpecialIndex ix;
-    int rc = build_special_index(t, allowed_ids, n_allowed, ix);
-    if (rc) return rc;
-    std::vector<uint8_t> seg_text;
-    std::vector<int64_t> seg_offs{0}, doc_seg{0};
+    if ((rc = build_special_index(t, allowed_bytes, allowed_offsets, allowed_ids, n_allowed, ix))) return rc;
+    // 1. host: cut every document at the earliest occurrences of allowed special strings (tiktoken semantics; the
+    //    reference's own loop, tiktoken.cpp:130-154,187-231, has iterator-invalidation UB).  Documents are independent:
+    //    a few host threads take contiguous document ranges.
+    std::vector<int64_t> starts, ends, doc_seg{0};
     std::vector<int32_t> seg_special;
-    seg_text.reserve((size_t)doc_offsets[n_docs]);
-    for (int64_t d = 0; d < n_docs; ++d) {
-        segment_document(ix, text, doc_offsets[d], doc_offsets[d + 1], seg_text, seg_offs, seg_special);
-        doc_seg.push_back((int64_t)seg_special.size());
+    {
+        const int64_t n = doc_offsets[n_docs];
+        unsigned hw = std::thread::hardware_concurrency();
+        int nth = (int)std::min<int64_t>(hw ? std::min(hw, 32u) : 4, std::max<int64_t>(1, n >> 22));  // one thread per 4 MiB, at most 32
+        if (nth <= 1 || n_docs < 2 * nth || ix.count == 0) {
+            for (int64_t d = 0; d < n_docs; ++d) {
+                segment_document(ix, text, doc_offsets[d], doc_offsets[d + 1], starts, ends, seg_special);
+                doc_seg.push_back((int64_t)seg_special.size());
+            }
+        } else {
+            struct Part { std::vector<int64_t> starts, ends, per_doc; std::vector<int32_t> sp; };
+            std::vector<Part> parts((size_t)nth);
+            std::vector<std::thread> th;
+            for (int k = 0; k < nth; ++k)
+                th.emplace_back([&, k] {
+                    Part& P = parts[(size_t)k];
+                    const int64_t da = n_docs * k / nth, db = n_docs * (k + 1) / nth;
+                    for (int64_t d = da; d < db; ++d) {
+                        segment_document(ix, text, doc_offsets[d], doc_offsets[d + 1], P.starts, P.ends, P.sp);
+                        P.per_doc.push_back((int64_t)P.sp.size());
+                    }
+                });
+            for (auto& x : th) x.join();
+            for (Part& P : parts) {
+                const int64_t base = (int64_t)seg_special.size();
+                starts.insert(starts.end(), P.starts.begin(), P.starts.end());
+                ends.insert(ends.end(), P.ends.begin(), P.ends.end());
+                seg_special.insert(seg_special.end(), P.sp.begin(), P.sp.end());
+                for (int64_t v : P.per_doc) doc_seg.push_back(base + v);
+            }
+        }
     }
     const int64_t nseg = (int64_t)seg_special.size();
-    std::vector<int32_t> toks((size_t)std::max<int64_t>((int64_t)seg_text.size(), 1));
-    std::vector<int64_t> toffs((size_t)nseg + 1);
-    int64_t ntok = 0;
-    rc = td_encode_batch(t, seg_text.data(), seg_offs.data(), nseg, TD_MODE_ENCODE, toks.data(), (int64_t)toks.size(), toffs.data(), &ntok);
-    if (rc) return rc;
+    if (last_seg_lo && nseg) { *last_seg_lo = starts[(size_t)nseg - 1]; *last_seg_hi = ends[(size_t)nseg - 1]; }
+    // 2. device: all ordinary segments of all documents as ONE batch.  No special was cut out: the segments are the
+    //    documents and the text goes down as it is; otherwise the segments are packed (the specials drop out).
     int64_t n_special = 0;
     for (int32_t v : seg_special) n_special += v >= 0;
+    std::vector<int64_t> toffs((size_t)nseg + 1);
+    int64_t ntok = 0;
+    if (n_special == 0) {
+        rc = encode_batch_locked(t, text, doc_offsets, n_docs, TD_MODE_ENCODE, out_tokens, out_capacity, out_offsets, &ntok);
+        if (n_tokens) *n_tokens = ntok;
+        return rc;
+    }
+    std::vector<uint8_t> seg_text;
+    std::vector<int64_t> seg_offs((size_t)nseg + 1, 0);
+    {
+        int64_t tot = 0;
+        for (int64_t sg = 0; sg < nseg; ++sg) { tot += ends[(size_t)sg] - starts[(size_t)sg]; seg_offs[(size_t)sg + 1] = tot; }
+        seg_text.resize((size_t)std::max<int64_t>(tot, 1));
+        for (int64_t sg = 0; sg < nseg; ++sg)
+            if (ends[(size_t)sg] > starts[(size_t)sg])
+                memcpy(seg_text.data() + seg_offs[(size_t)sg], text + starts[(size_t)sg], (size_t)(ends[(size_t)sg] - starts[(size_t)sg]));
+    }
+    std::vector<int32_t> toks((size_t)std::max<int64_t>(seg_offs[(size_t)nseg], 1));
+    rc = encode_batch_locked(t, seg_text.data(), seg_offs.data(), nseg, TD_MODE_ENCODE, toks.data(), (int64_t)toks.size(), toffs.data(), &ntok);
+    if (rc) return rc;
+    // 3. stitch: offsets first (they do not need the capacity), then the ids
     const int64_t need = ntok + n_special;
     if (n_tokens) *n_tokens = need;
-    // offsets first (they do not need the capacity), then the ids
     int64_t k = 0;
     for (int64_t d = 0; d < n_docs; ++d) {
         out_offsets[d] = k;
@@ -589,7 +745,7 @@ extern "C" int td_encode_batch_with_special(td_tokenizer* t, const uint8_t* text
     }
     out_offsets[n_docs] = k;
     if (need > out_capacity) { t->err = "output capacity too small: " + std::to_string(need) + " tokens needed"; return TD_E_CAPACITY; }
-    if (need > 0 && !out_tokens) return TD_E_INVALID;
+    if (need > 0 && !out_tokens) { t->err = "null out_tokens"; return TD_E_INVALID; }
     k = 0;
     for (int64_t sg = 0; sg < nseg; ++sg) {
         const int64_t cnt = toffs[(size_t)sg + 1] - toffs[(size_t)sg];
@@ -600,74 +756,90 @@ extern "C" int td_encode_batch_with_special(td_tokenizer* t, const uint8_t* text
     return TD_OK;
 }
 
+// Second element of the reference's return pair (tiktoken.cpp:185,213,218,225): number of ids of the last regex piece
+// of the trailing ordinary segment text[s_lo, s_hi), 0 after a special.  Metadata only, derived on the host tables.
+int32_t last_piece_token_len_host(td_tokenizer* t, const uint8_t* text, int64_t s_lo, int64_t s_hi) {
+    if (s_hi <= s_lo) return 0;
+    struct HostAcc {
+        using pos_t = int64_t;
+        const Tables* T; const uint8_t* p; int64_t lo, hi, lim;
+        uint32_t byte(int64_t i) const { return i < hi ? p[i] : 0u; }
+        bool doc(int64_t i) const { return i == lo; }
+        uint32_t cf(int64_t i) const {
+            if (i >= hi) return F_DOC;
+            uint32_t v = classify_at(*T, *this, i);
+            if (i == lo) v |= F_DOC;
+            return v;
+        }
+    };
+    const Tables hv = t->H.view();
+    HostAcc A{&hv, text, s_lo, s_hi, s_hi + 4};
+    int64_t p = s_lo, last = s_lo;
+    while (p < s_hi) { last = p; p = scan_piece(A, p, hv.pat_flags); }
+    std::vector<int32_t> tmp;
+    const uint32_t len = (uint32_t)(s_hi - last);
+    const uint8_t* pb = text + last;
+    const int32_t whole = (len == 1) ? t->H.byte_id[pb[0]]
+                                     : piece_lookup(hv, piece_key_host(pb, len), len, [pb](uint32_t i) { return (uint32_t)pb[i]; });
+    if (whole != NO_RANK) return 1;
+    if (merge_piece_host(hv, pb, len, tmp) == TD_OK) return (int32_t)tmp.size();
+    return 0;
+}
+}  // namespace
+
 extern "C" {
+
+int td_encode_batch_with_special(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
+                                 const int32_t* allowed_ids, int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity,
+                                 int64_t* out_offsets, int64_t* n_tokens) {
+    if (!t || !doc_offsets || n_docs < 0 || n_allowed < 0 || (n_allowed > 0 && !allowed_ids) || !out_offsets || out_capacity < 0) return TD_E_INVALID;
+    return locked(t, [&] {
+        return encode_special_locked(t, text, doc_offsets, n_docs, nullptr, nullptr, allowed_ids, n_allowed, out_tokens, out_capacity,
+                                     out_offsets, n_tokens, nullptr, nullptr);
+    });
+}
+
+int td_encode_batch_with_special_strs(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
+                                      const uint8_t* allowed_bytes, const int64_t* allowed_offsets, int64_t n_allowed,
+                                      int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
+    if (!t || !doc_offsets || n_docs < 0 || n_allowed < 0 || (n_allowed > 0 && (!allowed_bytes || !allowed_offsets)) || !out_offsets ||
+        out_capacity < 0)
+        return TD_E_INVALID;
+    static const int64_t no_offs[1] = {0};
+    return locked(t, [&] {
+        return encode_special_locked(t, text, doc_offsets, n_docs, allowed_bytes, n_allowed ? allowed_offsets : no_offs, nullptr, n_allowed,
+                                     out_tokens, out_capacity, out_offsets, n_tokens, nullptr, nullptr);
+    });
+}
+
 int td_encode_with_special(td_tokenizer* t, const uint8_t* text, int64_t n_bytes, const int32_t* allowed_ids,
                            int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity, int64_t* n_tokens,
                            int32_t* last_piece_token_len) {
-    if (!t || n_bytes < 0 || n_allowed < 0 || (n_allowed > 0 && !allowed_ids)) return TD_E_INVALID;
-    // 1. host: cut the text at the earliest occurrences of allowed special strings (tiktoken semantics;
-    //    the reference's own loop, tiktoken.cpp:130-154,187-231, has iterator-invalidation UB)
-    SpecialIndex ix;
-    {
-        const int rc0 = build_special_index(t, allowed_ids, n_allowed, ix);
-        if (rc0) return rc0;
-    }
-    std::vector<uint8_t> seg_text;
-    std::vector<int64_t> seg_offs{0};
-    std::vector<int32_t> seg_special;  // special id following each segment, -1 for the last one
-    seg_text.reserve((size_t)n_bytes);
-    segment_document(ix, text, 0, n_bytes, seg_text, seg_offs, seg_special);
-    // 2. device: all ordinary segments as one batch
-    const int64_t nseg = (int64_t)seg_special.size();
-    std::vector<int32_t> toks((size_t)std::max<int64_t>((int64_t)seg_text.size(), 1));
-    std::vector<int64_t> toffs((size_t)nseg + 1);
-    int64_t ntok = 0;
-    int rc = td_encode_batch(t, seg_text.data(), seg_offs.data(), nseg, TD_MODE_ENCODE, toks.data(), (int64_t)toks.size(),
-                             toffs.data(), &ntok);
-    if (rc) return rc;
-    // 3. stitch
-    int64_t k = 0;
-    const int64_t need = ntok + (nseg - 1);
-    if (n_tokens) *n_tokens = need;
-    if (need > out_capacity) { t->err = "output capacity too small"; return TD_E_CAPACITY; }
-    for (int64_t s = 0; s < nseg; ++s) {
-        for (int64_t i = toffs[s]; i < toffs[s + 1]; ++i) out_tokens[k++] = toks[(size_t)i];
-        if (seg_special[s] >= 0) out_tokens[k++] = seg_special[s];
-    }
-    if (last_piece_token_len) {
-        // metadata only (second element of the reference's return pair, tiktoken.cpp:185,213,218,225):
-        // number of ids of the last regex piece of the trailing ordinary segment, 0 after a special.
-        *last_piece_token_len = 0;
-        const int64_t s_lo = seg_offs[nseg - 1], s_hi = seg_offs[nseg];
-        if (s_hi > s_lo) {
-            struct HostAcc {
-                using pos_t = int64_t;
-                const Tables* T; const uint8_t* p; int64_t lo, hi, lim;
-                uint32_t byte(int64_t i) const { return i < hi ? p[i] : 0u; }
-                bool doc(int64_t i) const { return i == lo; }
-                uint32_t cf(int64_t i) const {
-                    if (i >= hi) return F_DOC;
-                    uint32_t v = classify_at(*T, *this, i);
-                    if (i == lo) v |= F_DOC;
-                    return v;
-                }
-            };
-            const Tables hv = t->H.view();
-            HostAcc A{&hv, seg_text.data(), s_lo, s_hi, s_hi + 4};
-            int64_t p = s_lo, last = s_lo;
-            while (p < s_hi) { last = p; p = scan_piece(A, p, hv.pat_flags); }
-            // ids of that piece == the tail of the batch result that starts at its first byte; count them
-            // by re-deriving the piece's merge on the host tables (metadata, not the id path)
-            std::vector<int32_t> tmp;
-            const uint32_t len = (uint32_t)(s_hi - last);
-            const uint8_t* pb = seg_text.data() + last;
-            int32_t whole = (len == 1) ? t->H.byte_id[pb[0]]
-                                       : piece_lookup(hv, piece_key_host(pb, len), len, [pb](uint32_t i) { return (uint32_t)pb[i]; });
-            if (whole != NO_RANK) *last_piece_token_len = 1;
-            else if (merge_piece_host(hv, pb, len, tmp) == TD_OK) *last_piece_token_len = (int32_t)tmp.size();
-        }
-    }
-    return TD_OK;
+    if (!t || n_bytes < 0 || (n_bytes > 0 && !text) || n_allowed < 0 || (n_allowed > 0 && !allowed_ids) || out_capacity < 0) return TD_E_INVALID;
+    return locked(t, [&] {
+        const int64_t doc[2] = {0, n_bytes};
+        int64_t offs[2] = {0, 0}, lo = 0, hi = 0;
+        const int rc = encode_special_locked(t, text, doc, 1, nullptr, nullptr, allowed_ids, n_allowed, out_tokens, out_capacity, offs,
+                                             n_tokens, &lo, &hi);
+        if (rc == TD_OK && last_piece_token_len) *last_piece_token_len = last_piece_token_len_host(t, text, lo, hi);
+        return rc;
+    });
+}
+
+int td_encode_with_special_strs(td_tokenizer* t, const uint8_t* text, int64_t n_bytes, const uint8_t* allowed_bytes,
+                                const int64_t* allowed_offsets, int64_t n_allowed, int32_t* out_tokens, int64_t out_capacity,
+                                int64_t* n_tokens, int32_t* last_piece_token_len) {
+    if (!t || n_bytes < 0 || (n_bytes > 0 && !text) || n_allowed < 0 || (n_allowed > 0 && (!allowed_bytes || !allowed_offsets)) || out_capacity < 0)
+        return TD_E_INVALID;
+    static const int64_t no_offs[1] = {0};
+    return locked(t, [&] {
+        const int64_t doc[2] = {0, n_bytes};
+        int64_t offs[2] = {0, 0}, lo = 0, hi = 0;
+        const int rc = encode_special_locked(t, text, doc, 1, allowed_bytes, n_allowed ? allowed_offsets : no_offs, nullptr, n_allowed,
+                                             out_tokens, out_capacity, offs, n_tokens, &lo, &hi);
+        if (rc == TD_OK && last_piece_token_len) *last_piece_token_len = last_piece_token_len_host(t, text, lo, hi);
+        return rc;
+    });
 }
 
 int64_t td_info(const td_tokenizer* t, int what) {
@@ -704,7 +876,7 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
 
 int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum, int64_t* launches) {
     if (!t) return TD_E_INVALID;
-    std::lock_guard<std::mutex> g(t->mu);
+    return locked(t, [&] {
     double s0 = 0, s1 = 0;
     int64_t n = 0;
     for (auto& ev : t->ev_pending) {
@@ -721,7 +893,8 @@ int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum
     if (split_ms_sum) *split_ms_sum = s0;
     if (encode_ms_sum) *encode_ms_sum = s1;
     if (launches) *launches = n;
-    return TD_OK;
+    return (int)TD_OK;
+    });
 }
 
 int64_t td_special_count(const td_tokenizer* t) { return t ? (int64_t)t->H.special_ids.size() : 0; }

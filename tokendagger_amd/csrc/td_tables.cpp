@@ -27,6 +27,9 @@ static const char kCl100k[] =
 static const char kCl100kPossessive[] =
     "'(?i:[sdmt]|ll|ve|re)|[^\\r\\n\\p{L}\\p{N}]?+\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]++[\\r\\n]*|\\s*[\\r\\n]|\\s+(?!\\S)|\\s+";
 
+static const char kCl100kCurrent[] =  // cl100k_base as tiktoken ships it today (openai_public.py): possessive everywhere, \s++$ spelled out
+    "'(?i:[sdmt]|ll|ve|re)|[^\\r\\n\\p{L}\\p{N}]?+\\p{L}++|\\p{N}{1,3}+| ?[^\\s\\p{L}\\p{N}]++[\\r\\n]*+|\\s++$|\\s*[\\r\\n]|\\s+(?!\\S)|\\s";
+
 static const char kGpt2[] =
     "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
 
@@ -40,7 +43,7 @@ const char* cl100k_pattern() { return kCl100k; }
 PatternKind classify_pattern(const std::string& pat) {
     if (pat == kO200k) return PATTERN_O200K;
     if (pat == kTekken) return PATTERN_TEKKEN;
-    if (pat == kCl100k || pat == kCl100kPossessive) return PATTERN_CL100K;
+    if (pat == kCl100k || pat == kCl100kPossessive || pat == kCl100kCurrent) return PATTERN_CL100K;
     if (pat == kGpt2 || pat == kGpt2Possessive) return PATTERN_GPT2;
     return PATTERN_UNSUPPORTED;
 }

@@ -38,6 +38,11 @@ CL100K_PAT_STR_POSSESSIVE = (
     r"'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]++[\r\n]*|\s*[\r\n]|\s+(?!\S)|\s+"
 )
 
+# cl100k_base as current tiktoken releases spell it (tiktoken_ext/openai_public.py): the same language again
+CL100K_PAT_STR_CURRENT = (
+    r"'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}++|\p{N}{1,3}+| ?[^\s\p{L}\p{N}]++[\r\n]*+|\s++$|\s*[\r\n]|\s+(?!\S)|\s"
+)
+
 # GPT-2 (r50k_base / p50k_base) split pattern
 GPT2_PAT_STR = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
 
