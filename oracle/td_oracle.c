@@ -102,10 +102,12 @@ static int64_t contraction(const uint8_t* s, int64_t e, int64_t n) {
  * config.pattern, read by tests/throughput_test.py:118): the same alternatives without the contraction suffix and with
  * \p{N} in place of \p{N}{1,3}. */
 static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n);
+static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int eos_first);
 static int64_t next_piece_gpt2(const uint8_t* s, int64_t pos, int64_t n);
 static int64_t next_piece_llama4(const uint8_t* s, int64_t pos, int64_t n, int variant) {
     if (variant == 2) return next_piece_cl100k(s, pos, n);
     if (variant == 3) return next_piece_gpt2(s, pos, n);
+    if (variant == 4) return next_piece_cl100k_v(s, pos, n, 1);
     const int contr = variant == 0, nmax = variant == 0 ? 3 : 1;
     int l0;
     int c0 = char_at(s, pos, n, &l0, NULL);
@@ -193,7 +195,13 @@ static int64_t next_piece_llama4(const uint8_t* s, int64_t pos, int64_t n, int v
  *   (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
  * \p{L} has no marks here: a combining mark is [^\s\p{L}\p{N}]. */
 static int is_L2(int c) { return c == C_UP || c == C_LW || c == C_LB; }
-static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n) {
+/* variant 4: cl100k_base as current tiktoken releases spell it,
+ *   '(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}++|\p{N}{1,3}+| ?[^\s\p{L}\p{N}]++[\r\n]*+|\s++$|\s*[\r\n]|\s+(?!\S)|\s
+ * : the possessive quantifiers change nothing, but `\s++$` now stands IN FRONT of `\s*[\r\n]`, so a whitespace run that
+ * reaches the end of the subject is one piece even if it contains CR/LF (eos_first). */
+static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int eos_first);
+static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n) { return next_piece_cl100k_v(s, pos, n, 0); }
+static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int eos_first) {
     int l0;
     int c0 = char_at(s, pos, n, &l0, NULL);
     /* alternative 1: the contraction on its own */
@@ -241,6 +249,7 @@ static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n) {
             q += l;
         }
         if (q > pos) {
+            if (eos_first && q == n) return q;
             if (last_crlf_end >= 0) return last_crlf_end;
             if (q == n) return q;
             if (last_char > pos) return last_char;

@@ -42,12 +42,24 @@ def test_restatement_vs_compiled_reference_fuzz_and_possessive_spelling():
     R, O = H.ref_tokenizer_cl100k(), H.port_tokenizer_cl100k()
     _, mr, special = H.llama4()
     R2 = ref.RefTokenizer(vocab_io.CL100K_PAT_STR_POSSESSIVE, mr, special)  # tiktoken's later spelling: same language
+    # the spelling current tiktoken releases ship puts `\s++$` in front of `\s*[\r\n]`: NOT the same language (a trailing
+    # whitespace run that contains CR/LF is one piece) -> a variant of its own in the restatement and a scanner flag
+    R3 = ref.RefTokenizer(vocab_io.CL100K_PAT_STR_CURRENT, mr, special)
+    O3 = port.OracleTokenizer(mr, port.VARIANT_CL100K_EOS)
+    tw3 = H.Twin(vocab_io.CL100K_PAT_STR_CURRENT, {bytes([i]): i for i in range(256)})
+    assert H.Twin(vocab_io.CL100K_PAT_STR_POSSESSIVE, {bytes([i]): i for i in range(256)}).info(3) == 255
+    assert not np.array_equal(R3.split(b"ab\r\t"), R.split(b"ab\r\t"))
     rng = random.Random(13)
     for i in range(4000):
         s = (EDGE[i] if i < len(EDGE) else H.fuzz_string(rng) if i % 2 else H.random_unicode_string(rng)).encode("utf-8")
         want = R.split(s)
         assert np.array_equal(port.split(s, port.VARIANT_CL100K), want), repr(s)
         assert np.array_equal(R2.split(s), want), repr(s)
+        want3 = R3.split(s)
+        assert np.array_equal(port.split(s, port.VARIANT_CL100K_EOS), want3), repr(s)
+        if len(s):
+            assert np.array_equal(tw3.split_serial(s), np.concatenate([[0], want3[:-1]])), repr(s)
+        assert np.array_equal(O3.encode(s), R3.encode(s)), repr(s)
         assert np.array_equal(O.encode(s), R.encode(s)), repr(s)
 
 
@@ -120,3 +132,25 @@ def test_gpu_cl100k_style_parity(golden, cl100k_golden):
         toks, toffs = tok.encode_batch(x, o)
         etoks, eoffs = O.encode_batch(x.tobytes(), o)
         assert np.array_equal(toffs, eoffs) and np.array_equal(toks, etoks)
+
+
+@pytest.mark.gpu
+def test_gpu_current_tiktoken_spelling_is_its_own_variant():
+    """`\\s++$` ahead of `\\s*[\\r\\n]` (cl100k_base in current tiktoken releases): trailing whitespace with CR/LF is one
+    piece.  GPU ids == the restatement's variant (which the CPU suite pins against PCRE2 running that very pattern)."""
+    from tokendagger_amd import capi
+    from oracle import port
+    _, mr, special = H.llama4()
+    tok = capi.HipTokenizer(vocab_io.CL100K_PAT_STR_CURRENT, mr, special, device=0)
+    O = port.OracleTokenizer(mr, port.VARIANT_CL100K_EOS)
+    rng = random.Random(23)
+    tails = ["\r\t", "\n ", " \n\t ", "\r\n\r\n  ", "\t", "  ", "\n", " \r", "x\n\t", " \n "]
+    for it in range(4):
+        docs = ["".join(H.fuzz_string(rng) for _ in range(rng.randint(1, 40))) + rng.choice(tails) * rng.randint(0, 3) for _ in range(400)]
+        docs += [("a" * rng.randint(1, 9000)) + rng.choice(tails) * rng.randint(1, 40) for _ in range(6)]  # tails across tile seams
+        docs += [e + t for e in EDGE[:40] for t in tails[:3]]
+        t, o = H.pack_docs([d.encode("utf-8") for d in docs])
+        toks, toffs = tok.encode_batch(t, o)
+        etoks, eoffs = O.encode_batch(t, o)
+        assert np.array_equal(toffs, eoffs) and np.array_equal(toks, etoks)
+    tok.close()

@@ -292,3 +292,15 @@ def test_decode_device_resident_and_errors(tok, golden):
     with pytest.raises(capi.TokenDaggerHipError) as e:
         tok.decode_bytes([5, -3])
     assert e.value.code == 8
+
+
+def test_code_performance_benchmark_file_set(tok):
+    """BASELINE config 5 on its real input: the 21 files of the reference's code benchmark, one document each, ids
+    from the compiled reference (tests/golden/code_corpus.npz), also tiled 40x as bench.py --corpus code_files does."""
+    g = np.load(H.ROOT / "tests" / "golden" / "code_corpus.npz", allow_pickle=False)
+    toks, toffs = tok.encode_batch(g["text"], g["offsets"])
+    assert np.array_equal(toffs, g["enc_offsets"]) and np.array_equal(toks, g["enc"])
+    x, o = td_corpus.code_files(40 * 2146667)
+    toks, toffs = tok.encode_batch(x, o)
+    assert len(toks) == 40 * len(g["enc"]) and np.array_equal(toks.reshape(40, -1), np.tile(g["enc"], (40, 1)))
+    assert tok.decode_bytes(toks[:len(g["enc"])]) == g["text"].tobytes()

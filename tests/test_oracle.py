@@ -95,3 +95,17 @@ def test_class_table_spot_checks():
     assert C(0x01C5) == 6, "Lt counts as upper"
     assert C(0x02B0) == 8, "Lm is in both letter classes"
     assert C(0x1F600) == 0 and C(0x10FFFF) == 0
+
+
+def test_code_corpus_fixture_matches_the_restatement():
+    """BASELINE config 5's file set (tests/golden/code_corpus.npz: the 21 files tests/code_performance_benchmark.py
+    selects, ids from the compiled reference): the restatement reproduces every file's ids."""
+    g = np.load(H.ROOT / "tests" / "golden" / "code_corpus.npz", allow_pickle=False)
+    text, offs, enc, eo = g["text"].tobytes(), g["offsets"], g["enc"], g["enc_offsets"]
+    assert len(offs) - 1 == 21 and len(text) == 2146667
+    O = H.port_tokenizer()
+    for d in range(len(offs) - 1):
+        assert np.array_equal(O.encode(text[offs[d]:offs[d + 1]]), enc[eo[d]:eo[d + 1]]), str(g["names"][d])
+    import td_corpus
+    x, o = td_corpus.code_files(5 << 20)
+    assert len(x) == 2 * 2146667 and len(o) - 1 == 42 and x[2146667:].tobytes() == text

@@ -198,3 +198,97 @@ def test_from_files_tekken_json(tmp_path):
     for s in ["Hello, world! It's 2024.", "def f(x):\n    return x**2  # 中文 😀", "12345 67", "  spaces   and\ttabs\n\n"]:
         ids = t.encode(s)
         assert ids == ref.encode(s) and min(ids) >= n_special and t.decode(ids) == s
+
+
+# ---- special tokens: property test against a restatement of tiktoken's splitting ------------------------------------
+def _tiktoken_special_split(data: bytes, allowed: dict[bytes, int]):
+    """tiktoken's encode() with allowed_special, restated (tiktoken: `_encode_native` / CoreBPE.encode in the reference,
+    tiktoken.cpp:169-234 minus its iterator bug): scan for the EARLIEST position where an allowed special
+    string occurs; the text before it is ordinary text, the special contributes its id, continue behind it.  Several
+    allowed strings at one position: tiktoken's alternation order is a hash-map order, i.e. unspecified; this
+    implementation defines it as the LONGEST one.  -> [(ordinary bytes, special id or None)]"""
+    out, start, p = [], 0, 0
+    while p < len(data):
+        best = None
+        for s in allowed:
+            if data.startswith(s, p) and (best is None or len(s) > len(best)):
+                best = s
+        if best is None:
+            p += 1
+            continue
+        out.append((data[start:p], allowed[best]))
+        p += len(best)
+        start = p
+    out.append((data[start:], None))
+    return out
+
+
+def test_special_splitting_property():
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from tokendagger_amd import capi
+    pat, mr, _ = H.llama4()
+    ranks = {b: r for b, r in mr.items() if r < 200000}
+    # overlapping / nested / prefix-sharing specials, one pair sharing an id, one single-byte special
+    specials = {"<|a|>": 200000, "<|a|><|b|>": 200001, "<|b|>": 200002, "<|": 200003, "|>": 200004, "<|ab|>": 200005,
+                "<|a|>x": 200006, "\u00a7": 200007, "<|alias1|>": 200008, "<|alias2|>": 200008, "<|a": 200009}
+    tok = capi.HipTokenizer(pat, ranks, specials, device=0)
+    O = H.port_tokenizer()
+    sp_bytes = {k.encode("utf-8"): v for k, v in specials.items()}
+    frag = st.sampled_from(list(specials) + ["<", "|", ">", "a", "b", "x", " ", "hello", "\n", "<|a|", "|><|", "\u00a7\u00a7", "wörld", "日本"])
+    texts = st.lists(frag, min_size=0, max_size=24).map("".join)
+    subsets = st.sets(st.sampled_from(list(specials)), max_size=len(specials))
+
+    @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st.lists(texts, min_size=1, max_size=6), subsets)
+    def run(docs, allowed):
+        allowed_b = {k.encode("utf-8"): specials[k] for k in allowed}
+        exp = []
+        for d in docs:
+            ids = []
+            for seg, sid in _tiktoken_special_split(d.encode("utf-8"), allowed_b):
+                ids += O.encode(seg).tolist()
+                if sid is not None:
+                    ids.append(sid)
+            exp.append(ids)
+        blob, offs = H.pack_docs([d.encode("utf-8") for d in docs])
+        toks, toffs = tok.encode_batch_with_special_strs(blob, offs, sorted(allowed))
+        got = [toks[toffs[i]:toffs[i + 1]].tolist() for i in range(len(docs))]
+        assert got == exp, (docs, allowed)
+        one, _ = tok.encode_with_special_strs(docs[0].encode("utf-8"), sorted(allowed))
+        assert one.tolist() == exp[0]
+
+    run()
+    # ids instead of strings: every string carrying an allowed id is cut out (alias1 and alias2 share 200008)
+    t, _ = tok.encode_with_special(b"x<|alias1|>y<|alias2|>z", [200008])
+    assert t.tolist() == O.encode(b"x").tolist() + [200008] + O.encode(b"y").tolist() + [200008] + O.encode(b"z").tolist()
+    t, _ = tok.encode_with_special_strs(b"x<|alias1|>y<|alias2|>z", ["<|alias1|>"])
+    assert t.tolist() == O.encode(b"x").tolist() + [200008] + O.encode(b"y<|alias2|>z").tolist()
+    with pytest.raises(capi.TokenDaggerHipError):
+        tok.encode_with_special_strs(b"x", ["<|nope|>"])
+    tok.close()
+
+
+def test_calls_leave_the_current_device_alone():
+    """Every entry point restores the caller's current HIP device (a tokenizer on another GPU must not
+    re-point torch); with one GPU: the device is 0 before and after, and last-error text is per thread."""
+    import threading
+    import torch
+    from tokendagger_amd import capi
+    pat, mr, sp = H.llama4()
+    tok = capi.HipTokenizer(pat, mr, sp, device=0)
+    assert torch.cuda.current_device() == 0
+    tok.encode(b"hello")
+    assert torch.cuda.current_device() == 0
+    errs = []
+
+    def bad():
+        try:
+            tok.decode_bytes([10 ** 8])
+        except capi.TokenDaggerHipError as e:
+            errs.append(str(e))
+
+    th = [threading.Thread(target=bad) for _ in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert len(errs) == 4 and all("Invalid token for decoding: 100000000" in e for e in errs)
+    tok.close()

@@ -110,7 +110,9 @@ struct Tables {
 // : case-sensitive contractions in front, the optional prefix is U+0020 only (also before digits), digit runs are not
 // cut, no [\r\n/]* trailer and no \s*[\r\n]+ alternative.  It has a scanner of its own (scan_piece_gpt2*), selected
 // by PV_GPT2, and the same two class remaps as cl100k.
-enum : uint32_t { PV_NO_CONTRACTION = 1, PV_SINGLE_DIGIT = 2, PV_LEADING_CONTRACTION = 4, PV_PLAIN_LETTERS = 8, PV_GPT2 = 16 };
+// PV_WS_EOS_FIRST: current tiktoken releases spell cl100k_base with `\s++$` IN FRONT of `\s*[\r\n]`: a whitespace run that
+// reaches the end of the subject is one piece even when it contains CR/LF ("\r\t" at the end: one piece, not two).
+enum : uint32_t { PV_NO_CONTRACTION = 1, PV_SINGLE_DIGIT = 2, PV_LEADING_CONTRACTION = 4, PV_PLAIN_LETTERS = 8, PV_GPT2 = 16, PV_WS_EOS_FIRST = 32 };
 
 // ------------------------------------------------------------------ hashing -----------------
 TD_HD uint32_t hash_piece(uint64_t key, uint32_t len) {
@@ -494,6 +496,7 @@ TD_HD typename A::pos_t scan_piece(const A& a, typename A::pos_t pos, uint32_t p
             if (!(v & F_CONT)) last_lead = q;
             ++q;
         }
+        if (eos && (pv & PV_WS_EOS_FIRST)) return q;
         if (last_crlf_end) return last_crlf_end;
         if (eos) return q;
         if (last_lead > pos) return last_lead;
@@ -816,6 +819,7 @@ TD_HD int scan_piece_p(const P& p, const B& bytes, uint32_t pv = 0) {
     if (s0) {  // \s*[\r\n]+ | \s+(?!\S) | \s+
         const int q = p.run_end(MK_S, o);
         if (q >= lim) return -1;
+        if ((pv & PV_WS_EOS_FIRST) && p.ebit(q)) return q;
         const int lc = p.last_set(MK_CR, o, q);
         if (lc >= 0) return lc + 1;
         if (p.ebit(q)) return q;

@@ -1464,6 +1464,9 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
         case 0u: hipLaunchKernelGGL(td_split_tiles<0u>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
         case PV_TEKKEN: hipLaunchKernelGGL(td_split_tiles<PV_TEKKEN>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
         case PV_CL100K: hipLaunchKernelGGL(td_split_tiles<PV_CL100K>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
+        case PV_CL100K | PV_WS_EOS_FIRST:
+            hipLaunchKernelGGL(td_split_tiles<(PV_CL100K | PV_WS_EOS_FIRST)>, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
+            break;
         default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(td_split_slow, dim3(64), dim3(64), 0, stream, a);

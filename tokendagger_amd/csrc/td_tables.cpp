@@ -27,7 +27,7 @@ static const char kCl100k[] =
 static const char kCl100kPossessive[] =
     "'(?i:[sdmt]|ll|ve|re)|[^\\r\\n\\p{L}\\p{N}]?+\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]++[\\r\\n]*|\\s*[\\r\\n]|\\s+(?!\\S)|\\s+";
 
-static const char kCl100kCurrent[] =  // cl100k_base as tiktoken ships it today (openai_public.py): possessive everywhere, \s++$ spelled out
+static const char kCl100kCurrent[] =  // cl100k_base as tiktoken ships it today (openai_public.py); NOT the same language: \s++$ comes first
     "'(?i:[sdmt]|ll|ve|re)|[^\\r\\n\\p{L}\\p{N}]?+\\p{L}++|\\p{N}{1,3}+| ?[^\\s\\p{L}\\p{N}]++[\\r\\n]*+|\\s++$|\\s*[\\r\\n]|\\s+(?!\\S)|\\s";
 
 static const char kGpt2[] =
@@ -43,7 +43,8 @@ const char* cl100k_pattern() { return kCl100k; }
 PatternKind classify_pattern(const std::string& pat) {
     if (pat == kO200k) return PATTERN_O200K;
     if (pat == kTekken) return PATTERN_TEKKEN;
-    if (pat == kCl100k || pat == kCl100kPossessive || pat == kCl100kCurrent) return PATTERN_CL100K;
+    if (pat == kCl100k || pat == kCl100kPossessive) return PATTERN_CL100K;
+    if (pat == kCl100kCurrent) return PATTERN_CL100K_EOS;
     if (pat == kGpt2 || pat == kGpt2Possessive) return PATTERN_GPT2;
     return PATTERN_UNSUPPORTED;
 }
@@ -51,6 +52,7 @@ PatternKind classify_pattern(const std::string& pat) {
 uint32_t pattern_flags(PatternKind k) {
     if (k == PATTERN_TEKKEN) return PV_NO_CONTRACTION | PV_SINGLE_DIGIT;
     if (k == PATTERN_CL100K) return PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS;
+    if (k == PATTERN_CL100K_EOS) return PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS | PV_WS_EOS_FIRST;
     if (k == PATTERN_GPT2) return PV_GPT2;
     return 0u;
 }
@@ -134,7 +136,7 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
 
     // Class tables: the probed Unicode table; cl100k reads marks as punctuation and gives '/' no trailer role, which is
     // a remap of two class ids (the scanners never see the difference)
-    if (H.pattern_kind == PATTERN_CL100K || H.pattern_kind == PATTERN_GPT2) {
+    if (H.pattern_kind == PATTERN_CL100K || H.pattern_kind == PATTERN_CL100K_EOS || H.pattern_kind == PATTERN_GPT2) {
         H.ucls2_remap.assign(td_ucls_stage2, td_ucls_stage2 + sizeof td_ucls_stage2);
         for (auto& c : H.ucls2_remap)
             if (c == C_MK || c == C_SLASH) c = C_OTHER;

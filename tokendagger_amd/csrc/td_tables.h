@@ -18,6 +18,8 @@ enum PatternKind : int {
     PATTERN_TEKKEN = 1, // Mistral tekken.json config.pattern (reference tests/throughput_test.py:118)
     PATTERN_CL100K = 2, // cl100k_base / Llama-3 (tiktoken's pat_str; any pattern is legal input to the reference: wrapper.py:39)
     PATTERN_GPT2 = 3,   // r50k_base / p50k_base (GPT-2)
+    PATTERN_CL100K_EOS = 4,  // cl100k_base as current tiktoken releases spell it: `\s++$` ahead of `\s*[\r\n]` (a different language
+                             // on trailing whitespace that contains CR/LF)
 };
 const char* cl100k_pattern();
 uint32_t pattern_flags(PatternKind k);  // PV_* bits for the scanners
