@@ -143,13 +143,17 @@ int64_t td_info(const td_tokenizer* t, int what);
 
 /* Options. */
 #define TD_OPT_LONG_POOL_BYTES 1 /* scratch for pieces longer than 64 bytes (default max(64 MiB, 2 x input)) */
-#define TD_OPT_PROFILE 2         /* 1: bracket the two tile kernels (td_split_tiles, td_encode_tiles) of every
-                                    td_encode_device call with HIP events on the call's stream */
+#define TD_OPT_PROFILE 2         /* 1: bracket the kernels of every td_encode_device call with HIP events on the
+                                    call's stream (td_profile_read_ex) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 
-/* Sums (ms) of the pre-tokenizer kernel and token kernel durations and the number of calls recorded since the
- * last read (TD_OPT_PROFILE); synchronises the recorded events. */
+/* Sums (ms) of the pre-tokenizer kernel and token kernel (probe + merge) durations and the number of calls recorded
+ * since the last read (TD_OPT_PROFILE); synchronises the recorded events. */
 int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum, int64_t* launches);
+/* The same per kernel segment: ms_sums[i] = summed duration of segment i (td_profile_segment_name(i); "" past the last
+ * one) over the calls recorded since the last read. */
+int td_profile_read_ex(td_tokenizer* t, double* ms_sums, int n_segments, int64_t* launches);
+const char* td_profile_segment_name(int i);
 
 /* Special-token table access: replaces CoreBPE::special_tokens() (tiktoken.cpp:258-265). */
 int64_t td_special_count(const td_tokenizer* t);

@@ -219,7 +219,24 @@ int64_t twin_encode(void* h, const uint8_t* text, int64_t n, const int64_t* offs
             int32_t r = NO_RANK;
             if (fast) r = piece_lookup(T, piece_key_host(pb, len), len, [pb](uint32_t i) { return (uint32_t)pb[i]; });
             if (r != NO_RANK) tmp.push_back(r);
-            else if (merge_piece_host(T, pb, len, tmp) != TD_OK) return -TD_E_UNKNOWN_BYTE;
+            else if (len <= (uint32_t)K_MAXSHORT) {
+                // what one lane of td_merge_tiles runs (mg_put / mg_pad / mg_round, td_common.h), on host arrays; the
+                // piece sits at a varying unit so that the slot swizzle is exercised
+                alignas(16) static thread_local uint32_t keys[256 * MG_UNIT + 64], ids[256 * MG_UNIT + 64];
+                MergeState st;
+                st.t = (uint32_t)(p % 250);
+                st.len = len;
+                st.alive = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+                for (uint32_t j = 0; j < len; ++j) mg_put(T, T.byte_id, keys, ids, st, j, pb[j], j + 1 < len ? pb[j + 1] : 0u);
+                mg_pad(keys, st);
+                if (len <= 32) { while (mg_round_t<uint32_t>(T, keys, ids, st)) {} }  // (as td_merge_pieces picks the mask width)
+                else { while (mg_round_t<uint64_t>(T, keys, ids, st)) {} }
+                for (uint64_t al = st.alive; al; al &= al - 1) {
+                    const uint32_t v = ids[mg_slot(st.t, (uint32_t)td_ctz64(al))];
+                    if ((int32_t)v >= T.pseudo_base) return -TD_E_UNKNOWN_BYTE;
+                    tmp.push_back((int32_t)v);
+                }
+            } else if (merge_piece_host(T, pb, len, tmp) != TD_OK) return -TD_E_UNKNOWN_BYTE;
         }
         for (int32_t v : tmp) {
             if (k >= cap) return -TD_E_CAPACITY;

@@ -30,7 +30,7 @@ EXPORTS = [
     "td_vocab_create", "td_vocab_destroy", "td_vocab_error", "td_vocab_load_tiktoken", "td_vocab_load_hf_special",
     "td_vocab_load_tekken", "td_vocab_load_json", "td_vocab_set_pattern", "td_vocab_pattern", "td_vocab_arrays",
     "td_create_from_vocab", "td_token_bytes", "td_single_token", "td_decode_device", "td_decode_batch", "td_encode_batch_with_special",
-    "td_encode_with_special_strs", "td_encode_batch_with_special_strs",
+    "td_encode_with_special_strs", "td_encode_batch_with_special_strs", "td_profile_read_ex", "td_profile_segment_name",
 ]
 
 
@@ -100,6 +100,10 @@ def load_library():
     lib.td_set_option.argtypes = [vp, i32, i64]
     lib.td_profile_read.restype = i32
     lib.td_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
+    lib.td_profile_read_ex.restype = i32
+    lib.td_profile_read_ex.argtypes = [vp, ctypes.POINTER(ctypes.c_double), i32, ctypes.POINTER(i64)]
+    lib.td_profile_segment_name.restype = ctypes.c_char_p
+    lib.td_profile_segment_name.argtypes = [i32]
     lib.td_special_count.restype = i64
     lib.td_special_count.argtypes = [vp]
     lib.td_special_get.restype = i32
@@ -445,6 +449,19 @@ class HipTokenizer:
         a = ctypes.c_double(0); b = ctypes.c_double(0); n = ctypes.c_int64(0)
         self._check(self._lib.td_profile_read(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
         return a.value, b.value, n.value
+
+    def profile_read_all(self) -> tuple[dict[str, float], int]:
+        """-> ({kernel segment: summed ms}, calls) since the last read (TD_OPT_PROFILE=1)."""
+        names = []
+        while True:
+            nm = self._lib.td_profile_segment_name(len(names)).decode()
+            if not nm:
+                break
+            names.append(nm)
+        arr = (ctypes.c_double * len(names))()
+        n = ctypes.c_int64(0)
+        self._check(self._lib.td_profile_read_ex(self._h, arr, len(names), ctypes.byref(n)))
+        return {nm: arr[i] for i, nm in enumerate(names)}, n.value
 
     def special_tokens(self) -> dict[str, int]:
         out = {}

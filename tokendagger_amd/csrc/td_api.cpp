@@ -66,13 +66,13 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, slow_list, stage, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf docbits, startbits, slow_list, stage, stage2, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
     bool profile = false;
     int stop_after = 0;
-    struct Ev3 { hipEvent_t e[3]; };
+    struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
     std::vector<Ev3> ev_pending, ev_free;
     int64_t last_long = 0;
     size_t ws_bytes = 0;
@@ -167,6 +167,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->startbits, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
     if ((rc = ensure(t, t->slow_list, (size_t)(n_tiles * 8 + 64) * 8))) return rc;
     if ((rc = ensure(t, t->stage, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;
+    if ((rc = ensure(t, t->stage2, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;  // ids of merged pieces
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
@@ -207,6 +208,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.slow_list = (int64_t*)t->slow_list.p;
     a.slow_cap = (uint32_t)std::min<size_t>(t->slow_list.cap / 8, 0x7FFFFFF0u);
     a.stage = (uint32_t*)t->stage.p;
+    a.merge_out = (uint32_t*)t->stage2.p;
     a.tile_count = (uint32_t*)t->tile_count.p;
     a.tile_extra = (uint32_t*)t->tile_extra.p;
     a.tile_base = (int64_t*)t->tile_base.p;
@@ -237,13 +239,13 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.use_fastpath = (mode == TD_MODE_ENCODE) || t->H.merge_closed;
     a.text_aligned = (((uintptr_t)d_text) & 15) == 0;
     a.stop_after = t->stop_after;
-    td_tokenizer::Ev3 ev{{nullptr, nullptr, nullptr}};
+    td_tokenizer::Ev3 ev{};
     if (t->profile) {
         if (!t->ev_free.empty()) { ev = t->ev_free.back(); t->ev_free.pop_back(); }
         else for (auto& e : ev.e) HIP_TRY(t, hipEventCreate(&e));
         t->ev_pending.push_back(ev);
     }
-    HIP_TRY(t, launch_encode(a, stream, ev.e[0], ev.e[1], ev.e[2]));
+    HIP_TRY(t, launch_encode(a, stream, t->profile ? ev.e : nullptr));
     return order_after(t, stream);
 }
 
@@ -365,7 +367,7 @@ void td_destroy(td_tokenizer* t) {
         for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
         for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
         if (t->last_done) (void)hipEventDestroy(t->last_done);
-        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->stage, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)
@@ -874,27 +876,38 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     return TD_E_INVALID;
 }
 
-int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum, int64_t* launches) {
-    if (!t) return TD_E_INVALID;
+static const char* const kProfSegments[TD_PROF_EVENTS - 1] = {"td_split_tiles", "td_probe_tiles", "td_merge_pieces", "td_long_pieces+td_scan_tiles+td_pack_tokens"};
+
+int td_profile_read_ex(td_tokenizer* t, double* ms_sums, int n_segments, int64_t* launches) {
+    if (!t || n_segments < 0 || (n_segments > 0 && !ms_sums)) return TD_E_INVALID;
     return locked(t, [&] {
-    double s0 = 0, s1 = 0;
-    int64_t n = 0;
-    for (auto& ev : t->ev_pending) {
-        HIP_TRY(t, hipEventSynchronize(ev.e[2]));
-        float ms = 0;
-        HIP_TRY(t, hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
-        s0 += ms;
-        HIP_TRY(t, hipEventElapsedTime(&ms, ev.e[1], ev.e[2]));
-        s1 += ms;
-        ++n;
-        t->ev_free.push_back(ev);
-    }
-    t->ev_pending.clear();
-    if (split_ms_sum) *split_ms_sum = s0;
-    if (encode_ms_sum) *encode_ms_sum = s1;
-    if (launches) *launches = n;
-    return (int)TD_OK;
+        double sum[TD_PROF_EVENTS - 1] = {};
+        int64_t n = 0;
+        for (auto& ev : t->ev_pending) {
+            HIP_TRY(t, hipEventSynchronize(ev.e[TD_PROF_EVENTS - 1]));
+            for (int k = 0; k + 1 < TD_PROF_EVENTS; ++k) {
+                float ms = 0;
+                HIP_TRY(t, hipEventElapsedTime(&ms, ev.e[k], ev.e[k + 1]));
+                sum[k] += ms;
+            }
+            ++n;
+            t->ev_free.push_back(ev);
+        }
+        t->ev_pending.clear();
+        for (int k = 0; k < n_segments; ++k) ms_sums[k] = k + 1 < TD_PROF_EVENTS ? sum[k] : 0.0;
+        if (launches) *launches = n;
+        return (int)TD_OK;
     });
+}
+
+const char* td_profile_segment_name(int i) { return (i >= 0 && i + 1 < TD_PROF_EVENTS) ? kProfSegments[i] : ""; }
+
+int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum, int64_t* launches) {
+    double s[TD_PROF_EVENTS - 1] = {};
+    const int rc = td_profile_read_ex(t, s, TD_PROF_EVENTS - 1, launches);
+    if (split_ms_sum) *split_ms_sum = s[0];
+    if (encode_ms_sum) *encode_ms_sum = s[1] + s[2];
+    return rc;
 }
 
 int64_t td_special_count(const td_tokenizer* t) { return t ? (int64_t)t->H.special_ids.size() : 0; }

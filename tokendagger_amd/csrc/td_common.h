@@ -62,6 +62,11 @@ TD_HD bool in_set(uint32_t mask, uint32_t c) { return (mask >> c) & 1u; }
 constexpr int32_t NO_RANK = 0x7FFFFFFF;       // the reference's INT_MAX "no such pair" (tiktoken.cpp:293)
 constexpr uint32_t TOK_NONE = 0xFFFFFFFFu;    // empty slot in the byte-indexed token array
 constexpr uint32_t TOK_LONGREF = 0x80000000u; // | index into the long-piece list
+constexpr uint32_t TOK_MISS = 0x40000000u;    // | tile position << 7 | length: a piece of 2..64 bytes that is not a token; td_merge_tiles
+                                              // replaces the slot by the ids its byte-pair merge produces
+// tile_count[]: slots of the tile (bits 0..12) | 16-byte units of its missed pieces (bits 13..25, written by td_probe_tiles,
+// cleared by td_merge_*) | flags
+constexpr uint32_t TILE_HAS_LONG = 0x80000000u, TILE_HAS_MISS = 0x40000000u, TILE_COUNT_MASK = 0x1FFFu;
 constexpr int ID_BITS = 21;                   // ids / ranks must be < 2^21 (pair slots pack 2 ids + rank in 64 bit)
 constexpr uint64_t PAIR_EMPTY = ~0ull;
 
@@ -897,6 +902,90 @@ TD_HD uint64_t sync_word(uint64_t U, uint64_t W, uint64_t X, uint64_t S, uint64_
     uint64_t sy = (S & ~CR & ~pS) | (pCR & ~S & ~SL) | num | (X & ~(U | W) & ~A & pL);
     return (sy & ~C) | D;
 }
+
+// ------------------------------------------------------------------ lane-per-piece merge ----
+// The byte-pair merge of one piece (bpe_merge, tiktoken.cpp:298-368) as ONE LANE runs it; 64 pieces per wavefront advance
+// together, one merge each per round.  A piece of `len` <= 64 bytes owns ceil(len/16) consecutive 16-slot units of two
+// arrays (LDS on the device): ids[] = the id of the part that STARTS at byte j (stale for absorbed parts), keys[] =
+// rank(part j, next part) << 6 | j, or MG_DEAD when that pair is no token or j is not a part start.  A round: minimum
+// over the piece's keys (lowest rank, leftmost on ties = the reference's strict '<' scan, tiktoken.cpp:334-342), the
+// right part is absorbed, the two pairs that touch the merged part are looked up again (tiktoken.cpp:324-331).
+// Slots are XOR-swizzled by unit so that 16-byte reads of different lanes fall into different LDS banks.
+constexpr uint32_t MG_DEAD = 0xFFFFFFFFu;
+constexpr int MG_UNIT = 16;
+TD_HD uint32_t mg_slot(uint32_t t, uint32_t j) { return (t << 4) + (j ^ (((t >> 2) & 3u) << 2)); }  // (bits 2..3 of j swizzled by the owner lane)
+struct MergeState {
+    uint64_t alive;  // bit j: a part starts at byte j
+    uint32_t t;      // first unit of the piece
+    uint32_t len;    // bytes; 0 = this lane has no piece
+};
+struct U4 { uint32_t x, y, z, w; };
+// part j of the piece: byte b, next byte bn (ignored for the last part)
+TD_HD void mg_put(const Tables& T, const int32_t* byte_id, uint32_t* keys, uint32_t* ids, const MergeState& st, uint32_t j, uint32_t b,
+                  uint32_t bn) {
+    const uint32_t sl = mg_slot(st.t, j);
+    ids[sl] = (uint32_t)byte_id[b];
+    uint32_t key = MG_DEAD;
+    if (j + 1 < st.len) {
+        const int32_t r = T.byte_pair[(b << 8) | bn];
+        if (r != NO_RANK) key = ((uint32_t)r << 6) | j;
+    }
+    keys[sl] = key;
+}
+TD_HD void mg_pad(uint32_t* keys, const MergeState& st) {  // key slots behind the last part of the last unit
+    const uint32_t end = ((st.len + 15u) >> 4) << 4;
+    for (uint32_t j = st.len; j < end; ++j) keys[mg_slot(st.t, j)] = MG_DEAD;
+}
+TD_HD uint32_t td_min3(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t ab = a < b ? a : b;
+    return ab < c ? ab : c;
+}
+// one merge; false when the piece has no mergeable pair left.  MaskT = uint32_t for pieces of at most 32 bytes (the part
+// mask fits one register), uint64_t otherwise.
+template <class MaskT>
+TD_HD bool mg_round_t(const Tables& T, uint32_t* keys, uint32_t* ids, MergeState& st) {
+    const uint32_t units = (st.len + 15u) >> 4;
+    const uint32_t base = st.t << 4, sx = ((st.t >> 2) & 3u) << 2;  // slot of part j = base + (j ^ sx)
+    uint32_t m = MG_DEAD;
+    for (uint32_t c = 0; c < units; ++c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t q = 0; q < 4; ++q) {
+            const U4 k = *reinterpret_cast<const U4*>(keys + base + ((16u * c + 4u * q) ^ sx));
+            m = td_min3(td_min3(k.x, k.y, k.z), k.w, m);
+        }
+    }
+    if (m == MG_DEAD) return false;
+    const uint32_t w = m & 63u, r = m >> 6;
+    constexpr uint32_t NB = sizeof(MaskT) * 8;
+    const MaskT one = 1;
+    MaskT alive = (MaskT)st.alive;
+    MaskT above = alive & ~(((one << w) << 1) - one);    // part starts behind w (there is one: the pair at w has a right part)
+    const uint32_t nx = sizeof(MaskT) == 8 ? (uint32_t)td_ctz64((uint64_t)above) : (uint32_t)td_ctz32((uint32_t)above);
+    above &= above - one;
+    const uint32_t nn = above ? (sizeof(MaskT) == 8 ? (uint32_t)td_ctz64((uint64_t)above) : (uint32_t)td_ctz32((uint32_t)above)) : 64u;
+    const MaskT below = alive & ((one << w) - one);
+    const uint32_t pw = below ? (sizeof(MaskT) == 8 ? (uint32_t)(td_top64((uint64_t)below) - 1) : 31u - (uint32_t)__builtin_clz((uint32_t)below)) : 64u;
+    (void)NB;
+    alive &= ~(one << nx);
+    st.alive = (uint64_t)alive;
+    const uint32_t id_nn = nn < 64u ? ids[base + (nn ^ sx)] : 0u;
+    const uint32_t id_pw = pw < 64u ? ids[base + (pw ^ sx)] : 0u;
+    ids[base + (w ^ sx)] = r;  // a merged part's id is its rank
+    // both pair lookups at once: four independent 8-byte probes in flight (a missing neighbour probes (r, 0) / (0, r) and
+    // the result is dropped: no divergent branch around the loads)
+    const uint64_t e1 = T.pair_slots[hash_pair(r, id_nn) & T.pair_mask], e2 = T.pair_slots[hash_pair2(r, id_nn) & T.pair_mask];
+    const uint64_t e3 = T.pair_slots[hash_pair(id_pw, r) & T.pair_mask], e4 = T.pair_slots[hash_pair2(id_pw, r) & T.pair_mask];
+    const int32_t r1 = pair_match(e1, e2, r, id_nn), r2 = pair_match(e3, e4, id_pw, r);
+    const uint32_t kw = (nn < 64u && r1 != NO_RANK) ? (((uint32_t)r1 << 6) | w) : MG_DEAD;
+    const uint32_t kp = (pw < 64u && r2 != NO_RANK) ? (((uint32_t)r2 << 6) | pw) : MG_DEAD;
+    keys[base + (w ^ sx)] = kw;
+    keys[base + (nx ^ sx)] = MG_DEAD;
+    if (pw < 64u) keys[base + (pw ^ sx)] = kp;
+    return true;
+}
+TD_HD bool mg_round(const Tables& T, uint32_t* keys, uint32_t* ids, MergeState& st) { return mg_round_t<uint64_t>(T, keys, ids, st); }
 
 // ------------------------------------------------------------------ tile geometry -----------
 // One workgroup of td_encode_tiles handles one tile of text at a time.

@@ -22,12 +22,13 @@ struct EncodeArgs {
     const int64_t* doc_offsets; // [n_docs+1], doc_offsets[0]==0, doc_offsets[n_docs]==n
     int64_t n_docs;
     uint32_t* docbits;          // [(n+31)/32+1] bit i set <=> a document starts at byte i
-    uint32_t* startbits;        // [(n+31)/32+8] bit i set <=> a regex piece starts at byte i (td_split_tiles -> td_encode_tiles)
+    uint32_t* startbits;        // [(n+31)/32+8] bit i set <=> a regex piece starts at byte i (td_split_tiles -> td_probe_tiles)
     int64_t* slow_list;         // [slow_cap] positions handed from td_split_tiles to td_split_slow: (byte << 1) | kind
     uint32_t slow_cap;
     uint32_t* slow_count;
-    uint32_t* stage;            // [n_tiles*K_STAGE] per-tile compacted slots (token ids / long markers)
-    uint32_t* tile_count;       // [n_tiles] slots in the tile
+    uint32_t* stage;            // [n_tiles*K_STAGE] per-tile slots, one per piece (td_probe_tiles): id | TOK_MISS.. | TOK_LONGREF..
+    uint32_t* merge_out;        // [n_tiles*K_STAGE] ids of the merged pieces, at tile * K_STAGE + the piece's tile position (td_merge_pieces)
+    uint32_t* tile_count;       // [n_tiles] slots in the tile | TILE_HAS_LONG | TILE_HAS_MISS
     uint32_t* tile_extra;       // [n_tiles] sum(ntok-1) over the tile's long pieces
     int64_t* tile_base;         // [n_tiles+1] exclusive scan of count+extra
     uint32_t* doc_slot;         // [n_docs] slot index (inside its tile) of each document's first token
@@ -72,11 +73,13 @@ struct DecodeArgs {
 };
 
 // All launches are asynchronous on `stream`; none of them synchronises or allocates.
-// ev0/ev1 (optional): recorded right before / after the fused tile kernel
-hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                         hipEvent_t ev2 = nullptr);  // ev0 | td_split_tiles | ev1 | td_encode_tiles | ev2
+// ev (optional, TD_PROF_EVENTS events): ev[0] | td_split_tiles, td_split_slow | ev[1] | td_probe_tiles | ev[2] | td_merge_pieces |
+// ev[3] | td_long_pieces, td_scan_tiles, td_pack_tokens | ev[4]
+constexpr int TD_PROF_EVENTS = 5;
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev = nullptr);
 // phases: 1 = lengths + offsets (td_decode_len, td_decode_chunks, document byte offsets), 2 = gather (td_decode_copy), 3 = both
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, int phases = 3);
-int encode_grid_blocks();  // persistent grid size used by the fused kernel
+int encode_grid_blocks();  // persistent grid size of td_probe_tiles
+int merge_grid_blocks();   // persistent grid size of td_merge_pieces
 
 }  // namespace td

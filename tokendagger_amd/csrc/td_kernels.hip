@@ -1,21 +1,17 @@
 // gfx950 (MI355X) kernels of the tokenizer hot path.  Integer / byte work, HBM- and latency-bound:
 // no MFMA anywhere.  Pipeline per encode call (all on one stream, no host round trips):
 //
-//   td_mark_docs     doc_offsets -> one bit per document start
-//   td_encode_tiles  persistent workgroups, one 4 KiB text tile at a time:
-//                      coalesced 16 B/lane loads of the tile (+halos) into LDS
-//                      -> per-byte class/flag array (ASCII LUT in LDS, 2-stage Unicode table in L2)
-//                      -> piece boundaries: every lane runs the deterministic scanner from the
-//                         first PROVABLE synchronisation point of its 16-byte chunk (td_common.h)
-//                      -> whole-piece table probe, one lane per piece (CoreBPE::encode fast path)
-//                      -> byte-pair merge of the misses: a wavefront takes a 64-byte window of
-//                         pieces, one lane per byte, ranks from the (id,id) pair table, segmented
-//                         wavefront min-reduce picks the lowest-rank leftmost pair of every piece
-//                      -> block scan + compaction of the byte-indexed token array to the tile's
-//                         staging area
-//   td_long_pieces   pieces longer than 64 bytes: one wavefront per piece, parts in HBM scratch
-//   td_scan_tiles    device-wide exclusive scan of per-tile token counts
-//   td_pack_tokens   staging -> densely packed int32 ids + int64 per-document token offsets
+//   td_prepare, td_mark_docs   clear the per-call state; doc_offsets -> one bit per document start
+//   td_split_tiles<pattern>    pre-tokenizer: 8 KiB text tiles (+halos) in LDS -> class masks (8x8 bit transpose) ->
+//                              bit-parallel scanner from provable synchronisation points -> START bitmap in HBM
+//   td_split_slow              the positions the LDS window could not decide (normally none)
+//   td_probe_tiles             4 KiB tiles: dense piece list -> ONE slot per piece: the id when the piece is a token
+//                              (whole-piece table probe), a TOK_MISS marker when it is not, TOK_LONGREF above 64 bytes
+//   td_merge_pieces            the TOK_MISS pieces: byte-pair merge, one LANE per piece (every lane advances its own merge
+//                              chain, a merge per round), batches of one length class filled across tiles
+//   td_long_pieces             pieces longer than 64 bytes: lane groups / a wavefront per piece, parts in LDS
+//   td_scan_tiles              device-wide exclusive scan of the per-tile id counts
+//   td_pack_tokens             per-tile slots -> densely packed int32 ids + int64 per-document token offsets
 //
 // Reference behaviour being reproduced: /root/reference/src/tiktoken/tiktoken.cpp:70-128
 // (split_text), :169-234 (encode), :282-378 (get_rank / bpe_merge / byte_pair_encode).
@@ -493,32 +489,39 @@ __global__ void td_split_slow(const EncodeArgs a) {
     }
 }
 
-// Everything the hot probe loop of td_encode_tiles leaves to a second, rolled loop: keys longer than 8 bytes (hashed +
-// verified against the token bytes), probe sequences longer than one slot, pieces longer than K_MAXSHORT (handed to
-// td_long_pieces), and the miss mark.  (An out-of-line call here cost +30 % kernel time: too many waves take it.)
-__device__ __forceinline__ void resolve_piece_cold(const EncodeArgs& a, const Tables& T, const uint8_t* s_txt, uint32_t* s_tok,
-                                                uint32_t* s_miss, const int32_t* s_byteid, uint32_t* s_haslong, int64_t wg0,
-                                                int i, uint32_t len) {
+// ------------------------------------------------------------------ td_probe_tiles ----------
+// Token kernel, first half: pieces (from the START bitmap) -> one SLOT per piece, in piece order, in the tile's staging
+// region: the id of the piece when it is a token (whole-piece lookup, CoreBPE::encode's fast path, tiktoken.cpp:209-215;
+// single bytes through the 256-entry table), TOK_MISS | position | length when it is not (td_merge_tiles expands those),
+// TOK_LONGREF | index for pieces above 64 bytes (td_long_pieces).  No per-byte token array and no compaction: slot k is
+// piece k, lane k mod 256 stores it, the stores of a wavefront are consecutive.
+constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per tile by this kernel
+
+#ifndef TD_PROBE_MIN_WAVES
+#define TD_PROBE_MIN_WAVES 8  // (measured on 256 MiB of English: 0.49 ms at 8 waves/SIMD, 0.66 ms at 5..7)
+#endif
+#ifndef TD_PROBE_NB
+#define TD_PROBE_NB 1
+#endif
+// everything the hot probe path leaves out: keys longer than 16 bytes (hashed + verified against the token bytes), probe
+// sequences longer than one slot, pieces longer than K_MAXSHORT (handed to td_long_pieces).  Returns the piece's slot.
+__device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const Tables& T, const uint8_t* s_txt, const int32_t* s_byteid,
+                                                     uint32_t* s_flags, int64_t wg0, int i, uint32_t len) {
     if (len > (uint32_t)K_MAXSHORT) {
-        if (len == 0xFFFFFFFFu) { raise(a, TD_E_SCRATCH, wg0 + i); return; }
+        if (len == 0xFFFFFFFFu) { raise(a, TD_E_SCRATCH, wg0 + i); return 0u; }
         const uint32_t idx = atomicAdd(a.long_count, 1u);
-        if (idx < a.long_cap) {
-            LongEntry le;
-            le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
-            a.long_list[idx] = le;
-            s_tok[i] = TOK_LONGREF | idx;
-            *s_haslong = 1;
-        } else {
-            raise(a, TD_E_SCRATCH, wg0 + i);
-        }
-        return;
+        if (idx >= a.long_cap) { raise(a, TD_E_SCRATCH, wg0 + i); return 0u; }
+        LongEntry le;
+        le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
+        a.long_list[idx] = le;
+        atomicOr(s_flags, TILE_HAS_LONG);
+        return TOK_LONGREF | idx;
     }
     const uint8_t* pb = s_txt + i;
     if (len == 1) {
         const int32_t id = s_byteid[pb[0]];
         if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
-        s_tok[i] = (uint32_t)id;
-        return;
+        return (uint32_t)id;
     }
     if (a.use_fastpath) {
         auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
@@ -530,66 +533,25 @@ __device__ __forceinline__ void resolve_piece_cold(const EncodeArgs& a, const Ta
             key = hash_bytes(get, len);
         }
         const int32_t r = piece_lookup(T, key, len, get);
-        if (r != NO_RANK) { s_tok[i] = (uint32_t)r; return; }
+        if (r != NO_RANK) return (uint32_t)r;
     }
-    atomicOr(&s_miss[i >> 5], 1u << (i & 31));
+    atomicOr(s_flags, TILE_HAS_MISS);
+    return TOK_MISS | ((uint32_t)i << 7) | len;
 }
 
-// Segmented inclusive min-scan across the wavefront with DPP (no LDS round trips): lane l ends up with the minimum
-// of x over lanes [max(ps, 0) .. l] where ps is the first lane of l's segment.  Rows of 16 lanes are scanned with
-// row_shr 1/2/4/8, then row_bcast15 (rows 1 and 3) and row_bcast31 (rows 2 and 3) carry the row totals across.
-__device__ __forceinline__ uint32_t seg_min_scan_dpp(uint32_t x, int lane, int ps) {
-    constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118, ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143;
-    uint32_t t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_SHR1, 0xF, 0xF, false);
-    if (lane - 1 >= ps) x = t < x ? t : x;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_SHR2, 0xF, 0xF, false);
-    if (lane - 2 >= ps) x = t < x ? t : x;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_SHR4, 0xF, 0xF, false);
-    if (lane - 4 >= ps) x = t < x ? t : x;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_SHR8, 0xF, 0xF, false);
-    if (lane - 8 >= ps) x = t < x ? t : x;
-    const int row0 = lane & ~15;  // first lane of my row
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_BCAST15, 0xA, 0xF, false);
-    if ((lane & 16) && ps < row0) x = t < x ? t : x;            // rows 1 and 3 take the total of rows 0 and 2
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ROW_BCAST31, 0xC, 0xF, false);
-    if (lane >= 32 && ps < 32) x = t < x ? t : x;               // rows 2 and 3 take the total of rows 0-1
-    return x;
-}
-
-// ------------------------------------------------------------------ td_encode_tiles ---------
-// Token kernel: pieces (from the START bitmap) -> token ids, compacted per tile.
-//   whole-piece table probe, one lane per piece      (CoreBPE::encode fast path, tiktoken.cpp:209-215)
-//   byte-pair merge of the misses, a wavefront per 64-byte window, one lane per byte, segmented
-//   wavefront min-reduce for the lowest-rank leftmost pair (bpe_merge, tiktoken.cpp:298-368)
-//   block scan + compaction into the tile's staging area; token slot of every document start.
-constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per tile by this kernel
-
-#ifndef TD_TILES_MIN_WAVES
-#define TD_TILES_MIN_WAVES 5
-#endif
-#ifndef TD_PROBE_NB
-#define TD_PROBE_NB 1  // whole-piece probes a lane keeps in flight (more cost registers: 4 in flight at 4 waves/SIMD
-                       // measured 17 % slower than 1 at 5 waves/SIMD)
-#endif
-__global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles(const EncodeArgs a) {
+__global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_BWIN + 16];
-    __shared__ __attribute__((aligned(16))) uint32_t s_tok[K_TILE + K_MAXSHORT];
     __shared__ uint32_t s_start[K_BWIN / 32 + 3];  // bit i: a piece starts at tile byte i
-    __shared__ uint32_t s_miss[K_BWIN / 32 + 3];   // bit i: the piece starting at i missed the whole-piece table
     __shared__ __attribute__((aligned(16))) uint16_t s_plist[K_TILE + 8];  // tile positions of the piece starts (+ end delimiter)
-    // phase 5 reuses the (then dead) piece list: token slots before each lane's chunk / which of its 16 slots hold a token
+    // after the probes the (then dead) piece list holds: pieces before each lane's 16-byte chunk / its START bits
     uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_plist);
     uint16_t* const s_valid = s_plist + 2 * K_THREADS;
     __shared__ int32_t s_byteid[256];
     __shared__ uint32_t s_wave[8];
     __shared__ long long s_ext_end;                // global end of the tile's last piece when it leaves the window (else 0)
-    __shared__ uint32_t s_haslong;
-    __shared__ uint32_t s_segctr;                  // phase 4: next 256-byte segment to merge
-    __shared__ uint32_t s_tailcnt;                 // phase 5: tokens in the slots past the tile end
+    __shared__ uint32_t s_flags;                   // TILE_HAS_LONG | TILE_HAS_MISS
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
 
@@ -610,12 +572,10 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
         const int64_t wg0 = tile_g0;                 // window index 0 == first byte of the tile
-        constexpr int K_HL = 0;                      // (shadows the split kernel's left halo: none here)
         const int tile_hi = (int)((a.n - tile_g0 < K_TILE) ? (a.n - tile_g0) : K_TILE);
         const int c0 = tid * K_CHUNK, c1 = c0 + K_CHUNK;
 
-        // ---- phase 0: stage text + START bits of the tile (+128 B look-ahead); clear token slots.  Text was
-        //      requested one iteration ago (pf0/pf1) -----------------------------------------------------------
+        // ---- stage text + START bits of the tile (+128 B look-ahead).  Both were requested one iteration ago ----
         reinterpret_cast<uint4*>(s_txt)[tid] = pf0;
         if (tid < (K_BWIN + 16) / 16 - K_THREADS) reinterpret_cast<uint4*>(s_txt)[K_THREADS + tid] = pf1;
         if (tid < K_BWIN / 32 + 3) {
@@ -623,7 +583,6 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
             const int64_t g = wg0 + (int64_t)tid * 32;
             if (a.n >= g && a.n < g + 32) sw |= 1u << (int)(a.n - g);  // the end of the text delimits the last piece
             s_start[tid] = sw;
-            s_miss[tid] = 0;
         }
         {
             const int64_t nwg0 = wg0 + (int64_t)gridDim.x * K_TILE;
@@ -633,25 +592,21 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                 pfs = load_startword(nwg0);
             }
         }
-        {
-            const uint4 none = make_uint4(TOK_NONE, TOK_NONE, TOK_NONE, TOK_NONE);
-            for (int v = tid; v < (K_TILE + K_MAXSHORT) / 4; v += K_THREADS) reinterpret_cast<uint4*>(s_tok)[v] = none;
-        }
-        if (tid == 0) { s_ext_end = 0; s_haslong = 0; s_segctr = 0; }
+        if (tid == 0) { s_ext_end = 0; s_flags = 0; }
         __syncthreads();
         if (a.stop_after == 30) continue;
 
-        // ---- phase 3: whole-piece lookup, one lane per piece ---------------------------------
-        // 3a: dense list of the tile's piece starts (so that every lane has a piece to look up)
-        uint32_t np_total;
+        // ---- dense list of the tile's piece starts (so that every lane has a piece to look up) ----
+        uint32_t np_total, pbase, smask0;
         {
             uint32_t smask = 0;  // START bits of my 16 bytes
             if (c0 < tile_hi) {
                 smask = (s_start[c0 >> 5] >> (c0 & 31)) & 0xFFFFu;
                 if (c1 > tile_hi) smask &= (1u << (tile_hi - c0)) - 1u;
             }
+            smask0 = smask;
             const uint32_t cnt = __popc(smask);
-            const uint32_t pbase = block_excl_scan(cnt, s_wave, np_total);
+            pbase = block_excl_scan(cnt, s_wave, np_total);
             uint32_t k = pbase;
             while (smask) {
                 const int b = __ffs(smask) - 1;
@@ -665,7 +620,6 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                 while (e < K_BWIN && !((s_start[e >> 5] >> (e & 31)) & 1u)) ++e;
                 if (e >= K_BWIN && np_total > 0) {
                     int64_t g = wg0 + K_BWIN;
-                    const int64_t nwords = (a.n + 31) >> 5;
                     int64_t found = a.n;
                     for (int64_t gw = g >> 5; gw < nwords; ++gw) {
                         uint32_t sw = a.startbits[gw];
@@ -673,7 +627,7 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
                         if (sw) { const int64_t f = gw * 32 + (__ffs(sw) - 1); if (f < a.n) found = f; break; }
                     }
                     s_ext_end = found;
-                    e = K_BWIN;  // placeholder; 3b uses s_ext_end for the last piece
+                    e = K_BWIN;  // placeholder; the probe uses s_ext_end for the last piece
                 }
                 s_plist[np_total] = (uint16_t)e;
             }
@@ -681,225 +635,99 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         __syncthreads();
         if (a.stop_after == 31) continue;
         const long long ext_end = s_ext_end;
-        // 3b: probe, piece k -> lane k mod 256, TD_PROBE_NB pieces per lane at a time.  Hot path = pieces of 2..16
-        //     bytes (key = the bytes): first slot of the HBM table for their length class; single bytes index the
-        //     256-entry LDS table; everything else (probe collisions, keys over 16 bytes, long pieces) goes through
-        //     resolve_piece_cold in a second, rolled loop.  (An LDS copy of the 512 lowest-rank tokens in front of the
-        //     HBM probe measured no faster: its 8 KB cost the fifth wavefront per SIMD.)
-        {
-            constexpr int NB = TD_PROBE_NB;
-            for (uint32_t k0 = tid; k0 < np_total; k0 += NB * K_THREADS) {
-                int pi[NB];          // piece start (tile position) still to be resolved in stage 3, -1 = done
-                uint32_t cold = 0;   // pieces of this batch left to the rolled loop below
-                uint32_t plen[NB];
-                uint64_t pkey[NB], pkey1[NB];
-                uint32_t ph[NB];
-                uint64_t sl0[NB], sl1[NB], sl2[NB];  // probed slot: {key, rank|len<<32, -} or {k0, k1, rank|len<<32}
+        // ---- probe: piece k -> lane k mod 256, one piece per lane at a time (more in flight cost registers, and
+        //      registers cost resident wavefronts: round 1 measured 2 and 4 in flight slower).  Hot path = pieces of 2..16
+        //      bytes (key = the bytes): first slot of the HBM table of their length class; single bytes index the
+        //      256-entry LDS table; everything else goes through probe_piece_cold. ----
+        uint32_t* const dst = a.stage + (size_t)tile * K_STAGE;
+        constexpr int NB = TD_PROBE_NB;  // pieces a lane keeps in flight
+        for (uint32_t k0 = tid; k0 < np_total; k0 += NB * K_THREADS) {
+            int pi[NB];
+            uint32_t plen[NB], res[NB], kind[NB];  // kind: 0 resolved, 1 probe of the <= 8-byte table, 2 of the 9..16-byte table, 3 cold
+            uint64_t pkey[NB], pkey1[NB], sl0[NB], sl1[NB], sl2[NB];
+            uint32_t ph[NB];
 #pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const uint32_t k = k0 + u * K_THREADS;
-                    pi[u] = -1;
-                    plen[u] = 0;
-                    if (k >= np_total) continue;
-                    const int i = s_plist[k];
-                    const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
-                    pi[u] = i;
-                    plen[u] = len;
-                    if (len == 1) {  // single byte: direct table
-                        const int32_t id = s_byteid[s_txt[i]];
-                        if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
-                        s_tok[i] = (uint32_t)id;
-                        pi[u] = -1;
-                        continue;
-                    }
-                    if (len > 16 || !a.use_fastpath || (ext_end && k == np_total - 1)) { cold |= 1u << u; pi[u] = -1; continue; }
-                    // up to 16 key bytes, read unaligned from LDS: five dwords, funnel-shifted
-                    const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
-                    const uint32_t sh = (i & 3) * 8;
-                    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-                    uint64_t key = ((uint64_t)__funnelshift_r(w1, w2, sh) << 32) | __funnelshift_r(w0, w1, sh);
-                    if (len <= 8) {
-                        if (len < 8) key &= (1ull << (8 * len)) - 1;
-                        const uint32_t hsh = hash_piece(key, len);
-                        pkey[u] = key;
-                        pkey1[u] = 0;
-                        ph[u] = hsh & T.piece_mask;
-                    } else {
-                        const uint32_t w3 = wp[3], w4 = wp[4];
-                        uint64_t key1 = ((uint64_t)__funnelshift_r(w3, w4, sh) << 32) | __funnelshift_r(w2, w3, sh);
-                        if (len < 16) key1 &= (1ull << (8 * (len - 8))) - 1;
-                        pkey[u] = key;
-                        pkey1[u] = key1;
-                        ph[u] = hash_piece16(key, key1, len) & T.piece16_mask;
-                    }
+            for (int u = 0; u < NB; ++u) {
+                const uint32_t k = k0 + u * K_THREADS;
+                kind[u] = 0; res[u] = 0; pi[u] = 0; plen[u] = 0; pkey[u] = 0; pkey1[u] = 0; ph[u] = 0;
+                if (k >= np_total) continue;
+                const int i = s_plist[k];
+                const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
+                pi[u] = i;
+                plen[u] = len;
+                if (len == 1) {  // single byte: direct table
+                    const int32_t id = s_byteid[s_txt[i]];
+                    if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
+                    res[u] = (uint32_t)id;
+                    continue;
                 }
-                if (a.stop_after == 32) continue;
+                if (len > 16 || !a.use_fastpath || (ext_end && k == np_total - 1)) { kind[u] = 3; continue; }
+                // up to 16 key bytes, read unaligned from LDS: five dwords, funnel-shifted
+                const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
+                const uint32_t sh = (i & 3) * 8;
+                const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                uint64_t key = ((uint64_t)__funnelshift_r(w1, w2, sh) << 32) | __funnelshift_r(w0, w1, sh);
+                if (len <= 8) {
+                    if (len < 8) key &= (1ull << (8 * len)) - 1;
+                    pkey[u] = key;
+                    ph[u] = hash_piece(key, len) & T.piece_mask;
+                    kind[u] = 1;
+                } else {
+                    const uint32_t w3 = wp[3], w4 = wp[4];
+                    uint64_t key1 = ((uint64_t)__funnelshift_r(w3, w4, sh) << 32) | __funnelshift_r(w2, w3, sh);
+                    if (len < 16) key1 &= (1ull << (8 * (len - 8))) - 1;
+                    pkey[u] = key;
+                    pkey1[u] = key1;
+                    ph[u] = hash_piece16(key, key1, len) & T.piece16_mask;
+                    kind[u] = 2;
+                }
+            }
 #pragma unroll
-                for (int u = 0; u < NB; ++u)
-                    if (pi[u] >= 0) {
-                        if (plen[u] <= 8) {
-                            const PieceSlot* sp = T.piece_slots + ph[u];
-                            sl0[u] = sp->key;
-                            sl1[u] = (uint64_t)sp->rank | ((uint64_t)sp->len << 32);
-                            sl2[u] = 0;
-                        } else {
-                            const Piece16Slot* sp = T.piece16_slots + ph[u];
-                            sl0[u] = sp->k0; sl1[u] = sp->rl; sl2[u] = sp->k1;
-                        }
-                    }
+            for (int u = 0; u < NB; ++u) {
+                sl0[u] = sl1[u] = sl2[u] = 0;
+                if (kind[u] == 1) {
+                    const PieceSlot* sp = T.piece_slots + ph[u];
+                    sl0[u] = sp->key;
+                    sl1[u] = (uint64_t)sp->rank | ((uint64_t)sp->len << 32);
+                } else if (kind[u] == 2) {
+                    const Piece16Slot* sp = T.piece16_slots + ph[u];
+                    sl0[u] = sp->k0; sl1[u] = sp->rl; sl2[u] = sp->k1;
+                }
+            }
 #pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int i = pi[u];
-                    if (i < 0) continue;
-                    const uint64_t want = (uint64_t)plen[u] << 32;
-                    if (sl0[u] == pkey[u] && sl2[u] == pkey1[u] && (sl1[u] & 0xFFFFFFFF00000000ull) == want) {  // the common case
-                        s_tok[i] = (uint32_t)sl1[u];
-                        continue;
+            for (int u = 0; u < NB; ++u) {
+                if (kind[u] != 1 && kind[u] != 2) continue;
+                if (sl0[u] == pkey[u] && sl2[u] == pkey1[u] && (sl1[u] >> 32) == plen[u]) { res[u] = (uint32_t)sl1[u]; kind[u] = 0; }  // the common case
+                else if ((sl1[u] >> 32) == 0) {                                                                      // empty slot: not a token
+                    res[u] = TOK_MISS | ((uint32_t)pi[u] << 7) | plen[u];
+                    atomicOr(&s_flags, TILE_HAS_MISS);
+                    kind[u] = 0;
+                } else kind[u] = 3;                                                                                  // occupied by another key
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const uint32_t k = k0 + u * K_THREADS;
+                if (kind[u] == 3) {
+                    uint32_t len = plen[u];
+                    if (ext_end && k == np_total - 1) {
+                        const long long l = ext_end - (wg0 + pi[u]);
+                        len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
                     }
-                    if ((sl1[u] >> 32) == 0) { atomicOr(&s_miss[i >> 5], 1u << (i & 31)); continue; }  // empty slot: not a token
-                    cold |= 1u << u;                                                                    // occupied by another key
+                    res[u] = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, pi[u], len);
                 }
-                if (a.stop_after == 33) continue;
-                if (__any(cold != 0)) {
-                    while (cold) {
-                        const int u = __ffs(cold) - 1;
-                        cold &= cold - 1;
-                        const uint32_t k = k0 + u * K_THREADS;
-                        const int i = s_plist[k];
-                        uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
-                        if (ext_end && k == np_total - 1) {
-                            const long long l = ext_end - (wg0 + i);
-                            len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
-                        }
-                        resolve_piece_cold(a, T, s_txt, s_tok, s_miss, s_byteid, &s_haslong, wg0, i, len);
-                    }
-                }
+                if (k < np_total) dst[k] = res[u];
             }
         }
         __syncthreads();
         if (a.stop_after == 3) continue;
-
-        // ---- phase 4: byte-pair merge of the missed pieces: a wavefront per 64-byte window of pieces, one lane per
-        //      byte.  (Measured alternative, round 1: one missed piece per LANE with ranks in L2 — 2.6x slower on
-        //      the mixed-script corpus, 1.5x on code: the serial per-lane rank scans are not latency-hidden.)
-        for (;;) {
-            // the tile is cut into 256-byte segments that the four wavefronts take from a shared counter (merge work
-            // is very uneven across a tile: static quarters left three wavefronts waiting at the barrier)
-            constexpr int SEG = 256;
-            int sg = 0;
-            if (lane == 0) sg = (int)atomicAdd(&s_segctr, 1u);
-            sg = __builtin_amdgcn_readfirstlane(sg);
-            if (sg >= K_TILE / SEG) break;
-            const int seg_lo = K_HL + sg * SEG;
-            if (seg_lo >= tile_hi) break;
-            const int seg_hi = (seg_lo + SEG < tile_hi) ? seg_lo + SEG : tile_hi;
-            int pos = seg_lo;
-            const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);  // lanes <= mine
-            {   // nothing missed in this segment (the common case on plain text): skip it
-                const int wlo = seg_lo >> 5;
-                const uint32_t mw = (lane < SEG / 32) ? s_miss[wlo + lane] : 0u;
-                if (!__any(mw != 0)) pos = seg_hi;
-            }
-            while (pos < seg_hi) {
-                uint64_t missm = bits64(s_miss, pos);
-                if (seg_hi - pos < 64) missm &= td_bits_below(seg_hi - pos);  // pieces that START in my segment
-                if (missm == 0) { pos += 64; continue; }
-                const int f = __ffsll((unsigned long long)missm) - 1;
-                if (f > 0) { pos += f; continue; }  // re-align: first missed piece at lane 0
-                const uint64_t startm = bits64(s_start, pos);
-                const bool next_is_start = (s_start[(pos + 64) >> 5] >> ((pos + 64) & 31)) & 1u;
-                const int idx = pos + lane;
-                const uint64_t below = startm & le;  // bit 0 is set
-                const int ps = 63 - __clzll((unsigned long long)below);
-                const uint64_t above = startm & ~le;
-                int pe;
-                bool fits;
-                if (above) { pe = __ffsll((unsigned long long)above) - 1; fits = true; }
-                else { pe = 64; fits = next_is_start; }
-                const bool active = fits && ((missm >> ps) & 1ull);
-                const uint64_t pendm = __ballot(((missm >> lane) & 1ull) && !active);
-
-                const uint32_t b = s_txt[idx];
-                uint32_t id = (uint32_t)s_byteid[b];
-                bool alive = active;
-                const uint32_t bn = __shfl_down(b, 1);
-                int32_t rank = NO_RANK;
-                if (active && lane + 1 < pe) rank = T.byte_pair[(b << 8) | bn];
-                for (;;) {
-                    const uint32_t key = (alive && rank != NO_RANK) ? (((uint32_t)rank << 6) | (uint32_t)lane) : 0xFFFFFFFFu;
-                    uint32_t m = seg_min_scan_dpp(key, lane, ps);  // segmented inclusive min over [ps, lane]
-                    m = __shfl(m, (pe - 1) & 63);                  // lowest-rank, leftmost pair of my piece
-                    const bool has = active && m != 0xFFFFFFFFu;
-                    if (!__any(has)) break;
-                    const uint64_t A = __ballot(alive);
-                    const int w = (int)(m & 63u);
-                    const uint64_t aw = A & ~((w == 63) ? ~0ull : ((2ull << w) - 1));
-                    const int nx = aw ? __ffsll((unsigned long long)aw) - 1 : 64;
-                    if (has) {
-                        if (lane == nx) alive = false;       // right part is absorbed
-                        if (lane == w) id = m >> 6;          // merged token id == its rank
-                    }
-                    const uint64_t A2 = __ballot(alive);
-                    const uint64_t an = A2 & ~le;
-                    const int nl = an ? __ffsll((unsigned long long)an) - 1 : 64;
-                    const uint32_t idn = __shfl(id, nl & 63);
-                    if (has && alive && (lane == w || nl == w))  // only the merged part and its left neighbour re-rank
-                        rank = (nl < pe) ? pair_lookup(T, id, idn) : NO_RANK;
-                }
-                if (alive) {
-                    if ((int32_t)id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + idx);
-                    s_tok[idx - K_HL] = id;
-                }
-                pos = pendm ? pos + (__ffsll((unsigned long long)pendm) - 1) : pos + 64;
-            }
-        }
+        // ---- per-tile results: slot count + flags; the slot of every document that starts in this tile (documents are
+        //      consecutive from the tile's first one, recorded by td_mark_docs; empty documents share a position) ----
+        s_off[tid] = pbase;
+        s_valid[tid] = (uint16_t)smask0;
+        if (tid == 0) a.tile_count[tile] = np_total | s_flags;
         __syncthreads();
-        if (a.stop_after == 4) continue;
-
-        // ---- phase 5: compact the byte-indexed token array (in place, in LDS: a token never moves to a higher
-        //      index, and every lane has read its slots before the scan's barriers), then stream the dense prefix to
-        //      the tile's staging area with 16-byte stores -------------------------------------------------------
         {
-            uint32_t vals[K_CHUNK];
-#pragma unroll
-            for (int k = 0; k < K_CHUNK / 4; ++k) {
-                const uint4 x = reinterpret_cast<const uint4*>(s_tok)[tid * (K_CHUNK / 4) + k];
-                vals[4 * k] = x.x; vals[4 * k + 1] = x.y; vals[4 * k + 2] = x.z; vals[4 * k + 3] = x.w;
-            }
-            uint32_t vmask = 0;
-#pragma unroll
-            for (int k = 0; k < K_CHUNK; ++k) vmask |= (vals[k] != TOK_NONE) ? (1u << k) : 0u;
-            const uint32_t cnt = __popc(vmask);
-            // tokens of the tile's last piece may sit past the tile end (slots K_TILE .. K_TILE+63): they follow
-            // everything else in byte order; the first wavefront carries them, one slot per lane
-            static_assert(K_MAXSHORT == 64, "one tail slot per lane of a wavefront");
-            uint32_t tv = TOK_NONE;
-            uint64_t tb = 0;
-            if (tid < 64) {
-                tv = s_tok[K_TILE + tid];
-                tb = __ballot(tv != TOK_NONE);
-                if (tid == 0) s_tailcnt = (uint32_t)__popcll((unsigned long long)tb);
-            }
-            uint32_t total;
-            const uint32_t off = block_excl_scan(cnt, s_wave, total);
-            const uint32_t total_regular = total;
-            total += s_tailcnt;
-            s_off[tid] = off;
-            s_valid[tid] = (uint16_t)vmask;
-            uint32_t k2 = off;
-#pragma unroll
-            for (int k = 0; k < K_CHUNK; ++k)
-                if (vals[k] != TOK_NONE) s_tok[k2++] = vals[k];
-            if (tid < 64 && tv != TOK_NONE)
-                s_tok[total_regular + (uint32_t)__popcll((unsigned long long)(tb & ((1ull << tid) - 1ull)))] = tv;
-            __syncthreads();
-            uint4* dst4 = reinterpret_cast<uint4*>(a.stage + (size_t)tile * K_STAGE);
-            for (uint32_t v = tid; v * 4 < total; v += K_THREADS) dst4[v] = reinterpret_cast<const uint4*>(s_tok)[v];
-            if (tid == 0) a.tile_count[tile] = total | (s_haslong ? 0x80000000u : 0u);
-            __syncthreads();
-            // token slot of every document that starts in this tile (documents are consecutive from the
-            // tile's first one, recorded by td_mark_docs; empty documents share a position)
-            const int64_t tile_end_g = tile_g0 + (tile_hi - K_HL);
+            const int64_t tile_end_g = tile_g0 + tile_hi;
             const int64_t fd = (int64_t)a.tile_first_doc[tile];
             for (int64_t d = fd + tid; d < a.n_docs; d += K_THREADS) {
                 const int64_t p = a.doc_offsets[d];
@@ -910,6 +738,185 @@ __global__ __launch_bounds__(K_THREADS, TD_TILES_MIN_WAVES) void td_encode_tiles
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------ byte-pair merge, one lane per piece ----
+// Token kernel, second half: the pieces td_probe_tiles marked TOK_MISS (2..64 bytes, not a token).  A piece is merged by ONE
+// LANE (mg_round, td_common.h: every lane advances its own merge chain, a merge per round; a round is a minimum over the
+// lane's keys in LDS, a handful of bit operations on its part mask and four pair-table probes in flight).
+// (Round 1 merged with one lane per BYTE and a segmented min-scan per 64-byte window: ~120 instructions per round for the
+// 5-10 pieces of a window, and only as many probes in flight as there were pieces in the window.  A first lane-per-piece
+// version that worked tile by tile — a workgroup per tile, the tile's ~80 missed pieces in five class batches one after
+// the other — ran 163 rounds per tile at 2 % lane utilisation and was slower than round 1; batches have to be FULL, so they
+// are filled across tiles.)
+// 17 text bytes at global offset g as five dwords (byte k = bits 8(k&3).. of w[k>>2]); zero past the end of the text
+__device__ __forceinline__ void load_piece_window(const EncodeArgs& a, int64_t g, uint32_t (&w)[5]) {
+    const uintptr_t addr = (uintptr_t)(a.text + g);
+    const int64_t g4 = g - (int64_t)(addr & 3);  // text offset of the aligned dword that holds byte g
+    if (g4 >= 0 && g4 + 24 <= a.n) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(a.text + g4);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
+        const uint32_t sh = (uint32_t)(addr & 3) * 8;
+        w[0] = __funnelshift_r(d0, d1, sh); w[1] = __funnelshift_r(d1, d2, sh); w[2] = __funnelshift_r(d2, d3, sh);
+        w[3] = __funnelshift_r(d3, d4, sh); w[4] = __funnelshift_r(d4, d5, sh);
+    } else {
+        for (int k = 0; k < 5; ++k) w[k] = 0;
+        for (int k = 0; k < 17; ++k)
+            if (g + k >= 0 && g + k < a.n) w[k >> 2] |= (uint32_t)a.text[g + k] << (8 * (k & 3));
+    }
+}
+
+// parts + keys of the piece text[g, g + st.len) into the lane's units: the piece's bytes 16 at a time in registers (+ the
+// byte behind them), so that the sixteen byte-pair ranks of a unit are independent loads that go out back to back
+__device__ __forceinline__ void mg_init_piece(const EncodeArgs& a, const Tables& T, const int32_t* s_byteid, uint32_t* keys, uint32_t* ids,
+                                              const MergeState& st, int64_t g) {
+    for (uint32_t c = 0; c * 16u < st.len; ++c) {
+        uint32_t w[5];
+        load_piece_window(a, g + 16 * c, w);
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t jj = 16u * c + j;
+            if (jj < st.len) {
+                const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                const uint32_t bn = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu;
+                mg_put(T, s_byteid, keys, ids, st, jj, b, bn);
+            }
+        }
+    }
+    mg_pad(keys, st);
+}
+
+// LDS traffic between the lanes of ONE wavefront: program order is execution order, the fence keeps the compiler from
+// moving the accesses and waits for the outstanding LDS operations
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// inclusive add-scan across the wavefront with DPP (no LDS round trips): rows of 16 lanes with row_shr 1/2/4/8 (lanes without
+// a source add 0), then row_bcast15 (rows 1 and 3 take the total of rows 0 and 2) and row_bcast31 (rows 2, 3 take rows 0-1)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int /*lane*/) {
+    constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118, ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR1, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR2, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR4, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR8, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_BCAST15, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_BCAST31, 0xC, 0xF, false);
+    return x;
+}
+
+// ------------------------------------------------------------------ td_merge_pieces ---------
+// Every wavefront works alone (no workgroup barrier): it walks its share of the tiles flagged TILE_HAS_MISS, collects their
+// TOK_MISS slots into five LDS queues by length class (<= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units), and whenever a
+// queue holds a full batch (64 / units pieces, whatever tiles they come from) merges it: one piece per owner lane, the
+// rounds of a batch run until its longest chain is done — pieces of one class need about the same number of rounds.
+// A merged piece's ids go to its own bytes' slots of the result buffer (a.merge_out[tile * K_STAGE + tile position + i]:
+// pieces do not overlap and a piece has at most as many ids as bytes), its slot becomes TOK_MISS | position << 7 | ids and
+// the tile's extra ids are added to tile_extra; td_pack_tokens expands the markers.
+constexpr int MQ_CLASSES = 5;
+constexpr int MQ_CAP = 128;  // queue capacity per class: a full batch + one row of slots
+__device__ __forceinline__ uint32_t mq_class(uint32_t len) { return len <= 8u ? 0u : len <= 16u ? 1u : len <= 32u ? 2u : len <= 48u ? 3u : 4u; }
+__device__ __forceinline__ uint32_t mq_units(uint32_t cls) { return cls < 2u ? 1u : cls; }
+
+#ifndef TD_MERGE_MIN_WAVES
+#define TD_MERGE_MIN_WAVES 3
+#endif
+__global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces(const EncodeArgs a) {
+    constexpr int NW = K_THREADS / 64;
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[NW][64 * MG_UNIT];
+    __shared__ __attribute__((aligned(16))) uint32_t s_ids[NW][64 * MG_UNIT];
+    __shared__ unsigned long long s_q[NW][MQ_CLASSES][MQ_CAP];  // tile << 32 | slot index << 19 | tile position << 7 | length
+    __shared__ int32_t s_byteid[256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const Tables T = uniform_tables(a.Tp);
+    for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
+    __syncthreads();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t* const keys = s_keys[wv];
+    uint32_t* const ids = s_ids[wv];
+    uint32_t qhead[MQ_CLASSES], qcnt[MQ_CLASSES];  // (wave-uniform)
+#pragma unroll
+    for (int c = 0; c < MQ_CLASSES; ++c) { qhead[c] = 0; qcnt[c] = 0; }
+
+    // one batch of class c: the first min(count, 64 / units) pieces of its queue
+    auto run_batch = [&](int c) {
+        const uint32_t u = mq_units((uint32_t)c);
+        const uint32_t np = qcnt[c] < 64u / u ? qcnt[c] : 64u / u;
+        const uint32_t i = (uint32_t)lane / u;
+        MergeState st;
+        st.alive = 0; st.t = (uint32_t)lane; st.len = 0;
+        unsigned long long rec = 0;
+        if ((uint32_t)lane == i * u && i < np) {
+            rec = s_q[wv][c][(qhead[c] + i) & (MQ_CAP - 1)];
+            st.len = (uint32_t)rec & 127u;
+            st.alive = st.len >= 64u ? ~0ull : ((1ull << st.len) - 1ull);
+        }
+        qhead[c] = (qhead[c] + np) & (MQ_CAP - 1);
+        qcnt[c] -= np;
+        const uint32_t tile = (uint32_t)(rec >> 32), pos = ((uint32_t)rec >> 7) & 0xFFFu;
+        const int64_t gpos = (int64_t)tile * K_TILE + pos;
+        if (st.len) mg_init_piece(a, T, s_byteid, keys, ids, st, gpos);
+        for (;;) {  // (pieces of at most 32 bytes: the part mask is one register)
+            const bool more = c <= 2 ? mg_round_t<uint32_t>(T, keys, ids, st) : mg_round_t<uint64_t>(T, keys, ids, st);
+            if (!__any(more)) break;
+        }
+        if (st.len) {
+            uint32_t* out = a.merge_out + (size_t)tile * K_STAGE + pos;
+            uint32_t nt = 0;
+            for (uint64_t al = st.alive; al; al &= al - 1ull) {
+                const uint32_t j = (uint32_t)td_ctz64(al);
+                const uint32_t id = ids[mg_slot(st.t, j)];
+                if ((int32_t)id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gpos + j);
+                out[nt++] = id;
+            }
+            a.stage[(size_t)tile * K_STAGE + (((uint32_t)rec >> 19) & 0x1FFFu)] = TOK_MISS | (pos << 7) | nt;
+            if (nt > 1) atomicAdd(&a.tile_extra[tile], nt - 1);
+        }
+        wave_sync();  // (the batch's LDS reads are done before the next batch's writes)
+    };
+
+    const int nwaves = gridDim.x * NW;
+    for (int tile = blockIdx.x * NW + wv; tile < a.n_tiles; tile += nwaves) {
+        const uint32_t tc = a.tile_count[tile];
+        if (!(tc & TILE_HAS_MISS)) continue;  // (uniform per wavefront)
+        const uint32_t cnt = tc & TILE_COUNT_MASK;
+        const uint32_t* slots = a.stage + (size_t)tile * K_STAGE;
+        // the tile's slots, eight rows of 64 at a time (eight independent loads in flight)
+        for (uint32_t r0 = 0; r0 * 64u < cnt; r0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t k = (r0 + r) * 64u + lane;
+                v[r] = k < cnt ? slots[k] : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bool miss = (v[r] & 0xC0000000u) == TOK_MISS;
+                if (!__any(miss)) continue;
+                const uint32_t cls = mq_class(v[r] & 127u);
+                const unsigned long long rec = ((unsigned long long)(uint32_t)tile << 32) | ((((r0 + r) * 64u + lane) & 0x1FFFu) << 19) | (v[r] & 0x7FFFFu);
+#pragma unroll
+                for (int c = 0; c < MQ_CLASSES; ++c) {
+                    const uint64_t b = __ballot(miss && cls == (uint32_t)c);
+                    if (b) {
+                        if (miss && cls == (uint32_t)c)
+                            s_q[wv][c][(qhead[c] + qcnt[c] + (uint32_t)__popcll((unsigned long long)(b & lt))) & (MQ_CAP - 1)] = rec;
+                        qcnt[c] += (uint32_t)__popcll((unsigned long long)b);
+                    }
+                }
+                wave_sync();
+#pragma unroll
+                for (int c = 0; c < MQ_CLASSES; ++c)
+                    while (qcnt[c] >= 64u / mq_units((uint32_t)c)) run_batch(c);
+            }
+        }
+    }
+    // what is left: partial batches
+#pragma unroll
+    for (int c = 0; c < MQ_CLASSES; ++c)
+        while (qcnt[c]) run_batch(c);
 }
 
 // ------------------------------------------------------------------ td_long_pieces ----------
@@ -1245,11 +1252,11 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
         if (e0 + 4 <= a.n_tiles) {
             const uint4 cnt = *reinterpret_cast<const uint4*>(a.tile_count + e0);
             const uint4 ext = *reinterpret_cast<const uint4*>(a.tile_extra + e0);
-            v[0] = (cnt.x & 0x7FFFFFFFu) + ext.x; v[1] = (cnt.y & 0x7FFFFFFFu) + ext.y;
-            v[2] = (cnt.z & 0x7FFFFFFFu) + ext.z; v[3] = (cnt.w & 0x7FFFFFFFu) + ext.w;
+            v[0] = (cnt.x & TILE_COUNT_MASK) + ext.x; v[1] = (cnt.y & TILE_COUNT_MASK) + ext.y;
+            v[2] = (cnt.z & TILE_COUNT_MASK) + ext.z; v[3] = (cnt.w & TILE_COUNT_MASK) + ext.w;
         } else {
             for (int k = 0; k < 4; ++k)
-                if (e0 + k < a.n_tiles) v[k] = (a.tile_count[e0 + k] & 0x7FFFFFFFu) + a.tile_extra[e0 + k];
+                if (e0 + k < a.n_tiles) v[k] = (a.tile_count[e0 + k] & TILE_COUNT_MASK) + a.tile_extra[e0 + k];
         }
         const unsigned long long mine = (unsigned long long)v[0] + v[1] + v[2] + v[3];
         unsigned long long x = mine;
@@ -1301,119 +1308,120 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
 }
 
 // ------------------------------------------------------------------ td_pack_tokens ----------
-// staging -> densely packed ids + per-document token offsets.  One WAVEFRONT per tile (a tile's ids are only a
-// few KB: many small independent copies in flight beat few large ones); tiles that contain long-piece markers
-// are left to a second, workgroup-wide pass that expands them.
+// per-tile slots -> densely packed ids + per-document token offsets.  One WAVEFRONT per tile (a tile's ids are only a few
+// KB: many small independent copies in flight beat few large ones), no workgroup barrier, no LDS.
+//   plain tiles (every slot is an id): 16-byte copies;
+//   tiles with markers: a sweep over rows of 64 slots with a running id count: a slot's size is 1, the ids of a merged
+//   piece (TOK_MISS | position | ids, from a.merge_out) or of a long piece (TOK_LONGREF, from the pool; copied by the whole
+//   wavefront); the documents that start in the tile pick their offset out of the row scan their slot falls in.
+// (A workgroup-per-tile version of the marker path with the tile's offsets in LDS cost 14-17 us per tile: five barriers
+// and six dependent global loads in a row; plain English has a marker in every third tile.)
 __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
-    constexpr int K_PCH = (K_STAGE + K_THREADS - 1) / K_THREADS;  // staging slots per lane in pass 2
-    __shared__ uint32_t s_off[K_THREADS * K_PCH];
-    __shared__ uint32_t s_wave[8];
-    __shared__ uint32_t s_mark[64];
-    __shared__ uint32_t s_nmark;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t total = a.tile_base[a.n_tiles];
     const int nwaves = gridDim.x * (K_THREADS / 64);
     auto base_of = [&](int tile) { return a.tile_base[tile] + a.chunk_pref[tile / K_SCAN_CHUNK]; };
-    // pass 1: plain tiles
     for (int tile = blockIdx.x * (K_THREADS / 64) + wv; tile < a.n_tiles; tile += nwaves) {
         const uint32_t tc = a.tile_count[tile];
-        if (tc >> 31) continue;
-        const uint32_t cnt = tc;
+        const uint32_t cnt = tc & TILE_COUNT_MASK;
         const int64_t base = base_of(tile);
         const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
-        if (base + cnt <= a.out_cap) {
-            // 16-byte stores to the (arbitrarily placed) destination: single ids up to its next 16-byte boundary, then
-            // four ids per lane (the staging side is read with dword-aligned 16-byte loads)
-            int32_t* dst = a.out_tokens + base;
-            uint32_t head = (uint32_t)((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2;
-            if (head > cnt) head = cnt;
-            if ((uint32_t)lane < head) dst[lane] = (int32_t)src[lane];
-            const uint32_t nv = (cnt - head) >> 2;
-            for (uint32_t v = lane; v < nv; v += 64) {
-                uint4 x;
-                __builtin_memcpy(&x, src + head + 4 * v, 16);
-                *reinterpret_cast<uint4*>(dst + head + 4 * v) = x;
-            }
-            const uint32_t done = head + 4 * nv;
-            if (done + (uint32_t)lane < cnt) dst[done + lane] = (int32_t)src[done + lane];
-        }
         const int64_t g_lo = (int64_t)tile * K_TILE;
         const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
-        for (int64_t d = (int64_t)a.tile_first_doc[tile] + lane; d < a.n_docs; d += 64) {
-            if (a.doc_offsets[d] >= g_hi) break;
-            a.out_offsets[d] = base + a.doc_slot[d];
+        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS))) {
+            if (base + cnt <= a.out_cap) {
+                // 16-byte stores to the (arbitrarily placed) destination: single ids up to its next 16-byte boundary, then
+                // four ids per lane (the staging side is read with dword-aligned 16-byte loads)
+                int32_t* dst = a.out_tokens + base;
+                uint32_t head = (uint32_t)((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2;
+                if (head > cnt) head = cnt;
+                if ((uint32_t)lane < head) dst[lane] = (int32_t)src[lane];
+                const uint32_t nv = (cnt - head) >> 2;
+                for (uint32_t v = lane; v < nv; v += 64) {
+                    uint4 x;
+                    __builtin_memcpy(&x, src + head + 4 * v, 16);
+                    *reinterpret_cast<uint4*>(dst + head + 4 * v) = x;
+                }
+                const uint32_t done = head + 4 * nv;
+                if (done + (uint32_t)lane < cnt) dst[done + lane] = (int32_t)src[done + lane];
+            }
+            for (int64_t d = (int64_t)a.tile_first_doc[tile] + lane; d < a.n_docs; d += 64) {
+                if (a.doc_offsets[d] >= g_hi) break;
+                a.out_offsets[d] = base + a.doc_slot[d];
+            }
+        } else {
+            // the documents that start in this tile, 64 at a time, in slot order (they are consecutive from the tile's first one)
+            int64_t dnext = (int64_t)a.tile_first_doc[tile], dmine = 0;
+            uint32_t dslot = 0xFFFFFFFFu;
+            bool dfull = false;
+            auto load_docs = [&]() {
+                dmine = dnext + lane;
+                const bool ok = dmine < a.n_docs && a.doc_offsets[dmine] < g_hi;
+                dslot = ok ? a.doc_slot[dmine] : 0xFFFFFFFFu;
+                dfull = __all(ok);
+                dnext += 64;
+            };
+            load_docs();
+            uint32_t carry = 0;  // ids of the rows above
+            for (uint32_t r0 = 0; r0 * 64u < cnt; r0 += 4) {
+                uint32_t v4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t k = (r0 + q) * 64u + lane;
+                    v4[q] = k < cnt ? src[k] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t r = r0 + q;
+                    if (r * 64u >= cnt) break;
+                    const uint32_t k = r * 64u + lane, v = v4[q];
+                    const bool is_long = (v & TOK_LONGREF) != 0, is_miss = !is_long && (v & TOK_MISS);
+                    LongEntry le;
+                    le.ntok = 0; le.pool_off = 0;
+                    if (is_long) le = a.long_list[v & 0x7FFFFFFFu];
+                    const uint32_t sz = k < cnt ? (is_long ? le.ntok : is_miss ? (v & 127u) : 1u) : 0u;
+                    const uint32_t incl = __any(is_long || is_miss) ? wave_incl_scan(sz, lane)
+                                                                    : ((cnt - r * 64u < 64u && k >= cnt) ? cnt - r * 64u : (uint32_t)lane + 1u);  // a row of plain ids
+                    const uint32_t off = carry + incl - sz;  // ids of this tile in front of my slot
+                    const int64_t o = base + off;
+                    if (k < cnt) {
+                        if (is_miss) {  // a merged piece: its ids sit at its own bytes' slots of the result buffer
+                            const uint32_t* ps = a.merge_out + (size_t)tile * K_STAGE + ((v >> 7) & 0xFFFu);
+                            for (uint32_t j = 0; j < sz; ++j)
+                                if (o + j < a.out_cap) a.out_tokens[o + j] = (int32_t)ps[j];
+                        } else if (!is_long && o < a.out_cap) {
+                            a.out_tokens[o] = (int32_t)v;
+                        }
+                    }
+                    for (uint64_t lb = __ballot(is_long && k < cnt); lb; lb &= lb - 1ull) {  // long pieces: the whole wavefront copies
+                        const int l = (int)td_ctz64(lb);
+                        const uint32_t n = __shfl(sz, l);
+                        const int64_t lo = base + (int64_t)__shfl(off, l);
+                        const uint64_t po = ((uint64_t)__shfl((uint32_t)(le.pool_off >> 32), l) << 32) | __shfl((uint32_t)le.pool_off, l);
+                        const uint32_t* ps = a.pool + po;
+                        for (uint32_t j = lane; j < n; j += 64)
+                            if (lo + j < a.out_cap) a.out_tokens[lo + j] = (int32_t)ps[j];
+                    }
+                    for (;;) {  // documents whose first slot lies in this row
+                        const uint32_t pref = __shfl(off, dslot & 63u);
+                        if (dslot != 0xFFFFFFFFu && (dslot >> 6) == r) a.out_offsets[dmine] = base + pref;
+                        const uint32_t last = __shfl(dslot, 63);
+                        if (dfull && (last >> 6) <= r) { load_docs(); continue; }  // all 64 used up: the next ones may start in this row too
+                        break;
+                    }
+                    carry += __shfl(incl, 63);
+                }
+            }
         }
         if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
             const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
             for (int64_t d = d_end + lane; d <= a.n_docs; d += 64) a.out_offsets[d] = total;
         }
     }
-    // pass 2: tiles with long pieces (slots expand: a marker becomes that piece's ntok ids)
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const uint32_t tc = a.tile_count[tile];
-        if (!(tc >> 31)) continue;  // uniform per workgroup
-        const uint32_t cnt = tc & 0x7FFFFFFFu;
-        const int64_t base = base_of(tile);
-        const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
-        uint32_t sz[K_PCH];
-        uint32_t mine = 0;
-        if (tid == 0) s_nmark = 0;
-        for (int k = 0; k < K_PCH; ++k) {
-            const uint32_t i = tid * K_PCH + k;
-            uint32_t sl = 0;
-            if (i < cnt) {
-                const uint32_t v = src[i];
-                sl = (v & TOK_LONGREF) ? a.long_list[v & 0x7FFFFFFFu].ntok : 1u;
-            }
-            sz[k] = sl;
-            mine += sl;
-        }
-        uint32_t tot;
-        uint32_t run = block_excl_scan(mine, s_wave, tot);
-        for (int k = 0; k < K_PCH; ++k) {
-            s_off[tid * K_PCH + k] = run;
-            run += sz[k];
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < cnt; i += K_THREADS) {
-            const uint32_t v = src[i];
-            if (v & TOK_LONGREF) {
-                const uint32_t q = atomicAdd(&s_nmark, 1u);
-                if (q < 64) s_mark[q] = i;
-            } else {
-                const int64_t o = base + s_off[i];
-                if (o < a.out_cap) a.out_tokens[o] = (int32_t)v;
-            }
-        }
-        __syncthreads();
-        const uint32_t nm = s_nmark < 64 ? s_nmark : 64;  // a tile holds at most 4096/65 = 63 long pieces
-        for (uint32_t q = 0; q < nm; ++q) {
-            const uint32_t i = s_mark[q];
-            const LongEntry le = a.long_list[src[i] & 0x7FFFFFFFu];
-            const uint32_t* ps = a.pool + le.pool_off;
-            for (uint32_t k = tid; k < le.ntok; k += K_THREADS) {
-                const int64_t o = base + s_off[i] + k;
-                if (o < a.out_cap) a.out_tokens[o] = (int32_t)ps[k];
-            }
-        }
-        {
-            const int64_t g_lo = (int64_t)tile * K_TILE;
-            const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
-            for (int64_t d = (int64_t)a.tile_first_doc[tile] + tid; d < a.n_docs; d += K_THREADS) {
-                if (a.doc_offsets[d] >= g_hi) break;
-                a.out_offsets[d] = base + s_off[a.doc_slot[d]];
-            }
-            if (tile == a.n_tiles - 1) {
-                const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
-                for (int64_t d = d_end + tid; d <= a.n_docs; d += K_THREADS) a.out_offsets[d] = total;
-            }
-        }
-        __syncthreads();
-    }
 }
 
 // ------------------------------------------------------------------ launches ----------------
-static int g_blocks_split = 0, g_blocks_encode = 0;
+static int g_blocks_split = 0, g_blocks_encode = 0, g_blocks_merge = 0;
 static int resident_blocks(const void* fn, int fallback_per_cu) {
     // persistent grid = exactly the workgroups that are resident at once (a larger grid would run in
     // uneven rounds: tiles are dealt round-robin to blockIdx)
@@ -1425,10 +1433,14 @@ static int resident_blocks(const void* fn, int fallback_per_cu) {
     return 256 * fallback_per_cu;
 }
 int encode_grid_blocks() {
-    if (!g_blocks_encode) g_blocks_encode = resident_blocks((const void*)td_encode_tiles, 3);
+    if (!g_blocks_encode) g_blocks_encode = resident_blocks((const void*)td_probe_tiles, 3);
     const char* e = getenv("TD_BLOCKS_PER_CU");
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_encode;
+}
+int merge_grid_blocks() {
+    if (!g_blocks_merge) g_blocks_merge = resident_blocks((const void*)td_merge_pieces, 3);
+    return g_blocks_merge;
 }
 static int split_grid_blocks() {
     if (!g_blocks_split) g_blocks_split = resident_blocks((const void*)td_split_tiles<0u>, 3);
@@ -1437,7 +1449,7 @@ static int split_grid_blocks() {
     return g_blocks_split;
 }
 
-hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2) {
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev) {
     if (a.n_tiles <= 0) return hipSuccess;
     {   // one launch clears what was seven memsets: document bits, per-tile long-piece counts, first-document
         // indices (0xFFFFFFFF = none) and the per-call counters
@@ -1456,7 +1468,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
     }
     const int sblocks = a.n_stiles < split_grid_blocks() ? a.n_stiles : split_grid_blocks();
     const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
-    if (ev0) (void)hipEventRecord(ev0, stream);
+    if (ev) (void)hipEventRecord(ev[0], stream);
     constexpr uint32_t PV_TEKKEN = PV_NO_CONTRACTION | PV_SINGLE_DIGIT;
     constexpr uint32_t PV_CL100K = PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS;
     switch (a.pat_flags) {
@@ -1470,14 +1482,22 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t ev0
         default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(td_split_slow, dim3(64), dim3(64), 0, stream, a);
-    if (ev1) (void)hipEventRecord(ev1, stream);
-    if (a.stop_after != 2 && a.stop_after != 11 && a.stop_after != 12) {
-        hipLaunchKernelGGL(td_encode_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
-        if (ev2) (void)hipEventRecord(ev2, stream);
+    if (ev) (void)hipEventRecord(ev[1], stream);
+    const bool tokens = a.stop_after != 2 && a.stop_after != 11 && a.stop_after != 12;
+    if (tokens) hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+    if (ev) (void)hipEventRecord(ev[2], stream);
+    if (tokens && a.stop_after != 3 && a.stop_after != 30 && a.stop_after != 31) {
+        const int wtiles = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
+        const int mblocks = wtiles < merge_grid_blocks() ? wtiles : merge_grid_blocks();
+        hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(K_THREADS), 0, stream, a);
+    }
+    if (ev) (void)hipEventRecord(ev[3], stream);
+    if (tokens) {
         hipLaunchKernelGGL(td_long_pieces, dim3(256 * 5), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
         hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
-    } else if (ev2) (void)hipEventRecord(ev2, stream);
+    }
+    if (ev) (void)hipEventRecord(ev[4], stream);
     return hipGetLastError();
 }
 

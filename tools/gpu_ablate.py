@@ -29,8 +29,13 @@ for stop in stops:
     for _ in range(5):
         tok.encode_device(dt.data_ptr(), n, do.data_ptr(), nd, dk.data_ptr(), cap, dto.data_ptr(), s)
     torch.cuda.synchronize(); el = (time.perf_counter() - t0) / 5
-    ms0, ms1, k = tok.profile_read()
-    print(f"{kind} {mb}MiB stop_after={stop}: split {ms0/k:.3f} ms + encode {ms1/k:.3f} ms, whole step {el*1e3:.3f} ms, {n/el/1e9:.1f} GB/s", flush=True)
+    if hasattr(tok._lib, "td_profile_read_ex"):
+        sums, k = tok.profile_read_all()
+        seg = " + ".join(f"{nm.split('+')[0].replace('td_', '')} {v / k:.3f}" for nm, v in sums.items())
+    else:
+        ms0, ms1, k = tok.profile_read()
+        seg = f"split {ms0/k:.3f} + encode {ms1/k:.3f}"
+    print(f"{kind} {mb}MiB stop_after={stop}: {seg} ms, whole step {el*1e3:.3f} ms, {n/el/1e9:.1f} GB/s", flush=True)
 try:
     tok.device_status(s)
 except Exception as e:

@@ -1,0 +1,8 @@
+set -u
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2_c6; mkdir -p $O
+cd $R
+( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_python_api.py -m gpu -x -q ) > $O/pytest_a.log 2>&1
+tail -15 $O/pytest_a.log
+for c in english mixed code; do
+  timeout 300 python tools/gpu_ablate.py $c 256 0 2>&1 | grep stop_after
+done | tee $O/ab.txt
