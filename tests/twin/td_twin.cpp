@@ -218,6 +218,18 @@ int64_t twin_encode(void* h, const uint8_t* text, int64_t n, const int64_t* offs
         } else {
             int32_t r = NO_RANK;
             if (fast) r = piece_lookup(T, piece_key_host(pb, len), len, [pb](uint32_t i) { return (uint32_t)pb[i]; });
+            if (len <= P12_MAXLEN) {
+                // what the hot probe of td_probe_tiles does: the FIRST slot of the exact-key table decides a hit (same key) or
+                // a miss (empty slot); any other slot sends the piece to the generic lookup.  Both must agree with it.
+                uint32_t k[3] = {0, 0, 0};
+                for (uint32_t i = 0; i < len; ++i) k[i >> 2] |= (uint32_t)pb[i] << (8 * (i & 3));
+                const Piece12Slot& sl = T.piece12_slots[hash_piece12(k[0], k[1], k[2], len) & T.piece12_mask];
+                const int32_t want = piece_lookup(T, piece_key_host(pb, len), len, [pb](uint32_t i) { return (uint32_t)pb[i]; });
+                if (sl.meta == 0) { if (want != NO_RANK) return -100; }
+                else if (sl.k0 == k[0] && sl.k1 == k[1] && sl.k2 == k[2] && (sl.meta >> 24) == (0x80u | len)) {
+                    if ((int32_t)(sl.meta & 0x1FFFFFu) != want) return -101;
+                }
+            }
             if (r != NO_RANK) tmp.push_back(r);
             else if (len <= (uint32_t)K_MAXSHORT) {
                 // what one lane of td_merge_tiles runs (mg_put / mg_pad / mg_round, td_common.h), on host arrays; the

@@ -332,7 +332,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     d.max_id = H.max_id;
     d.pseudo_base = H.pseudo_base;
     d.max_token_len = H.max_token_len;
-    d.piece16_mask = H.piece16_mask;
+    d.piece12_mask = H.piece12_mask;
     d.pat_flags = hv.pat_flags;
     if ((rc = upload(t, H.ascii_cls.data(), H.ascii_cls.size(), &d.ascii_cls))) return fail(rc);
     if ((rc = upload(t, hv.ucls1, (size_t)4352, &d.ucls1))) return fail(rc);
@@ -345,7 +345,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if ((rc = upload(t, H.byte_id.data(), H.byte_id.size(), &d.byte_id))) return fail(rc);
     if ((rc = upload(t, H.byte_pair.data(), H.byte_pair.size(), &d.byte_pair))) return fail(rc);
     if ((rc = upload(t, H.piece_slots.data(), H.piece_slots.size(), &d.piece_slots))) return fail(rc);
-    if ((rc = upload(t, H.piece16_slots.data(), H.piece16_slots.size(), &d.piece16_slots))) return fail(rc);
+    if ((rc = upload(t, H.piece12_slots.data(), H.piece12_slots.size(), &d.piece12_slots))) return fail(rc);
     if ((rc = upload(t, H.pair_slots.data(), H.pair_slots.size(), &d.pair_slots))) return fail(rc);
     if ((rc = upload(t, H.tok_off.data(), H.tok_off.size(), &d.tok_off))) return fail(rc);
     if ((rc = upload(t, H.tok_bytes.data(), H.tok_bytes.size(), &d.tok_bytes))) return fail(rc);

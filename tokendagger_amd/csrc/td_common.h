@@ -76,11 +76,12 @@ struct PieceSlot {  // 16 B; len == 0 marks an empty slot
     uint32_t len;
 };
 
-struct Piece16Slot {  // 24 B: tokens of 9..16 bytes, exact key in two words (no verification against tok_bytes needed)
-    uint64_t k0;      // bytes 0..7
-    uint64_t k1;      // bytes 8..len-1, little-endian, zero padded
-    uint64_t rl;      // rank | len << 32; 0 marks an empty slot
+struct Piece12Slot {  // 16 B: every token of 1..12 bytes with its exact key: ONE 16-byte load answers a probe, no verification
+    uint32_t k0, k1, k2;  // the bytes, little-endian, zero padded
+    uint32_t meta;        // rank | len << 24 | 1 << 31; 0 marks an empty slot
 };
+constexpr uint32_t P12_MAXLEN = 12;
+TD_HD uint32_t p12_meta(uint32_t rank, uint32_t len) { return rank | (len << 24) | 0x80000000u; }
 
 struct Tables {
     const uint8_t* ascii_cls;     // [128]
@@ -90,7 +91,7 @@ struct Tables {
     const int32_t* byte_pair;     // [65536]  rank of the 2-byte token (b0<<8|b1) or NO_RANK
     const PieceSlot* piece_slots; // open addressing, linear probing
     const uint64_t* pair_slots;   // cuckoo table: (left<<42 | right<<21 | rank), PAIR_EMPTY if empty
-    const Piece16Slot* piece16_slots;  // open addressing, linear probing (tokens of 9..16 bytes; they are also in piece_slots)
+    const Piece12Slot* piece12_slots;  // open addressing, linear probing, inserted in rank order (tokens of 1..12 bytes; they are also in piece_slots)
     const uint32_t* tok_off;      // [max_id+2] byte offsets of token id's bytes (decode + long-key verify)
     const uint8_t* tok_bytes;
     uint32_t piece_mask;
@@ -98,7 +99,7 @@ struct Tables {
     int32_t max_id;               // largest real id
     int32_t pseudo_base;          // ids >= pseudo_base stand for single bytes that are not tokens
     uint32_t max_token_len;
-    uint32_t piece16_mask;
+    uint32_t piece12_mask;
     uint32_t pat_flags;           // PV_* bits: which member of the split-pattern family the scanners implement
 };
 
@@ -150,8 +151,13 @@ TD_HD uint64_t hash_bytes(const Get& get, uint32_t len) {
     return k ^ (k >> 31);
 }
 
-TD_HD uint32_t hash_piece16(uint64_t k0, uint64_t k1, uint32_t len) {
-    return hash_piece(k0 ^ ((k1 << 29) | (k1 >> 35)) ^ (k1 * 0x9E3779B97F4A7C15ull), len);
+TD_HD uint32_t hash_piece12(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
+    uint32_t h = (k0 ^ (len * 0xC2B2AE3Du)) * 0x9E3779B1u;
+    h ^= h >> 15;
+    h += k1 * 0x85EBCA77u;
+    h ^= k2 * 0x27D4EB2Fu;
+    h *= 0x2C1B3C6Du;
+    return h ^ (h >> 13);
 }
 
 // (left id, right id) -> rank of the concatenation, NO_RANK if it is not a token.  The pair table is a CUCKOO table

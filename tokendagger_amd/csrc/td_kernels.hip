@@ -88,7 +88,7 @@ __device__ __forceinline__ Tables uniform_tables(const Tables* p) {
     t.byte_pair = uni_ptr(p->byte_pair);
     t.piece_slots = uni_ptr(p->piece_slots);
     t.pair_slots = uni_ptr(p->pair_slots);
-    t.piece16_slots = uni_ptr(p->piece16_slots);
+    t.piece12_slots = uni_ptr(p->piece12_slots);
     t.tok_off = uni_ptr(p->tok_off);
     t.tok_bytes = uni_ptr(p->tok_bytes);
     t.piece_mask = uni32(p->piece_mask);
@@ -96,7 +96,7 @@ __device__ __forceinline__ Tables uniform_tables(const Tables* p) {
     t.max_id = (int32_t)uni32((uint32_t)p->max_id);
     t.pseudo_base = (int32_t)uni32((uint32_t)p->pseudo_base);
     t.max_token_len = uni32(p->max_token_len);
-    t.piece16_mask = uni32(p->piece16_mask);
+    t.piece12_mask = uni32(p->piece12_mask);
     t.pat_flags = uni32(p->pat_flags);
     return t;
 }
@@ -500,9 +500,7 @@ constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per
 #ifndef TD_PROBE_MIN_WAVES
 #define TD_PROBE_MIN_WAVES 8  // (measured on 256 MiB of English: 0.49 ms at 8 waves/SIMD, 0.66 ms at 5..7)
 #endif
-#ifndef TD_PROBE_NB
-#define TD_PROBE_NB 1
-#endif
+
 // everything the hot probe path leaves out: keys longer than 16 bytes (hashed + verified against the token bytes), probe
 // sequences longer than one slot, pieces longer than K_MAXSHORT (handed to td_long_pieces).  Returns the piece's slot.
 __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const Tables& T, const uint8_t* s_txt, const int32_t* s_byteid,
@@ -547,6 +545,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
     uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_plist);
     uint16_t* const s_valid = s_plist + 2 * K_THREADS;
     __shared__ int32_t s_byteid[256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_kmask[(P12_MAXLEN + 1) * 4];  // row len: byte masks of a len-byte key
     __shared__ uint32_t s_wave[8];
     __shared__ long long s_ext_end;                // global end of the tile's last piece when it leaves the window (else 0)
     __shared__ uint32_t s_flags;                   // TILE_HAS_LONG | TILE_HAS_MISS
@@ -554,6 +553,10 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
     const int tid = threadIdx.x;
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
+    if (tid < (int)(P12_MAXLEN + 1) * 4) {
+        const int len = tid >> 2, w = tid & 3, nb = len - 4 * w;  // bytes of dword w that belong to a len-byte key
+        s_kmask[tid] = w == 3 || nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
+    }
 
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
     uint32_t pfs = 0;  // START bits of window word `tid`
@@ -635,88 +638,42 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
         __syncthreads();
         if (a.stop_after == 31) continue;
         const long long ext_end = s_ext_end;
-        // ---- probe: piece k -> lane k mod 256, one piece per lane at a time (more in flight cost registers, and
-        //      registers cost resident wavefronts: round 1 measured 2 and 4 in flight slower).  Hot path = pieces of 2..16
-        //      bytes (key = the bytes): first slot of the HBM table of their length class; single bytes index the
-        //      256-entry LDS table; everything else goes through probe_piece_cold. ----
+        // ---- probe: piece k -> lane k mod 256, one piece per lane at a time (more in flight cost registers, and registers
+        //      cost resident wavefronts: both round 1 and round 2 measured 2 and 4 in flight slower).  Hot path = pieces of
+        //      1..12 bytes: key = the bytes (three dwords cut out of LDS with funnel shifts, masked by length through a
+        //      13-row table), ONE 16-byte load of the first slot of the exact-key table, three compares.  An empty slot is
+        //      a miss; a slot held by another key, longer pieces, the piece that leaves the window: probe_piece_cold. ----
         uint32_t* const dst = a.stage + (size_t)tile * K_STAGE;
-        constexpr int NB = TD_PROBE_NB;  // pieces a lane keeps in flight
-        for (uint32_t k0 = tid; k0 < np_total; k0 += NB * K_THREADS) {
-            int pi[NB];
-            uint32_t plen[NB], res[NB], kind[NB];  // kind: 0 resolved, 1 probe of the <= 8-byte table, 2 of the 9..16-byte table, 3 cold
-            uint64_t pkey[NB], pkey1[NB], sl0[NB], sl1[NB], sl2[NB];
-            uint32_t ph[NB];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const uint32_t k = k0 + u * K_THREADS;
-                kind[u] = 0; res[u] = 0; pi[u] = 0; plen[u] = 0; pkey[u] = 0; pkey1[u] = 0; ph[u] = 0;
-                if (k >= np_total) continue;
-                const int i = s_plist[k];
-                const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
-                pi[u] = i;
-                plen[u] = len;
-                if (len == 1) {  // single byte: direct table
-                    const int32_t id = s_byteid[s_txt[i]];
-                    if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
-                    res[u] = (uint32_t)id;
-                    continue;
-                }
-                if (len > 16 || !a.use_fastpath || (ext_end && k == np_total - 1)) { kind[u] = 3; continue; }
-                // up to 16 key bytes, read unaligned from LDS: five dwords, funnel-shifted
-                const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
-                const uint32_t sh = (i & 3) * 8;
-                const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-                uint64_t key = ((uint64_t)__funnelshift_r(w1, w2, sh) << 32) | __funnelshift_r(w0, w1, sh);
-                if (len <= 8) {
-                    if (len < 8) key &= (1ull << (8 * len)) - 1;
-                    pkey[u] = key;
-                    ph[u] = hash_piece(key, len) & T.piece_mask;
-                    kind[u] = 1;
-                } else {
-                    const uint32_t w3 = wp[3], w4 = wp[4];
-                    uint64_t key1 = ((uint64_t)__funnelshift_r(w3, w4, sh) << 32) | __funnelshift_r(w2, w3, sh);
-                    if (len < 16) key1 &= (1ull << (8 * (len - 8))) - 1;
-                    pkey[u] = key;
-                    pkey1[u] = key1;
-                    ph[u] = hash_piece16(key, key1, len) & T.piece16_mask;
-                    kind[u] = 2;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                sl0[u] = sl1[u] = sl2[u] = 0;
-                if (kind[u] == 1) {
-                    const PieceSlot* sp = T.piece_slots + ph[u];
-                    sl0[u] = sp->key;
-                    sl1[u] = (uint64_t)sp->rank | ((uint64_t)sp->len << 32);
-                } else if (kind[u] == 2) {
-                    const Piece16Slot* sp = T.piece16_slots + ph[u];
-                    sl0[u] = sp->k0; sl1[u] = sp->rl; sl2[u] = sp->k1;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                if (kind[u] != 1 && kind[u] != 2) continue;
-                if (sl0[u] == pkey[u] && sl2[u] == pkey1[u] && (sl1[u] >> 32) == plen[u]) { res[u] = (uint32_t)sl1[u]; kind[u] = 0; }  // the common case
-                else if ((sl1[u] >> 32) == 0) {                                                                      // empty slot: not a token
-                    res[u] = TOK_MISS | ((uint32_t)pi[u] << 7) | plen[u];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef const u32x4 __attribute__((address_space(1)))* gslot_t;  // (global loads, not flat ones)
+        gslot_t const p12 = (gslot_t)(uintptr_t)T.piece12_slots;
+        for (uint32_t k = tid; k < np_total; k += K_THREADS) {
+            const int i = s_plist[k];
+            uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
+            const uint32_t sh = (i & 3) * 8;
+            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+            const uint4 km = reinterpret_cast<const uint4*>(s_kmask)[len < P12_MAXLEN ? len : P12_MAXLEN];
+            const uint32_t k0 = __funnelshift_r(w0, w1, sh) & km.x, k1 = __funnelshift_r(w1, w2, sh) & km.y,
+                           k2 = __funnelshift_r(w2, w3, sh) & km.z;
+            const u32x4 sl = p12[hash_piece12(k0, k1, k2, len) & T.piece12_mask];
+            const bool last_ext = ext_end && k == np_total - 1;
+            uint32_t res;
+            if (len <= P12_MAXLEN && a.use_fastpath && !last_ext && (sl.w == 0u || (sl.x == k0 && sl.y == k1 && sl.z == k2 && (sl.w >> 24) == (0x80u | len)))) {
+                const bool miss = sl.w == 0u;  // empty slot: not a token (a single byte that is no token is an error, not a merge)
+                res = miss ? (TOK_MISS | ((uint32_t)i << 7) | len) : (sl.w & 0x1FFFFFu);
+                if (miss) {
+                    if (len == 1) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
                     atomicOr(&s_flags, TILE_HAS_MISS);
-                    kind[u] = 0;
-                } else kind[u] = 3;                                                                                  // occupied by another key
-            }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const uint32_t k = k0 + u * K_THREADS;
-                if (kind[u] == 3) {
-                    uint32_t len = plen[u];
-                    if (ext_end && k == np_total - 1) {
-                        const long long l = ext_end - (wg0 + pi[u]);
-                        len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
-                    }
-                    res[u] = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, pi[u], len);
                 }
-                if (k < np_total) dst[k] = res[u];
+            } else {
+                if (last_ext) {
+                    const long long l = ext_end - (wg0 + i);
+                    len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
+                }
+                res = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);
             }
+            dst[k] = res;
         }
         __syncthreads();
         if (a.stop_after == 3) continue;

@@ -75,8 +75,8 @@ Tables HostTables::view() const {
     T.byte_id = byte_id.data();
     T.byte_pair = byte_pair.data();
     T.piece_slots = piece_slots.data();
-    T.piece16_slots = piece16_slots.data();
-    T.piece16_mask = piece16_mask;
+    T.piece12_slots = piece12_slots.data();
+    T.piece12_mask = piece12_mask;
     T.pat_flags = pattern_flags(pattern_kind);
     T.pair_slots = pair_slots.data();
     T.tok_off = tok_off.data();
@@ -220,26 +220,25 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
         if (len == 2) H.byte_pair[((uint32_t)p[0] << 8) | p[1]] = ranks[v];
     }
 
-    // exact-key table for tokens of 9..16 bytes (the hot probe loop handles them without the hash + verify route)
+    // exact-key table for the tokens of 1..12 bytes (the hot probe loop of td_probe_tiles: one 16-byte load per piece, first
+    // slot only).  Inserted in RANK order: a key leaves its home slot only when a lower-rank (as a rule: more frequent) key
+    // took it, so the pieces that matter are answered by the first slot.
     {
-        uint64_t n16 = 0;
-        for (int64_t v = 0; v < n_vocab; ++v) {
-            const int64_t len = token_offsets[v + 1] - token_offsets[v];
-            if (len >= 9 && len <= 16) ++n16;
-        }
-        const uint32_t cap16 = pow2_at_least(n16 * 2 + 2);
-        H.piece16_mask = cap16 - 1;
-        H.piece16_slots.assign(cap16, Piece16Slot{0, 0, 0});
-        for (int64_t v = 0; v < n_vocab; ++v) {
+        std::vector<int64_t> order;
+        for (int64_t v = 0; v < n_vocab; ++v)
+            if (token_offsets[v + 1] - token_offsets[v] <= (int64_t)P12_MAXLEN) order.push_back(v);
+        std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return ranks[x] < ranks[y]; });
+        const uint32_t cap12 = pow2_at_least((uint64_t)order.size() * 2 + 2);
+        H.piece12_mask = cap12 - 1;
+        H.piece12_slots.assign(cap12, Piece12Slot{0, 0, 0, 0});
+        for (int64_t v : order) {
             const uint32_t len = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
-            if (len < 9 || len > 16) continue;
             const uint8_t* p = token_bytes + token_offsets[v];
-            uint64_t k0 = 0, k1 = 0;
-            for (uint32_t i = 0; i < 8; ++i) k0 |= (uint64_t)p[i] << (8 * i);
-            for (uint32_t i = 8; i < len; ++i) k1 |= (uint64_t)p[i] << (8 * (i - 8));
-            uint32_t h = hash_piece16(k0, k1, len) & H.piece16_mask;
-            while (H.piece16_slots[h].rl != 0) h = (h + 1) & H.piece16_mask;
-            H.piece16_slots[h] = Piece16Slot{k0, k1, (uint64_t)(uint32_t)ranks[v] | ((uint64_t)len << 32)};
+            uint32_t k[3] = {0, 0, 0};
+            for (uint32_t i = 0; i < len; ++i) k[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+            uint32_t h = hash_piece12(k[0], k[1], k[2], len) & H.piece12_mask;
+            while (H.piece12_slots[h].meta != 0) h = (h + 1) & H.piece12_mask;
+            H.piece12_slots[h] = Piece12Slot{k[0], k[1], k[2], p12_meta((uint32_t)ranks[v], len)};
         }
     }
 

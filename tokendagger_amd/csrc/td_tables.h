@@ -35,8 +35,8 @@ struct HostTables {
     std::vector<int32_t> byte_id;
     std::vector<int32_t> byte_pair;
     std::vector<PieceSlot> piece_slots;
-    std::vector<Piece16Slot> piece16_slots;
-    uint32_t piece16_mask = 0;
+    std::vector<Piece12Slot> piece12_slots;
+    uint32_t piece12_mask = 0;
     std::vector<uint64_t> pair_slots;
     std::vector<uint32_t> tok_off;
     std::vector<uint8_t> tok_bytes;
