@@ -549,6 +549,8 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
     __shared__ uint32_t s_wave[8];
     __shared__ long long s_ext_end;                // global end of the tile's last piece when it leaves the window (else 0)
     __shared__ uint32_t s_flags;                   // TILE_HAS_LONG | TILE_HAS_MISS
+    __shared__ uint32_t s_ncold;                   // pieces put aside for the long route
+    __shared__ uint16_t s_coldk[K_THREADS];        // their indices in the piece list
 
     const int tid = threadIdx.x;
     const Tables T = uniform_tables(a.Tp);
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
                 pfs = load_startword(nwg0);
             }
         }
-        if (tid == 0) { s_ext_end = 0; s_flags = 0; }
+        if (tid == 0) { s_ext_end = 0; s_flags = 0; s_ncold = 0; }
         __syncthreads();
         if (a.stop_after == 30) continue;
 
@@ -667,13 +669,32 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
                     atomicOr(&s_flags, TILE_HAS_MISS);
                 }
             } else {
+                // everything else is put aside and handled densely after the loop, one piece per lane: 7 % of the pieces of
+                // mixed-script text are longer than 12 bytes, i.e. nearly every wavefront pass of this loop held one, and the
+                // whole wavefront then sat through the long route (hash over the bytes, verify against the token store)
+                const uint32_t j = atomicAdd(&s_ncold, 1u);
+                if (j < (uint32_t)K_THREADS) { s_coldk[j] = (uint16_t)k; continue; }
                 if (last_ext) {
                     const long long l = ext_end - (wg0 + i);
                     len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
                 }
-                res = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);
+                res = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);  // (more than 256 of them in one tile)
             }
             dst[k] = res;
+        }
+        __syncthreads();
+        {
+            const uint32_t nc = s_ncold < (uint32_t)K_THREADS ? s_ncold : (uint32_t)K_THREADS;
+            if ((uint32_t)tid < nc) {
+                const uint32_t k = s_coldk[tid];
+                const int i = s_plist[k];
+                uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
+                if (ext_end && k == np_total - 1) {
+                    const long long l = ext_end - (wg0 + i);
+                    len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
+                }
+                dst[k] = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);
+            }
         }
         __syncthreads();
         if (a.stop_after == 3) continue;
