@@ -38,6 +38,7 @@ def _lib():
     lib.tdo_split_variant.restype = ctypes.c_int64
     lib.tdo_split_variant.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
     lib.tdo_set_variant.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.tdo_set_heap_threshold.argtypes = [ctypes.c_int64]
     return lib
 
 
@@ -105,3 +106,9 @@ class OracleTokenizer:
         if n < 0:
             raise OracleError(self._lib.tdo_last_error().decode())
         return out[:n].tobytes()
+
+
+def set_heap_threshold(n: int) -> None:
+    """Pieces longer than n bytes are merged with the O(n log n) heap form of the merge loop (default 4096); 0 = always,
+    a huge value = never (the reference's own quadratic loop)."""
+    _lib().tdo_set_heap_threshold(int(n))

@@ -433,6 +433,74 @@ static int tdo_merge(const tdo_t* t, const uint8_t* piece, int64_t n, int32_t* o
     return rc;
 }
 
+/* The same merge (tiktoken.cpp:298-368: lowest rank first, leftmost on ties, ranks of the two pairs that touch the merged
+ * part recomputed) in O(n log n): parts as a doubly linked list over byte positions + a binary min-heap of (rank, position,
+ * right end of the pair when it was ranked) with lazy invalidation.  The O(n^2) form above IS the reference's loop; this one
+ * exists so that the checker can answer for pieces of a megabyte (the compiled reference needs hours there).  It is pinned
+ * against the quadratic form and against the compiled reference on pieces up to 20 KB (tests/test_oracle.py). */
+typedef struct { int32_t rank; int32_t pos; int32_t mid; int32_t end; } hent_t;  /* pair = [pos, mid) + [mid, end) */
+static int hless(const hent_t* a, const hent_t* b) { return a->rank < b->rank || (a->rank == b->rank && a->pos < b->pos); }
+static void hpush(hent_t* h, int64_t* n, hent_t e) {
+    int64_t i = (*n)++;
+    h[i] = e;
+    while (i > 0) { int64_t p = (i - 1) / 2; if (!hless(&h[i], &h[p])) break; hent_t t = h[i]; h[i] = h[p]; h[p] = t; i = p; }
+}
+static hent_t hpop(hent_t* h, int64_t* n) {
+    hent_t top = h[0];
+    h[0] = h[--(*n)];
+    int64_t i = 0;
+    for (;;) {
+        int64_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < *n && hless(&h[l], &h[m])) m = l;
+        if (r < *n && hless(&h[r], &h[m])) m = r;
+        if (m == i) break;
+        hent_t t = h[i]; h[i] = h[m]; h[m] = t; i = m;
+    }
+    return top;
+}
+static int tdo_merge_heap(const tdo_t* t, const uint8_t* piece, int64_t n, int32_t* out, int64_t* k, int64_t cap) {
+    /* nxt[i]: start of the part after the part that starts at i (n for the last); prv[i]: start of the part before (-1) */
+    int32_t* nxt = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    int32_t* prv = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    uint8_t* alive = (uint8_t*)malloc((size_t)n + 1);
+    hent_t* heap = (hent_t*)malloc(sizeof(hent_t) * (size_t)(3 * n + 8));
+    int64_t hn = 0;
+    for (int64_t i = 0; i < n; ++i) { nxt[i] = (int32_t)(i + 1); prv[i] = (int32_t)(i - 1); alive[i] = 1; }
+    for (int64_t i = 0; i + 1 < n; ++i) {
+        int32_t r = lookup(t, piece + i, 2);
+        if (r != INT_MAX) { hent_t e = {r, (int32_t)i, (int32_t)(i + 1), (int32_t)(i + 2)}; hpush(heap, &hn, e); }
+    }
+    while (hn > 0) {
+        hent_t e = hpop(heap, &hn);
+        /* stale unless both parts are exactly as they were when the pair was ranked */
+        if (!alive[e.pos] || nxt[e.pos] != e.mid || e.mid >= n || !alive[e.mid] || nxt[e.mid] != e.end) continue;
+        /* merge: the right part is absorbed */
+        alive[e.mid] = 0;
+        nxt[e.pos] = e.end;
+        if (e.end < n) prv[e.end] = e.pos;
+        if (e.end < n) {  /* pair (merged part, part after it) */
+            int32_t r = lookup(t, piece + e.pos, nxt[e.end] - e.pos);
+            if (r != INT_MAX) { hent_t x = {r, e.pos, e.end, nxt[e.end]}; hpush(heap, &hn, x); }
+        }
+        if (prv[e.pos] >= 0) {  /* pair (part before it, merged part) */
+            int32_t q = prv[e.pos];
+            int32_t r = lookup(t, piece + q, e.end - q);
+            if (r != INT_MAX) { hent_t x = {r, q, e.pos, e.end}; hpush(heap, &hn, x); }
+        }
+    }
+    int rc = 0;
+    for (int64_t i = 0; i < n; i = nxt[i]) {
+        int32_t r = lookup(t, piece + i, nxt[i] - i);
+        if (r == INT_MAX) { snprintf(g_err, sizeof g_err, "No value found for pair: %lld %lld", (long long)i, (long long)nxt[i]); rc = -1; break; }
+        if (*k >= cap) { snprintf(g_err, sizeof g_err, "encode capacity"); rc = -2; break; }
+        out[(*k)++] = r;
+    }
+    free(nxt); free(prv); free(alive); free(heap);
+    return rc;
+}
+static int64_t g_heap_threshold = 4096;  /* pieces longer than this use the heap form */
+void tdo_set_heap_threshold(int64_t n) { g_heap_threshold = n; }
+
 /* ordinary != 0: encode_ordinary (no whole-piece fast path). Returns #tokens or <0. */
 int64_t tdo_encode(void* h, const uint8_t* text, int64_t n, int32_t* out, int64_t cap, int ordinary) {
     const tdo_t* t = (const tdo_t*)h;
@@ -449,7 +517,7 @@ int64_t tdo_encode(void* h, const uint8_t* text, int64_t n, int32_t* out, int64_
             snprintf(g_err, sizeof g_err, "byte 0x%02x at offset %lld is not in the vocabulary", piece[0], (long long)pos);
             return -1;
         } else {
-            int rc = tdo_merge(t, piece, len, out, &k, cap);
+            int rc = len > g_heap_threshold ? tdo_merge_heap(t, piece, len, out, &k, cap) : tdo_merge(t, piece, len, out, &k, cap);
             if (rc < 0) return rc;
         }
         pos = e;

@@ -304,3 +304,36 @@ def test_code_performance_benchmark_file_set(tok):
     toks, toffs = tok.encode_batch(x, o)
     assert len(toks) == 40 * len(g["enc"]) and np.array_equal(toks.reshape(40, -1), np.tile(g["enc"], (40, 1)))
     assert tok.decode_bytes(toks[:len(g["enc"])]) == g["text"].tobytes()
+
+
+def test_giant_pieces_are_not_quadratic(tok):
+    """Single pieces of up to a megabyte (one such document stalled the batch for minutes).  Checker: the
+    restatement's O(n log n) heap form of the merge loop, pinned against the reference's own quadratic loop and against
+    the compiled reference on pieces up to 20 KB by tests/test_oracle.py."""
+    import time
+    from oracle import port
+    O = H.port_tokenizer()
+    rng = random.Random(77)
+    docs = [b"a" * 1_000_000, b" " * 1_000_000, ("ab" * 60_000).encode(), "".join(rng.choice("ACGT") for _ in range(300_000)).encode(),
+            "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(20_000)).encode(), ("=" * 70_000 + "\n").encode(),
+            ("的" * 30_000).encode("utf-8"), b"x" + b"\t" * 5000 + b"y", ("Ab" * 3000 + "cD" * 3000).encode(), b"short doc"]
+    port.set_heap_threshold(2048)
+    try:
+        text, offs = H.pack_docs(docs)
+        want_t, want_o = O.encode_batch(text, offs)
+        tok.encode_batch(text, offs)  # warm-up (workspace allocation)
+        t0 = time.perf_counter()
+        got_t, got_o = tok.encode_batch(text, offs)
+        dt = time.perf_counter() - t0
+        assert np.array_equal(got_o, want_o) and np.array_equal(got_t, want_t)
+        assert tok.decode_bytes(got_t) == text
+        for d in (docs[0], docs[1]):  # the two runs alone: well under 50 ms each, host copies included
+            tok.encode(d)
+            t0 = time.perf_counter()
+            ids = tok.encode(d)
+            one = time.perf_counter() - t0
+            assert np.array_equal(ids, O.encode(d))
+            assert one < 0.05, f"{one * 1e3:.1f} ms for a run of {len(d)} bytes"
+        print(f"giant pieces: {len(text)} bytes in {dt * 1e3:.1f} ms")
+    finally:
+        port.set_heap_threshold(4096)

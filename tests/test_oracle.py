@@ -109,3 +109,29 @@ def test_code_corpus_fixture_matches_the_restatement():
     import td_corpus
     x, o = td_corpus.code_files(5 << 20)
     assert len(x) == 2 * 2146667 and len(o) - 1 == 42 and x[2146667:].tobytes() == text
+
+
+def test_heap_form_of_the_merge_loop_is_the_same_function():
+    """oracle/td_oracle.c has the reference's quadratic merge loop and an O(n log n) heap form for pieces the quadratic one
+    cannot finish (the GPU suite checks megabyte pieces against it): both forms give the same ids, and on pieces the
+    compiled reference still finishes (<= 20 KB) they give the reference's."""
+    O = H.port_tokenizer()
+    rng = random.Random(99)
+    docs = [b"a" * 20000, b" " * 9000, ("ab" * 4000).encode(), "".join(rng.choice("ACGT") for _ in range(12000)).encode(),
+            "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(9000)).encode(), ("的一是不" * 1200).encode("utf-8"),
+            ("Ab" * 2500 + "cD" * 2500).encode(), b"x" + b"\t" * 3000, ("=-" * 3000).encode(), ("aaab" * 2500).encode()]
+    docs += ["".join(rng.choice("abAB ") for _ in range(rng.randint(2, 400))).replace(" ", "").encode() or b"ab" for _ in range(300)]
+    try:
+        for d in docs:
+            port.set_heap_threshold(1 << 40)
+            quad = O.encode(d)
+            port.set_heap_threshold(0)
+            heap = O.encode(d)
+            assert np.array_equal(quad, heap), d[:40]
+        if ref.available():
+            R = H.ref_tokenizer()
+            port.set_heap_threshold(0)
+            for d in docs[:10]:
+                assert np.array_equal(O.encode(d), R.encode(d)), d[:40]
+    finally:
+        port.set_heap_threshold(4096)

@@ -66,7 +66,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, slow_list, stage, stage2, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -166,6 +166,8 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->docbits, (size_t)((n + 31) / 32 + 2) * 4))) return rc;
     if ((rc = ensure(t, t->startbits, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
     if ((rc = ensure(t, t->slow_list, (size_t)(n_tiles * 8 + 64) * 8))) return rc;
+    if ((rc = ensure(t, t->tile_flag, (size_t)(n_tiles + 2) * 4))) return rc;   // (per pre-tokenizer tile: fewer than n_tiles)
+    if ((rc = ensure(t, t->tile_carry, (size_t)(n_tiles + 2) * 8))) return rc;
     if ((rc = ensure(t, t->stage, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;
     if ((rc = ensure(t, t->stage2, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;  // ids of merged pieces
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
@@ -206,6 +208,8 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.docbits = (uint32_t*)t->docbits.p;
     a.startbits = (uint32_t*)t->startbits.p;
     a.slow_list = (int64_t*)t->slow_list.p;
+    a.tile_flag = (uint32_t*)t->tile_flag.p;
+    a.tile_carry = (int64_t*)t->tile_carry.p;
     a.slow_cap = (uint32_t)std::min<size_t>(t->slow_list.cap / 8, 0x7FFFFFF0u);
     a.stage = (uint32_t*)t->stage.p;
     a.merge_out = (uint32_t*)t->stage2.p;
@@ -367,7 +371,7 @@ void td_destroy(td_tokenizer* t) {
         for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
         for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
         if (t->last_done) (void)hipEventDestroy(t->last_done);
-        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)

@@ -23,7 +23,9 @@ struct EncodeArgs {
     int64_t n_docs;
     uint32_t* docbits;          // [(n+31)/32+1] bit i set <=> a document starts at byte i
     uint32_t* startbits;        // [(n+31)/32+8] bit i set <=> a regex piece starts at byte i (td_split_tiles -> td_probe_tiles)
-    int64_t* slow_list;         // [slow_cap] positions handed from td_split_tiles to td_split_slow: (byte << 1) | kind
+    int64_t* slow_list;         // [slow_cap] piece starts whose end td_split_tiles could not see (td_split_far_pieces)
+    uint32_t* tile_flag;        // [n_stiles+1] pre-tokenizer tile has no sync point in its left halo (td_split_far_tiles)
+    int64_t* tile_carry;        // [n_stiles+1] first piece start at/after the tile start, where a scan from the left knows it
     uint32_t slow_cap;
     uint32_t* slow_count;
     uint32_t* stage;            // [n_tiles*K_STAGE] per-tile slots, one per piece (td_probe_tiles): id | TOK_MISS.. | TOK_LONGREF..

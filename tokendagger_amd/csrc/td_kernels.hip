@@ -4,12 +4,13 @@
 //   td_prepare, td_mark_docs   clear the per-call state; doc_offsets -> one bit per document start
 //   td_split_tiles<pattern>    pre-tokenizer: 8 KiB text tiles (+halos) in LDS -> class masks (8x8 bit transpose) ->
 //                              bit-parallel scanner from provable synchronisation points -> START bitmap in HBM
-//   td_split_slow              the positions the LDS window could not decide (normally none)
+//   td_split_far_pieces/_tiles pieces longer than the LDS window (normally none): a wavefront per piece, same matcher over HBM
 //   td_probe_tiles             4 KiB tiles: dense piece list -> ONE slot per piece: the id when the piece is a token
 //                              (whole-piece table probe), a TOK_MISS marker when it is not, TOK_LONGREF above 64 bytes
 //   td_merge_pieces            the TOK_MISS pieces: byte-pair merge, one LANE per piece (every lane advances its own merge
 //                              chain, a merge per round), batches of one length class filled across tiles
 //   td_long_pieces             pieces longer than 64 bytes: lane groups / a wavefront per piece, parts in LDS
+//   td_giant_pieces            pieces above 1 KiB: rounds over the whole piece (every pair of the lowest rank at once)
 //   td_scan_tiles              device-wide exclusive scan of the per-tile id counts
 //   td_pack_tokens             per-tile slots -> densely packed int32 ids + int64 per-document token offsets
 //
@@ -162,6 +163,10 @@ __global__ void td_prepare(const EncodeArgs a) {
     for (int64_t i = gid; i <= a.n_tiles; i += gsz) {
         a.tile_extra[i] = 0;
         a.tile_first_doc[i] = 0xFFFFFFFFu;
+    }
+    for (int64_t i = gid; i <= a.n_stiles; i += gsz) {
+        a.tile_flag[i] = 0;
+        a.tile_carry[i] = -1;
     }
     if (gid < a.ctl_reset_words) a.ctl_reset[gid] = 0;
 }
@@ -375,15 +380,15 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
 
         // ---- phase 2: piece boundaries.  Fast path: bit-parallel scanner on a 64-byte register window; pieces or
         //      look-ahead beyond that use the same matcher on the mask words in LDS.  What even the LDS window
-        //      cannot answer (no sync point in the left halo, a piece or its look-ahead leaving the window) flags
-        //      the tile for td_split_slow, which redoes it byte by byte from HBM. ---------------------------------
+        //      cannot answer is handed to the td_split_far_* kernels: a piece (or its look-ahead) that leaves the
+        //      window goes on a list ("this piece start is known, its end is not"); a tile without a sync point in its
+        //      left halo is flagged ("first piece start at/after the tile start unknown": it lies inside a piece longer
+        //      than the halo) and gets that position from whoever scans the piece: tile_carry. ----------------------
         {
             int s = -1;
-            // hand-off to td_split_slow: (global position << 1) | kind; kind 1 = "find the first piece start at/after
-            // this tile start", kind 0 = "this piece start is known, its end is not"
-            auto defer = [&](int64_t g, int kind) {
+            auto defer = [&](int64_t g) {
                 const uint32_t q = atomicAdd(a.slow_count, 1u);
-                if (q < a.slow_cap) a.slow_list[q] = (g << 1) | kind;
+                if (q < a.slow_cap) a.slow_list[q] = g;
                 else raise(a, TD_E_SCRATCH, g);
             };
             if (tid == 0) {
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                         if (w == 0) m &= ~0xFull;
                         if (m) s = w * 64 + td_top64(m) - 1;
                     }
-                    if (s < 0) defer(tile_g0, 1);
+                    if (s < 0) a.tile_flag[tile] = 1;
                 }
             } else if (c0 < tile_hi) {
                 static_assert(KS_CHUNK == 16 || KS_CHUNK == 32, "a lane's sync bits come out of one 64-bit mask word");
@@ -411,7 +416,11 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                 load_bitwin(wv, s_mask, base);
                 int p = s;
                 for (;;) {
-                    if (p >= tile_hi) { mark(p); break; }  // delimits the last owned piece
+                    if (p >= tile_hi) {  // delimits the last owned piece; the next tile's first piece start
+                        mark(p);
+                        if (tile + 1 < a.n_stiles) a.tile_carry[tile + 1] = wg0 + p;
+                        break;
+                    }
                     int off = p - base;
                     if (off >= 32) { base = p; off = 0; load_bitwin(wv, s_mask, base); }
                     // 32-bit view of every mask with bit 0 = the piece start: one funnel shift each
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                     }
                     if (e < 0) {
                         e = scan_piece_lds<PV>(s_mask, s_txt, p);  // piece or look-ahead beyond 32 bytes: mask words in LDS
-                        if (e < 0) { if (p >= K_HL) defer(wg0 + p, 0); break; }
+                        if (e < 0) { if (p >= K_HL) defer(wg0 + p); break; }
                     }
                     p = e;
                 }
@@ -449,42 +458,152 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
     }
 }
 
-// ------------------------------------------------------------------ td_split_slow -----------
-// What the LDS-window pre-tokenizer could not decide (next to or inside a piece longer than its halos): one lane
-// per deferred position continues from HBM with the byte scanner (classes computed on the fly) and ORs the
-// missing START bits in, until it lands on a provable sync point — from there on the fast kernel's bits are
-// right.  Exact, slow per byte, and proportional to the length of the offending piece.
-__global__ void td_split_slow(const EncodeArgs a) {
-    const Tables T = uniform_tables(a.Tp);
-    const uint32_t nslow = *a.slow_count < a.slow_cap ? *a.slow_count : a.slow_cap;
-    GlobAcc G;
-    G.T = &T; G.s.text = a.text; G.s.docbits = a.docbits; G.s.lo = 0; G.s.hi = a.n; G.n = a.n; G.lim = a.n + 4;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nslow; j += gridDim.x * blockDim.x) {
-        const int64_t ent = a.slow_list[j];
-        const int64_t g = ent >> 1;
-        const int64_t tile_g0 = g - (g % KS_TILE);
-        const int64_t tile_end = (tile_g0 + KS_TILE < a.n) ? tile_g0 + KS_TILE : a.n;
-        int64_t p;
-        if (ent & 1) {  // no sync point in the tile's left halo: walk back to one, then forward to the tile
-            p = 0;
-            for (int64_t gi = g; gi > 0; --gi)
-                if (is_sync(G.cf(gi - 1), G.cf(gi), T.pat_flags)) { p = gi; break; }
-            while (p < g) p = G.scan(p);
-        } else {        // piece start known (and already marked), its end is not
-            p = G.scan(g);
+// ------------------------------------------------------------------ td_split_far_* ----------
+// What the LDS-window pre-tokenizer could not decide: pieces longer than its window.  A WAVEFRONT per item runs the very
+// same matcher (scan_piece_p) on a mask provider that reads the text from HBM: a run search classifies 256 bytes per step
+// (four per lane) and ballots the class predicate, so a piece of a megabyte is a few thousand steps, not a million —
+// round 1's form (one LANE per item, the byte scanner, and for every tile inside a long piece a walk back to the piece
+// start) was quadratic in the piece length.
+//   td_split_far_pieces  list of piece starts whose end the window could not see: scan that piece, go on marking piece
+//                        starts to the end of its tile (or to where a lane of the fast kernel started), tell the tiles
+//                        that begin inside what was scanned their first piece start (tile_carry);
+//   td_split_far_tiles   chains of flagged tiles (no sync point in the left halo: lane 0 of the fast kernel did not run):
+//                        from tile_carry of the chain's first tile, piece by piece through the flagged tiles.
+struct WaveMaskP {  // mask provider over HBM for scan_piece_p; every method is executed by the whole wavefront, uniformly
+    const Tables& T;
+    const uint8_t* text;
+    const uint32_t* docbits;
+    int64_t n, g;  // text length; global position of the piece start (provider position 0)
+    int o, lim;
+    int lane;
+    __device__ __forceinline__ uint32_t cf_at(int64_t pos) const {  // class + flags of the byte at global position pos
+        if (pos >= n) return F_DOC;
+        GlobSrc src;
+        src.text = text; src.docbits = docbits; src.lo = 0; src.hi = n;
+        uint32_t v = classify_at(T, src, pos);
+        if (src.doc(pos)) v |= F_DOC;
+        return v;
+    }
+    __device__ __forceinline__ bool pred(int k, int64_t pos, bool mask_eos) const {  // bit of mask k at pos (end-of-subject bits after o cleared)
+        const uint32_t v = cf_at(pos);
+        if (mask_eos && pos > g && (v & F_DOC)) return false;
+        return (mask_bits_of(0, v) >> k) & 1u;
+    }
+    __device__ __forceinline__ bool bit(int k, int i) const { return pred(k, g + i, false); }
+    __device__ __forceinline__ bool ebit(int i) const { return i > 0 && (cf_at(g + i) & F_DOC); }
+    template <class F>
+    __device__ __forceinline__ int first_clear(const F& f, int from) const {  // first i >= from with !f(g + i), at most lim
+        int64_t w = g + from;
+        for (;;) {
+            uint64_t b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = __ballot(f(w + 64 * q + lane));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (~b[q]) return (int)(w - g) + 64 * q + td_ctz64(~b[q]);
+            w += 256;
+            if (w - g >= lim) return lim;
         }
+    }
+    __device__ __forceinline__ int run_end(int k, int from) const { return first_clear([&](int64_t pos) { return pred(k, pos, true); }, from); }
+    __device__ __forceinline__ int run_end2(int k1, int k2, int from) const {
+        return first_clear([&](int64_t pos) { return pred(k1, pos, true) || pred(k2, pos, true); }, from);
+    }
+    template <class F>
+    __device__ __forceinline__ int last_where(const F& f, int lo, int hi) const {  // highest i in [lo, hi) with f(g + i), -1 if none
+        for (int64_t w = hi; w > lo; w -= 64) {
+            const int64_t i = w - 64 + lane;  // window [w - 64, w)
+            const uint64_t b = __ballot(i >= lo && f(g + i));
+            if (b) return (int)(w - 64) + td_top64(b) - 1;
+        }
+        return -1;
+    }
+    __device__ __forceinline__ int last_and(int k1, int k2, int lo, int hi) const {
+        return last_where([&](int64_t pos) { return pred(k1, pos, false) && pred(k2, pos, false); }, lo, hi);
+    }
+    __device__ __forceinline__ int last_set(int k, int lo, int hi) const { return last_where([&](int64_t pos) { return pred(k, pos, false); }, lo, hi); }
+    __device__ __forceinline__ int last_clear(int k, int lo, int hi) const { return last_where([&](int64_t pos) { return !pred(k, pos, false); }, lo, hi); }
+};
+
+struct FarScan {  // one wavefront's view of the text for the far kernels
+    const EncodeArgs& a;
+    const Tables& T;
+    int lane;
+    __device__ __forceinline__ int64_t piece_end(int64_t g) const {  // end of the piece that starts at g
+        const int64_t room = a.n - g + 4;
+        WaveMaskP mp{T, a.text, a.docbits, a.n, g, 0, room > 0x7FFFFFF0ll ? 0x7FFFFFF0 : (int)room, lane};
+        const uint8_t* text = a.text;
+        const int64_t n = a.n;
+        const int r = scan_piece_p(mp, [=](int q) { return g + q < n ? (uint32_t)text[g + q] : 0u; }, T.pat_flags);
+        return r > 0 ? g + r : a.n;  // (r < 0 cannot happen: the provider reads to the end of the text)
+    }
+    __device__ __forceinline__ bool sync_at(int64_t p) const {
+        WaveMaskP mp{T, a.text, a.docbits, a.n, p, 0, 8, lane};
+        return is_sync(p > 0 ? mp.cf_at(p - 1) : 0u, mp.cf_at(p), T.pat_flags);
+    }
+    // does a lane of the fast kernel start at p?  (p is a sync point, the first one of its chunk, and not in the tile's first
+    // chunk: lane 0 starts from the left halo, never inside its own chunk)
+    __device__ __forceinline__ bool fast_lane_starts_at(int64_t p) const {
+        if (!sync_at(p)) return false;
+        const int64_t tile_g0 = p - (p % KS_TILE);
+        const int64_t cs = p - ((p - tile_g0) % KS_CHUNK);
+        if (cs == tile_g0) return false;
+        const int64_t q = cs + lane;  // (KS_CHUNK <= 64: one lane per byte of the chunk)
+        WaveMaskP mp{T, a.text, a.docbits, a.n, p, 0, 8, lane};
+        const bool earlier = q < p && is_sync(q > 0 ? mp.cf_at(q - 1) : 0u, mp.cf_at(q), T.pat_flags);
+        return !__any(earlier);
+    }
+    // piece starts from p (a piece start) to the end of p's tile, marked as they are found; returns the first piece start at or
+    // behind the tile end, or -1 when it stopped where a lane of the fast kernel took over
+    __device__ __forceinline__ int64_t mark_to_tile_end(int64_t p, bool first_is_marked) const {
+        const int64_t tile_end = (p - (p % KS_TILE) + KS_TILE < a.n) ? p - (p % KS_TILE) + KS_TILE : a.n;
+        bool skip = first_is_marked;
         while (p < tile_end) {
-            // stop where a lane of the fast kernel STARTED: the first provable sync point of a 16-byte chunk other
-            // than the tile's first chunk (lane 0 starts from the left halo, never inside its own chunk)
-            if (p != g && is_sync(G.cf(p - 1), G.cf(p), T.pat_flags)) {
-                const int64_t cs = p - ((p - tile_g0) % KS_CHUNK);
-                bool first = cs != tile_g0;
-                for (int64_t q = cs; first && q < p; ++q)
-                    if (is_sync(G.cf(q - 1), G.cf(q), T.pat_flags)) first = false;
-                if (first) break;
+            if (!skip) {
+                if (fast_lane_starts_at(p)) return -1;
+                if (lane == 0) atomicOr(&a.startbits[p >> 5], 1u << (p & 31));
             }
-            atomicOr(&a.startbits[p >> 5], 1u << (p & 31));
-            p = G.scan(p);
+            skip = false;
+            p = piece_end(p);
+        }
+        return p;
+    }
+    __device__ __forceinline__ void carry_to(int64_t from_tile, int64_t p) const {  // tiles (from_tile, tile of p]: first piece start = p
+        const int64_t last = p >= a.n ? (int64_t)a.n_stiles - 1 : p / KS_TILE;
+        for (int64_t t = from_tile + 1 + lane; t <= last; t += 64) a.tile_carry[t] = p;
+    }
+};
+
+__global__ __launch_bounds__(256) void td_split_far_pieces(const EncodeArgs a) {
+    const Tables T = uniform_tables(a.Tp);
+    const int lane = threadIdx.x & 63;
+    const uint32_t nitems = *a.slow_count < a.slow_cap ? *a.slow_count : a.slow_cap;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const FarScan F{a, T, lane};
+    for (uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); j < nitems; j += nwaves) {
+        const int64_t g = a.slow_list[j];  // a piece start the fast kernel marked; its end was beyond the window
+        const int64_t p = F.mark_to_tile_end(g, true);
+        if (p >= 0) F.carry_to(g / KS_TILE, p);
+    }
+}
+
+__global__ __launch_bounds__(256) void td_split_far_tiles(const EncodeArgs a) {
+    const Tables T = uniform_tables(a.Tp);
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const FarScan F{a, T, lane};
+    for (int64_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < a.n_stiles; t += nwaves) {
+        if (!a.tile_flag[t] || (t > 0 && a.tile_flag[t - 1])) continue;  // (uniform) heads of chains of flagged tiles only
+        // walk the chain tile by tile.  The first piece start of a tile is where the walk crossed into it, or — when a lane of
+        // the fast kernel took over in the tile before (it then scanned on to that tile's end), or a long piece was resolved by
+        // td_split_far_pieces — what that scan recorded in tile_carry
+        int64_t p = -1;
+        for (int64_t tt = t; tt < a.n_stiles && a.tile_flag[tt]; ++tt) {
+            const int64_t t0 = tt * (int64_t)KS_TILE;
+            if (p < t0) p = a.tile_carry[tt];
+            if (p < t0) { if (lane == 0) raise(a, TD_E_SCRATCH, t0); break; }  // (cannot happen: nobody told this tile)
+            if (p >= t0 + KS_TILE || p >= a.n) continue;                        // a piece covers the whole tile
+            p = F.mark_to_tile_end(p, false);
         }
     }
 }
@@ -618,23 +737,30 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
                 smask &= smask - 1;
                 s_plist[k++] = (uint16_t)(c0 + b);
             }
-            if (tid == 0) {
-                // end of the last owned piece: first START at/after the tile end; beyond the staged window
-                // (a piece longer than 128 bytes) walk the bitmap in HBM
+            if (tid < 64) {  // (first wavefront)
+                // end of the last owned piece: first START at/after the tile end; beyond the staged window (a piece longer
+                // than 128 bytes) walk the bitmap in HBM, 64 words per step (a megabyte piece: 500 steps, not 31 000)
                 int e = tile_hi;
                 while (e < K_BWIN && !((s_start[e >> 5] >> (e & 31)) & 1u)) ++e;
                 if (e >= K_BWIN && np_total > 0) {
-                    int64_t g = wg0 + K_BWIN;
+                    const int64_t g = wg0 + K_BWIN;
                     int64_t found = a.n;
-                    for (int64_t gw = g >> 5; gw < nwords; ++gw) {
-                        uint32_t sw = a.startbits[gw];
+                    for (int64_t gw0 = g >> 5; gw0 < nwords; gw0 += 64) {
+                        const int64_t gw = gw0 + tid;
+                        uint32_t sw = gw < nwords ? a.startbits[gw] : 0u;
                         if (gw == (g >> 5)) sw &= ~((1u << (g & 31)) - 1u);
-                        if (sw) { const int64_t f = gw * 32 + (__ffs(sw) - 1); if (f < a.n) found = f; break; }
+                        const uint64_t b = __ballot(sw != 0);
+                        if (b) {
+                            const int l = td_ctz64(b);
+                            const int64_t f = (gw0 + l) * 32 + (__ffs(__shfl(sw, l)) - 1);
+                            if (f < a.n) found = f;
+                            break;
+                        }
                     }
-                    s_ext_end = found;
+                    if (tid == 0) s_ext_end = found;
                     e = K_BWIN;  // placeholder; the probe uses s_ext_end for the last piece
                 }
-                s_plist[np_total] = (uint16_t)e;
+                if (tid == 0) s_plist[np_total] = (uint16_t)e;
             }
         }
         __syncthreads();
@@ -1134,81 +1260,209 @@ __global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
             if (len > LP_SMALL && len <= LP_MEDIUM) lp_do_piece<64>(a, T, j, id, rk, lane);
         }
     }
-    // pass 3: anything longer: parts in the HBM pool (4 u32 arrays of `len`: id, rank, next, prev), lane 0 applies
-    // each merge.  O(len^2/64) like the reference's O(len^2), but only for single pieces above 1 KiB.
-    for (uint32_t j = wave_global; j < nlong; j += nwaves) {
-        const int64_t gs = a.long_list[j].gs;
+    // (pieces above LP_MEDIUM bytes: td_giant_pieces)
+}
+
+// ------------------------------------------------------------------ td_giant_pieces ---------
+// Pieces above 1 KiB (a megabyte of one letter, of blanks, of DNA ...): the reference's merge loop is O(len^2) there
+// (tiktoken.cpp:322-343: erase + full rescan per merge; 20 KB take 0.3 s, a megabyte hours), and so was round 1's path (one
+// wavefront, lane 0 applying one merge per HBM round trip).  Here: ROUNDS over the whole piece, a 1024-thread workgroup per
+// piece, parts dense in HBM (ids + pair ranks, two generations).  A round takes g = the lowest rank present and merges
+// EVERY pair of rank g at once — in a run of consecutive g-pairs every second one, from the left, which is what the
+// sequential leftmost-first rule does to the run — compacts, and looks the changed pairs up again.  That equals the
+// sequential order as long as no pair that the sequential execution would see while it works through the g-pairs (the new
+// neighbours of a merged part, including the transient neighbour that is itself about to be merged) ranks below g; every
+// such pair is looked up and checked, and a round that fails the check is redone with only the leftmost g-pair merged (the
+// plain sequential step, always exact).  'a' * 1 000 000: 16 rounds of sweeps over a shrinking array instead of 10^6 steps.
+// Cost: (distinct ranks that occur) x (len / 1024) sweep steps — far from quadratic for the repetitive inputs that produce
+// such pieces, still slow for a megabyte of random letters.
+constexpr int GP_THREADS = 1024;
+constexpr uint32_t GP_SEL = 0x80000000u;  // rank word: the pair that starts here merges in this round
+template <bool IS_MAX>
+__device__ __forceinline__ int gp_wave_scan(int x) {  // inclusive add- or max-scan across the wavefront (DPP)
+    constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118, ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143;
+    constexpr int ID = IS_MAX ? (int)0x80000000 : 0;
+    auto op = [](int p, int q) { return IS_MAX ? (p > q ? p : q) : p + q; };
+    x = op(x, __builtin_amdgcn_update_dpp(ID, x, ROW_SHR1, 0xF, 0xF, false));
+    x = op(x, __builtin_amdgcn_update_dpp(ID, x, ROW_SHR2, 0xF, 0xF, false));
+    x = op(x, __builtin_amdgcn_update_dpp(ID, x, ROW_SHR4, 0xF, 0xF, false));
+    x = op(x, __builtin_amdgcn_update_dpp(ID, x, ROW_SHR8, 0xF, 0xF, false));
+    x = op(x, __builtin_amdgcn_update_dpp(ID, x, ROW_BCAST15, 0xA, 0xF, false));
+    x = op(x, __builtin_amdgcn_update_dpp(ID, x, ROW_BCAST31, 0xC, 0xF, false));
+    return x;
+}
+// inclusive scan over the 1024 threads of the workgroup; `total` = the last thread's value (two barriers)
+template <bool IS_MAX>
+__device__ __forceinline__ int gp_block_scan(int x, int* s_w, int& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int ID = IS_MAX ? (int)0x80000000 : 0;
+    int y = gp_wave_scan<IS_MAX>(x);
+    if (lane == 63) s_w[wv] = y;
+    __syncthreads();
+    int pre = ID, tot = ID;
+#pragma unroll
+    for (int w = 0; w < GP_THREADS / 64; ++w) {
+        const int sw = s_w[w];
+        if (w < wv) pre = IS_MAX ? (pre > sw ? pre : sw) : pre + sw;
+        tot = IS_MAX ? (tot > sw ? tot : sw) : tot + sw;
+    }
+    __syncthreads();
+    total = tot;
+    return IS_MAX ? (y > pre ? y : pre) : y + pre;
+}
+__device__ __forceinline__ uint32_t gp_block_min(uint32_t x, uint32_t* s_m) {  // minimum over the workgroup (two barriers)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(x, d);
+        x = o < x ? o : x;
+    }
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = x;
+    __syncthreads();
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < GP_THREADS / 64; ++w) m = s_m[w] < m ? s_m[w] : m;
+    __syncthreads();
+    return m;
+}
+
+__global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a) {
+    __shared__ int s_w[GP_THREADS / 64];
+    __shared__ uint32_t s_m[GP_THREADS / 64];
+    __shared__ uint32_t s_viol;
+    const Tables T = uniform_tables(a.Tp);
+    const int tid = threadIdx.x;
+    const uint32_t nlong = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
+    for (uint32_t j = blockIdx.x; j < nlong; j += gridDim.x) {
         const uint32_t len = a.long_list[j].len;
-        if (len <= LP_MEDIUM) continue;
+        if (len <= (uint32_t)LP_MEDIUM) continue;  // (uniform: td_long_pieces')
+        const int64_t gs = a.long_list[j].gs;
         const uint8_t* p = a.text + gs;
-        const uint64_t need = 4ull * len;
         unsigned long long off = 0;
-        if (lane == 0) off = atomicAdd(a.pool_used, (unsigned long long)need);
-        off = __shfl(off, 0);
-        if (off + need > a.pool_cap) {
-            if (lane == 0) raise(a, TD_E_SCRATCH, gs);
+        if (tid == 0) off = atomicAdd(a.pool_used, 4ull * len);
+        {   // (broadcast through LDS: 64-bit)
+            __shared__ unsigned long long s_off;
+            if (tid == 0) s_off = off;
+            __syncthreads();
+            off = s_off;
+            __syncthreads();
+        }
+        if (off + 4ull * len > a.pool_cap) {
+            if (tid == 0) raise(a, TD_E_SCRATCH, gs);
             continue;
         }
-        uint32_t ntok = 0;
-        {
-            volatile uint32_t* id = a.pool + off;
-            volatile uint32_t* rk = id + len;
-            volatile uint32_t* nx = rk + len;
-            volatile uint32_t* pv = nx + len;
-            for (uint32_t i = lane; i < len; i += 64) {
-                const uint32_t b = p[i];
-                id[i] = (uint32_t)T.byte_id[b];
-                rk[i] = (i + 1 < len) ? (uint32_t)T.byte_pair[(b << 8) | p[i + 1]] : (uint32_t)NO_RANK;
-                nx[i] = i + 1;
-                pv[i] = i - 1;  // 0xFFFFFFFF for i == 0
+        uint32_t* id_cur = a.pool + off;       // two generations of (ids, pair ranks): the round reads one, writes the other
+        uint32_t* rk_cur = id_cur + len;
+        uint32_t* id_nxt = rk_cur + len;
+        uint32_t* rk_nxt = id_nxt + len;
+        // generation 0: one part per byte, rank of every byte pair
+        uint32_t m = len, lmin = (uint32_t)NO_RANK;
+        for (uint32_t i = tid; i < len; i += GP_THREADS) {
+            const uint32_t b = p[i];
+            const uint32_t r = (i + 1 < len) ? (uint32_t)T.byte_pair[(b << 8) | p[i + 1]] : (uint32_t)NO_RANK;
+            id_cur[i] = (uint32_t)T.byte_id[b];
+            rk_cur[i] = r;
+            lmin = r < lmin ? r : lmin;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t g = gp_block_min(lmin, s_m);
+        bool single = false;  // redo of a round that failed the order check: only the leftmost pair of rank g merges
+        while (g != (uint32_t)NO_RANK) {
+            // ---- which pairs merge: rank g and an even distance from the start of their run of g-pairs ----
+            int carry = -1;  // last position so far whose pair is not of rank g
+            uint32_t first_sel = 0xFFFFFFFFu;
+            for (uint32_t i0 = 0; i0 < m; i0 += GP_THREADS) {
+                const uint32_t i = i0 + tid;
+                const uint32_t r = i < m ? __hip_atomic_load(rk_cur + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~GP_SEL : (uint32_t)NO_RANK;
+                const bool isg = r == g;
+                int tot;
+                int lastnon = gp_block_scan<true>(isg ? (int)0x80000000 : (int)i, s_w, tot);
+                lastnon = lastnon > carry ? lastnon : carry;
+                const bool sel = isg && !(((int)i - lastnon - 1) & 1);
+                if (i < m) rk_cur[i] = sel ? (r | GP_SEL) : r;
+                if (sel && i < first_sel) first_sel = i;
+                carry = tot > carry ? tot : carry;
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            for (;;) {
-                unsigned long long best = ~0ull;
-                for (uint32_t i = lane; i < len; i += 64) {
-                    const uint32_t r = rk[i];
-                    if (r != (uint32_t)NO_RANK && id[i] != TOK_NONE) {
-                        const unsigned long long k = ((unsigned long long)r << 32) | i;
-                        best = k < best ? k : best;
+            if (single) {  // keep the leftmost selection only
+                first_sel = gp_block_min(first_sel, s_m);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                for (uint32_t i = tid; i < m; i += GP_THREADS)
+                    if (i != first_sel) rk_cur[i] = __hip_atomic_load(rk_cur + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~GP_SEL;
+            }
+            if (tid == 0) s_viol = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            // ---- next generation: surviving parts compacted, changed pairs looked up, the order assumption checked ----
+            uint32_t out_base = 0;
+            lmin = (uint32_t)NO_RANK;
+            auto ld = [](const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };  // (written by other lanes: past the L1)
+            for (uint32_t i0 = 0; i0 < m; i0 += GP_THREADS) {
+                const uint32_t i = i0 + tid;
+                bool surv = false;
+                uint32_t A = 0, nr = (uint32_t)NO_RANK;
+                if (i < m) {
+                    const uint32_t r0 = ld(rk_cur + i);
+                    const bool selm1 = i > 0 && (ld(rk_cur + i - 1) & GP_SEL);
+                    surv = !selm1;
+                    if (surv) {
+                        const bool sel0 = (r0 & GP_SEL) != 0;
+                        const bool sel1 = i + 1 < m && (ld(rk_cur + i + 1) & GP_SEL);
+                        const bool sel2 = i + 2 < m && (ld(rk_cur + i + 2) & GP_SEL);
+                        A = sel0 ? g : ld(id_cur + i);
+                        const uint32_t n1 = sel0 ? i + 2 : i + 1;  // the part that follows mine in the next generation
+                        if (n1 < m) {
+                            const bool seln1 = sel0 ? sel2 : sel1;
+                            const uint32_t B = seln1 ? g : ld(id_cur + n1);
+                            if (!sel0 && !sel1) nr = r0 & ~GP_SEL;  // neither part changed
+                            else {
+                                nr = (uint32_t)pair_lookup(T, A, B);
+                                if (nr < g) s_viol = 1;             // a new pair below g: the sequential order would differ
+                            }
+                            if (sel0 && sel2) {  // between my merge and the next one of the run the sequential loop sees (g, id[i+2])
+                                const uint32_t tr = (uint32_t)pair_lookup(T, g, ld(id_cur + i + 2));
+                                if (tr < g) s_viol = 1;
+                            }
+                        }
                     }
                 }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const unsigned long long o = __shfl_xor(best, d);
-                    best = o < best ? o : best;
+                int tot;
+                const int incl = gp_block_scan<false>(surv ? 1 : 0, s_w, tot);
+                if (surv) {
+                    const uint32_t o = out_base + (uint32_t)incl - 1u;
+                    id_nxt[o] = A;
+                    rk_nxt[o] = nr;
+                    lmin = nr < lmin ? nr : lmin;
                 }
-                if (best == ~0ull) break;
-                if (lane == 0) {
-                    const uint32_t w = (uint32_t)best, r = (uint32_t)(best >> 32);
-                    const uint32_t n1 = nx[w];         // absorbed part
-                    const uint32_t n2 = nx[n1];        // new right neighbour (== len if none)
-                    const uint32_t pw = pv[w];
-                    id[w] = r;
-                    id[n1] = TOK_NONE;
-                    rk[n1] = (uint32_t)NO_RANK;
-                    nx[w] = n2;
-                    if (n2 < len) pv[n2] = w;
-                    rk[w] = (n2 < len) ? (uint32_t)pair_lookup(T, r, id[n2]) : (uint32_t)NO_RANK;
-                    if (pw != 0xFFFFFFFFu) rk[pw] = (uint32_t)pair_lookup(T, id[pw], r);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                out_base += (uint32_t)tot;
             }
-            if (lane == 0) {  // compact surviving ids to the front of the id array (k <= i always)
-                uint32_t k = 0;
-                for (uint32_t i = 0; i < len; i = nx[i]) {
-                    const uint32_t v = id[i];
-                    if ((int32_t)v >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gs + i);
-                    id[k++] = v;
-                }
-                ntok = k;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const uint32_t gn = gp_block_min(lmin, s_m);  // (barriers: s_viol is final)
+            if (s_viol && !single) {  // redo this round sequentially: drop the selection marks, keep generation `cur`
+                __syncthreads();
+                for (uint32_t i = tid; i < m; i += GP_THREADS) rk_cur[i] = ld(rk_cur + i) & ~GP_SEL;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                single = true;
+                continue;
             }
-            ntok = __shfl(ntok, 0);
+            single = false;
+            m = out_base;
+            g = gn;
+            uint32_t* t0 = id_cur; id_cur = id_nxt; id_nxt = t0;
+            uint32_t* t1 = rk_cur; rk_cur = rk_nxt; rk_nxt = t1;
+            __syncthreads();
         }
-        if (lane == 0) {
-            a.long_list[j].ntok = ntok;
-            a.long_list[j].pool_off = off;
-            if (ntok > 1) atomicAdd(&a.tile_extra[gs / K_TILE], ntok - 1);
+        // the ids of the piece: generation `cur`
+        for (uint32_t i = tid; i < m; i += GP_THREADS) {
+            const uint32_t v = __hip_atomic_load(id_cur + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int32_t)v >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gs);
         }
+        if (tid == 0) {
+            a.long_list[j].ntok = m;
+            a.long_list[j].pool_off = (unsigned long long)(id_cur - a.pool);
+            if (m > 1) atomicAdd(&a.tile_extra[gs / K_TILE], m - 1);
+        }
+        __syncthreads();
     }
 }
 
@@ -1459,7 +1713,8 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
             break;
         default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(td_split_slow, dim3(64), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(td_split_far_pieces, dim3(64), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(td_split_far_tiles, dim3(256), dim3(256), 0, stream, a);
     if (ev) (void)hipEventRecord(ev[1], stream);
     const bool tokens = a.stop_after != 2 && a.stop_after != 11 && a.stop_after != 12;
     if (tokens) hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
@@ -1472,6 +1727,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     if (ev) (void)hipEventRecord(ev[3], stream);
     if (tokens) {
         hipLaunchKernelGGL(td_long_pieces, dim3(256 * 5), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(td_giant_pieces, dim3(128), dim3(GP_THREADS), 0, stream, a);
         hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
         hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
     }
