@@ -71,7 +71,8 @@ const char* td_last_error(const td_tokenizer* t);
  * tokendagger/wrapper.py:212-235).  out_tokens (capacity out_capacity ids) receives all ids,
  * out_offsets[n_docs+1] the per-document token offsets, *n_tokens the total.  If the capacity is
  * too small the call fails with TD_E_CAPACITY and *n_tokens holds the required size.
- * Copies text to the device, runs the kernels, copies ids back; synchronous.
+ * Copies text to the device, runs the kernels, copies ids back; synchronous.  Inputs of 64 MiB and more go through a
+ * three-stage pipeline of pinned bounce buffers (host copy || H2D || kernels || D2H || host copy, TD_OPT_PIPE_*).
  */
 int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
                     int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens);
@@ -145,6 +146,9 @@ int64_t td_info(const td_tokenizer* t, int what);
 #define TD_OPT_LONG_POOL_BYTES 1 /* scratch for pieces longer than 64 bytes (default max(64 MiB, 2 x input)) */
 #define TD_OPT_PROFILE 2         /* 1: bracket the kernels of every td_encode_device call with HIP events on the
                                     call's stream (td_profile_read_ex) */
+#define TD_OPT_PIPE_CHUNK_BYTES 3 /* td_encode_batch cuts inputs of at least two chunks into chunks of whole documents of about
+                                    this many bytes (default 32 MiB) and overlaps host copies, PCIe transfers and kernels */
+#define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 8) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 
 /* Sums (ms) of the pre-tokenizer kernel and token kernel (probe + merge) durations and the number of calls recorded

@@ -337,3 +337,39 @@ def test_giant_pieces_are_not_quadratic(tok):
         print(f"giant pieces: {len(text)} bytes in {dt * 1e3:.1f} ms")
     finally:
         port.set_heap_threshold(4096)
+
+
+def test_pipelined_host_batches_equal_the_plain_path():
+    """td_encode_batch cuts large inputs into chunks of whole documents (pinned bounce buffers, H2D || kernels || D2H).  With
+    the chunk size turned down the pipeline runs on a few MiB: same ids, same offsets, capacity protocol and device
+    errors as the one-shot path."""
+    from tokendagger_amd import capi
+    pat, mr, special = H.llama4()
+    tok = capi.HipTokenizer(pat, mr, special, device=0)
+    x, o = td_corpus.mixed(6 << 20, seed=31)
+    y, p = td_corpus.english(5 << 20, seed=32)
+    big = (b"z" * 700_000)  # one document larger than a chunk
+    text = np.concatenate([x, np.frombuffer(big, dtype=np.uint8), y])
+    offs = np.concatenate([o, [o[-1] + len(big)], o[-1] + len(big) + p[1:]]).astype(np.int64)
+    want_t, want_o = tok.encode_batch(text, offs)                 # below two chunks of 32 MiB: the plain path
+    tok.set_option(capi.TD_OPT_PIPE_CHUNK_BYTES, 512 << 10)
+    for threads in (1, 3):
+        tok.set_option(capi.TD_OPT_PIPE_THREADS, threads)
+        got_t, got_o = tok.encode_batch(text, offs)
+        assert np.array_equal(got_o, want_o) and np.array_equal(got_t, want_t)
+    with pytest.raises(capi.TokenDaggerHipError) as ei:           # capacity too small: the needed size is reported
+        tok.encode_batch(text, offs, capacity=len(want_t) - 5)
+    assert ei.value.code == capi.TD_E_CAPACITY and str(len(want_t)) in str(ei.value)
+    got_t, got_o = tok.encode_batch(text, offs, mode=1)           # encode_ordinary semantics through the pipeline
+    assert np.array_equal(got_t, want_t)
+    tok.close()
+    toy = capi.HipTokenizer(pat, {b"a": 0, b"b": 1, b"ab": 2, b" ": 3}, {}, device=0)
+    toy.set_option(capi.TD_OPT_PIPE_CHUNK_BYTES, 4096)
+    docs = [b"ab ab a b " * 100] * 40 + [b"ab c ab"] + [b"ba " * 50] * 40
+    t, o2 = H.pack_docs(docs)
+    with pytest.raises(capi.TokenDaggerHipError) as ei:
+        toy.encode_batch(t, o2)
+    assert ei.value.code == 4  # TD_E_UNKNOWN_BYTE, raised by a chunk in the middle
+    ok_t, ok_o = toy.encode_batch(*H.pack_docs(docs[:40] + docs[41:]))  # the handle is usable afterwards
+    assert len(ok_o) == 81 and ok_o[-1] == len(ok_t)
+    toy.close()

@@ -22,6 +22,8 @@ TD_INFO_N_PAIRS, TD_INFO_MERGE_CLOSED, TD_INFO_MAX_ID, TD_INFO_TILE_BYTES = 1, 2
 TD_INFO_WORKSPACE_BYTES, TD_INFO_N_SPECIAL, TD_INFO_LONG_PIECES = 5, 6, 7
 TD_OPT_LONG_POOL_BYTES = 1
 TD_OPT_PROFILE = 2
+TD_OPT_PIPE_CHUNK_BYTES = 3
+TD_OPT_PIPE_THREADS = 4
 
 EXPORTS = [
     "td_create", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",

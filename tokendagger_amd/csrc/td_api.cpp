@@ -5,6 +5,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -57,6 +61,81 @@ struct DevBuf {
 
 }  // namespace
 
+namespace {
+// Host threads that fill and drain the pinned bounce buffers of the td_encode_batch pipeline: a copy job is cut into
+// segments that the workers take from one queue; copies into the pipeline and out of it run side by side.
+class CopyPool {
+public:
+    struct Job { std::atomic<int> remaining{0}; };
+    explicit CopyPool(int n) {
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { run(); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    int size() const { return (int)workers_.size(); }
+    std::shared_ptr<Job> copy(void* dst, const void* src, size_t bytes) {
+        auto job = std::make_shared<Job>();
+        if (bytes == 0) return job;
+        const size_t seg = std::max<size_t>(1u << 20, ((bytes / (size_t)(2 * std::max(size(), 1))) + 4095) & ~(size_t)4095);
+        int nseg = 0;
+        for (size_t lo = 0; lo < bytes; lo += seg) ++nseg;
+        job->remaining.store(nseg);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t lo = 0; lo < bytes; lo += seg) q_.push_back({(char*)dst + lo, (const char*)src + lo, std::min(seg, bytes - lo), job});
+        }
+        cv_.notify_all();
+        return job;
+    }
+    void wait(const std::shared_ptr<Job>& job) {  // (the caller helps)
+        while (job->remaining.load() > 0) {
+            Seg sg;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                if (q_.empty()) { done_.wait_for(g, std::chrono::microseconds(50)); continue; }
+                sg = q_.front(); q_.pop_front();
+            }
+            memcpy(sg.dst, sg.src, sg.len);
+            if (sg.job->remaining.fetch_sub(1) == 1) done_.notify_all();
+        }
+    }
+private:
+    struct Seg { char* dst; const char* src; size_t len; std::shared_ptr<Job> job; };
+    void run() {
+        for (;;) {
+            Seg sg;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this] { return stop_ || !q_.empty(); });
+                if (stop_ && q_.empty()) return;
+                sg = q_.front(); q_.pop_front();
+            }
+            memcpy(sg.dst, sg.src, sg.len);
+            if (sg.job->remaining.fetch_sub(1) == 1) done_.notify_all();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::deque<Seg> q_;
+    bool stop_ = false;
+};
+
+struct Ctl {  // small control block in device memory
+    int err;
+    int pad;
+    long long err_pos;
+    uint32_t long_count;   // --- from here on: reset before every call
+    uint32_t slow_count;
+    unsigned long long pool_used;
+    uint32_t scan_done;
+    uint32_t pad2;
+};
+}  // namespace
+
 struct td_tokenizer {
     HostTables H;
     Tables dT;  // device pointers
@@ -82,6 +161,21 @@ struct td_tokenizer {
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     std::vector<void*> graveyard;  // workspace buffers replaced by larger ones; freed at the next synchronisation point
+    // host-buffer pipeline (td_encode_batch on large inputs): three slots of pinned bounce buffers + device buffers, three
+    // streams (H2D, kernels, D2H)
+    struct PipeSlot {
+        void* h_text = nullptr; size_t h_text_cap = 0;   // pinned
+        void* h_offs = nullptr; size_t h_offs_cap = 0;   // pinned: rebased document offsets in, token offsets out
+        void* h_tok = nullptr; size_t h_tok_cap = 0;     // pinned
+        DevBuf d_text, d_offs, d_tok, d_toff;
+        hipEvent_t ev_h2d = nullptr, ev_k = nullptr, ev_off = nullptr, ev_tok = nullptr;
+        Ctl* h_ctl = nullptr;                            // pinned copy of the device control block after the chunk's kernels
+    };
+    PipeSlot pipe[3];
+    hipStream_t s_h2d = nullptr, s_k = nullptr, s_d2h = nullptr;
+    int64_t pipe_chunk_bytes = 16ll << 20;
+    int pipe_threads = 16;
+    std::unique_ptr<CopyPool> pool_threads;
 };
 
 namespace {
@@ -149,16 +243,6 @@ int upload(td_tokenizer* t, const V* src, size_t count, const V** dst) {
     return TD_OK;
 }
 
-struct Ctl {  // small control block in device memory
-    int err;
-    int pad;
-    long long err_pos;
-    uint32_t long_count;   // --- from here on: reset before every call
-    uint32_t slow_count;
-    unsigned long long pool_used;
-    uint32_t scan_done;
-    uint32_t pad2;
-};
 
 int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
@@ -371,6 +455,12 @@ void td_destroy(td_tokenizer* t) {
         for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
         for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
         if (t->last_done) (void)hipEventDestroy(t->last_done);
+        for (auto& sl : t->pipe) {
+            for (void* hp : {sl.h_text, sl.h_offs, sl.h_tok, (void*)sl.h_ctl}) if (hp) (void)hipHostFree(hp);
+            for (DevBuf* b : {&sl.d_text, &sl.d_offs, &sl.d_tok, &sl.d_toff}) if (b->p) (void)hipFree(b->p);
+            for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_off, sl.ev_tok}) if (e) (void)hipEventDestroy(e);
+        }
+        for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h}) if (st) (void)hipStreamDestroy(st);
         DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
@@ -419,11 +509,162 @@ int check_offsets(td_tokenizer* t, const char* what, const int64_t* offs, int64_
     return TD_OK;
 }
 
+
+// ---- td_encode_batch on large inputs: chunks of documents through pinned bounce buffers, H2D || kernels || D2H -------
+// A plain hipMemcpy from pageable memory runs at 9-10 GB/s (the runtime stages it through one pinned buffer on one thread)
+// and round 1's td_encode_batch did copy in, kernels, copy out one after the other: 29 ms for 256 MiB of which 1.7 ms were
+// kernels.  Here several host threads copy a chunk into a pinned buffer while the previous chunk is on the wire, the kernels
+// of chunk i run while chunk i + 1 goes down and the ids of chunk i - 1 come up, and the ids are copied out of their pinned
+// buffer by the same threads.
+void parallel_memcpy(void* dst, const void* src, size_t bytes, int threads) {
+    if (bytes < (4u << 20) || threads <= 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t part = ((bytes / (size_t)threads) + 4095) & ~(size_t)4095;
+    for (int k = 1; k < threads; ++k) {
+        const size_t lo = part * (size_t)k;
+        if (lo >= bytes) break;
+        const size_t len = std::min(part, bytes - lo);
+        th.emplace_back([=] { memcpy((char*)dst + lo, (const char*)src + lo, len); });
+    }
+    memcpy(dst, src, std::min(part, bytes));
+    for (auto& x : th) x.join();
+}
+
+int pinned_ensure(td_tokenizer* t, void*& p, size_t& cap, size_t bytes) {
+    if (cap >= bytes && p) return TD_OK;
+    if (p) HIP_TRY(t, hipHostFree(p));
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    HIP_TRY(t, hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return TD_OK;
+}
+
+int pipe_init(td_tokenizer* t) {
+    if (t->s_h2d) return TD_OK;
+    HIP_TRY(t, hipStreamCreateWithFlags(&t->s_h2d, hipStreamNonBlocking));
+    HIP_TRY(t, hipStreamCreateWithFlags(&t->s_k, hipStreamNonBlocking));
+    HIP_TRY(t, hipStreamCreateWithFlags(&t->s_d2h, hipStreamNonBlocking));
+    for (auto& sl : t->pipe) {
+        for (hipEvent_t* e : {&sl.ev_h2d, &sl.ev_k, &sl.ev_off, &sl.ev_tok}) HIP_TRY(t, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        HIP_TRY(t, hipHostMalloc((void**)&sl.h_ctl, sizeof(Ctl), hipHostMallocDefault));
+    }
+    return TD_OK;
+}
+
+int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
+                           int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
+    int rc;
+    if ((rc = pipe_init(t))) return rc;
+    if (!t->pool_threads || t->pool_threads->size() != std::max(t->pipe_threads - 1, 1)) t->pool_threads.reset(new CopyPool(std::max(t->pipe_threads - 1, 1)));
+    if ((rc = order_before(t, t->s_k))) return rc;
+    // chunks: whole documents, about pipe_chunk_bytes each
+    std::vector<int64_t> cd{0};
+    for (int64_t d = 0; d < n_docs;) {
+        const int64_t lo = doc_offsets[d];
+        int64_t e = d + 1;
+        // (binary search for the last document that still fits)
+        int64_t a = d + 1, b = n_docs;
+        while (a < b) { const int64_t mid = (a + b + 1) >> 1; if (doc_offsets[mid] - lo <= t->pipe_chunk_bytes) a = mid; else b = mid - 1; }
+        e = std::max(e, a);
+        cd.push_back(e);
+        d = e;
+    }
+    const int nchunks = (int)cd.size() - 1;
+    struct Pending { int64_t d0, d1, b0, nbytes, ntok; };
+    std::vector<Pending> pend((size_t)nchunks);
+    int64_t tok_base = 0;
+    bool capacity_miss = false;
+    int first_err = TD_OK;
+    auto submit = [&](int i) -> int {
+        td_tokenizer::PipeSlot& sl = t->pipe[i % 3];
+        const int64_t d0 = cd[(size_t)i], d1 = cd[(size_t)i + 1], b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0, nd = d1 - d0;
+        pend[(size_t)i] = {d0, d1, b0, nb, 0};
+        int r;
+        if ((r = pinned_ensure(t, sl.h_text, sl.h_text_cap, (size_t)nb + 64))) return r;
+        if ((r = pinned_ensure(t, sl.h_offs, sl.h_offs_cap, (size_t)(nd + 1) * 8))) return r;
+        if ((r = ensure(t, sl.d_text, (size_t)nb + 64))) return r;
+        if ((r = ensure(t, sl.d_offs, (size_t)(nd + 1) * 8))) return r;
+        if ((r = ensure(t, sl.d_toff, (size_t)(nd + 1) * 8))) return r;
+        if ((r = ensure(t, sl.d_tok, (size_t)std::max<int64_t>(nb, 1) * 4))) return r;  // worst case one id per byte
+        auto in_job = t->pool_threads->copy(sl.h_text, text + b0, (size_t)nb);
+        int64_t* ho = (int64_t*)sl.h_offs;
+        for (int64_t k = 0; k <= nd; ++k) ho[k] = doc_offsets[d0 + k] - b0;
+        t->pool_threads->wait(in_job);
+        if (nb > 0) HIP_TRY(t, hipMemcpyAsync(sl.d_text.p, sl.h_text, (size_t)nb, hipMemcpyHostToDevice, t->s_h2d));
+        HIP_TRY(t, hipMemcpyAsync(sl.d_offs.p, sl.h_offs, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, t->s_h2d));
+        HIP_TRY(t, hipEventRecord(sl.ev_h2d, t->s_h2d));
+        HIP_TRY(t, hipStreamWaitEvent(t->s_k, sl.ev_h2d, 0));
+        if ((r = encode_device_locked(t, sl.d_text.p, nb, sl.d_offs.p, nd, mode, sl.d_tok.p, std::max<int64_t>(nb, 1), sl.d_toff.p, t->s_k))) return r;
+        // the chunk's error word and the workspace counters travel with its offsets (the next chunk resets the counters)
+        HIP_TRY(t, hipMemcpyAsync(sl.h_ctl, t->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, t->s_k));
+        HIP_TRY(t, hipMemcpyAsync(sl.h_offs, sl.d_toff.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, t->s_k));
+        HIP_TRY(t, hipEventRecord(sl.ev_off, t->s_k));
+        return TD_OK;
+    };
+    auto fetch = [&](int i) -> int {  // chunk i's kernels are done: its total is known, its ids start their way up
+        td_tokenizer::PipeSlot& sl = t->pipe[i % 3];
+        Pending& P = pend[(size_t)i];
+        HIP_TRY(t, hipEventSynchronize(sl.ev_off));
+        const int64_t nd = P.d1 - P.d0;
+        const int64_t* to = (const int64_t*)sl.h_offs;
+        P.ntok = to[nd];
+        if (sl.h_ctl->err != 0 && first_err == TD_OK) {
+            first_err = sl.h_ctl->err;
+            const long long pos = sl.h_ctl->err_pos + (first_err == TD_E_UNKNOWN_BYTE || first_err == TD_E_SCRATCH ? P.b0 : 0);
+            t->err = first_err == TD_E_UNKNOWN_BYTE ? "No value found for piece at byte offset " + std::to_string(pos) + ": byte sequence is not in the vocabulary"
+                                                    : "device error " + std::to_string(first_err) + " near byte offset " + std::to_string(pos);
+        }
+        for (int64_t k = 0; k < nd; ++k) out_offsets[P.d0 + k] = tok_base + to[k];
+        if (tok_base + P.ntok > out_capacity) capacity_miss = true;
+        int r;
+        if ((r = pinned_ensure(t, sl.h_tok, sl.h_tok_cap, (size_t)std::max<int64_t>(P.ntok, 1) * 4))) return r;
+        if (P.ntok > 0 && !capacity_miss && first_err == TD_OK)
+            HIP_TRY(t, hipMemcpyAsync(sl.h_tok, sl.d_tok.p, (size_t)P.ntok * 4, hipMemcpyDeviceToHost, t->s_d2h));
+        HIP_TRY(t, hipEventRecord(sl.ev_tok, t->s_d2h));
+        const int64_t base = tok_base;
+        tok_base += P.ntok;
+        P.nbytes = base;  // (reused: where the chunk's ids go in the caller's buffer)
+        return TD_OK;
+    };
+    std::shared_ptr<CopyPool::Job> out_job[3];
+    auto deliver = [&](int i) -> int {  // chunk i's ids are in its pinned buffer: the pool copies them out while the next chunk goes in
+        td_tokenizer::PipeSlot& sl = t->pipe[i % 3];
+        const Pending& P = pend[(size_t)i];
+        HIP_TRY(t, hipEventSynchronize(sl.ev_tok));
+        if (P.ntok > 0 && !capacity_miss && first_err == TD_OK) out_job[i % 3] = t->pool_threads->copy(out_tokens + P.nbytes, sl.h_tok, (size_t)P.ntok * 4);
+        return TD_OK;
+    };
+    for (int i = 0; i < nchunks + 2; ++i) {
+        // slot i % 3 was chunk i - 3's: its ids left the pinned buffer (out_job), its kernels were done long before
+        if (out_job[i % 3]) { t->pool_threads->wait(out_job[i % 3]); out_job[i % 3].reset(); }
+        if (i < nchunks && (rc = submit(i))) return rc;
+        if (i - 1 >= 0 && i - 1 < nchunks && (rc = fetch(i - 1))) return rc;
+        if (i - 2 >= 0 && i - 2 < nchunks && (rc = deliver(i - 2))) return rc;
+    }
+    for (auto& j : out_job) if (j) t->pool_threads->wait(j);
+    out_offsets[n_docs] = tok_base;
+    if (n_tokens) *n_tokens = tok_base;
+    HIP_TRY(t, hipStreamSynchronize(t->s_k));
+    if (first_err != TD_OK) {
+        HIP_TRY(t, hipMemset(t->ctl.p, 0, sizeof(Ctl)));
+        return first_err;
+    }
+    if (capacity_miss) {
+        t->err = "output capacity too small: " + std::to_string(tok_base) + " tokens needed";
+        return TD_E_CAPACITY;
+    }
+    if (tok_base > 0 && !out_tokens) { t->err = "null out_tokens"; return TD_E_INVALID; }
+    return TD_OK;
+}
+
 int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
                         int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
     int rc;
     if ((rc = check_offsets(t, "doc_offsets", doc_offsets, n_docs, text))) return rc;
     const int64_t n = doc_offsets[n_docs];
+    if (n >= 2 * t->pipe_chunk_bytes && out_tokens)
+        return encode_batch_pipelined(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
     if ((rc = ensure(t, t->h2d_text, (size_t)n + 64))) return rc;
     if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;
     if ((rc = ensure(t, t->d_offsets, (size_t)(n_docs + 1) * 8))) return rc;
@@ -875,6 +1116,14 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     }
     if (what == TD_OPT_PROFILE) {
         t->profile = value != 0;
+        return TD_OK;
+    }
+    if (what == TD_OPT_PIPE_CHUNK_BYTES && value >= 4096) {
+        t->pipe_chunk_bytes = value;
+        return TD_OK;
+    }
+    if (what == TD_OPT_PIPE_THREADS && value >= 1 && value <= 256) {
+        t->pipe_threads = (int)value;
         return TD_OK;
     }
     return TD_E_INVALID;
