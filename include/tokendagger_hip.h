@@ -72,7 +72,8 @@ const char* td_last_error(const td_tokenizer* t);
  * out_offsets[n_docs+1] the per-document token offsets, *n_tokens the total.  If the capacity is
  * too small the call fails with TD_E_CAPACITY and *n_tokens holds the required size.
  * Copies text to the device, runs the kernels, copies ids back; synchronous.  Inputs of 64 MiB and more go through a
- * three-stage pipeline of pinned bounce buffers (host copy || H2D || kernels || D2H || host copy, TD_OPT_PIPE_*).
+ * three-stage pipeline of pinned bounce buffers (host copy || H2D || kernels || D2H || host copy, TD_OPT_PIPE_*);
+ * inputs of at most 4 KiB (and 1024 documents) take ONE kernel launch that reads and writes pinned host memory directly.
  */
 int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
                     int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens);
@@ -148,6 +149,7 @@ int64_t td_info(const td_tokenizer* t, int what);
                                     call's stream (td_profile_read_ex) */
 #define TD_OPT_PIPE_CHUNK_BYTES 3 /* td_encode_batch cuts inputs of at least two chunks into chunks of whole documents of about
                                     this many bytes (default 32 MiB) and overlaps host copies, PCIe transfers and kernels */
+#define TD_OPT_SMALL_PATH 5       /* 0: never take the one-launch path for inputs of at most 4 KiB (default 1: on) */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 8) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 

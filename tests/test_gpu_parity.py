@@ -373,3 +373,48 @@ def test_pipelined_host_batches_equal_the_plain_path():
     ok_t, ok_o = toy.encode_batch(*H.pack_docs(docs[:40] + docs[41:]))  # the handle is usable afterwards
     assert len(ok_o) == 81 and ok_o[-1] == len(ok_t)
     toy.close()
+
+
+def test_one_launch_path_for_small_inputs(golden):
+    """Inputs of at most 4 KiB take td_small_encode (one launch, pinned host buffers).  Every golden document that fits,
+    alone and in small batches with empty documents, against the compiled reference's ids; the same calls with the path
+    switched off give the same answer; pieces above 64 bytes fall back to the general path."""
+    from tokendagger_amd import capi
+    pat, mr, special = H.llama4()
+    tok = capi.HipTokenizer(pat, mr, special, device=0)
+    text, offs = golden["text"].tobytes(), golden["offsets"]
+    gold, go = golden["enc"], golden["enc_offsets"]
+    small = [d for d in range(len(offs) - 1) if offs[d + 1] - offs[d] <= 4096]
+    assert len(small) > 3000
+    for d in small:
+        doc = text[offs[d]:offs[d + 1]]
+        assert np.array_equal(tok.encode(doc), gold[go[d]:go[d + 1]]), golden["names"][d]
+        if d % 5 == 0:
+            assert np.array_equal(tok.encode(doc, mode=1), gold[go[d]:go[d + 1]]), golden["names"][d]
+    rng = random.Random(4)
+    O = H.port_tokenizer()
+    for _ in range(300):  # small batches: several documents, empties, total <= 4096 bytes
+        docs, tot = [], 0
+        while True:
+            d = rng.choice(small)
+            doc = b"" if rng.random() < 0.15 else text[offs[d]:offs[d + 1]]
+            if tot + len(doc) > 4096 or len(docs) > 40:
+                break
+            docs.append(doc); tot += len(doc)
+        if not docs:
+            continue
+        t, o = H.pack_docs(docs)
+        _check_batch(tok, O, t, o)
+    tok.set_option(capi.TD_OPT_SMALL_PATH, 0)
+    for d in small[::37]:
+        doc = text[offs[d]:offs[d + 1]]
+        assert np.array_equal(tok.encode(doc), gold[go[d]:go[d + 1]])
+    tok.set_option(capi.TD_OPT_SMALL_PATH, 1)
+    for doc in (b"x" + b" " * 300 + b"y", ("=" * 100 + "\n").encode(), ("的" * 200).encode("utf-8"), b"a" * 4096):
+        assert np.array_equal(tok.encode(doc), O.encode(doc))     # long pieces: handed back to the general path
+    toy = capi.HipTokenizer(pat, {b"a": 0, b"b": 1, b"ab": 2}, {}, device=0)
+    assert toy.encode(b"abba").tolist() == [2, 1, 0]
+    with pytest.raises(capi.TokenDaggerHipError):
+        toy.encode(b"abc")
+    assert toy.encode(b"ab").tolist() == [2]
+    tok.close(); toy.close()

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -176,6 +177,11 @@ struct td_tokenizer {
     int64_t pipe_chunk_bytes = 16ll << 20;
     int pipe_threads = 16;
     std::unique_ptr<CopyPool> pool_threads;
+    // one-launch path for inputs of at most 4 KiB: pinned host buffers the kernel reads and writes directly
+    void* small_in = nullptr;
+    void* small_out = nullptr;
+    unsigned long long small_seq = 0;
+    bool small_enabled = true;
 };
 
 namespace {
@@ -461,6 +467,8 @@ void td_destroy(td_tokenizer* t) {
             for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_off, sl.ev_tok}) if (e) (void)hipEventDestroy(e);
         }
         for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h}) if (st) (void)hipStreamDestroy(st);
+        if (t->small_in) (void)hipHostFree(t->small_in);
+        if (t->small_out) (void)hipHostFree(t->small_out);
         DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
@@ -658,11 +666,77 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
     return TD_OK;
 }
 
+// ---- td_encode_batch on tiny inputs: ONE launch, no hipMemcpy, no stream synchronisation ------------------------------
+constexpr int64_t SMALL_MAX_BYTES = 4096, SMALL_MAX_DOCS = 1024;
+constexpr size_t SMALL_IN_BYTES = (SMALL_MAX_DOCS + 2) * 8 + SMALL_MAX_BYTES + 256;
+constexpr size_t SMALL_OUT_BYTES = 64 + (SMALL_MAX_DOCS + 2) * 8 + SMALL_MAX_BYTES * 4 + 256;
+// returns TD_OK, a TD_E_* code, or -1: the kernel handed the call back (a piece above 64 bytes)
+int encode_batch_small(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
+                       int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
+    const int64_t n = doc_offsets[n_docs];
+    if (!t->small_in) {
+        HIP_TRY(t, hipHostMalloc(&t->small_in, SMALL_IN_BYTES, hipHostMallocDefault));
+        HIP_TRY(t, hipHostMalloc(&t->small_out, SMALL_OUT_BYTES, hipHostMallocDefault));
+        memset(t->small_out, 0, SMALL_OUT_BYTES);
+    }
+    int rc;
+    hipStream_t s = nullptr;
+    if ((rc = order_before(t, s))) return rc;
+    const size_t offs_bytes = (((size_t)(n_docs + 1) * 8) + 15) & ~(size_t)15;
+    uint8_t* in = (uint8_t*)t->small_in;
+    memcpy(in, doc_offsets, (size_t)(n_docs + 1) * 8);
+    memcpy(in + offs_bytes, text, (size_t)n);
+    uint8_t* out = (uint8_t*)t->small_out;
+    SmallArgs a;
+    a.Tp = t->dTp;
+    a.doc_offsets = (const int64_t*)in;
+    a.text = in + offs_bytes;
+    a.status = (SmallStatus*)out;
+    a.out_offsets = (int64_t*)(out + 64);
+    a.out_tokens = (int32_t*)(out + 64 + offs_bytes);
+    a.seq = ++t->small_seq;
+    a.n = (int)n;
+    a.n_docs = (int)n_docs;
+    a.use_fastpath = (mode == TD_MODE_ENCODE) || t->H.merge_closed;
+    HIP_TRY(t, launch_small_encode(a, s));
+    // the kernel releases its sequence number (system scope) after everything else it wrote: spin on it
+    volatile unsigned long long* seqp = &a.status->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == a.seq) break;
+        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            HIP_TRY(t, hipStreamSynchronize(s));  // (a launch failure surfaces here)
+            if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == a.seq) break;
+            t->err = "td_small_encode did not complete";
+            return TD_E_HIP;
+        }
+    }
+    const SmallStatus st = *a.status;
+    if (st.fallback) return -1;
+    if (st.err) {
+        t->err = st.err == TD_E_UNKNOWN_BYTE ? "No value found for piece at byte offset " + std::to_string(st.err_pos) + ": byte sequence is not in the vocabulary"
+                                             : "device error " + std::to_string(st.err);
+        return st.err;
+    }
+    memcpy(out_offsets, a.out_offsets, (size_t)(n_docs + 1) * 8);
+    if (n_tokens) *n_tokens = st.n_tokens;
+    if ((int64_t)st.n_tokens > out_capacity) { t->err = "output capacity too small: " + std::to_string(st.n_tokens) + " tokens needed"; return TD_E_CAPACITY; }
+    if (st.n_tokens) {
+        if (!out_tokens) { t->err = "null out_tokens"; return TD_E_INVALID; }
+        memcpy(out_tokens, a.out_tokens, (size_t)st.n_tokens * 4);
+    }
+    return TD_OK;
+}
+
 int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
                         int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
     int rc;
     if ((rc = check_offsets(t, "doc_offsets", doc_offsets, n_docs, text))) return rc;
     const int64_t n = doc_offsets[n_docs];
+    if (n > 0 && n <= SMALL_MAX_BYTES && n_docs <= SMALL_MAX_DOCS && t->small_enabled) {
+        rc = encode_batch_small(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
+        if (rc != -1) return rc;  // (-1: a piece above 64 bytes; the general path below handles it)
+    }
     if (n >= 2 * t->pipe_chunk_bytes && out_tokens)
         return encode_batch_pipelined(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
     if ((rc = ensure(t, t->h2d_text, (size_t)n + 64))) return rc;
@@ -836,30 +910,49 @@ namespace {
 struct SpecialIndex {
     struct Ent { const std::string* s; int32_t id; };
     bool first[256] = {};
-    std::vector<std::vector<Ent>> bucket;  // [65536] by (b0 << 8 | b1), longest first; 1-byte specials in `single`
-    std::vector<Ent> single[256];
+    std::vector<Ent> ents;       // sorted by (first byte, second byte or -1, longer first)
+    uint32_t lo[257] = {};       // ents[lo[b0] .. lo[b0 + 1]): the literals that start with byte b0
     size_t count = 0;
-    SpecialIndex() : bucket(65536) {}
+    static int second(const std::string& x) { return x.size() > 1 ? (uint8_t)x[1] : -1; }
     void add(const std::string* s, int32_t id) {
         if (s->empty()) return;
         ++count;
-        const uint8_t b0 = (uint8_t)(*s)[0];
-        first[b0] = true;
-        if (s->size() == 1) single[b0].push_back({s, id});
-        else bucket[((size_t)b0 << 8) | (uint8_t)(*s)[1]].push_back({s, id});
+        ents.push_back({s, id});
     }
-    void finish() {
-        for (auto& b : bucket)
-            std::sort(b.begin(), b.end(), [](const Ent& x, const Ent& y) { return x.s->size() > y.s->size(); });
+    void finish() {  // (cost proportional to the allowed set: nothing for an empty one)
+        std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) {
+            const uint8_t a0 = (uint8_t)(*x.s)[0], b0 = (uint8_t)(*y.s)[0];
+            if (a0 != b0) return a0 < b0;
+            const int a1 = second(*x.s), b1 = second(*y.s);
+            if (a1 != b1) return a1 < b1;
+            return x.s->size() > y.s->size();
+        });
+        uint32_t k = 0;
+        for (int b = 0; b < 256; ++b) {
+            lo[b] = k;
+            while (k < ents.size() && (uint8_t)(*ents[k].s)[0] == b) ++k;
+            first[b] = k > lo[b];
+        }
+        lo[256] = k;
     }
     // longest special starting at text[p] (p < hi), or nullptr
     const Ent* match(const uint8_t* text, int64_t p, int64_t hi) const {
         const uint8_t b0 = text[p];
         if (!first[b0]) return nullptr;
-        if (p + 1 < hi)
-            for (const Ent& e : bucket[((size_t)b0 << 8) | text[p + 1]])
-                if (p + (int64_t)e.s->size() <= hi && memcmp(text + p, e.s->data(), e.s->size()) == 0) return &e;
-        return single[b0].empty() ? nullptr : &single[b0][0];
+        const Ent* single = nullptr;
+        const Ent* e = ents.data() + lo[b0];
+        const Ent* end = ents.data() + lo[b0 + 1];
+        if (e < end && e->s->size() == 1) { single = e; ++e; }  // (second byte -1 sorts first)
+        if (p + 1 < hi) {
+            const int b1 = text[p + 1];
+            // first literal whose second byte is b1 (binary search over the literals of this first byte)
+            const Ent* a = e;
+            const Ent* z = end;
+            while (a < z) { const Ent* m = a + (z - a) / 2; if (second(*m->s) < b1) a = m + 1; else z = m; }
+            for (; a < end && second(*a->s) == b1; ++a)
+                if (p + (int64_t)a->s->size() <= hi && memcmp(text + p, a->s->data(), a->s->size()) == 0) return a;
+        }
+        return single;
     }
 };
 
@@ -917,6 +1010,10 @@ int encode_special_locked(td_tokenizer* t, const uint8_t* text, const int64_t* d
                           int64_t* last_seg_lo, int64_t* last_seg_hi) {
     int rc;
     if ((rc = check_offsets(t, "doc_offsets", doc_offsets, n_docs, text))) return rc;
+    if (n_allowed == 0) {  // nothing to cut out: the documents are the segments
+        if (last_seg_lo) { *last_seg_lo = n_docs ? doc_offsets[n_docs - 1] : 0; *last_seg_hi = doc_offsets[n_docs]; }
+        return encode_batch_locked(t, text, doc_offsets, n_docs, TD_MODE_ENCODE, out_tokens, out_capacity, out_offsets, n_tokens);
+    }
     SpecialIndex ix;
     if ((rc = build_special_index(t, allowed_bytes, allowed_offsets, allowed_ids, n_allowed, ix))) return rc;
     // 1. host: cut every document at the earliest occurrences of allowed special strings (tiktoken semantics; the
@@ -1021,7 +1118,12 @@ int32_t last_piece_token_len_host(td_tokenizer* t, const uint8_t* text, int64_t 
     };
     const Tables hv = t->H.view();
     HostAcc A{&hv, text, s_lo, s_hi, s_hi + 4};
-    int64_t p = s_lo, last = s_lo;
+    // the last piece starts at or behind the last provable sync point of the segment: walk back to it instead of scanning
+    // the whole segment (this runs on the host for every CoreBPE.encode call)
+    int64_t p = s_lo;
+    for (int64_t q = s_hi - 1; q > s_lo; --q)
+        if (is_sync(A.cf(q - 1), A.cf(q), hv.pat_flags)) { p = q; break; }
+    int64_t last = p;
     while (p < s_hi) { last = p; p = scan_piece(A, p, hv.pat_flags); }
     std::vector<int32_t> tmp;
     const uint32_t len = (uint32_t)(s_hi - last);
@@ -1120,6 +1222,10 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     }
     if (what == TD_OPT_PIPE_CHUNK_BYTES && value >= 4096) {
         t->pipe_chunk_bytes = value;
+        return TD_OK;
+    }
+    if (what == TD_OPT_SMALL_PATH) {
+        t->small_enabled = value != 0;
         return TD_OK;
     }
     if (what == TD_OPT_PIPE_THREADS && value >= 1 && value <= 256) {

@@ -74,6 +74,27 @@ struct DecodeArgs {
     long long* err_pos;
 };
 
+// One-launch path for inputs of at most 4 KiB (td_small_encode): everything the kernel reads and writes except the tables
+// lives in pinned host memory.
+struct SmallStatus {
+    unsigned long long seq;  // written last (system-scope release): the call's sequence number
+    long long err_pos;
+    int err, fallback;       // TD_E_* or 0; 1 = a piece above 64 bytes: rerun on the general path
+    unsigned int n_tokens;
+    unsigned int pad;
+};
+struct SmallArgs {
+    const Tables* Tp;
+    const uint8_t* text;         // [n] (pinned host memory)
+    const int64_t* doc_offsets;  // [n_docs + 1]
+    int32_t* out_tokens;         // [n]
+    int64_t* out_offsets;        // [n_docs + 1]
+    SmallStatus* status;
+    unsigned long long seq;
+    int n, n_docs, use_fastpath;
+};
+hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream);
+
 // All launches are asynchronous on `stream`; none of them synchronises or allocates.
 // ev (optional, TD_PROF_EVENTS events): ev[0] | td_split_tiles, td_split_slow | ev[1] | td_probe_tiles | ev[2] | td_merge_pieces |
 // ev[3] | td_long_pieces, td_scan_tiles, td_pack_tokens | ev[4]

@@ -1652,6 +1652,213 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
     }
 }
 
+// ------------------------------------------------------------------ td_small_encode ---------
+// The whole path in ONE launch for inputs of at most 4 KiB (a chat message, a line of code: the calls the reference's
+// tests/performance_benchmark.py:239-387 times): one workgroup reads the text and the document offsets straight out of a
+// pinned host buffer, classifies, finds the piece boundaries (every lane from the first provable sync point of its 16
+// bytes, scan_piece on the class bytes in LDS), looks the pieces up, merges the misses one lane per piece (mg_round), packs
+// and writes ids + offsets + status back into pinned host memory, and releases a sequence number the host spins on.
+// (The batch pipeline is thirteen launches: ~160 us for "Hello, world!", against microseconds on the reference's CPU path.)
+// A piece above 64 bytes makes the kernel hand the call back (fallback = 1) to the general path.
+constexpr int SM_MAXBYTES = K_TILE;
+struct SmallCfAcc {  // scanner accessor over the class bytes in LDS; positions >= n read as end of subject
+    using pos_t = int;
+    const uint8_t* cfs;
+    const uint8_t* txt;
+    int lim;
+    __device__ __forceinline__ uint32_t cf(int i) const { return cfs[i]; }
+    __device__ __forceinline__ uint32_t byte(int i) const { return txt[i]; }
+};
+__global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_txt[SM_MAXBYTES + 80];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cf[SM_MAXBYTES + 80];
+    __shared__ uint32_t s_doc[SM_MAXBYTES / 32 + 4];
+    __shared__ uint32_t s_start[SM_MAXBYTES / 32 + 4];
+    __shared__ uint16_t s_plist[SM_MAXBYTES + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tok[SM_MAXBYTES + 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[K_THREADS * MG_UNIT];
+    __shared__ __attribute__((aligned(16))) uint32_t s_ids[K_THREADS * MG_UNIT];
+    __shared__ uint16_t s_miss[SM_MAXBYTES / 2 + 8];
+    __shared__ uint32_t s_off[K_THREADS];
+    __shared__ uint16_t s_valid[K_THREADS];
+    __shared__ int32_t s_byteid[256];
+    __shared__ uint32_t s_wave[8];
+    __shared__ uint32_t s_nmiss, s_err, s_errpos, s_fallback;
+
+    const int tid = threadIdx.x;
+    const Tables T = uniform_tables(a.Tp);
+    const int n = a.n;
+    for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
+    // ---- text, document bits ----
+    for (int q = tid; q < (SM_MAXBYTES + 80) / 16; q += K_THREADS) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q * 16 + 16 <= n) v = reinterpret_cast<const uint4*>(a.text)[q];
+        else if (q * 16 < n)
+            for (int k = 0; k < 16 && q * 16 + k < n; ++k) reinterpret_cast<uint8_t*>(&v)[k] = a.text[q * 16 + k];
+        reinterpret_cast<uint4*>(s_txt)[q] = v;
+    }
+    for (int q = tid; q < SM_MAXBYTES / 32 + 4; q += K_THREADS) { s_doc[q] = 0; s_start[q] = 0; }
+    for (int q = tid; q < (SM_MAXBYTES + 64) / 4; q += K_THREADS) reinterpret_cast<uint4*>(s_tok)[q] = make_uint4(TOK_NONE, TOK_NONE, TOK_NONE, TOK_NONE);
+    if (tid == 0) { s_nmiss = 0; s_err = 0; s_errpos = 0; s_fallback = 0; }
+    __syncthreads();
+    for (int d = tid; d < a.n_docs; d += K_THREADS) {
+        const int64_t p = a.doc_offsets[d];
+        if (p >= 0 && p < n) atomicOr(&s_doc[p >> 5], 1u << (p & 31));
+    }
+    __syncthreads();
+    auto fail = [&](int code, int pos) { if (atomicCAS(&s_err, 0u, (uint32_t)code) == 0u) s_errpos = (uint32_t)pos; };
+    // ---- class + flags of every byte (positions >= n: end of subject) ----
+    {
+        LdsSrc src;
+        src.txt = s_txt; src.docw = s_doc; src.lo = 0; src.hi = n;
+        for (int i = tid; i < SM_MAXBYTES + 80; i += K_THREADS) {
+            uint32_t v = F_DOC;
+            if (i < n) {
+                v = classify_at(T, src, i);
+                if (src.doc(i)) v |= F_DOC;
+            }
+            s_cf[i] = (uint8_t)v;
+        }
+    }
+    __syncthreads();
+    // ---- piece boundaries: every lane from the first provable sync point of its 16 bytes ----
+    {
+        const SmallCfAcc A{s_cf, s_txt, n + 64};
+        const int c0 = tid * K_CHUNK, c1 = c0 + K_CHUNK;
+        int s = -1;
+        if (c0 < n) {
+            const int cend = c1 < n ? c1 : n;
+            for (int i = c0; i < cend; ++i)
+                if (is_sync(i > 0 ? s_cf[i - 1] : 0u, s_cf[i], T.pat_flags)) { s = i; break; }
+        }
+        for (int p = s; p >= 0 && p < n;) {
+            if (p >= c1 && is_sync(s_cf[p - 1], s_cf[p], T.pat_flags)) break;  // the lane owning p starts there
+            atomicOr(&s_start[p >> 5], 1u << (p & 31));
+            p = scan_piece(A, p, T.pat_flags);
+        }
+    }
+    __syncthreads();
+    // ---- dense piece list ----
+    uint32_t np_total;
+    {
+        const int c0 = tid * K_CHUNK;
+        uint32_t smask = (c0 < n) ? (s_start[c0 >> 5] >> (c0 & 31)) & 0xFFFFu : 0u;
+        if (c0 + K_CHUNK > n && c0 < n) smask &= (1u << (n - c0)) - 1u;
+        const uint32_t pbase = block_excl_scan(__popc(smask), s_wave, np_total);
+        uint32_t k = pbase;
+        while (smask) {
+            const int b = __ffs(smask) - 1;
+            smask &= smask - 1;
+            s_plist[k++] = (uint16_t)(c0 + b);
+        }
+        if (tid == 0) s_plist[np_total] = (uint16_t)n;
+    }
+    __syncthreads();
+    // ---- lookup: a hit writes its id at the piece's first byte, a miss goes on the list ----
+    for (uint32_t k = tid; k < np_total; k += K_THREADS) {
+        const int i = s_plist[k];
+        const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
+        const uint8_t* pb = s_txt + i;
+        if (len == 1) {
+            const int32_t id = s_byteid[pb[0]];
+            if (id >= T.pseudo_base) fail(TD_E_UNKNOWN_BYTE, i);
+            s_tok[i] = (uint32_t)id;
+            continue;
+        }
+        if (len > (uint32_t)K_MAXSHORT) { s_fallback = 1; continue; }
+        int32_t r = NO_RANK;
+        if (a.use_fastpath) {
+            auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
+            uint64_t key = 0;
+            if (len <= 8) for (uint32_t q = 0; q < len; ++q) key |= (uint64_t)pb[q] << (8 * q);
+            else key = hash_bytes(get, len);
+            r = piece_lookup(T, key, len, get);
+        }
+        if (r != NO_RANK) s_tok[i] = (uint32_t)r;
+        else s_miss[atomicAdd(&s_nmiss, 1u)] = (uint16_t)k;
+    }
+    __syncthreads();
+    // ---- merge the misses, one lane per piece: pieces of at most 16 bytes 256 at a time, longer ones 64 at a time ----
+    {
+        const uint32_t nmiss = s_nmiss;
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t u = pass == 0 ? 1u : 4u;
+            const uint32_t per = (uint32_t)K_THREADS / u;
+            // (both passes walk the whole list and take the pieces of their class: the list is short)
+            uint32_t done = 0;
+            while (done < nmiss) {
+                // this batch: the next `per` list entries of the class
+                MergeState st;
+                st.alive = 0; st.t = (uint32_t)tid; st.len = 0;
+                int pos = 0;
+                uint32_t taken = 0, scan = done;
+                // every lane walks the list the same way (uniform), lane (taken * u) takes the piece
+                while (scan < nmiss && taken < per) {
+                    const uint32_t k = s_miss[scan];
+                    const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)s_plist[k];
+                    if ((len <= 16u) == (pass == 0)) {
+                        if ((uint32_t)tid == taken * u) { st.len = len; pos = s_plist[k]; }
+                        ++taken;
+                    }
+                    ++scan;
+                }
+                done = scan;
+                if (st.len) {
+                    st.alive = st.len >= 64u ? ~0ull : ((1ull << st.len) - 1ull);
+                    for (uint32_t j = 0; j < st.len; ++j) mg_put(T, s_byteid, s_keys, s_ids, st, j, s_txt[pos + j], s_txt[pos + j + 1]);
+                    mg_pad(s_keys, st);
+                }
+                for (;;) {
+                    const bool more = mg_round_t<uint64_t>(T, s_keys, s_ids, st);
+                    if (!__any(more)) break;
+                }
+                if (st.len) {
+                    for (uint64_t al = st.alive; al; al &= al - 1ull) {
+                        const uint32_t j = (uint32_t)td_ctz64(al);
+                        const uint32_t id = s_ids[mg_slot(st.t, j)];
+                        if ((int32_t)id >= T.pseudo_base) fail(TD_E_UNKNOWN_BYTE, pos + (int)j);
+                        s_tok[pos + j] = id;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pack: ids in byte order, document offsets ----
+    {
+        const int c0 = tid * K_CHUNK;
+        uint32_t vmask = 0;
+#pragma unroll
+        for (int k = 0; k < K_CHUNK; ++k) vmask |= (s_tok[c0 + k] != TOK_NONE) ? (1u << k) : 0u;
+        uint32_t total;
+        const uint32_t off = block_excl_scan(__popc(vmask), s_wave, total);
+        s_off[tid] = off;
+        s_valid[tid] = (uint16_t)vmask;
+        uint32_t o = off;
+        if (!s_fallback && !s_err)
+            for (uint32_t m = vmask; m; m &= m - 1) a.out_tokens[o++] = (int32_t)s_tok[c0 + __ffs(m) - 1];
+        __syncthreads();
+        for (int d = tid; d <= a.n_docs; d += K_THREADS) {
+            const int64_t p = a.doc_offsets[d];
+            a.out_offsets[d] = p >= n ? (int64_t)total : (int64_t)(s_off[p >> 4] + __popc((uint32_t)s_valid[p >> 4] & ((1u << (p & 15)) - 1u)));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            a.status->n_tokens = total;
+            a.status->err = (int)s_err;
+            a.status->err_pos = (long long)s_errpos;
+            a.status->fallback = (int)s_fallback;
+            __hip_atomic_store(&a.status->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(td_small_encode, dim3(1), dim3(K_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ launches ----------------
 static int g_blocks_split = 0, g_blocks_encode = 0, g_blocks_merge = 0;
 static int resident_blocks(const void* fn, int fallback_per_cu) {
