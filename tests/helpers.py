@@ -212,7 +212,7 @@ class Twin:
     def split_tiled(self, data: bytes, offs=None):
         offs = self._offs(data, offs)
         out = np.zeros(max(len(data), 1), dtype=np.uint8)
-        stats = np.zeros(4, dtype=np.int64)
+        stats = np.zeros(8, dtype=np.int64)
         rc = self._lib.twin_split_tiled(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, out.ctypes.data,
                                         None, stats.ctypes.data)
         assert rc == 0, rc
@@ -231,6 +231,23 @@ class Twin:
         bad = self._lib.twin_bits_check(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, ctypes.byref(un),
                                         ctypes.byref(ck))
         return int(bad), un.value, ck.value
+
+    def fast_stats(self) -> tuple[int, int]:
+        """-> (pieces seen, pieces the branch-free scanner answered) since the last call"""
+        t = ctypes.c_int64(0); h = ctypes.c_int64(0)
+        self._lib.twin_fast_stats(ctypes.byref(t), ctypes.byref(h))
+        return t.value, h.value
+
+    def word_rules_check(self, data: bytes, offs=None) -> tuple[int, list[int]]:
+        """-> (mismatches, [heads, unresolved heads, pieces, pieces in unresolved regions]) of the whole-word boundary
+        rules (split_unresolved_heads) against the byte scanner"""
+        offs = self._offs(data, offs)
+        st = (ctypes.c_int64 * 4)()
+        self._lib.twin_word_rules_check.restype = ctypes.c_int64
+        self._lib.twin_word_rules_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
+                                                    ctypes.c_int64, ctypes.c_void_p]
+        bad = self._lib.twin_word_rules_check(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, st)
+        return int(bad), list(st)
 
     def arrmask_check(self, data: bytes, offs=None) -> tuple[int, int]:
         """-> (mismatches, checked) of the array-mask scanner (no run-length limit) against the byte scanner"""

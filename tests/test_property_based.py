@@ -38,6 +38,8 @@ def _check(tw, O, docs):
     if len(text):
         bad, _, _ = tw.bits_check(text, offs)
         assert bad == 0, docs
+        bad, _ = tw.word_rules_check(text, offs)  # a head the whole-word rules resolve is exactly one piece
+        assert bad == 0, docs
 
 
 @settings(**_CFG)

@@ -61,6 +61,8 @@ def test_twin_scanners_match_golden(golden, tekken_golden):
     assert bad == 0 and n > 100000
     bad, unres, checked = tw.bits_check(text, offs)  # bit-parallel scanner == byte scanner
     assert bad == 0 and checked > 100000
+    bad, st = tw.word_rules_check(text, offs)         # whole-word boundary rules never resolve a head wrongly
+    assert bad == 0 and st[0] > 1000
     bad, checked = tw.arrmask_check(text, offs)
     assert bad == 0 and checked > 100000
     toks, toffs = tw.encode_batch(text, offs)

@@ -57,6 +57,8 @@ def test_tiled_speculative_scan_on_whole_golden_batch(golden):
     got, stats = tw.split_tiled(text, offs)
     assert np.array_equal(got, exp)
     assert stats[0] > 0, "golden set contains pieces that leave their tile window"
+    assert stats[1] > 0, "... and tiles that lie inside a piece longer than the left halo"
+    assert 0 < stats[4] < stats[3] // 2, "the whole-word rules resolve most synchronisation points"
 
 
 def test_sync_points_are_always_piece_starts(golden):
@@ -69,6 +71,23 @@ def test_sync_points_are_always_piece_starts(golden):
         s = (H.fuzz_string(rng, 30) if i % 2 else H.random_unicode_string(rng, 60)).encode("utf-8")
         bad, _ = tw.sync_violations(s)
         assert bad == 0, repr(s)
+
+
+def test_whole_word_rules_only_resolve_single_pieces(golden):
+    """split_unresolved_heads (carry arithmetic on 64-byte mask windows): a head it calls resolved is one piece that ends
+    at the next synchronisation point; on running text it resolves most heads."""
+    text, offs = golden["text"].tobytes(), golden["offsets"]
+    for tw in (H.twin_llama4(), H.twin_tekken()):
+        bad, st = tw.word_rules_check(text, offs)
+        assert bad == 0 and st[0] > 100000 and st[1] < st[0] // 2
+        rng = random.Random(11)
+        for i in range(6000):
+            s = (H.fuzz_string(rng, 90) if i % 2 else H.random_unicode_string(rng, 120)).encode("utf-8")
+            if i % 7 == 0:
+                s = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 200)))  # not UTF-8
+            if s:
+                bad, _ = tw.word_rules_check(s)
+                assert bad == 0, repr(s)
 
 
 def test_twin_encode_matches_golden(golden):

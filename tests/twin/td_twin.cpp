@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY: CPU "twin" of the device algorithm.
 //
 // Compiles the SAME header code the kernels use (tokendagger_amd/csrc/td_common.h: classify_at,
-// is_sync, scan_piece, scan_lane, piece/pair table probes) plus the host table builder with the
+// is_sync, scan_piece, split_unresolved_heads, scan_chain, piece/pair table probes) plus the host table builder with the
 // host compiler and runs it lane by lane / tile by tile on the CPU, so that the not-gpu test-suite
 // can check the product's host logic (tables, scanner, sync-point speculation, tile ownership)
 // against the oracle without a GPU.  It is NOT reachable from the product: nothing under
@@ -72,7 +72,11 @@ void classify_all(const Tables& T, const uint8_t* text, int64_t n, const int64_t
 
 }  // namespace
 
+static int64_t g_fast_total = 0, g_fast_hit = 0;
+
 extern "C" {
+
+void twin_fast_stats(int64_t* total, int64_t* hit) { *total = g_fast_total; *hit = g_fast_hit; g_fast_total = g_fast_hit = 0; }
 
 void* twin_create(const char* pat, int64_t n_vocab, const uint8_t* bytes, const int64_t* offs, const int32_t* ranks,
                   int64_t n_special, const uint8_t* sbytes, const int64_t* soffs, const int32_t* sranks, int* rc_out) {
@@ -127,9 +131,9 @@ int twin_split_serial(void* h, const uint8_t* text, int64_t n, const int64_t* of
     return 0;
 }
 
-// piece starts found the way td_encode_tiles finds them: tile windows, one scan_lane per lane.
-// stats[0] = pieces that left their window (ext), stats[1] = lanes that used the HBM slow path for
-// the back-search, stats[2] = START marks outside [tile_lo, lim).
+// piece starts found the way td_split_tiles finds them: tile windows, whole-word rules, one scan_chain per open head.
+// stats[0] = pieces that left their window (ext), stats[1] = tiles without a sync point in the left halo,
+// stats[3] = synchronisation points, stats[4] = those the whole-word rules left open.
 int twin_split_tiled(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, uint8_t* flags,
                      int64_t* ext_ends /* [n] or NULL: global end for ext pieces, else 0 */, int64_t* stats) {
     Twin* t = (Twin*)h;
@@ -154,9 +158,50 @@ int twin_split_tiled(void* h, const uint8_t* text, int64_t n, const int64_t* off
         // differ from the whole-text classification, which is why the scanner is limited to < K_LIM
         // and the back-search to >= 4.
         WAcc w{wcls.data(), wtxt.data(), K_LIM, -1, 0};
-        // lanes run sequentially here; they only communicate through F_START marks, which no lane reads
-        // for its decisions (is_sync / scan_piece ignore F_START), so the order does not matter.
-        for (int tid = 0; tid < K_THREADS; ++tid) scan_lane(w, g, tid, tile_hi, wg0, T.pat_flags);
+        // the kernel's phase 2: (a) whole-word rules per 32-byte stride on 64-bit mask windows, START = the sync points;
+        // (b) chains from the unresolved heads, the last sync point before the tile and the tile's last head.  Chains only
+        // communicate through F_START marks, which no chain reads for its decisions, so the order does not matter.
+        std::vector<int> heads;
+        int last_head = -1;
+        for (int b0 = K_HL; b0 < tile_hi; b0 += 32) {
+            BitWin bw;
+            for (int k = 0; k < MK_COUNT; ++k) bw.m[k] = 0;
+            for (int i = 0; i < 64; ++i) {
+                const int q = b0 + i;
+                if (q >= K_WIN) break;  // (zero word behind the window)
+                const uint32_t bits = mask_bits_of(w.cf(q - 1), w.cf(q), T.pat_flags);
+                for (int k = 0; k < MK_COUNT; ++k) bw.m[k] |= (uint64_t)((bits >> k) & 1u) << i;
+            }
+            uint32_t sy = (uint32_t)bw.m[MK_SYNC];
+            if (tile_hi - b0 < 32) sy &= (1u << (tile_hi - b0)) - 1u;
+            const uint32_t un = (uint32_t)split_unresolved_heads(bw, T.pat_flags) & sy;
+            for (int i = 0; i < 32; ++i) {
+                if ((sy >> i) & 1u) { w.mark(b0 + i); last_head = b0 + i; }
+                if ((un >> i) & 1u) heads.push_back(b0 + i);
+            }
+            if (stats) { stats[3] += __builtin_popcount(sy); stats[4] += __builtin_popcount(un); }
+        }
+        if (!is_sync(w.cf(K_HL - 1), w.cf(K_HL), T.pat_flags)) {
+            int s = -1;
+            for (int i = K_HL - 1; i >= 4; --i)
+                if (is_sync(w.cf(i - 1), w.cf(i), T.pat_flags)) { s = i; break; }
+            if (s >= 0) heads.push_back(s);
+            else {  // flagged tile (inside a piece longer than the halo): what the td_split_far_* kernels do
+                if (stats) stats[1]++;
+                int64_t gs = 0;
+                for (int64_t gi = wg0 + 3; gi > 0; --gi)
+                    if (is_sync(g.cf(gi - 1), g.cf(gi), T.pat_flags)) { gs = gi; break; }
+                int64_t p = gs;
+                while (p < tile_g0) p = g.scan(p);
+                // piece by piece up to the first synchronisation point of the tile (the fast kernel's heads take over)
+                if (p - wg0 < (int64_t)tile_hi && !is_sync(g.cf(p - 1), g.cf(p), T.pat_flags)) {
+                    w.mark((int)(p - wg0));
+                    heads.push_back((int)(p - wg0));
+                }
+            }
+        }
+        if (last_head >= 0) heads.push_back(last_head);
+        for (int hd : heads) scan_chain(w, g, hd, tile_hi, wg0, T.pat_flags);
         for (int i = K_HL; i < tile_hi; ++i)
             if (wcls[i] & F_START) flags[wg0 + i] = 1;
         if (w.ext_start >= 0) {
@@ -334,6 +379,12 @@ int64_t twin_bits_check(void* h, const uint8_t* text, int64_t n, const int64_t* 
                 auto b32 = [&](int i) { return g.byte(p + i); };
                 const int r32 = scan_piece_p(WinP32(v, 32), b32, T.pat_flags);
                 if (r32 >= 0 && p + r32 != e) ++bad;
+                // the branch-free form of the common alternatives: whenever it answers, it answers the same
+                for (int av : {32, 24, 9}) {
+                    const int f32 = scan_piece_fast32(v, av, b32, T.pat_flags);
+                    if (f32 >= 0 && p + f32 != e) ++bad;
+                    if (av == 32) { ++g_fast_total; g_fast_hit += f32 >= 0; }
+                }
             }
             const int r = scan_piece_bits(w, bytes, (int)(p - base), avail, T.pat_flags);
             ++checked;
@@ -375,6 +426,46 @@ int64_t twin_arrmask_check(void* h, const uint8_t* text, int64_t n, const int64_
         p = e;
     }
     if (n_checked) *n_checked = checked;
+    return bad;
+}
+
+// split_unresolved_heads (the whole-word boundary rules) on 64-byte windows at every multiple of 32: a head the rules
+// call resolved must be a piece whose end is the next synchronisation point.  stats: [0] heads, [1] unresolved heads,
+// [2] pieces, [3] pieces inside unresolved regions (what the piece-by-piece matcher still has to do).
+int64_t twin_word_rules_check(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, int64_t* stats) {
+    Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
+    std::vector<uint8_t> cls;
+    classify_all(t->H.view(), text, n, offs, n_docs, cls);
+    GAcc g{cls.data(), text, n, n + 4, T.pat_flags};
+    const int64_t m = n + 96;
+    std::vector<uint16_t> bits((size_t)m);
+    for (int64_t i = 0; i < m; ++i) bits[(size_t)i] = (uint16_t)mask_bits_of(i > 0 ? g.cf(i - 1) : 0u, g.cf(i), T.pat_flags);
+    std::vector<uint8_t> start((size_t)n + 1, 0);
+    for (int64_t p = 0; p < n;) { start[(size_t)p] = 1; p = scan_piece(g, p, T.pat_flags); }
+    start[(size_t)n] = 1;
+    int64_t bad = 0, heads = 0, unres = 0, pieces = 0, upieces = 0;
+    for (int64_t base = 0; base < n; base += 32) {
+        BitWin w;
+        for (int k = 0; k < MK_COUNT; ++k) w.m[k] = 0;
+        for (int i = 0; i < 64; ++i)
+            for (int k = 0; k < MK_COUNT; ++k) w.m[k] |= (uint64_t)((bits[(size_t)(base + i)] >> k) & 1u) << i;
+        const uint64_t un = split_unresolved_heads(w, T.pat_flags);
+        if (un & ~w.m[MK_SYNC]) ++bad;
+        for (int i = 0; i < 32 && base + i < n; ++i) {
+            if (!((w.m[MK_SYNC] >> i) & 1ull)) continue;
+            const int64_t hd = base + i;
+            if (!start[(size_t)hd]) { ++bad; continue; }  // a synchronisation point is a piece start
+            int64_t nx = hd + 1;
+            while (nx < n && !((bits[(size_t)nx] >> MK_SYNC) & 1u)) ++nx;
+            int64_t np = 0;
+            for (int64_t q = hd; q < nx; ++q) np += start[(size_t)q];
+            ++heads; pieces += np;
+            if ((un >> i) & 1ull) { ++unres; upieces += np; }
+            else if (np != 1) ++bad;
+        }
+    }
+    if (stats) { stats[0] = heads; stats[1] = unres; stats[2] = pieces; stats[3] = upieces; }
     return bad;
 }
 

@@ -633,6 +633,138 @@ struct WinP32 {
     }
 };
 
+// The common pieces of the o200k / Llama-4 and tekken patterns WITHOUT divergent control flow: every alternative is a few
+// lines of mask arithmetic on the 32-bit view (bit 0 = the piece start), the result is selected at the end.  Returns the
+// piece end, or -1 for everything it does not cover (runs that reach `avail`, a first character that is both a prefix and a
+// letter class, multi-byte digits, the other patterns): the caller then runs scan_piece_p, which is the definition.  In a
+// wavefront every lane sits in a different alternative, so the branchy matcher costs the SUM of all paths per piece.
+// `b1`, `b2`: text bytes at the two positions behind a candidate apostrophe are fetched by `bytes(i)` only there.
+template <class B>
+TD_HD int scan_piece_fast32(const BitWin32& v, int avail, const B& bytes, uint32_t pv) {
+    if (pv & (PV_GPT2 | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS | PV_WS_EOS_FIRST)) return -1;
+    const uint32_t U = v.m[MK_U], W = v.m[MK_W], X = v.m[MK_X], S = v.m[MK_S], N = v.m[MK_N], CR = v.m[MK_CR], TR = v.m[MK_TR];
+    const uint32_t C = v.m[MK_C], A = v.m[MK_A], SP = v.m[MK_SP];
+    const uint32_t E = v.m[MK_D] & ~1u;                    // end of subject behind the start
+    const uint32_t lim = avail >= 32 ? 0u : ~0u << avail;  // unknown positions
+    const uint32_t Ue = U & ~E, We = W & ~E, Xe = X & ~E, Se = S & ~E, TRe = TR & ~E;
+    const int p1 = 1 + td_ctz32(~(C >> 1));               // end of the first character
+    const bool u0 = U & 1u, w0 = W & 1u, x0 = X & 1u, s0 = S & 1u, n0 = N & 1u, cr0 = CR & 1u;
+    bool bad = p1 >= avail || p1 > 4;
+    const int p1c = p1 > 31 ? 31 : p1;
+    // ---- letters: [prefix] U* W+ | [prefix] U+ W*, then the contraction ----
+    const bool l0 = u0 || w0;
+    const bool l1 = (x0 || s0) && !((E >> p1c) & 1u) && (((U | W) >> p1c) & 1u);
+    const bool letters = !cr0 && !n0 && (l0 || l1);
+    bad = bad || (letters && l0 && l1);
+    const int st = l1 ? p1c : 0;
+    const int q = st + td_ctz32(~(Ue >> st));             // end of the U run (bits shifted in from the top are 0: a run never passes 32)
+    const int qc = q > 31 ? 31 : q;
+    const bool wf = ((We >> qc) & 1u) && q < 32;
+    const int ew = wf ? qc + td_ctz32(~(We >> qc)) : q;
+    const uint32_t uw = U & W & ((qc == 0 ? 0u : (~0u >> (32 - qc)))) & (~0u << st);  // letters of both classes in [st, q)
+    const int e1 = wf ? ew : (uw ? 32 - (int)__builtin_clz(uw) : 0);
+    const int el = e1 ? e1 : (q > st ? ew : 0);
+    int e_let = el;
+    if (!(pv & PV_NO_CONTRACTION)) {
+        // (?i:'s|'t|'re|'ve|'m|'ll|'d)? behind the letters
+        const int ec = el > 29 ? 29 : el;
+        const bool apo = ((A >> ec) & 1u) && !((v.m[MK_D] >> ec) & 1u) && !((v.m[MK_D] >> (ec + 1)) & 1u);
+        if (letters && el > 0 && apo) {
+            if (el + 3 > avail) bad = true;
+            else {
+                const uint32_t b1 = bytes(el + 1), b2 = bytes(el + 2);
+                const bool d2 = (v.m[MK_D] >> (ec + 2)) & 1u;
+                const uint32_t c1 = b1 | 0x20u, c2 = b2 | 0x20u;
+                if (b1 < 0x80u && (c1 == 's' || c1 == 't' || c1 == 'm' || c1 == 'd')) e_let = el + 2;
+                else if (b1 < 0x80u && !d2 && b2 < 0x80u && ((c1 == 'r' && c2 == 'e') || (c1 == 'v' && c2 == 'e') || (c1 == 'l' && c2 == 'l'))) e_let = el + 3;
+                else if (b1 == 0xC5u && !d2 && b2 == 0xBFu) e_let = el + 3;
+            }
+        }
+    }
+    bad = bad || (letters && (el == 0 || q >= avail || ew >= avail || el + 3 > avail));
+    // ---- \p{N}{1,3} (tekken: one digit); ASCII digits only ----
+    const int nmax = (pv & PV_SINGLE_DIGIT) ? 1 : 3;
+    const int nrun = td_ctz32(~(N & ~E) | (1u << nmax));   // consecutive digits from the start, at most nmax
+    const int e_num = nrun < 1 ? 1 : nrun;
+    bad = bad || (n0 && ((C & 0xEu) || e_num + 1 > avail));
+    // ----  ?[^\s\p{L}\p{N}]+[\r\n/]* ----
+    const bool psp = (SP & 1u) && ((X >> 1) & 1u) && !((E >> 1) & 1u);
+    const bool punct = psp || x0;
+    const int pst = psp ? 1 : 0;
+    const int px = pst + td_ctz32(~(Xe >> pst));
+    const int pxc = px > 31 ? 31 : px;
+    const int e_p = px >= 32 ? 32 : pxc + td_ctz32(~(TRe >> pxc));
+    bad = bad || (!letters && !n0 && punct && (px >= avail || e_p >= avail));
+    // ---- \s*[\r\n]+ | \s+(?!\S) | \s+ ----
+    const int sq = td_ctz32(~Se);
+    const uint32_t below = sq >= 32 ? ~0u : ((1u << sq) - 1u);
+    const uint32_t crs = CR & below;
+    const uint32_t leads = ~C & below & ~1u;              // character starts inside the run, behind the first
+    const int e_s = crs ? 32 - (int)__builtin_clz(crs)
+                        : (sq < 32 && ((E >> sq) & 1u)) ? sq
+                        : leads ? 31 - (int)__builtin_clz(leads) : sq;
+    bad = bad || (!letters && !n0 && !punct && s0 && sq >= avail);
+    (void)lim;
+    const int e = letters ? e_let : n0 ? e_num : punct ? e_p : s0 ? e_s : p1;
+    return (bad || e <= 0 || e > avail) ? -1 : e;
+}
+
+// ------------------------------------------------------------------ whole-word boundary rules ----
+// Most regions between two consecutive synchronisation points ARE one piece (" word", ",", "2024"[:3], ".\n\n").  That can
+// be proven for all heads of a 64-byte mask window at once with carry arithmetic: adding a start bit to a class mask runs
+// through the run of ones it starts and lands on the first byte behind it (td_land).  A head is RESOLVED when the piece
+// the pattern's alternatives give it lands exactly on the next synchronisation point; only the other heads (and what
+// follows them up to the next synchronisation point) need the piece-by-piece matcher.  Every rule errs to "unresolved":
+//   letters   [prefix char] pure-upper* lower-class+ | pure-upper+     (greedy U* W+ / U+ W* have this extent, see scan_letters)
+//   digits    a run of at most 3 bytes (tekken: 1)
+//   other     [space] non-letter punctuation+ [\r\n/]*
+//   space     whitespace ending in \r or \n, or one whitespace byte
+// Heads at document starts are left to the matcher (their masks are cut at F_DOC so that no run crosses a document).
+TD_HD uint64_t td_land(uint64_t M, uint64_t A) { return ((M + (A & M)) & ~M) | (A & ~M); }
+TD_HD uint64_t td_brev64(uint64_t x) {
+#if defined(__clang__)
+    return __builtin_bitreverse64(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+#endif
+}
+constexpr uint32_t PV_WORD_RULES_OK = PV_NO_CONTRACTION | PV_SINGLE_DIGIT;  // patterns the rules below are written for
+// -> the heads (MK_SYNC bits) of the window whose region is NOT proven to be exactly one piece.  A region that is not
+// closed by a synchronisation point inside the window is unresolved.
+TD_HD uint64_t split_unresolved_heads(const BitWin& w, uint32_t pv) {
+    const uint64_t SY = w.m[MK_SYNC];
+    if (pv & ~PV_WORD_RULES_OK) return SY;
+    const uint64_t nD = ~w.m[MK_D];
+    const uint64_t U = w.m[MK_U] & nD, W = w.m[MK_W] & nD, X = w.m[MK_X] & nD, S = w.m[MK_S] & nD, N = w.m[MK_N] & nD;
+    const uint64_t CR = w.m[MK_CR] & nD, TR = w.m[MK_TR] & nD, C = w.m[MK_C] & nD, SP = w.m[MK_SP] & nD;
+    const uint64_t H = SY & nD;
+    const uint64_t L = U | W, Up = U & ~W, Xn = X & ~L;
+    // letters
+    const uint64_t pfx = H & (X | S) & ~CR & ~L;
+    const uint64_t p1 = td_land(C, pfx << 1);  // end of the prefix character
+    const uint64_t a1 = (H & L) | (p1 & L);
+    uint64_t good = td_land(W, td_land(Up, a1));
+    // digits
+    const uint64_t hn = H & N;
+    const uint64_t near = (pv & PV_SINGLE_DIGIT) ? (hn << 1) : ((hn << 1) | (hn << 2) | (hn << 3));
+    good |= td_land(N, hn) & near;
+    // other
+    const uint64_t b1 = (H & Xn) | ((H & SP & (Xn >> 1)) << 1);
+    good |= td_land(TR, td_land(Xn, b1));
+    // whitespace
+    const uint64_t hs = H & S;
+    good |= td_land(S, hs) & ((CR << 1) | (hs << 1));
+    // regions whose end carries no landing: back to their heads (the same carry trick on the reversed window; the bit
+    // shifted in closes the last region, whose end lies outside)
+    const uint64_t bad_end = SY & ~good;
+    const uint64_t zr = td_brev64(~SY);
+    const uint64_t start = (td_brev64(bad_end) << 1) | 1ull;
+    return td_brev64(td_land(zr, start));
+}
+
 // Provider over a word-major mask array (word i>>6 of mask k at arr[(i>>6)*MK_COUNT + k]): no limit on run
 // length below `lim`.  Used for pieces / look-ahead that do not fit a 64-bit register window.
 struct ArrMaskP {
@@ -1006,9 +1138,8 @@ constexpr int K_TILE = K_THREADS * K_CHUNK;    // 4096 text bytes per tile
 #endif
 constexpr int K_HL = TD_K_HL;                  // left halo (sync-point back-search)
 constexpr int K_HR = 192;                      // right halo (piece overrun / look-ahead)
-// The pre-tokenizer (td_split_tiles / td_split_slow, and the CPU twin's scan_lane) has its own geometry: a lane owns
-// KS_CHUNK = 32 bytes.  Its scan loop runs as long as the busiest lane of the wavefront (pieces per chunk + 1); with
-// 16-byte chunks that was 5.8 wavefront-iterations per KiB of English for 3.3 pieces per lane, with 32 it is 4.7.
+// The pre-tokenizer (td_split_tiles and the CPU twin's tile loop) has its own geometry: a lane applies the whole-word
+// rules to a stride of KS_CHUNK = 32 bytes (one 32-bit word of every class mask, + 32 bytes of look-ahead).
 #ifndef TD_KS_CHUNK
 #define TD_KS_CHUNK 32
 #endif
@@ -1020,51 +1151,31 @@ constexpr int K_MAXSHORT = 64;                 // pieces up to this many bytes m
 constexpr int K_STAGE = K_TILE + K_MAXSHORT;   // staging slots per tile: a tile owns the tokens of the pieces that START in it,
                                                // and its last piece may end up to K_MAXSHORT - 1 bytes into the next tile
 
-// One lane's share of the boundary scan of a tile (phase 2 of td_encode_tiles; the CPU twin runs the
-// same code lane by lane).  Window coordinates: index i <-> global byte wg0 + i; the tile owns
-// [K_HL, tile_hi).  W: window accessor (pos_t = int; cf, byte, lim) plus mark(i) (set F_START) and
-// set_ext(i, global_end) (the one piece that leaves the window).  G: accessor over the whole text in
-// HBM (pos_t = int64_t; cf, byte, lim, scan(pos)) for what the window cannot answer.
-//   lane 0 starts at the last provable sync point at or before the tile start (left halo, else HBM);
-//   lane t > 0 starts at the first provable sync point inside its chunk, if any;
-//   every lane scans piece by piece until it lands on a provable sync point at/after its chunk end
-//   (the lane owning that chunk started there) or leaves the tile.
+// One head's share of the boundary scan of a tile (phase 2 (b) of td_split_tiles; the CPU twin runs the same rules head
+// by head).  Window coordinates: index i <-> global byte wg0 + i; the tile owns [K_HL, tile_hi).  W: window accessor
+// (pos_t = int; cf, byte, lim) plus mark(i) (set F_START) and set_ext(i, global_end) (the one piece that leaves the
+// window).  G: accessor over the whole text in HBM (pos_t = int64_t; cf, byte, lim, scan(pos)) for what the window
+// cannot answer (on the device: the td_split_far_* kernels).
+//   heads = the synchronisation points of the tile the whole-word rules (split_unresolved_heads) do not resolve,
+//           the last synchronisation point before the tile start (its pieces lead into the tile) and the tile's last head
+//           (its pieces delimit the tile's last piece);
+//   a head's pieces are matched one after the other until a piece ends on a synchronisation point or leaves the tile.
 template <class W, class G>
-TD_HD void scan_lane(W& w, const G& g, int tid, int tile_hi, int64_t wg0, uint32_t pv = 0) {
-    const int c0 = K_HL + tid * KS_CHUNK, c1 = c0 + KS_CHUNK;
-    int s = -1;
-    if (tid == 0) {
-        for (int i = c0; i >= 4; --i)
-            if (is_sync(w.cf(i - 1), w.cf(i), pv)) { s = i; break; }
-        if (s < 0) {  // no sync point in the left halo: walk back through HBM (inside a giant piece)
-            int64_t gs = 0;
-            for (int64_t gi = wg0 + 3; gi > 0; --gi)
-                if (is_sync(g.cf(gi - 1), g.cf(gi), pv)) { gs = gi; break; }
-            int64_t p = gs;
-            const int64_t tile_g0 = wg0 + K_HL;
-            while (p < tile_g0) p = g.scan(p);
-            s = (p - wg0 < (int64_t)tile_hi) ? (int)(p - wg0) : -1;
-        }
-    } else if (c0 < tile_hi) {
-        const int cend = c1 < tile_hi ? c1 : tile_hi;
-        for (int i = c0; i < cend; ++i)
-            if (is_sync(w.cf(i - 1), w.cf(i), pv)) { s = i; break; }
-    }
-    if (s < 0) return;
-    int p = s;
+TD_HD void scan_chain(W& w, const G& g, int head, int tile_hi, int64_t wg0, uint32_t pv = 0) {
+    int p = head;  // a piece start; marked by the caller when it lies in the tile
     for (;;) {
-        if (p >= tile_hi) { w.mark(p); break; }                       // delimits the last owned piece
-        if (p >= c1 && is_sync(w.cf(p - 1), w.cf(p), pv)) break;           // the lane owning p starts there
-        if (p >= K_HL) w.mark(p);
         int e = scan_piece(w, p, pv);
         if (e < 0) {
             const int64_t ge = g.scan(wg0 + p);
-            if (ge - wg0 > (int64_t)K_LIM) {                           // piece leaves the window: one per tile at most
+            if (ge - wg0 > (int64_t)K_LIM) {  // piece leaves the window: one per tile at most
                 if (p >= K_HL) w.set_ext(p, ge);
-                break;
+                return;
             }
             e = (int)(ge - wg0);
         }
+        if (e >= tile_hi) { w.mark(e); return; }  // delimits the last owned piece
+        if (is_sync(w.cf(e - 1), w.cf(e), pv)) return;
+        if (e >= K_HL) w.mark(e);
         p = e;
     }
 }

@@ -216,6 +216,19 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
     return make_uint4(0, 0, 0, 0);
 }
 
+// inclusive add-scan across the wavefront with DPP (no LDS round trips): rows of 16 lanes with row_shr 1/2/4/8 (lanes without
+// a source add 0), then row_bcast15 (rows 1 and 3 take the total of rows 0 and 2) and row_bcast31 (rows 2, 3 take rows 0-1)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int /*lane*/) {
+    constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118, ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR1, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR2, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR4, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR8, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_BCAST15, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_BCAST31, 0xC, 0xF, false);
+    return x;
+}
+
 // ------------------------------------------------------------------ td_split_tiles ----------
 // Pre-tokenizer: the regex split of the reference (CoreBPE::split_text, tiktoken.cpp:70-128) as a
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
@@ -225,6 +238,8 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
 #endif
 // PV = the pattern's scanner flags as a compile-time constant: one instantiation per member of the pattern family, so
 // the hot scan loop of the Llama-4 pattern carries no trace of the others (as run-time flags they cost 5 % of it).
+constexpr int KS_HCAP = 1024;  // heads the list holds per tile (what does not fit is matched by the lane that found it)
+constexpr int KS_CCAP = 256;
 template <uint32_t PV>
 __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
@@ -232,6 +247,10 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
     __shared__ uint32_t s_start[K_WIN / 32 + 3];  // bit i: a piece starts at window byte i
     __shared__ uint32_t s_doc[K_WIN / 32 + 2];
     __shared__ uint8_t s_lut[128];                // ASCII byte -> feature byte
+    __shared__ uint16_t s_heads[KS_HCAP + 2];     // unresolved heads (window positions)
+    __shared__ uint16_t s_cold[KS_CCAP];          // piece starts the branch-free matcher left open
+    __shared__ uint32_t s_nh, s_cur, s_ncold;
+    __shared__ int s_last;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         const int64_t tile_g0 = (int64_t)tile * KS_TILE;
         const int64_t wg0 = tile_g0 - K_HL;  // global offset of window index 0 (multiple of 64)
         const int tile_hi = K_HL + (int)((a.n - tile_g0 < KS_TILE) ? (a.n - tile_g0) : KS_TILE);
-        const int c0 = K_HL + tid * KS_CHUNK, c1 = c0 + KS_CHUNK;
+        static_assert(KS_CHUNK == 32, "a lane's stride is one 32-bit word of the masks");
 
         // ---- phase 0: stage the text window and the document bits.  The text of this tile was requested one
         //      iteration ago (registers pf[]), so its HBM latency is hidden behind the previous tile --------------
@@ -269,6 +288,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         }
         if (tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);  // next tile of this workgroup
         for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
+        if (tid == 0) { s_nh = 0; s_cur = 0; s_ncold = 0; s_last = -1; }
         __syncthreads();
 
         // ---- phase 1: class masks.  Every lane takes 8 text bytes: feature byte per byte (ASCII: 128-B LUT in LDS;
@@ -378,69 +398,143 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         __syncthreads();
         if (a.stop_after == 12) continue;
 
-        // ---- phase 2: piece boundaries.  Fast path: bit-parallel scanner on a 64-byte register window; pieces or
-        //      look-ahead beyond that use the same matcher on the mask words in LDS.  What even the LDS window
-        //      cannot answer is handed to the td_split_far_* kernels: a piece (or its look-ahead) that leaves the
-        //      window goes on a list ("this piece start is known, its end is not"); a tile without a sync point in its
-        //      left halo is flagged ("first piece start at/after the tile start unknown": it lies inside a piece longer
-        //      than the halo) and gets that position from whoever scans the piece: tile_carry. ----------------------
+        // ---- phase 2: piece boundaries.
+        //  (a) whole-word rules: every lane takes the 32 bytes of its stride + 32 bytes of look-ahead as 64-bit masks and
+        //      proves with carry arithmetic (split_unresolved_heads) which synchronisation points ("heads") are followed by
+        //      exactly one piece up to the next one.  START = the synchronisation points themselves; on English text 98 %
+        //      of the heads end here.
+        //  (b) the other heads go on a list in LDS (+ the last sync point at or before the tile start, whose pieces lead
+        //      into the tile, + the tile's last head, whose pieces find the next tile's first piece start: tile_carry).
+        //      Wavefronts draw 64 heads at a time; a lane walks its head's pieces with the branch-free matcher until it
+        //      lands on a synchronisation point, then draws the next head: no lane waits for the busiest chunk.
+        //  (c) what the branch-free matcher leaves open (1 % of the pieces) is put aside and matched by the general
+        //      matcher on the mask words in LDS afterwards; pieces that leave the window go to the td_split_far_* kernels
+        //      ("this piece start is known, its end is not"), and a tile without a sync point in its left halo is flagged
+        //      ("first piece start unknown": it lies inside a piece longer than the halo) and gets it through tile_carry.
         {
-            int s = -1;
+            constexpr bool FAST = !(PV & (PV_GPT2 | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS | PV_WS_EOS_FIRST));
+            const uint32_t* s_mask32 = reinterpret_cast<const uint32_t*>(s_mask);
+            auto dword_at = [](int j) { return (j >> 1) * (MK_COUNT * 2) + (j & 1); };  // mask 0 of dword j; mask k: + 2 k
             auto defer = [&](int64_t g) {
                 const uint32_t q = atomicAdd(a.slow_count, 1u);
                 if (q < a.slow_cap) a.slow_list[q] = g;
                 else raise(a, TD_E_SCRATCH, g);
             };
+            auto mark = [&](int q) { atomicOr(&s_start[q >> 5], 1u << (q & 31)); };
+            auto sync_at = [&](int q) { return (s_mask32[dword_at(q >> 5) + 2 * MK_SYNC] >> (q & 31)) & 1u; };
+            auto crossed = [&](int e) { if (tile + 1 < a.n_stiles) a.tile_carry[tile + 1] = wg0 + e; };  // first piece start of the next tile
+            // general matcher from the piece start p (marked) to the end of its chain
+            auto walk = [&](int p) {
+                for (;;) {
+                    const int e = scan_piece_lds<PV>(s_mask, s_txt, p);
+                    if (e < 0) { if (p >= K_HL) defer(wg0 + p); return; }
+                    if (e >= tile_hi) { crossed(e); return; }
+                    if (sync_at(e)) return;
+                    if (e >= K_HL) mark(e);
+                    p = e;
+                }
+            };
+            // (a)
+            const int b0 = K_HL + tid * 32;
+            uint32_t mine = 0;  // unresolved heads of my stride that found no room on the list
+            {
+                const uint32_t* lo = s_mask32 + dword_at(b0 >> 5);
+                const uint32_t* hi = s_mask32 + dword_at((b0 >> 5) + 1);
+                BitWin wv;
+#pragma unroll
+                for (int k = 0; k < MK_COUNT; ++k) wv.m[k] = ((uint64_t)hi[2 * k] << 32) | lo[2 * k];
+                uint32_t sy = (uint32_t)wv.m[MK_SYNC];
+                const int room = tile_hi - b0;
+                if (room < 32) sy = room <= 0 ? 0u : sy & ((1u << room) - 1u);
+                s_start[b0 >> 5] = sy;
+                uint32_t un = (uint32_t)split_unresolved_heads(wv, PV) & sy;
+                if (sy) atomicMax(&s_last, b0 + 31 - (int)__clz(sy));
+                const uint32_t cnt = __popc(un);
+                const uint32_t incl = wave_incl_scan(cnt, lane);
+                uint32_t base = 0;
+                if (lane == 63 && incl) base = atomicAdd(&s_nh, incl);
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+                uint32_t idx = base + incl - cnt;
+                while (un) {
+                    const int bit = __ffs(un) - 1;
+                    un &= un - 1u;
+                    if (idx < (uint32_t)KS_HCAP) s_heads[idx] = (uint16_t)(b0 + bit); else mine |= 1u << bit;
+                    ++idx;
+                }
+            }
+            __syncthreads();
             if (tid == 0) {
-                // last provable sync point at or before the tile start (window bytes 4..K_HL)
+                uint32_t nh = s_nh < (uint32_t)KS_HCAP ? s_nh : (uint32_t)KS_HCAP;
+                // last provable sync point before the tile start (window bytes 4..K_HL), unless the tile starts on one
                 static_assert(K_HL % 64 == 0 && K_HL >= 64, "left halo = whole mask words");
-                if (s_mask[(K_HL / 64) * MK_COUNT + MK_SYNC] & 1ull) s = K_HL;
-                else {
+                if (!(s_mask[(K_HL / 64) * MK_COUNT + MK_SYNC] & 1ull)) {
+                    int s = -1;
                     for (int w = K_HL / 64 - 1; w >= 0 && s < 0; --w) {
                         uint64_t m = s_mask[w * MK_COUNT + MK_SYNC];
                         if (w == 0) m &= ~0xFull;
                         if (m) s = w * 64 + td_top64(m) - 1;
                     }
                     if (s < 0) a.tile_flag[tile] = 1;
+                    else s_heads[nh++] = (uint16_t)s;
                 }
-            } else if (c0 < tile_hi) {
-                static_assert(KS_CHUNK == 16 || KS_CHUNK == 32, "a lane's sync bits come out of one 64-bit mask word");
-                uint32_t sy = (uint32_t)(s_mask[(c0 >> 6) * MK_COUNT + MK_SYNC] >> (c0 & 63)) & (uint32_t)((1ull << KS_CHUNK) - 1ull);
-                if (c1 > tile_hi) sy &= (1u << (tile_hi - c0)) - 1u;
-                if (sy) s = c0 + __ffs(sy) - 1;
+                if (s_last >= 0) s_heads[nh++] = (uint16_t)s_last;
+                s_nh = nh;
             }
-            if (s >= 0) {
-                auto mark = [&](int q) { atomicOr(&s_start[q >> 5], 1u << (q & 31)); };
-                BitWin wv;
-                int base = s;
-                load_bitwin(wv, s_mask, base);
-                int p = s;
+            __syncthreads();
+            if (a.stop_after == 13) continue;
+            // (b)
+            {
+                const uint32_t nh = s_nh;
+                int p = -1;
+                bool more = true;  // (uniform) the list may still hold heads
                 for (;;) {
-                    if (p >= tile_hi) {  // delimits the last owned piece; the next tile's first piece start
-                        mark(p);
-                        if (tile + 1 < a.n_stiles) a.tile_carry[tile + 1] = wg0 + p;
-                        break;
+                    const uint64_t nb = __ballot(p < 0);
+                    if (nb && more) {
+                        uint32_t base = 0;
+                        if (lane == __ffsll((unsigned long long)nb) - 1) base = atomicAdd(&s_cur, (uint32_t)__popcll(nb));
+                        base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((unsigned long long)nb) - 1);
+                        more = base + (uint32_t)__popcll(nb) < nh;
+                        if (p < 0) {
+                            const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nb, 0u));
+                            if (idx < nh) p = s_heads[idx];
+                        }
                     }
-                    int off = p - base;
-                    if (off >= 32) { base = p; off = 0; load_bitwin(wv, s_mask, base); }
-                    // 32-bit view of every mask with bit 0 = the piece start: one funnel shift each
-                    BitWin32 v;
+                    if (!__ballot(p >= 0)) break;
+                    if (p >= 0) {
+                        const int sh = p & 31;
+                        const uint32_t* lo = s_mask32 + dword_at(p >> 5);
+                        const uint32_t* hi = s_mask32 + dword_at((p >> 5) + 1);
+                        BitWin32 v;  // 32-bit view of every mask with bit 0 = the piece start
 #pragma unroll
-                    for (int k = 0; k < MK_COUNT; ++k)
-                        v.m[k] = __funnelshift_r((uint32_t)wv.m[k], (uint32_t)(wv.m[k] >> 32), (uint32_t)off);
-                    if (p >= c1 && (v.m[MK_SYNC] & 1u)) break;  // the lane owning p starts there
-                    if (p >= K_HL) mark(p);
-                    const int avail = (K_LIM - p < 32) ? (K_LIM - p) : 32;
-                    int e = -1;
-                    {
-                        const int r = scan_piece_p(WinP32(v, avail), [&](int q) { return (uint32_t)s_txt[p + q]; }, PV);
-                        if (r >= 0) e = p + r;
+                        for (int k = 0; k < MK_COUNT; ++k) v.m[k] = __funnelshift_r(lo[2 * k], hi[2 * k], (uint32_t)sh);
+                        const int avail = (K_LIM - p < 32) ? (K_LIM - p) : 32;
+                        auto bytes = [&](int q) { return (uint32_t)s_txt[p + q]; };
+                        const int r = FAST ? scan_piece_fast32(v, avail, bytes, PV) : scan_piece_p(WinP32(v, avail), bytes, PV);
+                        if (r < 0) {  // (c)
+                            const uint32_t ci = atomicAdd(&s_ncold, 1u);
+                            if (ci < (uint32_t)KS_CCAP) s_cold[ci] = (uint16_t)p; else walk(p);
+                            p = -1;
+                        } else {
+                            const int e = p + r;
+                            bool stop = true;
+                            if (e >= tile_hi) crossed(e);
+                            else {
+                                stop = (r < 32) ? ((v.m[MK_SYNC] >> r) & 1u) : sync_at(e);
+                                if (!stop && e >= K_HL) mark(e);
+                            }
+                            p = stop ? -1 : e;
+                        }
                     }
-                    if (e < 0) {
-                        e = scan_piece_lds<PV>(s_mask, s_txt, p);  // piece or look-ahead beyond 32 bytes: mask words in LDS
-                        if (e < 0) { if (p >= K_HL) defer(wg0 + p); break; }
-                    }
-                    p = e;
+                }
+            }
+            __syncthreads();
+            {
+                const uint32_t nc = s_ncold < (uint32_t)KS_CCAP ? s_ncold : (uint32_t)KS_CCAP;
+                for (uint32_t i = tid; i < nc; i += K_THREADS) walk(s_cold[i]);
+                while (mine) {
+                    const int bit = __ffs(mine) - 1;
+                    mine &= mine - 1u;
+                    walk(b0 + bit);
                 }
             }
         }
@@ -541,18 +635,8 @@ struct FarScan {  // one wavefront's view of the text for the far kernels
         WaveMaskP mp{T, a.text, a.docbits, a.n, p, 0, 8, lane};
         return is_sync(p > 0 ? mp.cf_at(p - 1) : 0u, mp.cf_at(p), T.pat_flags);
     }
-    // does a lane of the fast kernel start at p?  (p is a sync point, the first one of its chunk, and not in the tile's first
-    // chunk: lane 0 starts from the left halo, never inside its own chunk)
-    __device__ __forceinline__ bool fast_lane_starts_at(int64_t p) const {
-        if (!sync_at(p)) return false;
-        const int64_t tile_g0 = p - (p % KS_TILE);
-        const int64_t cs = p - ((p - tile_g0) % KS_CHUNK);
-        if (cs == tile_g0) return false;
-        const int64_t q = cs + lane;  // (KS_CHUNK <= 64: one lane per byte of the chunk)
-        WaveMaskP mp{T, a.text, a.docbits, a.n, p, 0, 8, lane};
-        const bool earlier = q < p && is_sync(q > 0 ? mp.cf_at(q - 1) : 0u, mp.cf_at(q), T.pat_flags);
-        return !__any(earlier);
-    }
+    // does the fast kernel take over at p?  Every synchronisation point inside a tile is a head there.
+    __device__ __forceinline__ bool fast_lane_starts_at(int64_t p) const { return sync_at(p); }
     // piece starts from p (a piece start) to the end of p's tile, marked as they are found; returns the first piece start at or
     // behind the tile end, or -1 when it stopped where a lane of the fast kernel took over
     __device__ __forceinline__ int64_t mark_to_tile_end(int64_t p, bool first_is_marked) const {
@@ -895,19 +979,6 @@ __device__ __forceinline__ void mg_init_piece(const EncodeArgs& a, const Tables&
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-}
-
-// inclusive add-scan across the wavefront with DPP (no LDS round trips): rows of 16 lanes with row_shr 1/2/4/8 (lanes without
-// a source add 0), then row_bcast15 (rows 1 and 3 take the total of rows 0 and 2) and row_bcast31 (rows 2, 3 take rows 0-1)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int /*lane*/) {
-    constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118, ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143;
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR1, 0xF, 0xF, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR2, 0xF, 0xF, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR4, 0xF, 0xF, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_SHR8, 0xF, 0xF, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_BCAST15, 0xA, 0xF, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ROW_BCAST31, 0xC, 0xF, false);
-    return x;
 }
 
 // ------------------------------------------------------------------ td_merge_pieces ---------
