@@ -238,15 +238,16 @@ class Twin:
         self._lib.twin_fast_stats(ctypes.byref(t), ctypes.byref(h))
         return t.value, h.value
 
-    def word_rules_check(self, data: bytes, offs=None) -> tuple[int, list[int]]:
+    def word_rules_check(self, data: bytes, offs=None, head_state=None) -> tuple[int, list[int]]:
         """-> (mismatches, [heads, unresolved heads, pieces, pieces in unresolved regions]) of the whole-word boundary
         rules (split_unresolved_heads) against the byte scanner"""
         offs = self._offs(data, offs)
         st = (ctypes.c_int64 * 4)()
         self._lib.twin_word_rules_check.restype = ctypes.c_int64
         self._lib.twin_word_rules_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
-                                                    ctypes.c_int64, ctypes.c_void_p]
-        bad = self._lib.twin_word_rules_check(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, st)
+                                                    ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        bad = self._lib.twin_word_rules_check(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, st,
+                                              None if head_state is None else head_state.ctypes.data)
         return int(bad), list(st)
 
     def arrmask_check(self, data: bytes, offs=None) -> tuple[int, int]:

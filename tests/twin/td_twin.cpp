@@ -432,7 +432,8 @@ int64_t twin_arrmask_check(void* h, const uint8_t* text, int64_t n, const int64_
 // split_unresolved_heads (the whole-word boundary rules) on 64-byte windows at every multiple of 32: a head the rules
 // call resolved must be a piece whose end is the next synchronisation point.  stats: [0] heads, [1] unresolved heads,
 // [2] pieces, [3] pieces inside unresolved regions (what the piece-by-piece matcher still has to do).
-int64_t twin_word_rules_check(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, int64_t* stats) {
+int64_t twin_word_rules_check(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, int64_t* stats,
+                              uint8_t* head_state /* NULL or [n]: 1 = resolved head, 2 = unresolved head */) {
     Twin* t = (Twin*)h;
     const Tables T = t->H.view();
     std::vector<uint8_t> cls;
@@ -461,6 +462,7 @@ int64_t twin_word_rules_check(void* h, const uint8_t* text, int64_t n, const int
             int64_t np = 0;
             for (int64_t q = hd; q < nx; ++q) np += start[(size_t)q];
             ++heads; pieces += np;
+            if (head_state) head_state[hd] = ((un >> i) & 1ull) ? 2 : 1;
             if ((un >> i) & 1ull) { ++unres; upieces += np; }
             else if (np != 1) ++bad;
         }

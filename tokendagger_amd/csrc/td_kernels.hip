@@ -247,15 +247,19 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
     __shared__ uint32_t s_start[K_WIN / 32 + 3];  // bit i: a piece starts at window byte i
     __shared__ uint32_t s_doc[K_WIN / 32 + 2];
     __shared__ uint8_t s_lut[128];                // ASCII byte -> feature byte
+    __shared__ uint8_t s_fcls[16];                // class -> feature byte
     __shared__ uint16_t s_heads[KS_HCAP + 2];     // unresolved heads (window positions)
     __shared__ uint16_t s_cold[KS_CCAP];          // piece starts the branch-free matcher left open
-    __shared__ uint32_t s_nh, s_cur, s_ncold;
+    __shared__ uint32_t s_nh, s_cur, s_ncold, s_nonascii;
     __shared__ int s_last;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 128; q += K_THREADS) s_lut[q] = (uint8_t)feature_of_class(T.ascii_cls[q]);
+    if (tid < 16) s_fcls[tid] = (uint8_t)feature_of_class((uint32_t)tid);
+    if (tid == 0) s_nonascii = 0;
+    __syncthreads();
 
     constexpr int NPF = (K_WIN / 16 + K_THREADS - 1) / K_THREADS;  // 16-byte prefetch registers per lane for one window
     uint4 pf[NPF];
@@ -276,9 +280,13 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
 
         // ---- phase 0: stage the text window and the document bits.  The text of this tile was requested one
         //      iteration ago (registers pf[]), so its HBM latency is hidden behind the previous tile --------------
+        uint32_t hib = 0;  // (any byte >= 0x80 in what this lane stages?)
 #pragma unroll
         for (int q = 0; q < NPF; ++q)
-            if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) reinterpret_cast<uint4*>(s_txt)[q * K_THREADS + tid] = pf[q];
+            if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) {
+                reinterpret_cast<uint4*>(s_txt)[q * K_THREADS + tid] = pf[q];
+                hib |= pf[q].x | pf[q].y | pf[q].z | pf[q].w;
+            }
         for (int w = tid; w < K_WIN / 32; w += K_THREADS) {
             const int64_t gw = (wg0 >> 5) + w;
             uint32_t dw = (gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
@@ -289,7 +297,9 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         if (tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);  // next tile of this workgroup
         for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
         if (tid == 0) { s_nh = 0; s_cur = 0; s_ncold = 0; s_last = -1; }
+        if (__ballot((hib & 0x80808080u) != 0) && lane == 0) s_nonascii = 1;  // (reset behind phase 1; __syncthreads_or costs extra barriers)
         __syncthreads();
+        const bool tile_ascii = !s_nonascii;
 
         // ---- phase 1: class masks.  Every lane takes 8 text bytes: feature byte per byte (ASCII: 128-B LUT in LDS;
         //      otherwise UTF-8 decode + 2-stage Unicode table in L2), an 8x8 bit transpose turns the 8 feature bytes
@@ -301,86 +311,8 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         src.lo = (wg0 < 0) ? -wg0 : 0;
         src.hi = (a.n - wg0 < K_WIN) ? (a.n - wg0) : K_WIN;
         if (tid < MK_COUNT) s_mask[K_MWORDS * MK_COUNT + tid] = 0;  // zero word behind the last one
-        for (int it = tid; it < K_WIN / 8; it += K_THREADS) {
-            const uint2 t8 = reinterpret_cast<const uint2*>(s_txt)[it];
-            uint32_t flo, fhi;
-            // state handed to the next lane: class features of my last character and how many continuation bytes it
-            // still claims (0x100 = "unknown": this item held continuation bytes only)
-            uint32_t st_out = 0;
-            int lead_conts = 0;  // continuation bytes at the start of my item (they belong to the previous lane's char)
-            if (!((t8.x | t8.y) & 0x80808080u)) {
-                flo = (uint32_t)s_lut[t8.x & 0x7F] | ((uint32_t)s_lut[(t8.x >> 8) & 0x7F] << 8) |
-                      ((uint32_t)s_lut[(t8.x >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.x >> 24] << 24);
-                fhi = (uint32_t)s_lut[t8.y & 0x7F] | ((uint32_t)s_lut[(t8.y >> 8) & 0x7F] << 8) |
-                      ((uint32_t)s_lut[(t8.y >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.y >> 24] << 24);
-            } else {
-                // non-ASCII: one iteration and one table walk per CHARACTER.  Well-formed sequences (the lead's
-                // continuation bytes all present, no document start inside) are decoded inline from a 16-byte register
-                // window; anything else takes the general per-byte route (feature_at).
-                flo = fhi = 0;
-                uint32_t cur = 0;
-                int remaining = 0;  // continuation bytes my last lead still claims beyond this item
-                bool seen_start = false;
-                const uint2 t8n = (it + 1 < K_WIN / 8) ? reinterpret_cast<const uint2*>(s_txt)[it + 1] : make_uint2(0, 0);
-                const uint64_t lo8 = ((uint64_t)t8.y << 32) | t8.x, hi8 = ((uint64_t)t8n.y << 32) | t8n.x;
-                const uint32_t docb = (uint32_t)reinterpret_cast<const uint8_t*>(s_doc)[it] |
-                                      ((it + 1 < K_WIN / 8) ? (uint32_t)reinterpret_cast<const uint8_t*>(s_doc)[it + 1] << 8 : 0u);
-                auto put = [&](int k, uint32_t f) { if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4)); };
-                int k = 0;
-                // continuation bytes at the very start belong to the previous lane's character (resolved below)
-                while (k < 8 && (((uint32_t)(lo8 >> (8 * k)) & 0xC0u) == 0x80u) && !((docb >> k) & 1u)) ++k;
-                lead_conts = k;
-                while (k < 8) {
-                    const uint32_t b = (uint32_t)(lo8 >> (8 * k)) & 0xFFu;
-                    const int pos = it * 8 + k;
-                    seen_start = true;
-                    if (b < 0x80) { cur = s_lut[b]; put(k, cur); remaining = 0; ++k; continue; }
-                    const int need = (int)utf8_declared_len(b) - 1;
-                    // bytes k+1 .. k+3 of the 16-byte window
-                    const int shb = 8 * (k + 1);
-                    const uint32_t nxt = (uint32_t)((shb < 64) ? ((lo8 >> shb) | (hi8 << (64 - shb))) : hi8);
-                    const uint32_t c1 = nxt & 0xFF, c2 = (nxt >> 8) & 0xFF, c3 = (nxt >> 16) & 0xFF;
-                    const bool ok = need > 0 && pos + need < (int)src.hi && pos >= (int)src.lo && !((docb >> (k + 1)) & ((1u << need) - 1u)) &&
-                                    (c1 & 0xC0) == 0x80 && (need < 2 || (c2 & 0xC0) == 0x80) && (need < 3 || (c3 & 0xC0) == 0x80);
-                    if (!ok) {  // invalid lead, truncated sequence, stray continuation byte, document boundary inside
-                        const uint32_t f = feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, pos);
-                        put(k, f);
-                        cur = f & ~(uint32_t)FB_C;
-                        remaining = 0;
-                        ++k;
-                        continue;
-                    }
-                    uint32_t cp = (need == 1) ? ((b & 0x1F) << 6) | (c1 & 0x3F)
-                                : (need == 2) ? ((b & 0x0F) << 12) | ((c1 & 0x3F) << 6) | (c2 & 0x3F)
-                                              : ((b & 0x07) << 18) | ((c1 & 0x3F) << 12) | ((c2 & 0x3F) << 6) | (c3 & 0x3F);
-                    cur = feature_of_class(class_of_cp(T, cp));
-                    put(k, cur);
-                    for (int q = 1; q <= need && k + q < 8; ++q) put(k + q, cur | FB_C);
-                    remaining = (k + need >= 8) ? (k + need - 7) : 0;
-                    k += need + 1;
-                }
-                st_out = seen_start ? (cur | ((uint32_t)remaining << 9)) : 0x100u;
-            }
-            {   // continuation bytes at the start of the item: the previous lane's last character claims them
-                const uint32_t st_in = __shfl_up(st_out, 1);
-                if (lead_conts) {
-                    const bool known = lane != 0 && !(st_in & 0x100u);
-                    const int claim = (int)(st_in >> 9);
-                    for (int k = 0; k < lead_conts; ++k) {
-                        const uint32_t f = (known && k < claim) ? ((st_in & 0xFFu) | FB_C) : feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 + k);
-                        if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4));
-                    }
-                }
-            }
-            // feature byte of the byte in front of my 8 (for the sync predicate)
-            uint32_t pf = __shfl_up(fhi >> 24, 1);
-            if (lane == 0) {
-                pf = 0;
-                if (it > 0) {
-                    const uint32_t pb = s_txt[it * 8 - 1];
-                    pf = (pb < 0x80) ? (uint32_t)s_lut[pb] : feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 - 1);
-                }
-            }
+        // masks of one item from its eight feature bytes and the feature byte in front of them
+        auto emit_masks = [&](int it, uint32_t flo, uint32_t fhi, uint32_t pf) {
             const uint64_t P = transpose8x8(((uint64_t)fhi << 32) | flo);  // byte k = bit plane of feature bit k
             const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
             const uint32_t mU = plo & 0xFF, mW = (plo >> 8) & 0xFF, mX = (plo >> 16) & 0xFF, mS = plo >> 24;
@@ -394,8 +326,154 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
             o[0 * 8] = (uint8_t)mU; o[1 * 8] = (uint8_t)mW; o[2 * 8] = (uint8_t)mX; o[3 * 8] = (uint8_t)mS;
             o[4 * 8] = (uint8_t)mN; o[5 * 8] = (uint8_t)mCR; o[6 * 8] = (uint8_t)(mCR | mSL); o[7 * 8] = (uint8_t)mC;
             o[8 * 8] = (uint8_t)mD; o[9 * 8] = (uint8_t)mA; o[10 * 8] = (uint8_t)mSP; o[11 * 8] = (uint8_t)mSY;
+        };
+        constexpr int P1_ITEMS = K_WIN / 8;
+        if (tile_ascii) {
+            // no byte >= 0x80 in the whole window (most tiles of English text and of source code): LUT only
+            for (int it = tid; it < P1_ITEMS; it += K_THREADS) {
+                const uint2 t8 = reinterpret_cast<const uint2*>(s_txt)[it];
+                const uint32_t flo = (uint32_t)s_lut[t8.x & 0x7F] | ((uint32_t)s_lut[(t8.x >> 8) & 0x7F] << 8) |
+                                     ((uint32_t)s_lut[(t8.x >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.x >> 24] << 24);
+                const uint32_t fhi = (uint32_t)s_lut[t8.y & 0x7F] | ((uint32_t)s_lut[(t8.y >> 8) & 0x7F] << 8) |
+                                     ((uint32_t)s_lut[(t8.y >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.y >> 24] << 24);
+                uint32_t pf = __shfl_up(fhi >> 24, 1);
+                if (lane == 0) pf = it > 0 ? (uint32_t)s_lut[s_txt[it * 8 - 1]] : 0u;
+                emit_masks(it, flo, fhi, pf);
+            }
+        } else {
+        // (a wavefront takes a contiguous quarter of the items, 64 per pass: what lane 0 needs from the item in front of its
+        // own — the last character's features — is lane 63's of the pass before, not another wavefront's)
+        constexpr int P1_WAVES = K_THREADS / 64, P1_PER_WAVE = (P1_ITEMS / P1_WAVES) & ~63;
+        static_assert(P1_ITEMS - P1_WAVES * P1_PER_WAVE <= 64, "the items left over are one more pass of the last wavefront");
+        uint32_t carry_st = 0x100u, carry_pf = 0;
+        const int n_pass = P1_PER_WAVE / 64 + ((tid >> 6) == P1_WAVES - 1 ? 1 : 0);
+        for (int q = 0; q < n_pass; ++q) {
+            const int it = (tid >> 6) * P1_PER_WAVE + q * 64 + lane;
+            if (it >= P1_ITEMS) break;
+            const uint2 t8 = reinterpret_cast<const uint2*>(s_txt)[it];
+            uint32_t flo, fhi;
+            // state handed to the next lane: class features of my last character and how many continuation bytes it
+            // still claims (0x100 = "unknown": this item held continuation bytes only)
+            uint32_t st_out = 0;
+            int lead_conts = 0;  // continuation bytes at the start of my item (they belong to the previous lane's char)
+            if (!((t8.x | t8.y) & 0x80808080u)) {
+                flo = (uint32_t)s_lut[t8.x & 0x7F] | ((uint32_t)s_lut[(t8.x >> 8) & 0x7F] << 8) |
+                      ((uint32_t)s_lut[(t8.x >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.x >> 24] << 24);
+                fhi = (uint32_t)s_lut[t8.y & 0x7F] | ((uint32_t)s_lut[(t8.y >> 8) & 0x7F] << 8) |
+                      ((uint32_t)s_lut[(t8.y >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[t8.y >> 24] << 24);
+            } else {
+                // non-ASCII.  UTF-8 is self-synchronising, so the item is classified without walking it character by
+                // character: every byte gets the ASCII LUT's answer first; the lead bytes (at most four well-formed
+                // multi-byte characters fit) are picked out of byte-flag words, decoded from a 16-byte register window, and
+                // the two table loads of ALL of them go out together (a loop over the characters with two dependent L2
+                // round trips each made this phase 80 % of the kernel on mixed-script text); their features overwrite the
+                // bytes they span.  What is left (invalid leads, truncated sequences, stray continuation bytes, a fifth
+                // lead) takes the general per-byte route (feature_at_v).
+                const uint2 t8n = (it + 1 < K_WIN / 8) ? reinterpret_cast<const uint2*>(s_txt)[it + 1] : make_uint2(0, 0);
+                const uint64_t lo8 = ((uint64_t)t8.y << 32) | t8.x, hi8 = ((uint64_t)t8n.y << 32) | t8n.x;
+                const uint32_t docb = (uint32_t)reinterpret_cast<const uint8_t*>(s_doc)[it] |
+                                      ((it + 1 < K_WIN / 8) ? (uint32_t)reinterpret_cast<const uint8_t*>(s_doc)[it + 1] << 8 : 0u);
+                const int pos0 = it * 8;
+                uint64_t F = (uint64_t)((uint32_t)s_lut[t8.x & 0x7F] | ((uint32_t)s_lut[(t8.x >> 8) & 0x7F] << 8) |
+                                        ((uint32_t)s_lut[(t8.x >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[(t8.x >> 24) & 0x7F] << 24)) |
+                             ((uint64_t)((uint32_t)s_lut[t8.y & 0x7F] | ((uint32_t)s_lut[(t8.y >> 8) & 0x7F] << 8) |
+                                         ((uint32_t)s_lut[(t8.y >> 16) & 0x7F] << 16) | ((uint32_t)s_lut[(t8.y >> 24) & 0x7F] << 24)) << 32);
+                constexpr uint64_t HB = 0x8080808080808080ull;  // flag words: bit 8k+7 <-> byte k
+                const uint64_t na = lo8 & HB;                   // non-ASCII bytes
+                const uint64_t ct = na & ~(lo8 << 1);           // continuation bytes (10xxxxxx)
+                uint64_t ld = na & (lo8 << 1);                  // bytes >= 0xC0
+                auto bytes_below = [](int nb) { return nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull); };
+                {   // continuation bytes at the very start belong to the previous lane's character (resolved below); one
+                    // that starts a document is a character of its own
+                    const int lc0 = td_ctz64(~ct & HB) >> 3, lcd = (int)td_ctz32(docb | 0x100u);
+                    lead_conts = lc0 < lcd ? lc0 : lcd;
+                }
+                uint32_t kj[4], ndj[4], cpj[4], uj[4];
+                bool tbj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool have = ld != 0;
+                    const int k = have ? td_ctz64(ld) >> 3 : 0;
+                    ld &= ld - 1ull;
+                    const uint64_t w = (lo8 >> (8 * k)) | ((hi8 << 8) << (56 - 8 * k));  // bytes k .. k+7
+                    const uint32_t b = (uint32_t)w & 0xFFu, c1 = (uint32_t)(w >> 8) & 0xFFu, c2 = (uint32_t)(w >> 16) & 0xFFu, c3 = (uint32_t)(w >> 24) & 0xFFu;
+                    const uint32_t need = utf8_declared_len(b) - 1u;
+                    const int pos = pos0 + k;
+                    const bool ok = have && need > 0 && pos + (int)need < (int)src.hi && pos >= (int)src.lo && !((docb >> (k + 1)) & ((1u << need) - 1u)) &&
+                                    (c1 & 0xC0) == 0x80 && (need < 2 || (c2 & 0xC0) == 0x80) && (need < 3 || (c3 & 0xC0) == 0x80);
+                    const uint32_t c = (need == 1) ? ((b & 0x1F) << 6) | (c1 & 0x3F)
+                                     : (need == 2) ? ((b & 0x0F) << 12) | ((c1 & 0x3F) << 6) | (c2 & 0x3F)
+                                                   : ((b & 0x07) << 18) | ((c1 & 0x3F) << 12) | ((c2 & 0x3F) << 6) | (c3 & 0x3F);
+                    tbj[j] = ok && c <= 0x10FFFFu && !(c >= 0xD800u && c <= 0xDFFFu);  // (class_of_cp: everything else is C_OTHER)
+                    cpj[j] = tbj[j] ? c : 0u;
+                    kj[j] = (uint32_t)k;
+                    ndj[j] = ok ? need : 0u;
+                    uj[j] = T.ucls1[cpj[j] >> 8];  // (unconditional, independent loads: they leave back to back)
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) uj[j] = T.ucls2[uj[j] * 256u + (cpj[j] & 255u)];
+                uint64_t cov = 0;  // flags of the bytes the well-formed characters span
+                int remaining = 0, last_lead = -1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ndj[j]) {
+                        const uint32_t f = tbj[j] ? (uint32_t)s_fcls[uj[j] & 15u] : (uint32_t)FB_X;
+                        const uint32_t bm = ndj[j] == 3u ? 0xFFFFFFFFu : ((1u << (8u * (ndj[j] + 1u))) - 1u);
+                        const uint32_t pat = ((f * 0x01010101u) | 0x80808000u) & bm;  // the lead, then its continuation bytes (FB_C)
+                        const int sh = 8 * (int)kj[j];
+                        F = (F & ~((uint64_t)bm << sh)) | ((uint64_t)pat << sh);
+                        cov |= (uint64_t)(bm & 0x80808080u) << sh;
+                        last_lead = (int)kj[j];
+                        remaining = ((int)kj[j] + (int)ndj[j] > 7) ? (int)kj[j] + (int)ndj[j] - 7 : 0;
+                    }
+                }
+                const uint64_t lcm = bytes_below(lead_conts);
+                for (uint64_t gen = na & ~cov & ~lcm; gen; gen &= gen - 1ull) {  // (rare)
+                    const int k = td_ctz64(gen) >> 3;
+                    const uint32_t f = feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, pos0 + k);
+                    F = (F & ~(0xFFull << (8 * k))) | ((uint64_t)f << (8 * k));
+                }
+                F &= ~lcm;
+                flo = (uint32_t)F;
+                fhi = (uint32_t)(F >> 32);
+                // the item's last character: its features and the continuation bytes it claims from the next item
+                const uint64_t starts = HB & ~(cov & ct) & ~lcm;
+                if (starts) {
+                    const int last = (63 - (int)__builtin_clzll(starts)) >> 3;
+                    st_out = ((uint32_t)(F >> (8 * last)) & 0x7Fu) | ((uint32_t)(last == last_lead ? remaining : 0) << 9);
+                } else {
+                    st_out = 0x100u;
+                }
+            }
+            {   // continuation bytes at the start of the item: the previous lane's last character claims them
+                uint32_t st_in = __shfl_up(st_out, 1);
+                if (lane == 0) st_in = carry_st;
+                carry_st = (uint32_t)__builtin_amdgcn_readlane((int)st_out, 63);
+                if (lead_conts) {
+                    const bool known = !(st_in & 0x100u);
+                    const int claim = (int)(st_in >> 9);
+                    for (int k = 0; k < lead_conts; ++k) {
+                        const uint32_t f = (known && k < claim) ? ((st_in & 0xFFu) | FB_C) : feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 + k);
+                        if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4));
+                    }
+                }
+            }
+            // feature byte of the byte in front of my 8 (for the sync predicate)
+            uint32_t pf = __shfl_up(fhi >> 24, 1);
+            if (lane == 0 && q > 0) pf = carry_pf;
+            carry_pf = (uint32_t)__builtin_amdgcn_readlane((int)(fhi >> 24), 63);
+            if (lane == 0 && q == 0) {
+                pf = 0;
+                if (it > 0) {
+                    const uint32_t pb = s_txt[it * 8 - 1];
+                    pf = (pb < 0x80) ? (uint32_t)s_lut[pb] : feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 - 1);
+                }
+            }
+            emit_masks(it, flo, fhi, pf);
+        }
         }
         __syncthreads();
+        if (tid == 0) s_nonascii = 0;
         if (a.stop_after == 12) continue;
 
         // ---- phase 2: piece boundaries.
