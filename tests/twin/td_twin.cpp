@@ -73,8 +73,13 @@ void classify_all(const Tables& T, const uint8_t* text, int64_t n, const int64_t
 }  // namespace
 
 static int64_t g_fast_total = 0, g_fast_hit = 0;
+static int64_t g_mg_pieces[5] = {0, 0, 0, 0, 0}, g_mg_rounds[5] = {0, 0, 0, 0, 0};  // merged pieces / merge rounds by length class
 
 extern "C" {
+
+void twin_merge_stats(int64_t* out10) {
+    for (int c = 0; c < 5; ++c) { out10[c] = g_mg_pieces[c]; out10[5 + c] = g_mg_rounds[c]; g_mg_pieces[c] = g_mg_rounds[c] = 0; }
+}
 
 void twin_fast_stats(int64_t* total, int64_t* hit) { *total = g_fast_total; *hit = g_fast_hit; g_fast_total = g_fast_hit = 0; }
 
@@ -286,8 +291,10 @@ int64_t twin_encode(void* h, const uint8_t* text, int64_t n, const int64_t* offs
                 st.alive = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
                 for (uint32_t j = 0; j < len; ++j) mg_put(T, T.byte_id, keys, ids, st, j, pb[j], j + 1 < len ? pb[j + 1] : 0u);
                 mg_pad(keys, st);
-                if (len <= 32) { while (mg_round_t<uint32_t>(T, keys, ids, st)) {} }  // (as td_merge_pieces picks the mask width)
-                else { while (mg_round_t<uint64_t>(T, keys, ids, st)) {} }
+                uint32_t rounds = 0;
+                if (len <= 32) { while (mg_round_t<uint32_t>(T, keys, ids, st)) ++rounds; }  // (as td_merge_pieces picks the mask width)
+                else { while (mg_round_t<uint64_t>(T, keys, ids, st)) ++rounds; }
+                { const int c = len <= 8 ? 0 : len <= 16 ? 1 : len <= 32 ? 2 : len <= 48 ? 3 : 4; g_mg_pieces[c]++; g_mg_rounds[c] += rounds; }
                 for (uint64_t al = st.alive; al; al &= al - 1) {
                     const uint32_t v = ids[mg_slot(st.t, (uint32_t)td_ctz64(al))];
                     if ((int32_t)v >= T.pseudo_base) return -TD_E_UNKNOWN_BYTE;

@@ -133,7 +133,7 @@ struct Ctl {  // small control block in device memory
     uint32_t slow_count;
     unsigned long long pool_used;
     uint32_t scan_done;
-    uint32_t pad2;
+    uint32_t merge_next;   // td_merge_pieces: next tile nobody has taken yet
 };
 }  // namespace
 
@@ -317,6 +317,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.pool_cap = t->pool.cap / 4;
     a.pool_used = &ctl->pool_used;
     a.scan_done = &ctl->scan_done;
+    a.merge_next = &ctl->merge_next;
     a.chunk_pref = (int64_t*)t->chunk_pref.p;
     a.ctl_reset = &ctl->long_count;  // keep a sticky error (err / err_pos) but reset the per-call counters
     a.ctl_reset_words = (uint32_t)((sizeof(Ctl) - offsetof(Ctl, long_count)) / 4);

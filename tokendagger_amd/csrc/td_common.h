@@ -171,10 +171,12 @@ TD_HD uint32_t hash_pair2(uint32_t left, uint32_t right) {
     return h;
 }
 TD_HD int32_t pair_match(uint64_t e1, uint64_t e2, uint32_t left, uint32_t right) {
+    // (selects, no early return: with one, the compiler sinks the second slot's load behind the first compare and a
+    // lookup becomes two dependent round trips)
     const uint64_t key = ((uint64_t)left << ID_BITS) | right;
-    if ((e1 >> ID_BITS) == key) return (int32_t)(e1 & ((1u << ID_BITS) - 1));
-    if ((e2 >> ID_BITS) == key) return (int32_t)(e2 & ((1u << ID_BITS) - 1));
-    return NO_RANK;  // (an empty slot is all ones and matches no key: ids are < 2^21)
+    const bool m1 = (e1 >> ID_BITS) == key, m2 = (e2 >> ID_BITS) == key;
+    const uint32_t v = (uint32_t)(m1 ? e1 : e2) & ((1u << ID_BITS) - 1);
+    return (m1 || m2) ? (int32_t)v : NO_RANK;  // (an empty slot is all ones and matches no key: ids are < 2^21)
 }
 TD_HD int32_t pair_lookup(const Tables& T, uint32_t left, uint32_t right) {
     const uint64_t e1 = T.pair_slots[hash_pair(left, right) & T.pair_mask];
@@ -1111,10 +1113,20 @@ TD_HD bool mg_round_t(const Tables& T, uint32_t* keys, uint32_t* ids, MergeState
     const uint32_t id_nn = nn < 64u ? ids[base + (nn ^ sx)] : 0u;
     const uint32_t id_pw = pw < 64u ? ids[base + (pw ^ sx)] : 0u;
     ids[base + (w ^ sx)] = r;  // a merged part's id is its rank
-    // both pair lookups at once: four independent 8-byte probes in flight (a missing neighbour probes (r, 0) / (0, r) and
-    // the result is dropped: no divergent branch around the loads)
+    // both pair lookups at once: four independent 8-byte probes in flight.  A neighbour that does not exist is not looked
+    // up (the loads sit under the lanes' execution mask: every lane of a divergent load is a separate request to the
+    // vector L1, and their number is what bounds td_merge_pieces)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const uint64_t __attribute__((address_space(1)))* gpair_t;  // (global loads, not flat ones)
+    gpair_t const ps = (gpair_t)(uintptr_t)T.pair_slots;
+    uint64_t e1 = PAIR_EMPTY, e2 = PAIR_EMPTY, e3 = PAIR_EMPTY, e4 = PAIR_EMPTY;
+    if (nn < 64u) { e1 = ps[hash_pair(r, id_nn) & T.pair_mask]; e2 = ps[hash_pair2(r, id_nn) & T.pair_mask]; }
+    if (pw < 64u) { e3 = ps[hash_pair(id_pw, r) & T.pair_mask]; e4 = ps[hash_pair2(id_pw, r) & T.pair_mask]; }
+    asm volatile("" : "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4));  // all four are in flight before the first one is looked at
+#else
     const uint64_t e1 = T.pair_slots[hash_pair(r, id_nn) & T.pair_mask], e2 = T.pair_slots[hash_pair2(r, id_nn) & T.pair_mask];
     const uint64_t e3 = T.pair_slots[hash_pair(id_pw, r) & T.pair_mask], e4 = T.pair_slots[hash_pair2(id_pw, r) & T.pair_mask];
+#endif
     const int32_t r1 = pair_match(e1, e2, r, id_nn), r2 = pair_match(e3, e4, id_pw, r);
     const uint32_t kw = (nn < 64u && r1 != NO_RANK) ? (((uint32_t)r1 << 6) | w) : MG_DEAD;
     const uint32_t kp = (pw < 64u && r2 != NO_RANK) ? (((uint32_t)r2 << 6) | pw) : MG_DEAD;

@@ -42,6 +42,7 @@ struct EncodeArgs {
     uint64_t pool_cap;          // in u32
     unsigned long long* pool_used;
     uint32_t* scan_done;        // chunks of td_scan_tiles finished (the last one scans the chunk totals)
+    uint32_t* merge_next;       // td_merge_pieces: next tile nobody has taken yet (wavefronts draw runs of tiles)
     int64_t* chunk_pref;        // [n_tiles/4096 + 2] token base of every 4096-tile chunk (exclusive scan of the chunk totals)
     uint32_t* ctl_reset; uint32_t ctl_reset_words;  // per-call counters td_prepare clears
     int32_t* out_tokens;        // [out_cap]

@@ -1039,13 +1039,25 @@ __device__ __forceinline__ void mg_init_piece(const EncodeArgs& a, const Tables&
     for (uint32_t c = 0; c * 16u < st.len; ++c) {
         uint32_t w[5];
         load_piece_window(a, g + 16 * c, w);
+        // all sixteen byte-pair ranks first (loads only: with the LDS stores of mg_put in between, every load waited for
+        // the one before it), then the slots
+        int32_t rk[16];
+        typedef const int32_t __attribute__((address_space(1)))* gbp_t;  // (global loads, not flat ones)
+        gbp_t const bp = (gbp_t)(uintptr_t)T.byte_pair;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const uint32_t bn = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu;
+            rk[j] = bp[(b << 8) | bn];
+        }
 #pragma unroll
         for (uint32_t j = 0; j < 16; ++j) {
             const uint32_t jj = 16u * c + j;
             if (jj < st.len) {
                 const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                const uint32_t bn = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu;
-                mg_put(T, s_byteid, keys, ids, st, jj, b, bn);
+                const uint32_t sl = mg_slot(st.t, jj);
+                ids[sl] = (uint32_t)s_byteid[b];
+                keys[sl] = (jj + 1 < st.len && rk[j] != NO_RANK) ? (((uint32_t)rk[j] << 6) | jj) : MG_DEAD;  // (= mg_put)
             }
         }
     }
@@ -1089,32 +1101,56 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t* const keys = s_keys[wv];
     uint32_t* const ids = s_ids[wv];
-    uint32_t qhead[MQ_CLASSES], qcnt[MQ_CLASSES];  // (wave-uniform)
-#pragma unroll
-    for (int c = 0; c < MQ_CLASSES; ++c) { qhead[c] = 0; qcnt[c] = 0; }
+    // queue heads and fill counts, one byte per class (wave-uniform; read with a run-time class so that the batch code
+    // exists once: unrolled over the classes and inlined at both call sites the kernel was 20 000 instructions, twice the
+    // instruction cache)
+    uint64_t qheads = 0, qcnts = 0;
+    static_assert(MQ_CAP + 64 <= 255 && MQ_CLASSES <= 8, "one byte per class");
+    auto qhead_of = [&](int c) { return (uint32_t)(qheads >> (8 * c)) & 0xFFu; };
+    auto qcnt_of = [&](int c) { return (uint32_t)(qcnts >> (8 * c)) & 0xFFu; };
+    auto qset = [](uint64_t& word, int c, uint32_t v) { word = (word & ~(0xFFull << (8 * c))) | ((uint64_t)v << (8 * c)); };
 
     // one batch of class c: the first min(count, 64 / units) pieces of its queue
+#ifdef TD_MERGE_TIMING
+    unsigned long long t_init = 0, t_rounds = 0, t_out = 0, t_total0 = __builtin_readcyclecounter(), n_batches = 0, n_rounds = 0;
+#define TD_TICK(var) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_now = __builtin_readcyclecounter(); var += t_now - t_last; t_last = t_now; }
+#else
+#define TD_TICK(var)
+#endif
     auto run_batch = [&](int c) {
+#ifdef TD_MERGE_TIMING
+        unsigned long long t_last = __builtin_readcyclecounter(), t_dummy = 0;
+        ++n_batches;
+#endif
         const uint32_t u = mq_units((uint32_t)c);
-        const uint32_t np = qcnt[c] < 64u / u ? qcnt[c] : 64u / u;
+        const uint32_t qc = qcnt_of(c), qh = qhead_of(c);
+        const uint32_t np = qc < 64u / u ? qc : 64u / u;
         const uint32_t i = (uint32_t)lane / u;
         MergeState st;
         st.alive = 0; st.t = (uint32_t)lane; st.len = 0;
         unsigned long long rec = 0;
         if ((uint32_t)lane == i * u && i < np) {
-            rec = s_q[wv][c][(qhead[c] + i) & (MQ_CAP - 1)];
+            rec = s_q[wv][c][(qh + i) & (MQ_CAP - 1)];
             st.len = (uint32_t)rec & 127u;
             st.alive = st.len >= 64u ? ~0ull : ((1ull << st.len) - 1ull);
         }
-        qhead[c] = (qhead[c] + np) & (MQ_CAP - 1);
-        qcnt[c] -= np;
+        qset(qheads, c, (qh + np) & (MQ_CAP - 1));
+        qset(qcnts, c, qc - np);
         const uint32_t tile = (uint32_t)(rec >> 32), pos = ((uint32_t)rec >> 7) & 0xFFFu;
         const int64_t gpos = (int64_t)tile * K_TILE + pos;
+        TD_TICK(t_dummy)
         if (st.len) mg_init_piece(a, T, s_byteid, keys, ids, st, gpos);
+        TD_TICK(t_init)
         for (;;) {  // (pieces of at most 32 bytes: the part mask is one register)
-            const bool more = c <= 2 ? mg_round_t<uint32_t>(T, keys, ids, st) : mg_round_t<uint64_t>(T, keys, ids, st);
+            if (a.stop_after == 41) break;
+#ifdef TD_MERGE_TIMING
+            ++n_rounds;
+#endif
+            const bool more = c <= 2 ? mg_round_t<uint32_t>(T, keys, ids, st) : mg_round_t<uint64_t>(T, keys, ids, st);  // (c is uniform)
             if (!__any(more)) break;
         }
+        TD_TICK(t_rounds)
+        uint32_t extra = 0;
         if (st.len) {
             uint32_t* out = a.merge_out + (size_t)tile * K_STAGE + pos;
             uint32_t nt = 0;
@@ -1125,51 +1161,114 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
                 out[nt++] = id;
             }
             a.stage[(size_t)tile * K_STAGE + (((uint32_t)rec >> 19) & 0x1FFFu)] = TOK_MISS | (pos << 7) | nt;
-            if (nt > 1) atomicAdd(&a.tile_extra[tile], nt - 1);
+            extra = nt > 1 ? nt - 1 : 0;
+        }
+        // the tiles' extra ids: one atomic per TILE of the batch, not per piece (a batch's pieces come from one or two tiles,
+        // and 64 atomics on one address are served one after the other)
+        for (uint64_t pend = __ballot(extra != 0); pend;) {
+            const int l = td_ctz64(pend);
+            const uint32_t tl = (uint32_t)__shfl((int)tile, l);
+            const bool same = extra != 0 && tile == tl;
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(same ? extra : 0u, lane), 63);
+            if (lane == l) atomicAdd(&a.tile_extra[tl], tot);
+            pend &= ~__ballot(same);
         }
         wave_sync();  // (the batch's LDS reads are done before the next batch's writes)
+        TD_TICK(t_out)
     };
 
     const int nwaves = gridDim.x * NW;
-    for (int tile = blockIdx.x * NW + wv; tile < a.n_tiles; tile += nwaves) {
-        const uint32_t tc = a.tile_count[tile];
-        if (!(tc & TILE_HAS_MISS)) continue;  // (uniform per wavefront)
-        const uint32_t cnt = tc & TILE_COUNT_MASK;
-        const uint32_t* slots = a.stage + (size_t)tile * K_STAGE;
-        // the tile's slots, eight rows of 64 at a time (eight independent loads in flight)
-        for (uint32_t r0 = 0; r0 * 64u < cnt; r0 += 8) {
-            uint32_t v[8];
+    // Wavefronts DRAW their tiles (runs of a few consecutive ones from a counter): dealt round-robin, a corpus whose heavy
+    // stretches repeat with a period (a file set read again and again) sent them all to the same wavefronts, and the kernel
+    // lasted as long as the unluckiest one (2.8 ms for 3 workgroups per CU, 2.3 ms for 2, 3.0 ms for 1: the stride decided).
+    // The tile one past the last is a virtual one: no rows, it drains the partial batches through the same single call
+    // site of run_batch.
+    // (run length: same-address atomics are served one after the other, ~10 ns each, so wavefronts that race through tiles
+    // without missed pieces must not draw them one by one: a run that needed no batch doubles the next one (up to 32), one with batches
+    // halves it, a busy one goes back to single tiles)
+    const int run_min = (a.stop_after >= 50 && a.stop_after < 60) ? 1 << (a.stop_after - 50) : 2;  // (50..59: tuning aid)
+    int run = 4, tile = 0, run_end = 0;
+    uint32_t batches_in_run = 0, run_counts = 0;
+    int run_first = 0;
+    for (;;) {
+        if (tile >= run_end) {
+            run = batches_in_run == 0 ? (run < 32 ? run * 2 : 32) : (run / 2 > run_min ? run / 2 : run_min);
+            batches_in_run = 0;
+            uint32_t t0 = 0;
+            if (lane == 0) t0 = atomicAdd(a.merge_next, (uint32_t)run);
+            tile = (int)uni32(t0);
+            run_end = tile + run;
+            run_counts = (lane < run && tile + lane < a.n_tiles) ? a.tile_count[tile + lane] : 0u;  // the run's tile_count words: one load
+            run_first = tile;
+        }
+        const bool drain = tile >= a.n_tiles;
+        uint32_t cnt = 0;
+        if (!drain) {
+            const uint32_t tc = (uint32_t)__builtin_amdgcn_readlane((int)run_counts, tile - run_first);
+            if (!(tc & TILE_HAS_MISS)) { ++tile; continue; }  // (uniform per wavefront)
+            cnt = tc & TILE_COUNT_MASK;
+        }
+        const uint32_t* slots = a.stage + (size_t)(drain ? 0 : tile) * K_STAGE;
+        const uint32_t rows = drain ? 1u : (cnt + 63u) >> 6;
+        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rowbits = 0;
+#pragma unroll 1
+        for (uint32_t row = 0; row < rows; ++row) {
+            if (!drain) {
+                if ((row & 7u) == 0) {  // the tile's slots, eight rows of 64 at a time (eight independent loads in flight)
+                    uint32_t mm = 0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t k = (r0 + r) * 64u + lane;
-                v[r] = k < cnt ? slots[k] : 0u;
-            }
+                    for (int r = 0; r < 8; ++r) {
+                        const uint32_t k = (row + r) * 64u + lane;
+                        v[r] = k < cnt ? slots[k] : 0u;
+                    }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const bool miss = (v[r] & 0xC0000000u) == TOK_MISS;
-                if (!__any(miss)) continue;
-                const uint32_t cls = mq_class(v[r] & 127u);
-                const unsigned long long rec = ((unsigned long long)(uint32_t)tile << 32) | ((((r0 + r) * 64u + lane) & 0x1FFFu) << 19) | (v[r] & 0x7FFFFu);
+                    for (int r = 0; r < 8; ++r) mm |= ((v[r] & 0xC0000000u) == TOK_MISS ? 1u : 0u) << r;
+                    rowbits = 0;  // (uniform) rows of the group that hold a missed piece
+                    if (__ballot(mm != 0)) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) rowbits |= (__ballot((mm >> r) & 1u) ? 1u : 0u) << r;
+                    }
+                }
+                const uint32_t rr = row & 7u;
+                if (!((rowbits >> rr) & 1u)) {
+                    if (!(rowbits >> rr)) row |= 7u;  // nothing in the rest of the group either
+                    continue;
+                }
+                const uint32_t vr = rr < 4 ? (rr < 2 ? (rr == 0 ? v[0] : v[1]) : (rr == 2 ? v[2] : v[3]))
+                                           : (rr < 6 ? (rr == 4 ? v[4] : v[5]) : (rr == 6 ? v[6] : v[7]));
+                const bool miss = (vr & 0xC0000000u) == TOK_MISS;
+                const uint32_t cls = mq_class(vr & 127u);
+                const unsigned long long rec = ((unsigned long long)(uint32_t)tile << 32) | (((row * 64u + lane) & 0x1FFFu) << 19) | (vr & 0x7FFFFu);
 #pragma unroll
                 for (int c = 0; c < MQ_CLASSES; ++c) {
                     const uint64_t b = __ballot(miss && cls == (uint32_t)c);
                     if (b) {
+                        const uint32_t qc = qcnt_of(c);
                         if (miss && cls == (uint32_t)c)
-                            s_q[wv][c][(qhead[c] + qcnt[c] + (uint32_t)__popcll((unsigned long long)(b & lt))) & (MQ_CAP - 1)] = rec;
-                        qcnt[c] += (uint32_t)__popcll((unsigned long long)b);
+                            s_q[wv][c][(qhead_of(c) + qc + (uint32_t)__popcll((unsigned long long)(b & lt))) & (MQ_CAP - 1)] = rec;
+                        qset(qcnts, c, qc + (uint32_t)__popcll((unsigned long long)b));
                     }
                 }
                 wave_sync();
+            }
+            for (;;) {  // full batches (when draining: whatever is left), the classes in turn
+                int c = -1;
 #pragma unroll
-                for (int c = 0; c < MQ_CLASSES; ++c)
-                    while (qcnt[c] >= 64u / mq_units((uint32_t)c)) run_batch(c);
+                for (int q = MQ_CLASSES - 1; q >= 0; --q)
+                    if (drain ? qcnt_of(q) != 0u : qcnt_of(q) >= 64u / mq_units((uint32_t)q)) c = q;
+                if (c < 0) break;
+                run_batch(c);
+                ++batches_in_run;
             }
         }
+        if (drain) break;
+        ++tile;
     }
-    // what is left: partial batches
-#pragma unroll
-    for (int c = 0; c < MQ_CLASSES; ++c)
-        while (qcnt[c]) run_batch(c);
+#ifdef TD_MERGE_TIMING
+    if (lane == 0 && (blockIdx.x % 97) == 0 && wv == 0)
+        printf("merge wave b%d: total %llu init %llu rounds %llu out %llu cycles, %llu batches %llu rounds\n", (int)blockIdx.x,
+               (unsigned long long)(__builtin_readcyclecounter() - t_total0), t_init, t_rounds, t_out, n_batches, n_rounds);
+#endif
 }
 
 // ------------------------------------------------------------------ td_long_pieces ----------
@@ -2016,8 +2115,10 @@ static int resident_blocks(const void* fn, int fallback_per_cu) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K_THREADS, 0) == hipSuccess && per_cu > 0)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K_THREADS, 0) == hipSuccess && per_cu > 0) {
+        if (getenv("TD_DEBUG_GRID")) fprintf(stderr, "[tokendagger] persistent grid: %d CUs x %d workgroups\n", prop.multiProcessorCount, per_cu);
         return prop.multiProcessorCount * per_cu;
+    }
     return 256 * fallback_per_cu;
 }
 int encode_grid_blocks() {
@@ -2028,6 +2129,8 @@ int encode_grid_blocks() {
 }
 int merge_grid_blocks() {
     if (!g_blocks_merge) g_blocks_merge = resident_blocks((const void*)td_merge_pieces, 3);
+    const char* e = getenv("TD_MERGE_BLOCKS_PER_CU");
+    if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_merge;
 }
 static int split_grid_blocks() {
