@@ -54,6 +54,8 @@ struct WAcc {  // one tile window
     uint32_t byte(int i) const { return txt[i]; }
     void mark(int i) { cls[i] |= F_START; }
     void set_ext(int i, int64_t ge) { ext_start = i; ext_end = ge; }
+    int n_far = 0, last_far = -1;
+    void note_far(int i) { ++n_far; last_far = i; }
 };
 
 void classify_all(const Tables& T, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs,
@@ -209,6 +211,7 @@ int twin_split_tiled(void* h, const uint8_t* text, int64_t n, const int64_t* off
         for (int hd : heads) scan_chain(w, g, hd, tile_hi, wg0, T.pat_flags);
         for (int i = K_HL; i < tile_hi; ++i)
             if (wcls[i] & F_START) flags[wg0 + i] = 1;
+        if (stats && w.n_far) { stats[2] += w.n_far; stats[5] = wg0 + w.last_far; }
         if (w.ext_start >= 0) {
             if (stats) stats[0]++;
             if (ext_ends) ext_ends[wg0 + w.ext_start] = w.ext_end;

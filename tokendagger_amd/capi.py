@@ -19,7 +19,7 @@ TD_E_CAPACITY = 5
 TD_MODE_ENCODE = 0
 TD_MODE_ORDINARY = 1
 TD_INFO_N_PAIRS, TD_INFO_MERGE_CLOSED, TD_INFO_MAX_ID, TD_INFO_TILE_BYTES = 1, 2, 3, 4
-TD_INFO_WORKSPACE_BYTES, TD_INFO_N_SPECIAL, TD_INFO_LONG_PIECES = 5, 6, 7
+TD_INFO_WORKSPACE_BYTES, TD_INFO_N_SPECIAL, TD_INFO_LONG_PIECES, TD_INFO_FAR_PIECES = 5, 6, 7, 8
 TD_OPT_LONG_POOL_BYTES = 1
 TD_OPT_PROFILE = 2
 TD_OPT_PIPE_CHUNK_BYTES = 3

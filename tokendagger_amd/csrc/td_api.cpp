@@ -146,7 +146,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, tile_mfill, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -154,7 +154,7 @@ struct td_tokenizer {
     int stop_after = 0;
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
     std::vector<Ev3> ev_pending, ev_free;
-    int64_t last_long = 0;
+    int64_t last_long = 0, last_far = 0;
     size_t ws_bytes = 0;
     // One workspace per handle: work of this handle may be in flight on one stream at a time.  A call on another
     // stream first waits (on the device, not the host) for the previous call's last kernel.
@@ -262,6 +262,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->stage2, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;  // ids of merged pieces
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->tile_mfill, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
     if ((rc = ensure(t, t->doc_slot, (size_t)(n_docs + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_first_doc, (size_t)(n_tiles + 1) * 4))) return rc;
@@ -305,6 +306,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.merge_out = (uint32_t*)t->stage2.p;
     a.tile_count = (uint32_t*)t->tile_count.p;
     a.tile_extra = (uint32_t*)t->tile_extra.p;
+    a.tile_mfill = (uint32_t*)t->tile_mfill.p;
     a.tile_base = (int64_t*)t->tile_base.p;
     a.doc_slot = (uint32_t*)t->doc_slot.p;
     a.tile_first_doc = (uint32_t*)t->tile_first_doc.p;
@@ -351,6 +353,7 @@ int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) 
     Ctl c;
     HIP_TRY(t, hipMemcpy(&c, t->ctl.p, sizeof c, hipMemcpyDeviceToHost));
     t->last_long = c.long_count;
+    t->last_far = c.slow_count;
     if (err_pos) *err_pos = c.err_pos;
     if (c.err != 0) {
         HIP_TRY(t, hipMemset(t->ctl.p, 0, sizeof(Ctl)));
@@ -470,7 +473,7 @@ void td_destroy(td_tokenizer* t) {
         for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h}) if (st) (void)hipStreamDestroy(st);
         if (t->small_in) (void)hipHostFree(t->small_in);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->tile_mfill, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)
@@ -1202,6 +1205,7 @@ int64_t td_info(const td_tokenizer* t, int what) {
         case TD_INFO_WORKSPACE_BYTES: return (int64_t)t->ws_bytes;
         case TD_INFO_N_SPECIAL: return (int64_t)t->H.special_ids.size();
         case TD_INFO_LONG_PIECES: return t->last_long;
+        case TD_INFO_FAR_PIECES: return t->last_far;
     }
     return -1;
 }

@@ -1178,6 +1178,7 @@ TD_HD void scan_chain(W& w, const G& g, int head, int tile_hi, int64_t wg0, uint
     for (;;) {
         int e = scan_piece(w, p, pv);
         if (e < 0) {
+            w.note_far(p);  // (the device hands this piece start to td_split_far_pieces)
             const int64_t ge = g.scan(wg0 + p);
             if (ge - wg0 > (int64_t)K_LIM) {  // piece leaves the window: one per tile at most
                 if (p >= K_HL) w.set_ext(p, ge);

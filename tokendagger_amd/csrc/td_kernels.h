@@ -32,6 +32,7 @@ struct EncodeArgs {
     uint32_t* merge_out;        // [n_tiles*K_STAGE] ids of the merged pieces, at tile * K_STAGE + the piece's tile position (td_merge_pieces)
     uint32_t* tile_count;       // [n_tiles] slots in the tile | TILE_HAS_LONG | TILE_HAS_MISS
     uint32_t* tile_extra;       // [n_tiles] sum(ntok-1) over the tile's long pieces
+    uint32_t* tile_mfill;       // [n_tiles] ids of merged pieces written to the tile's region of merge_out so far (td_merge_pieces fills it densely)
     int64_t* tile_base;         // [n_tiles+1] exclusive scan of count+extra
     uint32_t* doc_slot;         // [n_docs] slot index (inside its tile) of each document's first token
     uint32_t* tile_first_doc;   // [n_tiles] index of the first document starting in the tile (0xFFFFFFFF: none)

@@ -162,6 +162,7 @@ __global__ void td_prepare(const EncodeArgs a) {
     for (int64_t i = gid; i < (words + 3) / 4; i += gsz) d4[i] = make_uint4(0, 0, 0, 0);
     for (int64_t i = gid; i <= a.n_tiles; i += gsz) {
         a.tile_extra[i] = 0;
+        a.tile_mfill[i] = 0;
         a.tile_first_doc[i] = 0xFFFFFFFFu;
     }
     for (int64_t i = gid; i <= a.n_stiles; i += gsz) {
@@ -744,7 +745,15 @@ __global__ __launch_bounds__(256) void td_split_far_pieces(const EncodeArgs a) {
     const FarScan F{a, T, lane};
     for (uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); j < nitems; j += nwaves) {
         const int64_t g = a.slow_list[j];  // a piece start the fast kernel marked; its end was beyond the window
+#ifdef TD_FAR_DEBUG
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        const int64_t pe = F.piece_end(g);
+        const unsigned long long t1 = __builtin_readcyclecounter();
+#endif
         const int64_t p = F.mark_to_tile_end(g, true);
+#ifdef TD_FAR_DEBUG
+        if (lane == 0) printf("far piece at %lld (tile %lld + %lld): ends %lld, walked to %lld; piece_end %llu ticks, all %llu ticks\n", (long long)g, (long long)(g / KS_TILE), (long long)(g % KS_TILE), (long long)pe, (long long)p, t1 - t0, (unsigned long long)__builtin_readcyclecounter() - t0);
+#endif
         if (p >= 0) F.carry_to(g / KS_TILE, p);
     }
 }
@@ -1076,8 +1085,8 @@ __device__ __forceinline__ void wave_sync() {
 // TOK_MISS slots into five LDS queues by length class (<= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units), and whenever a
 // queue holds a full batch (64 / units pieces, whatever tiles they come from) merges it: one piece per owner lane, the
 // rounds of a batch run until its longest chain is done — pieces of one class need about the same number of rounds.
-// A merged piece's ids go to its own bytes' slots of the result buffer (a.merge_out[tile * K_STAGE + tile position + i]:
-// pieces do not overlap and a piece has at most as many ids as bytes), its slot becomes TOK_MISS | position << 7 | ids and
+// A merged piece's ids go to the tile's region of the result buffer, which fills densely (a.merge_out[tile * K_STAGE + ...]: a
+// tile's merged pieces have at most as many ids as the tile has bytes), its slot becomes TOK_MISS | offset there << 7 | ids and
 // the tile's extra ids are added to tile_extra; td_pack_tokens expands the markers.
 constexpr int MQ_CLASSES = 5;
 constexpr int MQ_CAP = 128;  // queue capacity per class: a full batch + one row of slots
@@ -1150,34 +1159,43 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
             if (!__any(more)) break;
         }
         TD_TICK(t_rounds)
-        uint32_t extra = 0;
+        // A tile's merged ids fill its region of merge_out DENSELY, in the order the batches get to them (at the pieces' own
+        // byte positions they were 4-byte islands in a gigabyte, and td_pack_tokens fetched a cache line for each): one
+        // atomic per TILE of the batch hands out the room (a batch's pieces come from one or two tiles, and 64 atomics on
+        // one address are served one after the other); the same loop adds the tile's extra ids.
+        const uint32_t nt = st.len ? (uint32_t)__popcll((unsigned long long)st.alive) : 0u;
+        uint32_t dense = 0;
+        for (uint64_t pend = __ballot(nt != 0); pend;) {
+            const int l = td_ctz64(pend);
+            const uint32_t tl = (uint32_t)__shfl((int)tile, l);
+            const bool same = nt != 0 && tile == tl;
+            const uint32_t incl = wave_incl_scan(same ? nt : 0u, lane);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t npc = (uint32_t)__popcll((unsigned long long)__ballot(same));
+            uint32_t room = 0;
+            if (lane == l) {
+                room = atomicAdd(&a.tile_mfill[tl], tot);
+                if (tot > npc) atomicAdd(&a.tile_extra[tl], tot - npc);
+            }
+            room = (uint32_t)__shfl((int)room, l);
+            if (same) dense = room + incl - nt;
+            pend &= ~__ballot(same);
+        }
         if (st.len) {
-            uint32_t* out = a.merge_out + (size_t)tile * K_STAGE + pos;
-            uint32_t nt = 0;
+            uint32_t* out = a.merge_out + (size_t)tile * K_STAGE + dense;
+            uint32_t k = 0;
             for (uint64_t al = st.alive; al; al &= al - 1ull) {
                 const uint32_t j = (uint32_t)td_ctz64(al);
                 const uint32_t id = ids[mg_slot(st.t, j)];
                 if ((int32_t)id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gpos + j);
-                out[nt++] = id;
+                out[k++] = id;
             }
-            a.stage[(size_t)tile * K_STAGE + (((uint32_t)rec >> 19) & 0x1FFFu)] = TOK_MISS | (pos << 7) | nt;
-            extra = nt > 1 ? nt - 1 : 0;
-        }
-        // the tiles' extra ids: one atomic per TILE of the batch, not per piece (a batch's pieces come from one or two tiles,
-        // and 64 atomics on one address are served one after the other)
-        for (uint64_t pend = __ballot(extra != 0); pend;) {
-            const int l = td_ctz64(pend);
-            const uint32_t tl = (uint32_t)__shfl((int)tile, l);
-            const bool same = extra != 0 && tile == tl;
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(same ? extra : 0u, lane), 63);
-            if (lane == l) atomicAdd(&a.tile_extra[tl], tot);
-            pend &= ~__ballot(same);
+            a.stage[(size_t)tile * K_STAGE + (((uint32_t)rec >> 19) & 0x1FFFu)] = TOK_MISS | (dense << 7) | nt;
         }
         wave_sync();  // (the batch's LDS reads are done before the next batch's writes)
         TD_TICK(t_out)
     };
 
-    const int nwaves = gridDim.x * NW;
     // Wavefronts DRAW their tiles (runs of a few consecutive ones from a counter): dealt round-robin, a corpus whose heavy
     // stretches repeat with a period (a file set read again and again) sent them all to the same wavefronts, and the kernel
     // lasted as long as the unluckiest one (2.8 ms for 3 workgroups per CU, 2.3 ms for 2, 3.0 ms for 1: the stride decided).
@@ -1792,46 +1810,109 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
 // KB: many small independent copies in flight beat few large ones), no workgroup barrier, no LDS.
 //   plain tiles (every slot is an id): 16-byte copies;
 //   tiles with markers: a sweep over rows of 64 slots with a running id count: a slot's size is 1, the ids of a merged
-//   piece (TOK_MISS | position | ids, from a.merge_out) or of a long piece (TOK_LONGREF, from the pool; copied by the whole
+//   piece (TOK_MISS | offset | ids, from a.merge_out) or of a long piece (TOK_LONGREF, from the pool; copied by the whole
 //   wavefront); the documents that start in the tile pick their offset out of the row scan their slot falls in.
 // (A workgroup-per-tile version of the marker path with the tile's offsets in LDS cost 14-17 us per tile: five barriers
 // and six dependent global loads in a row; plain English has a marker in every third tile.)
+constexpr int PK_G = 8;       // rows of 64 slots per group of the marker path
+constexpr int PK_ECAP = 256;  // merged pieces the expansion list holds
 __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
+    __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];  // dst offset << 32 | offset in the tile's merged ids << 7 | ids
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef TD_PACK_TIMING
+    unsigned long long t_meta = 0, t_rows = 0, t_scan = 0, t_plain = 0, t_list = 0, t_flush = 0, t_docs = 0, t_plainpath = 0, n_mt = 0, n_pt = 0, n_fl = 0;
+    unsigned long long t_last = __builtin_readcyclecounter(), t_total0 = t_last;
+#define PK_TICK(var) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_now = __builtin_readcyclecounter(); var += t_now - t_last; t_last = t_now; }
+#else
+#define PK_TICK(var)
+#endif
     const int64_t total = a.tile_base[a.n_tiles];
     const int nwaves = gridDim.x * (K_THREADS / 64);
     auto base_of = [&](int tile) { return a.tile_base[tile] + a.chunk_pref[tile / K_SCAN_CHUNK]; };
     for (int tile = blockIdx.x * (K_THREADS / 64) + wv; tile < a.n_tiles; tile += nwaves) {
+        // everything that depends on the tile index only goes out together (one round trip, not four in a row)
         const uint32_t tc = a.tile_count[tile];
-        const uint32_t cnt = tc & TILE_COUNT_MASK;
         const int64_t base = base_of(tile);
+        const int64_t dfirst = (int64_t)a.tile_first_doc[tile];
+        const uint32_t cnt = tc & TILE_COUNT_MASK;
         const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
         const int64_t g_lo = (int64_t)tile * K_TILE;
         const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
-        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS))) {
+        PK_TICK(t_meta)
+        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS)) || a.stop_after == 60) {  // (60: tuning aid, every tile down the plain path)
+            // the first 64 documents of the tile (nearly always all of them): offsets and slots are loaded with the ids
+            const int64_t dm = dfirst + lane;
+            int64_t dpos = a.n;
+            uint32_t dsl = 0;
+            if (dm < a.n_docs) { dpos = a.doc_offsets[dm]; dsl = a.doc_slot[dm]; }
             if (base + cnt <= a.out_cap) {
                 // 16-byte stores to the (arbitrarily placed) destination: single ids up to its next 16-byte boundary, then
-                // four ids per lane (the staging side is read with dword-aligned 16-byte loads)
+                // four ids per lane (the staging side is read with dword-aligned 16-byte loads); all loads of up to 1024 ids
+                // first, then the stores
                 int32_t* dst = a.out_tokens + base;
                 uint32_t head = (uint32_t)((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2;
                 if (head > cnt) head = cnt;
-                if ((uint32_t)lane < head) dst[lane] = (int32_t)src[lane];
                 const uint32_t nv = (cnt - head) >> 2;
-                for (uint32_t v = lane; v < nv; v += 64) {
-                    uint4 x;
-                    __builtin_memcpy(&x, src + head + 4 * v, 16);
-                    *reinterpret_cast<uint4*>(dst + head + 4 * v) = x;
-                }
                 const uint32_t done = head + 4 * nv;
-                if (done + (uint32_t)lane < cnt) dst[done + lane] = (int32_t)src[done + lane];
+                uint32_t h0 = 0, tl = 0;
+                if ((uint32_t)lane < head) h0 = src[lane];
+                if (done + (uint32_t)lane < cnt) tl = src[done + lane];
+                for (uint32_t v0 = 0; v0 < nv; v0 += 256) {
+                    uint4 x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t v = v0 + q * 64 + lane;
+                        if (v < nv) __builtin_memcpy(&x[q], src + head + 4 * v, 16);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t v = v0 + q * 64 + lane;
+                        if (v < nv) *reinterpret_cast<uint4*>(dst + head + 4 * v) = x[q];
+                    }
+                }
+                if ((uint32_t)lane < head) dst[lane] = (int32_t)h0;
+                if (done + (uint32_t)lane < cnt) dst[done + lane] = (int32_t)tl;
             }
-            for (int64_t d = (int64_t)a.tile_first_doc[tile] + lane; d < a.n_docs; d += 64) {
-                if (a.doc_offsets[d] >= g_hi) break;
-                a.out_offsets[d] = base + a.doc_slot[d];
+            if (dpos < g_hi) a.out_offsets[dm] = base + dsl;
+            if (__all(dpos < g_hi)) {  // more than 64 documents start in this tile
+                for (int64_t d = dfirst + 64 + lane; d < a.n_docs; d += 64) {
+                    if (a.doc_offsets[d] >= g_hi) break;
+                    a.out_offsets[d] = base + a.doc_slot[d];
+                }
             }
         } else {
+            // Tiles with markers, PK_G rows of 64 slots at a time.  On this hardware loads and stores share one in-order
+            // counter, so a wait for a load also waits for every store issued before it: a row-by-row sweep (load the
+            // merged ids of the row's pieces, store them, next row) paid a full store round trip per row.  Here a group's
+            // loads all come first (its slots, the sizes of its long pieces), then the offsets (scans, no memory), then all
+            // its plain ids are stored; the merged pieces only go on a list in LDS (destination, position, ids) that is
+            // worked off one piece per lane, four ids per round trip, when it fills up or the tile ends.
+            unsigned long long* const elist = s_elist[wv];
+            uint32_t ecount = 0;  // (uniform) pieces on the list
+            const uint64_t lt = (1ull << lane) - 1ull;
+            auto flush = [&]() {
+                PK_TICK(t_list)
+                wave_sync();
+                for (uint32_t c0 = 0; c0 < ecount; c0 += 64) {
+                    const unsigned long long e = c0 + lane < ecount ? elist[c0 + lane] : 0ull;
+                    const uint32_t n = (uint32_t)e & 127u;
+                    const uint32_t* ps = a.merge_out + (size_t)tile * K_STAGE + (((uint32_t)e >> 7) & 0x1FFFu);
+                    const int64_t o = base + (int64_t)(uint32_t)(e >> 32);
+                    for (uint32_t j = 0; __any(j < n); j += 4) {
+                        uint32_t t[4];
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; ++q) t[q] = j + q < n ? ps[j + q] : 0u;
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; ++q)
+                            if (j + q < n && o + j + q < a.out_cap) a.out_tokens[o + j + q] = (int32_t)t[q];
+                    }
+                }
+                ecount = 0;
+                wave_sync();
+                PK_TICK(t_flush)
+            };
             // the documents that start in this tile, 64 at a time, in slot order (they are consecutive from the tile's first one)
-            int64_t dnext = (int64_t)a.tile_first_doc[tile], dmine = 0;
+            int64_t dnext = dfirst, dmine = 0;
             uint32_t dslot = 0xFFFFFFFFu;
             bool dfull = false;
             auto load_docs = [&]() {
@@ -1843,61 +1924,101 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
             };
             load_docs();
             uint32_t carry = 0;  // ids of the rows above
-            for (uint32_t r0 = 0; r0 * 64u < cnt; r0 += 4) {
-                uint32_t v4[4];
+            for (uint32_t r0 = 0; r0 * 64u < cnt; r0 += PK_G) {
+                uint32_t v[PK_G], sz[PK_G], off[PK_G];
+                uint32_t lmask = 0, mmask = 0;  // bit q: my slot of row r0 + q is a long piece / a merged piece
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < PK_G; ++q) {
                     const uint32_t k = (r0 + q) * 64u + lane;
-                    v4[q] = k < cnt ? src[k] : 0u;
+                    v[q] = k < cnt ? src[k] : 0u;
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t r = r0 + q;
-                    if (r * 64u >= cnt) break;
-                    const uint32_t k = r * 64u + lane, v = v4[q];
-                    const bool is_long = (v & TOK_LONGREF) != 0, is_miss = !is_long && (v & TOK_MISS);
-                    LongEntry le;
-                    le.ntok = 0; le.pool_off = 0;
-                    if (is_long) le = a.long_list[v & 0x7FFFFFFFu];
-                    const uint32_t sz = k < cnt ? (is_long ? le.ntok : is_miss ? (v & 127u) : 1u) : 0u;
-                    const uint32_t incl = __any(is_long || is_miss) ? wave_incl_scan(sz, lane)
-                                                                    : ((cnt - r * 64u < 64u && k >= cnt) ? cnt - r * 64u : (uint32_t)lane + 1u);  // a row of plain ids
-                    const uint32_t off = carry + incl - sz;  // ids of this tile in front of my slot
-                    const int64_t o = base + off;
-                    if (k < cnt) {
-                        if (is_miss) {  // a merged piece: its ids sit at its own bytes' slots of the result buffer
-                            const uint32_t* ps = a.merge_out + (size_t)tile * K_STAGE + ((v >> 7) & 0xFFFu);
-                            for (uint32_t j = 0; j < sz; ++j)
-                                if (o + j < a.out_cap) a.out_tokens[o + j] = (int32_t)ps[j];
-                        } else if (!is_long && o < a.out_cap) {
-                            a.out_tokens[o] = (int32_t)v;
+                for (int q = 0; q < PK_G; ++q) {
+                    const uint32_t k = (r0 + q) * 64u + lane;
+                    const bool is_long = k < cnt && (v[q] & TOK_LONGREF) != 0, is_miss = k < cnt && !is_long && (v[q] & TOK_MISS);
+                    lmask |= (is_long ? 1u : 0u) << q;
+                    mmask |= (is_miss ? 1u : 0u) << q;
+                    sz[q] = k < cnt ? (is_miss ? (v[q] & 127u) : 1u) : 0u;
+                }
+                PK_TICK(t_rows)
+                const bool anylong = __any(lmask != 0);
+                if (anylong) {
+#pragma unroll
+                    for (int q = 0; q < PK_G; ++q)
+                        if ((lmask >> q) & 1u) sz[q] = a.long_list[v[q] & 0x7FFFFFFFu].ntok;
+                }
+#pragma unroll
+                for (int q = 0; q < PK_G; ++q) {
+                    const uint32_t r = r0 + q, k = r * 64u + lane;
+                    const uint32_t incl = __any(((lmask | mmask) >> q) & 1u) ? wave_incl_scan(sz[q], lane)
+                                        : ((r * 64u < cnt && cnt - r * 64u < 64u && k >= cnt) ? cnt - r * 64u : (r * 64u < cnt ? (uint32_t)lane + 1u : 0u));  // a row of plain ids
+                    off[q] = carry + incl - sz[q];  // ids of this tile in front of my slot
+                    carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+                PK_TICK(t_scan)
+#pragma unroll
+                for (int q = 0; q < PK_G; ++q) {  // plain ids
+                    const uint32_t k = (r0 + q) * 64u + lane;
+                    const int64_t o = base + off[q];
+                    if (k < cnt && !(((lmask | mmask) >> q) & 1u) && o < a.out_cap) a.out_tokens[o] = (int32_t)v[q];
+                }
+                PK_TICK(t_plain)
+#pragma unroll
+                for (int q = 0; q < PK_G; ++q) {  // merged pieces: on the list
+                    const bool m = (mmask >> q) & 1u;
+                    const uint64_t bm = __ballot(m);
+                    if (bm) {
+                        if (m) elist[ecount + (uint32_t)__popcll((unsigned long long)(bm & lt))] = ((unsigned long long)off[q] << 32) | (v[q] & 0xFFFFFu);
+                        ecount += (uint32_t)__popcll((unsigned long long)bm);
+                        if (ecount > (uint32_t)PK_ECAP - 64u) flush();
+                    }
+                }
+                if (anylong) {  // long pieces: the whole wavefront copies
+#pragma unroll
+                    for (int q = 0; q < PK_G; ++q) {
+                        for (uint64_t lb = __ballot((lmask >> q) & 1u); lb; lb &= lb - 1ull) {
+                            const int l = (int)td_ctz64(lb);
+                            const LongEntry le = a.long_list[(uint32_t)__shfl((int)v[q], l) & 0x7FFFFFFFu];
+                            const int64_t lo = base + (int64_t)(uint32_t)__shfl((int)off[q], l);
+                            const uint32_t* ps = a.pool + le.pool_off;
+                            for (uint32_t j = lane; j < le.ntok; j += 64)
+                                if (lo + j < a.out_cap) a.out_tokens[lo + j] = (int32_t)ps[j];
                         }
                     }
-                    for (uint64_t lb = __ballot(is_long && k < cnt); lb; lb &= lb - 1ull) {  // long pieces: the whole wavefront copies
-                        const int l = (int)td_ctz64(lb);
-                        const uint32_t n = __shfl(sz, l);
-                        const int64_t lo = base + (int64_t)__shfl(off, l);
-                        const uint64_t po = ((uint64_t)__shfl((uint32_t)(le.pool_off >> 32), l) << 32) | __shfl((uint32_t)le.pool_off, l);
-                        const uint32_t* ps = a.pool + po;
-                        for (uint32_t j = lane; j < n; j += 64)
-                            if (lo + j < a.out_cap) a.out_tokens[lo + j] = (int32_t)ps[j];
-                    }
-                    for (;;) {  // documents whose first slot lies in this row
-                        const uint32_t pref = __shfl(off, dslot & 63u);
-                        if (dslot != 0xFFFFFFFFu && (dslot >> 6) == r) a.out_offsets[dmine] = base + pref;
-                        const uint32_t last = __shfl(dslot, 63);
-                        if (dfull && (last >> 6) <= r) { load_docs(); continue; }  // all 64 used up: the next ones may start in this row too
-                        break;
-                    }
-                    carry += __shfl(incl, 63);
                 }
+                PK_TICK(t_list)
+                for (;;) {  // documents whose first slot lies in this group of rows
+                    uint32_t pref = 0;
+#pragma unroll
+                    for (int q = 0; q < PK_G; ++q) {
+                        const uint32_t pq = (uint32_t)__shfl((int)off[q], (int)(dslot & 63u));
+                        if ((dslot >> 6) == r0 + (uint32_t)q) pref = pq;
+                    }
+                    if (dslot != 0xFFFFFFFFu && (dslot >> 6) >= r0 && (dslot >> 6) < r0 + (uint32_t)PK_G) a.out_offsets[dmine] = base + pref;
+                    const uint32_t last = (uint32_t)__shfl((int)dslot, 63);
+                    if (dfull && (last >> 6) < r0 + (uint32_t)PK_G) { load_docs(); continue; }  // all 64 used up: the next ones may start in this group too
+                    break;
+                }
+                PK_TICK(t_docs)
             }
+            flush();
+#ifdef TD_PACK_TIMING
+            ++n_mt;
+#endif
         }
+#ifdef TD_PACK_TIMING
+        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS))) { PK_TICK(t_plainpath) ++n_pt; }
+#endif
         if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
             const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
             for (int64_t d = d_end + lane; d <= a.n_docs; d += 64) a.out_offsets[d] = total;
         }
     }
+#ifdef TD_PACK_TIMING
+    if (lane == 0 && (blockIdx.x % 257) == 0 && wv == 0)
+        printf("pack wave b%d: total %llu meta %llu plainpath %llu (%llu tiles) | marker tiles %llu: rows %llu scan %llu plain %llu list %llu flush %llu docs %llu\n", (int)blockIdx.x,
+               (unsigned long long)(__builtin_readcyclecounter() - t_total0), t_meta, t_plainpath, n_pt, n_mt, t_rows, t_scan, t_plain, t_list, t_flush, t_docs);
+#endif
 }
 
 // ------------------------------------------------------------------ td_small_encode ---------

@@ -12,6 +12,7 @@ name, pat, ranks, special = vocab_io.load_tdv(vocab_io.default_vocab_path())
 tok = capi.HipTokenizer(pat, ranks, special, device=0)
 n = mb << 20
 x, offs = bench.build_corpus(kind, n, 1000)
+n = len(x)  # (the file set is tiled whole: shorter than asked for)
 nd = len(offs) - 1
 dt = torch.from_numpy(x).cuda(); do = torch.from_numpy(offs).cuda()
 cap = n // 2 + 1024 if kind == 'english' else n
