@@ -75,10 +75,12 @@ void classify_all(const Tables& T, const uint8_t* text, int64_t n, const int64_t
 }  // namespace
 
 static int64_t g_fast_total = 0, g_fast_hit = 0;
+static int64_t g_mg_len[17] = {0};
 static int64_t g_mg_pieces[5] = {0, 0, 0, 0, 0}, g_mg_rounds[5] = {0, 0, 0, 0, 0};  // merged pieces / merge rounds by length class
 
 extern "C" {
 
+void twin_merge_lens(int64_t* out17) { for (int i = 0; i < 17; ++i) { out17[i] = g_mg_len[i]; g_mg_len[i] = 0; } }
 void twin_merge_stats(int64_t* out10) {
     for (int c = 0; c < 5; ++c) { out10[c] = g_mg_pieces[c]; out10[5 + c] = g_mg_rounds[c]; g_mg_pieces[c] = g_mg_rounds[c] = 0; }
 }
@@ -297,7 +299,7 @@ int64_t twin_encode(void* h, const uint8_t* text, int64_t n, const int64_t* offs
                 uint32_t rounds = 0;
                 if (len <= 32) { while (mg_round_t<uint32_t>(T, keys, ids, st)) ++rounds; }  // (as td_merge_pieces picks the mask width)
                 else { while (mg_round_t<uint64_t>(T, keys, ids, st)) ++rounds; }
-                { const int c = len <= 8 ? 0 : len <= 16 ? 1 : len <= 32 ? 2 : len <= 48 ? 3 : 4; g_mg_pieces[c]++; g_mg_rounds[c] += rounds; }
+                { const int c = len <= 8 ? 0 : len <= 16 ? 1 : len <= 32 ? 2 : len <= 48 ? 3 : 4; g_mg_pieces[c]++; g_mg_rounds[c] += rounds; g_mg_len[len < 16 ? len : 16]++; }
                 for (uint64_t al = st.alive; al; al &= al - 1) {
                     const uint32_t v = ids[mg_slot(st.t, (uint32_t)td_ctz64(al))];
                     if ((int32_t)v >= T.pseudo_base) return -TD_E_UNKNOWN_BYTE;

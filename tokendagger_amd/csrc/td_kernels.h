@@ -32,7 +32,6 @@ struct EncodeArgs {
     uint32_t* merge_out;        // [n_tiles*K_STAGE] ids of the merged pieces, at tile * K_STAGE + the piece's tile position (td_merge_pieces)
     uint32_t* tile_count;       // [n_tiles] slots in the tile | TILE_HAS_LONG | TILE_HAS_MISS
     uint32_t* tile_extra;       // [n_tiles] sum(ntok-1) over the tile's long pieces
-    uint32_t* tile_mfill;       // [n_tiles] ids of merged pieces written to the tile's region of merge_out so far (td_merge_pieces fills it densely)
     int64_t* tile_base;         // [n_tiles+1] exclusive scan of count+extra
     uint32_t* doc_slot;         // [n_docs] slot index (inside its tile) of each document's first token
     uint32_t* tile_first_doc;   // [n_tiles] index of the first document starting in the tile (0xFFFFFFFF: none)
@@ -44,6 +43,11 @@ struct EncodeArgs {
     unsigned long long* pool_used;
     uint32_t* scan_done;        // chunks of td_scan_tiles finished (the last one scans the chunk totals)
     uint32_t* merge_next;       // td_merge_pieces: next tile nobody has taken yet (wavefronts draw runs of tiles)
+    unsigned long long* miss_list;  // missed pieces of tiles that have only a few (tile << 32 | slot << 19 | tile position << 7 | length),
+                                    // one list per length class, miss_cap entries apart
+    uint32_t* miss_count;       // [K_MISS_CLASSES] entries on them
+    uint32_t miss_cap;          // (room for K_MISS_LISTED_MAX per tile on every list)
+    uint32_t* any_flagged;      // set by td_probe_tiles when it flags a tile TILE_HAS_MISS
     int64_t* chunk_pref;        // [n_tiles/4096 + 2] token base of every 4096-tile chunk (exclusive scan of the chunk totals)
     uint32_t* ctl_reset; uint32_t ctl_reset_words;  // per-call counters td_prepare clears
     int32_t* out_tokens;        // [out_cap]

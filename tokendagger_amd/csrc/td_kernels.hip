@@ -162,7 +162,6 @@ __global__ void td_prepare(const EncodeArgs a) {
     for (int64_t i = gid; i < (words + 3) / 4; i += gsz) d4[i] = make_uint4(0, 0, 0, 0);
     for (int64_t i = gid; i <= a.n_tiles; i += gsz) {
         a.tile_extra[i] = 0;
-        a.tile_mfill[i] = 0;
         a.tile_first_doc[i] = 0xFFFFFFFFu;
     }
     for (int64_t i = gid; i <= a.n_stiles; i += gsz) {
@@ -215,6 +214,19 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
     if (g >= 0 && g + 16 <= a.n && a.text_aligned) return *reinterpret_cast<const uint4*>(a.text + g);
     if (g + 16 > 0 && g < a.n) return load_text16_edge(a.text, a.n, g);
     return make_uint4(0, 0, 0, 0);
+}
+
+// LDS traffic between the lanes of ONE wavefront: program order is execution order, the fence keeps the compiler from
+// moving the accesses and waits for the outstanding LDS operations
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// the same without waiting for the wavefront's outstanding GLOBAL memory operations (a workgroup-scope fence drains them
+// all, e.g. the next tile's prefetch): wavefront scope only keeps the compiler from reordering
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // inclusive add-scan across the wavefront with DPP (no LDS round trips): rows of 16 lanes with row_shr 1/2/4/8 (lanes without
@@ -787,6 +799,10 @@ __global__ __launch_bounds__(256) void td_split_far_tiles(const EncodeArgs a) {
 // piece k, lane k mod 256 stores it, the stores of a wavefront are consecutive.
 constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per tile by this kernel
 
+// length classes of the missed pieces (<= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units of 16 key slots in td_merge_pieces)
+__device__ __forceinline__ uint32_t mq_class(uint32_t len) { return len <= 8u ? 0u : len <= 16u ? 1u : len <= 32u ? 2u : len <= 48u ? 3u : 4u; }
+__device__ __forceinline__ uint32_t mq_units(uint32_t cls) { return cls < 2u ? 1u : cls; }
+
 #ifndef TD_PROBE_MIN_WAVES
 #define TD_PROBE_MIN_WAVES 8  // (measured on 256 MiB of English: 0.49 ms at 8 waves/SIMD, 0.66 ms at 5..7)
 #endif
@@ -823,8 +839,7 @@ __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const 
         const int32_t r = piece_lookup(T, key, len, get);
         if (r != NO_RANK) return (uint32_t)r;
     }
-    atomicOr(s_flags, TILE_HAS_MISS);
-    return TOK_MISS | ((uint32_t)i << 7) | len;
+    return TOK_MISS | ((uint32_t)i << 7) | len;  // (the caller notes it: note_miss)
 }
 
 __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(const EncodeArgs a) {
@@ -839,12 +854,17 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
     __shared__ uint32_t s_wave[8];
     __shared__ long long s_ext_end;                // global end of the tile's last piece when it leaves the window (else 0)
     __shared__ uint32_t s_flags;                   // TILE_HAS_LONG | TILE_HAS_MISS
+    __shared__ uint32_t s_nrec;                    // missed pieces of the tile
+    __shared__ uint32_t s_rec[K_MISS_LISTED_MAX];  // the first few: slot << 19 | tile position << 7 | length
+    __shared__ unsigned long long s_pend[64];      // miss-list entries of the last tiles, not appended yet
+    __shared__ uint32_t s_npend;
     __shared__ uint32_t s_ncold;                   // pieces put aside for the long route
     __shared__ uint16_t s_coldk[K_THREADS];        // their indices in the piece list
 
     const int tid = threadIdx.x;
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
+    if (tid == 0) s_npend = 0;
     if (tid < (int)(P12_MAXLEN + 1) * 4) {
         const int len = tid >> 2, w = tid & 3, nb = len - 4 * w;  // bytes of dword w that belong to a len-byte key
         s_kmask[tid] = w == 3 || nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
@@ -852,6 +872,27 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
 
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
     uint32_t pfs = 0;  // START bits of window word `tid`
+    bool told_flagged = false;
+    const uint32_t list_max = a.stop_after == 70 ? 0u : (uint32_t)K_MISS_LISTED_MAX;  // (70: tuning aid, no miss lists)
+    // first wavefront: the np entries waiting in s_pend go to their class's global list; ONE atomic per class (same-address
+    // atomics are served one after the other, tens of nanoseconds each: one per entry was +50 % on the whole kernel)
+    auto append_pending = [&](uint32_t np) {
+        const int ln = tid & 63;
+        const bool have = (uint32_t)ln < np;
+        const unsigned long long rec = have ? s_pend[ln] : 0ull;
+        const uint32_t c = mq_class((uint32_t)rec & 127u);
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)K_MISS_CLASSES; ++q) {
+            const uint64_t b = __ballot(have && c == q);
+            if (b) {
+                const int leader = (int)td_ctz64(b);
+                uint32_t at = 0;
+                if (ln == leader) at = atomicAdd(&a.miss_count[q], (uint32_t)__popcll((unsigned long long)b));
+                at = (uint32_t)__shfl((int)at, leader);
+                if (have && c == q) a.miss_list[(size_t)q * a.miss_cap + at + (uint32_t)__popcll((unsigned long long)(b & ((1ull << ln) - 1ull)))] = rec;
+            }
+        }
+    };
     static_assert(K_BWIN / 32 + 3 <= K_THREADS, "one prefetched START word per lane covers the window");
     const int64_t nwords = (a.n + 31) >> 5;
     auto load_startword = [&](int64_t wg0_) -> uint32_t {
@@ -887,7 +928,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
                 pfs = load_startword(nwg0);
             }
         }
-        if (tid == 0) { s_ext_end = 0; s_flags = 0; s_ncold = 0; }
+        if (tid == 0) { s_ext_end = 0; s_flags = 0; s_ncold = 0; s_nrec = 0; }
         __syncthreads();
         if (a.stop_after == 30) continue;
 
@@ -943,6 +984,11 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
         //      13-row table), ONE 16-byte load of the first slot of the exact-key table, three compares.  An empty slot is
         //      a miss; a slot held by another key, longer pieces, the piece that leaves the window: probe_piece_cold. ----
         uint32_t* const dst = a.stage + (size_t)tile * K_STAGE;
+        // a missed piece (2..64 bytes, not a token): counted; the first few of a tile are remembered for the global list
+        auto note_miss = [&](uint32_t k, uint32_t res) {
+            const uint32_t mi = atomicAdd(&s_nrec, 1u);
+            if (mi < (uint32_t)K_MISS_LISTED_MAX) s_rec[mi] = (k << 19) | (res & 0x7FFFFu);
+        };
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef const u32x4 __attribute__((address_space(1)))* gslot_t;  // (global loads, not flat ones)
         gslot_t const p12 = (gslot_t)(uintptr_t)T.piece12_slots;
@@ -955,7 +1001,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
             const uint4 km = reinterpret_cast<const uint4*>(s_kmask)[len < P12_MAXLEN ? len : P12_MAXLEN];
             const uint32_t k0 = __funnelshift_r(w0, w1, sh) & km.x, k1 = __funnelshift_r(w1, w2, sh) & km.y,
                            k2 = __funnelshift_r(w2, w3, sh) & km.z;
-            const u32x4 sl = p12[hash_piece12(k0, k1, k2, len) & T.piece12_mask];
+            const u32x4 sl = p12[hash_piece12(k0, k1, k2, len) & (a.stop_after == 32 ? 0xFu : T.piece12_mask)];  // (32: tuning aid, 16 slots only)
             const bool last_ext = ext_end && k == np_total - 1;
             uint32_t res;
             if (len <= P12_MAXLEN && a.use_fastpath && !last_ext && (sl.w == 0u || (sl.x == k0 && sl.y == k1 && sl.z == k2 && (sl.w >> 24) == (0x80u | len)))) {
@@ -963,7 +1009,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
                 res = miss ? (TOK_MISS | ((uint32_t)i << 7) | len) : (sl.w & 0x1FFFFFu);
                 if (miss) {
                     if (len == 1) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
-                    atomicOr(&s_flags, TILE_HAS_MISS);
+                    note_miss(k, res);
                 }
             } else {
                 // everything else is put aside and handled densely after the loop, one piece per lane: 7 % of the pieces of
@@ -976,6 +1022,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
                     len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
                 }
                 res = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);  // (more than 256 of them in one tile)
+                if ((res & 0xC0000000u) == TOK_MISS) note_miss(k, res);
             }
             dst[k] = res;
         }
@@ -990,7 +1037,9 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
                     const long long l = ext_end - (wg0 + i);
                     len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
                 }
-                dst[k] = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);
+                const uint32_t res = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);
+                if ((res & 0xC0000000u) == TOK_MISS) note_miss(k, res);
+                dst[k] = res;
             }
         }
         __syncthreads();
@@ -999,7 +1048,38 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
         //      consecutive from the tile's first one, recorded by td_mark_docs; empty documents share a position) ----
         s_off[tid] = pbase;
         s_valid[tid] = (uint16_t)smask0;
-        if (tid == 0) a.tile_count[tile] = np_total | s_flags;
+        {
+            // tiles with only a few missed pieces (running text: one in three tiles has one or two) put them on global lists,
+            // one per length class, so that td_merge_pieces does not read every slot of a third of the tiles to find them and
+            // does not end with a handful of pieces of every class per wavefront (a row of a list is a full batch); tiles with
+            // many are flagged and scanned there
+            // (collected in LDS over several tiles and appended 64 - K_MISS_LISTED_MAX or more at a time: a list position
+            // comes from an atomic, and waiting for one per tile cost 5 % of the kernel)
+            const uint32_t nr = s_nrec, np0 = s_npend;
+            if (tid < 64) {  // (first wavefront: program order between its lanes' LDS accesses)
+                const bool listed = nr && nr <= list_max;
+                if (listed && (uint32_t)tid < nr) s_pend[np0 + tid] = ((unsigned long long)(uint32_t)tile << 32) | s_rec[tid];
+                const uint32_t np1 = listed ? np0 + nr : np0;
+                wave_sync_lds();
+                if (np1 > 64u - (uint32_t)K_MISS_LISTED_MAX) {
+                    append_pending(np1);
+                    wave_sync_lds();
+                    if (tid == 0) s_npend = 0;
+                } else if (tid == 0) {
+                    s_npend = np1;
+                }
+            }
+        }
+        if (tid == 0) {
+            uint32_t fl = s_flags;
+            const uint32_t nr = s_nrec;
+            if (nr > list_max) {
+                fl |= TILE_HAS_MISS;
+                if (!told_flagged) { *a.any_flagged = 1u; told_flagged = true; }  // (once per workgroup: stores to one address queue up)
+            }
+            else if (nr) fl |= TILE_MISS_LISTED;
+            a.tile_count[tile] = np_total | fl;
+        }
         __syncthreads();
         {
             const int64_t tile_end_g = tile_g0 + tile_hi;
@@ -1013,6 +1093,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
         }
         __syncthreads();
     }
+    if (tid < 64) append_pending(s_npend);  // (what is still waiting in LDS)
 }
 
 // ------------------------------------------------------------------ byte-pair merge, one lane per piece ----
@@ -1073,25 +1154,16 @@ __device__ __forceinline__ void mg_init_piece(const EncodeArgs& a, const Tables&
     mg_pad(keys, st);
 }
 
-// LDS traffic between the lanes of ONE wavefront: program order is execution order, the fence keeps the compiler from
-// moving the accesses and waits for the outstanding LDS operations
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-
 // ------------------------------------------------------------------ td_merge_pieces ---------
 // Every wavefront works alone (no workgroup barrier): it walks its share of the tiles flagged TILE_HAS_MISS, collects their
 // TOK_MISS slots into five LDS queues by length class (<= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units), and whenever a
 // queue holds a full batch (64 / units pieces, whatever tiles they come from) merges it: one piece per owner lane, the
 // rounds of a batch run until its longest chain is done — pieces of one class need about the same number of rounds.
-// A merged piece's ids go to the tile's region of the result buffer, which fills densely (a.merge_out[tile * K_STAGE + ...]: a
-// tile's merged pieces have at most as many ids as the tile has bytes), its slot becomes TOK_MISS | offset there << 7 | ids and
+// A merged piece's ids go to its own bytes' slots of the result buffer (a.merge_out[tile * K_STAGE + tile position + i]:
+// pieces do not overlap and a piece has at most as many ids as bytes), its slot becomes TOK_MISS | position << 7 | ids and
 // the tile's extra ids are added to tile_extra; td_pack_tokens expands the markers.
 constexpr int MQ_CLASSES = 5;
 constexpr int MQ_CAP = 128;  // queue capacity per class: a full batch + one row of slots
-__device__ __forceinline__ uint32_t mq_class(uint32_t len) { return len <= 8u ? 0u : len <= 16u ? 1u : len <= 32u ? 2u : len <= 48u ? 3u : 4u; }
-__device__ __forceinline__ uint32_t mq_units(uint32_t cls) { return cls < 2u ? 1u : cls; }
 
 #ifndef TD_MERGE_MIN_WAVES
 #define TD_MERGE_MIN_WAVES 3
@@ -1159,38 +1231,31 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
             if (!__any(more)) break;
         }
         TD_TICK(t_rounds)
-        // A tile's merged ids fill its region of merge_out DENSELY, in the order the batches get to them (at the pieces' own
-        // byte positions they were 4-byte islands in a gigabyte, and td_pack_tokens fetched a cache line for each): one
-        // atomic per TILE of the batch hands out the room (a batch's pieces come from one or two tiles, and 64 atomics on
-        // one address are served one after the other); the same loop adds the tile's extra ids.
-        const uint32_t nt = st.len ? (uint32_t)__popcll((unsigned long long)st.alive) : 0u;
-        uint32_t dense = 0;
-        for (uint64_t pend = __ballot(nt != 0); pend;) {
-            const int l = td_ctz64(pend);
-            const uint32_t tl = (uint32_t)__shfl((int)tile, l);
-            const bool same = nt != 0 && tile == tl;
-            const uint32_t incl = wave_incl_scan(same ? nt : 0u, lane);
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            const uint32_t npc = (uint32_t)__popcll((unsigned long long)__ballot(same));
-            uint32_t room = 0;
-            if (lane == l) {
-                room = atomicAdd(&a.tile_mfill[tl], tot);
-                if (tot > npc) atomicAdd(&a.tile_extra[tl], tot - npc);
-            }
-            room = (uint32_t)__shfl((int)room, l);
-            if (same) dense = room + incl - nt;
-            pend &= ~__ballot(same);
-        }
+        // A merged piece's ids go to its own bytes' slots of the tile's region of merge_out (pieces do not overlap and a
+        // piece has at most as many ids as bytes); the tile's extra ids are added with ONE atomic per tile of the batch (a
+        // batch's pieces come from one or two tiles, and 64 atomics on one address are served one after the other).
+        // (Filling the region densely instead needs the atomic's answer before the ids can be written: +0.2 ms on
+        // mixed-script text, and td_pack_tokens was no faster for it.)
+        uint32_t extra = 0;
         if (st.len) {
-            uint32_t* out = a.merge_out + (size_t)tile * K_STAGE + dense;
-            uint32_t k = 0;
+            uint32_t* out = a.merge_out + (size_t)tile * K_STAGE + pos;
+            uint32_t nt = 0;
             for (uint64_t al = st.alive; al; al &= al - 1ull) {
                 const uint32_t j = (uint32_t)td_ctz64(al);
                 const uint32_t id = ids[mg_slot(st.t, j)];
                 if ((int32_t)id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gpos + j);
-                out[k++] = id;
+                out[nt++] = id;
             }
-            a.stage[(size_t)tile * K_STAGE + (((uint32_t)rec >> 19) & 0x1FFFu)] = TOK_MISS | (dense << 7) | nt;
+            a.stage[(size_t)tile * K_STAGE + (((uint32_t)rec >> 19) & 0x1FFFu)] = TOK_MISS | (pos << 7) | nt;
+            extra = nt > 1 ? nt - 1 : 0;
+        }
+        for (uint64_t pend = __ballot(extra != 0); pend;) {
+            const int l = td_ctz64(pend);
+            const uint32_t tl = (uint32_t)__shfl((int)tile, l);
+            const bool same = extra != 0 && tile == tl;
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(same ? extra : 0u, lane), 63);
+            if (lane == l) atomicAdd(&a.tile_extra[tl], tot);
+            pend &= ~__ballot(same);
         }
         wave_sync();  // (the batch's LDS reads are done before the next batch's writes)
         TD_TICK(t_out)
@@ -1208,8 +1273,47 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
     int run = 4, tile = 0, run_end = 0;
     uint32_t batches_in_run = 0, run_counts = 0;
     int run_first = 0;
+    // first the global miss lists (the few missed pieces of sparsely hit tiles, one list per length class): a "row" is one
+    // batch's worth of records of one class, dealt round-robin; then the flagged tiles.  list_row >= 0: the next draw is a row.
+    uint32_t n_listed[MQ_CLASSES], rows_before[MQ_CLASSES + 1];
+    static_assert(MQ_CLASSES == K_MISS_CLASSES, "one miss list per queue class");
+    rows_before[0] = 0;
+#pragma unroll
+    for (int c = 0; c < MQ_CLASSES; ++c) {
+        n_listed[c] = a.miss_count[c] < a.miss_cap ? a.miss_count[c] : a.miss_cap;
+        const uint32_t per = 64u / mq_units((uint32_t)c);
+        rows_before[c + 1] = rows_before[c] + (n_listed[c] + per - 1u) / per;
+    }
+    const int list_rows = (int)rows_before[MQ_CLASSES];
+    const int nwaves_all = gridDim.x * NW;
+    int list_row = blockIdx.x * NW + wv;
     for (;;) {
-        if (tile >= run_end) {
+        if (list_row >= 0 && list_row < list_rows) {
+            int c = 0;
+#pragma unroll
+            for (int q = 1; q < MQ_CLASSES; ++q)
+                if ((uint32_t)list_row >= rows_before[q]) c = q;
+            uint32_t nl = 0, rb = 0;
+#pragma unroll
+            for (int q = 0; q < MQ_CLASSES; ++q)
+                if (q == c) { nl = n_listed[q]; rb = rows_before[q]; }
+            const uint32_t per = 64u / mq_units((uint32_t)c);
+            const uint32_t li = ((uint32_t)list_row - rb) * per + lane;
+            const bool have = (uint32_t)lane < per && li < nl;
+            const uint64_t b = __ballot(have);
+            const uint32_t qc = qcnt_of(c);
+            if (have) s_q[wv][c][(qhead_of(c) + qc + (uint32_t)lane) & (MQ_CAP - 1)] = a.miss_list[(size_t)c * a.miss_cap + li];
+            qset(qcnts, c, qc + (uint32_t)__popcll((unsigned long long)b));
+            wave_sync();
+            list_row += nwaves_all;
+            tile = 0; run_end = 0;      // (not a tile: falls through to the batch loop below with no rows)
+        } else if (list_row >= 0) {
+            list_row = -1;              // lists done: tiles from here on
+            if (!*a.any_flagged) { tile = a.n_tiles; run_end = a.n_tiles + 1; }  // (no tile to scan: straight to the drain; drawing tiles costs an atomic per run)
+            continue;
+        }
+        const bool from_list = list_row >= 0;
+        if (!from_list && tile >= run_end) {
             run = batches_in_run == 0 ? (run < 32 ? run * 2 : 32) : (run / 2 > run_min ? run / 2 : run_min);
             batches_in_run = 0;
             uint32_t t0 = 0;
@@ -1219,19 +1323,19 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
             run_counts = (lane < run && tile + lane < a.n_tiles) ? a.tile_count[tile + lane] : 0u;  // the run's tile_count words: one load
             run_first = tile;
         }
-        const bool drain = tile >= a.n_tiles;
+        const bool drain = !from_list && tile >= a.n_tiles;
         uint32_t cnt = 0;
-        if (!drain) {
+        if (!drain && !from_list) {
             const uint32_t tc = (uint32_t)__builtin_amdgcn_readlane((int)run_counts, tile - run_first);
             if (!(tc & TILE_HAS_MISS)) { ++tile; continue; }  // (uniform per wavefront)
             cnt = tc & TILE_COUNT_MASK;
         }
-        const uint32_t* slots = a.stage + (size_t)(drain ? 0 : tile) * K_STAGE;
-        const uint32_t rows = drain ? 1u : (cnt + 63u) >> 6;
+        const uint32_t* slots = a.stage + (size_t)((drain || from_list) ? 0 : tile) * K_STAGE;
+        const uint32_t rows = (drain || from_list) ? 1u : (cnt + 63u) >> 6;
         uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rowbits = 0;
 #pragma unroll 1
         for (uint32_t row = 0; row < rows; ++row) {
-            if (!drain) {
+            if (!drain && !from_list) {
                 if ((row & 7u) == 0) {  // the tile's slots, eight rows of 64 at a time (eight independent loads in flight)
                     uint32_t mm = 0;
 #pragma unroll
@@ -1280,7 +1384,7 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
             }
         }
         if (drain) break;
-        ++tile;
+        if (!from_list) ++tile;
     }
 #ifdef TD_MERGE_TIMING
     if (lane == 0 && (blockIdx.x % 97) == 0 && wv == 0)
@@ -1810,14 +1914,14 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
 // KB: many small independent copies in flight beat few large ones), no workgroup barrier, no LDS.
 //   plain tiles (every slot is an id): 16-byte copies;
 //   tiles with markers: a sweep over rows of 64 slots with a running id count: a slot's size is 1, the ids of a merged
-//   piece (TOK_MISS | offset | ids, from a.merge_out) or of a long piece (TOK_LONGREF, from the pool; copied by the whole
+//   piece (TOK_MISS | position | ids, from a.merge_out) or of a long piece (TOK_LONGREF, from the pool; copied by the whole
 //   wavefront); the documents that start in the tile pick their offset out of the row scan their slot falls in.
 // (A workgroup-per-tile version of the marker path with the tile's offsets in LDS cost 14-17 us per tile: five barriers
 // and six dependent global loads in a row; plain English has a marker in every third tile.)
 constexpr int PK_G = 8;       // rows of 64 slots per group of the marker path
 constexpr int PK_ECAP = 256;  // merged pieces the expansion list holds
 __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
-    __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];  // dst offset << 32 | offset in the tile's merged ids << 7 | ids
+    __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];  // dst offset << 32 | tile position << 7 | ids
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef TD_PACK_TIMING
     unsigned long long t_meta = 0, t_rows = 0, t_scan = 0, t_plain = 0, t_list = 0, t_flush = 0, t_docs = 0, t_plainpath = 0, n_mt = 0, n_pt = 0, n_fl = 0;
@@ -1839,7 +1943,7 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         const int64_t g_lo = (int64_t)tile * K_TILE;
         const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
         PK_TICK(t_meta)
-        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS)) || a.stop_after == 60) {  // (60: tuning aid, every tile down the plain path)
+        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_MISS_LISTED)) || a.stop_after == 60) {  // (60: tuning aid, every tile down the plain path)
             // the first 64 documents of the tile (nearly always all of them): offsets and slots are loaded with the ids
             const int64_t dm = dfirst + lane;
             int64_t dpos = a.n;
@@ -1896,7 +2000,7 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
                 for (uint32_t c0 = 0; c0 < ecount; c0 += 64) {
                     const unsigned long long e = c0 + lane < ecount ? elist[c0 + lane] : 0ull;
                     const uint32_t n = (uint32_t)e & 127u;
-                    const uint32_t* ps = a.merge_out + (size_t)tile * K_STAGE + (((uint32_t)e >> 7) & 0x1FFFu);
+                    const uint32_t* ps = a.merge_out + (size_t)tile * K_STAGE + (((uint32_t)e >> 7) & 0xFFFu);
                     const int64_t o = base + (int64_t)(uint32_t)(e >> 32);
                     for (uint32_t j = 0; __any(j < n); j += 4) {
                         uint32_t t[4];
@@ -1968,7 +2072,7 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
                     const bool m = (mmask >> q) & 1u;
                     const uint64_t bm = __ballot(m);
                     if (bm) {
-                        if (m) elist[ecount + (uint32_t)__popcll((unsigned long long)(bm & lt))] = ((unsigned long long)off[q] << 32) | (v[q] & 0xFFFFFu);
+                        if (m) elist[ecount + (uint32_t)__popcll((unsigned long long)(bm & lt))] = ((unsigned long long)off[q] << 32) | (v[q] & 0x7FFFFu);
                         ecount += (uint32_t)__popcll((unsigned long long)bm);
                         if (ecount > (uint32_t)PK_ECAP - 64u) flush();
                     }
@@ -2007,7 +2111,7 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
 #endif
         }
 #ifdef TD_PACK_TIMING
-        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS))) { PK_TICK(t_plainpath) ++n_pt; }
+        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_MISS_LISTED))) { PK_TICK(t_plainpath) ++n_pt; }
 #endif
         if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
             const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
@@ -2229,7 +2333,7 @@ hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------ launches ----------------
-static int g_blocks_split = 0, g_blocks_encode = 0, g_blocks_merge = 0;
+static int g_blocks_split = 0, g_blocks_encode = 0, g_blocks_merge = 0, g_blocks_long = 0;
 static int resident_blocks(const void* fn, int fallback_per_cu) {
     // persistent grid = exactly the workgroups that are resident at once (a larger grid would run in
     // uneven rounds: tiles are dealt round-robin to blockIdx)
@@ -2253,6 +2357,12 @@ int merge_grid_blocks() {
     const char* e = getenv("TD_MERGE_BLOCKS_PER_CU");
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_merge;
+}
+static int long_grid_blocks() {  // (work is dealt round-robin to the wavefronts: a grid larger than what is resident runs in uneven rounds)
+    if (!g_blocks_long) g_blocks_long = resident_blocks((const void*)td_long_pieces, 3);
+    const char* e = getenv("TD_LONG_BLOCKS_PER_CU");
+    if (e && atoi(e) > 0) return 256 * atoi(e);
+    return g_blocks_long;
 }
 static int split_grid_blocks() {
     if (!g_blocks_split) g_blocks_split = resident_blocks((const void*)td_split_tiles<0u>, 3);
@@ -2299,14 +2409,14 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     const bool tokens = a.stop_after != 2 && a.stop_after != 11 && a.stop_after != 12;
     if (tokens) hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
     if (ev) (void)hipEventRecord(ev[2], stream);
-    if (tokens && a.stop_after != 3 && a.stop_after != 30 && a.stop_after != 31) {
+    if (tokens && a.stop_after != 3 && a.stop_after != 30 && a.stop_after != 31 && a.stop_after != 32) {
         const int wtiles = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
         const int mblocks = wtiles < merge_grid_blocks() ? wtiles : merge_grid_blocks();
         hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(K_THREADS), 0, stream, a);
     }
     if (ev) (void)hipEventRecord(ev[3], stream);
     if (tokens) {
-        hipLaunchKernelGGL(td_long_pieces, dim3(256 * 5), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(td_giant_pieces, dim3(128), dim3(GP_THREADS), 0, stream, a);
         hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
         hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
