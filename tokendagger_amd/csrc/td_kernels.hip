@@ -775,18 +775,24 @@ __global__ __launch_bounds__(256) void td_split_far_tiles(const EncodeArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const FarScan F{a, T, lane};
-    for (int64_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < a.n_stiles; t += nwaves) {
-        if (!a.tile_flag[t] || (t > 0 && a.tile_flag[t - 1])) continue;  // (uniform) heads of chains of flagged tiles only
-        // walk the chain tile by tile.  The first piece start of a tile is where the walk crossed into it, or — when a lane of
-        // the fast kernel took over in the tile before (it then scanned on to that tile's end), or a long piece was resolved by
-        // td_split_far_pieces — what that scan recorded in tile_carry
-        int64_t p = -1;
-        for (int64_t tt = t; tt < a.n_stiles && a.tile_flag[tt]; ++tt) {
-            const int64_t t0 = tt * (int64_t)KS_TILE;
-            if (p < t0) p = a.tile_carry[tt];
-            if (p < t0) { if (lane == 0) raise(a, TD_E_SCRATCH, t0); break; }  // (cannot happen: nobody told this tile)
-            if (p >= t0 + KS_TILE || p >= a.n) continue;                        // a piece covers the whole tile
-            p = F.mark_to_tile_end(p, false);
+    // (64 tiles per step and wavefront, a lane each, looking for the heads of chains of flagged tiles: one tile per step was
+    // 60 us per GiB of text for a kernel that normally finds nothing)
+    for (int64_t t0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; t0 < a.n_stiles; t0 += nwaves * 64) {
+        const int64_t tl = t0 + lane;
+        const bool head = tl < a.n_stiles && a.tile_flag[tl] && !(tl > 0 && a.tile_flag[tl - 1]);
+        for (uint64_t hb = __ballot(head); hb; hb &= hb - 1ull) {
+            const int64_t t = t0 + td_ctz64(hb);
+            // walk the chain tile by tile.  The first piece start of a tile is where the walk crossed into it, or — when a lane of
+            // the fast kernel took over in the tile before (it then scanned on to that tile's end), or a long piece was resolved by
+            // td_split_far_pieces — what that scan recorded in tile_carry
+            int64_t p = -1;
+            for (int64_t tt = t; tt < a.n_stiles && a.tile_flag[tt]; ++tt) {
+                const int64_t tg0 = tt * (int64_t)KS_TILE;
+                if (p < tg0) p = a.tile_carry[tt];
+                if (p < tg0) { if (lane == 0) raise(a, TD_E_SCRATCH, tg0); break; }  // (cannot happen: nobody told this tile)
+                if (p >= tg0 + KS_TILE || p >= a.n) continue;                        // a piece covers the whole tile
+                p = F.mark_to_tile_end(p, false);
+            }
         }
     }
 }
