@@ -42,7 +42,7 @@ def _lib():
     return lib
 
 
-VARIANT_LLAMA4, VARIANT_TEKKEN, VARIANT_CL100K, VARIANT_GPT2, VARIANT_CL100K_EOS = 0, 1, 2, 3, 4
+VARIANT_LLAMA4, VARIANT_TEKKEN, VARIANT_CL100K, VARIANT_GPT2, VARIANT_CL100K_EOS, VARIANT_QWEN2 = 0, 1, 2, 3, 4, 5
 
 
 def split(data: bytes, variant: int = VARIANT_LLAMA4) -> np.ndarray:

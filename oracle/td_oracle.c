@@ -102,12 +102,13 @@ static int64_t contraction(const uint8_t* s, int64_t e, int64_t n) {
  * config.pattern, read by tests/throughput_test.py:118): the same alternatives without the contraction suffix and with
  * \p{N} in place of \p{N}{1,3}. */
 static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n);
-static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int eos_first);
+static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int eos_first, int nmax);
 static int64_t next_piece_gpt2(const uint8_t* s, int64_t pos, int64_t n);
 static int64_t next_piece_llama4(const uint8_t* s, int64_t pos, int64_t n, int variant) {
     if (variant == 2) return next_piece_cl100k(s, pos, n);
     if (variant == 3) return next_piece_gpt2(s, pos, n);
-    if (variant == 4) return next_piece_cl100k_v(s, pos, n, 1);
+    if (variant == 4) return next_piece_cl100k_v(s, pos, n, 1, 3);
+    if (variant == 5) return next_piece_cl100k_v(s, pos, n, 0, 1);
     const int contr = variant == 0, nmax = variant == 0 ? 3 : 1;
     int l0;
     int c0 = char_at(s, pos, n, &l0, NULL);
@@ -199,9 +200,10 @@ static int is_L2(int c) { return c == C_UP || c == C_LW || c == C_LB; }
  *   '(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}++|\p{N}{1,3}+| ?[^\s\p{L}\p{N}]++[\r\n]*+|\s++$|\s*[\r\n]|\s+(?!\S)|\s
  * : the possessive quantifiers change nothing, but `\s++$` now stands IN FRONT of `\s*[\r\n]`, so a whitespace run that
  * reaches the end of the subject is one piece even if it contains CR/LF (eos_first). */
-static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int eos_first);
-static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n) { return next_piece_cl100k_v(s, pos, n, 0); }
-static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int eos_first) {
+/* variant 5: Qwen2 / Qwen2.5 / Qwen3 (tokenizer.json pre_tokenizer): variant 2 with `\p{N}` (one digit per piece, nmax = 1). */
+static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int eos_first, int nmax);
+static int64_t next_piece_cl100k(const uint8_t* s, int64_t pos, int64_t n) { return next_piece_cl100k_v(s, pos, n, 0, 3); }
+static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int eos_first, int nmax) {
     int l0;
     int c0 = char_at(s, pos, n, &l0, NULL);
     /* alternative 1: the contraction on its own */
@@ -220,7 +222,7 @@ static int64_t next_piece_cl100k_v(const uint8_t* s, int64_t pos, int64_t n, int
     /* alternative 3: \p{N}{1,3} */
     if (c0 == C_NUM) {
         int64_t e = pos + l0;
-        for (int k = 1; k < 3 && e < n; ++k) {
+        for (int k = 1; k < nmax && e < n; ++k) {
             int l, c = char_at(s, e, n, &l, NULL);
             if (c != C_NUM) break;
             e += l;

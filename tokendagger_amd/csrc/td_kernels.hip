@@ -2407,6 +2407,9 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         case PV_CL100K | PV_WS_EOS_FIRST:
             hipLaunchKernelGGL(td_split_tiles<(PV_CL100K | PV_WS_EOS_FIRST)>, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
             break;
+        case PV_CL100K | PV_SINGLE_DIGIT:
+            hipLaunchKernelGGL(td_split_tiles<(PV_CL100K | PV_SINGLE_DIGIT)>, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
+            break;
         default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(td_split_far_pieces, dim3(64), dim3(256), 0, stream, a);

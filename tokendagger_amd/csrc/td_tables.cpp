@@ -30,6 +30,10 @@ static const char kCl100kPossessive[] =
 static const char kCl100kCurrent[] =  // cl100k_base as tiktoken ships it today (openai_public.py); NOT the same language: \s++$ comes first
     "'(?i:[sdmt]|ll|ve|re)|[^\\r\\n\\p{L}\\p{N}]?+\\p{L}++|\\p{N}{1,3}+| ?[^\\s\\p{L}\\p{N}]++[\\r\\n]*+|\\s++$|\\s*[\\r\\n]|\\s+(?!\\S)|\\s";
 
+// Qwen2 / Qwen2.5 / Qwen3: cl100k_base's classic form with `\\p{N}` in place of `\\p{N}{1,3}`.
+static const char kQwen2[] =
+    "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+
 static const char kGpt2[] =
     "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
 
@@ -45,6 +49,7 @@ PatternKind classify_pattern(const std::string& pat) {
     if (pat == kTekken) return PATTERN_TEKKEN;
     if (pat == kCl100k || pat == kCl100kPossessive) return PATTERN_CL100K;
     if (pat == kCl100kCurrent) return PATTERN_CL100K_EOS;
+    if (pat == kQwen2) return PATTERN_QWEN2;
     if (pat == kGpt2 || pat == kGpt2Possessive) return PATTERN_GPT2;
     return PATTERN_UNSUPPORTED;
 }
@@ -53,6 +58,7 @@ uint32_t pattern_flags(PatternKind k) {
     if (k == PATTERN_TEKKEN) return PV_NO_CONTRACTION | PV_SINGLE_DIGIT;
     if (k == PATTERN_CL100K) return PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS;
     if (k == PATTERN_CL100K_EOS) return PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS | PV_WS_EOS_FIRST;
+    if (k == PATTERN_QWEN2) return PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS | PV_SINGLE_DIGIT;
     if (k == PATTERN_GPT2) return PV_GPT2;
     return 0u;
 }
@@ -128,7 +134,7 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
     H.pattern_kind = classify_pattern(H.pattern);
     if (H.pattern_kind == PATTERN_UNSUPPORTED) {
         err = "split pattern is not supported by the device pre-tokenizer (supported: the o200k/Llama-4 pattern, the "
-              "Mistral tekken pattern, the cl100k_base/Llama-3 pattern and the GPT-2 pattern); "
+              "Mistral tekken pattern, the cl100k_base/Llama-3 pattern, the Qwen2 pattern and the GPT-2 pattern); "
               "there is no CPU regex fallback";
         return TD_E_PATTERN;
     }
@@ -136,7 +142,7 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
 
     // Class tables: the probed Unicode table; cl100k reads marks as punctuation and gives '/' no trailer role, which is
     // a remap of two class ids (the scanners never see the difference)
-    if (H.pattern_kind == PATTERN_CL100K || H.pattern_kind == PATTERN_CL100K_EOS || H.pattern_kind == PATTERN_GPT2) {
+    if (H.pattern_kind == PATTERN_CL100K || H.pattern_kind == PATTERN_CL100K_EOS || H.pattern_kind == PATTERN_QWEN2 || H.pattern_kind == PATTERN_GPT2) {
         H.ucls2_remap.assign(td_ucls_stage2, td_ucls_stage2 + sizeof td_ucls_stage2);
         for (auto& c : H.ucls2_remap)
             if (c == C_MK || c == C_SLASH) c = C_OTHER;

@@ -20,6 +20,7 @@ enum PatternKind : int {
     PATTERN_GPT2 = 3,   // r50k_base / p50k_base (GPT-2)
     PATTERN_CL100K_EOS = 4,  // cl100k_base as current tiktoken releases spell it: `\s++$` ahead of `\s*[\r\n]` (a different language
                              // on trailing whitespace that contains CR/LF)
+    PATTERN_QWEN2 = 5,  // Qwen2 / Qwen2.5 / Qwen3 (tokenizer.json pre_tokenizer): the cl100k_base pattern with single-digit number pieces (`\p{N}`)
 };
 const char* cl100k_pattern();
 uint32_t pattern_flags(PatternKind k);  // PV_* bits for the scanners

@@ -38,6 +38,10 @@ CL100K_PAT_STR_POSSESSIVE = (
     r"'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]++[\r\n]*|\s*[\r\n]|\s+(?!\S)|\s+"
 )
 
+# Qwen2 / Qwen2.5 / Qwen3 (tokenizer.json pre_tokenizer Split regex): cl100k_base with single-digit number pieces
+QWEN2_PAT_STR = (
+    r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+)
 # cl100k_base as current tiktoken releases spell it (tiktoken_ext/openai_public.py): the same language again
 CL100K_PAT_STR_CURRENT = (
     r"'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}++|\p{N}{1,3}+| ?[^\s\p{L}\p{N}]++[\r\n]*+|\s++$|\s*[\r\n]|\s+(?!\S)|\s"
