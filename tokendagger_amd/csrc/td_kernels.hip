@@ -1169,7 +1169,10 @@ __device__ __forceinline__ void mg_init_piece(const EncodeArgs& a, const Tables&
 // pieces do not overlap and a piece has at most as many ids as bytes), its slot becomes TOK_MISS | position << 7 | ids and
 // the tile's extra ids are added to tile_extra; td_pack_tokens expands the markers.
 constexpr int MQ_CLASSES = 5;
-constexpr int MQ_CAP = 128;  // queue capacity per class: a full batch + one row of slots
+constexpr int MQ_CAP = 128;  // largest queue: a full batch + one row of slots (classes of 2+ units: batches of 32 / 21 / 16 -> 96)
+__device__ __forceinline__ uint32_t mq_base(uint32_t c) { return c < 2u ? c * 128u : 256u + (c - 2u) * 96u; }  // a wavefront's queues, end to end
+__device__ __forceinline__ uint32_t mq_size(uint32_t c) { return c < 2u ? 128u : 96u; }
+constexpr int MQ_WORDS = 2 * 128 + 3 * 96;  // (sized so that THREE workgroups fit a CU: with 128 entries for every class two did)
 
 #ifndef TD_MERGE_MIN_WAVES
 #define TD_MERGE_MIN_WAVES 3
@@ -1178,10 +1181,11 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
     constexpr int NW = K_THREADS / 64;
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[NW][64 * MG_UNIT];
     __shared__ __attribute__((aligned(16))) uint32_t s_ids[NW][64 * MG_UNIT];
-    __shared__ unsigned long long s_q[NW][MQ_CLASSES][MQ_CAP];  // tile << 32 | slot index << 19 | tile position << 7 | length
+    __shared__ unsigned long long s_q[NW][MQ_WORDS];  // tile << 32 | slot index << 19 | tile position << 7 | length
     __shared__ int32_t s_byteid[256];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto q_at = [&](uint32_t c, uint32_t i) -> unsigned long long& { return s_q[wv][mq_base(c) + i % mq_size(c)]; };
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
     __syncthreads();
@@ -1217,11 +1221,11 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
         st.alive = 0; st.t = (uint32_t)lane; st.len = 0;
         unsigned long long rec = 0;
         if ((uint32_t)lane == i * u && i < np) {
-            rec = s_q[wv][c][(qh + i) & (MQ_CAP - 1)];
+            rec = q_at((uint32_t)c, qh + i);
             st.len = (uint32_t)rec & 127u;
             st.alive = st.len >= 64u ? ~0ull : ((1ull << st.len) - 1ull);
         }
-        qset(qheads, c, (qh + np) & (MQ_CAP - 1));
+        qset(qheads, c, (qh + np) % mq_size((uint32_t)c));
         qset(qcnts, c, qc - np);
         const uint32_t tile = (uint32_t)(rec >> 32), pos = ((uint32_t)rec >> 7) & 0xFFFu;
         const int64_t gpos = (int64_t)tile * K_TILE + pos;
@@ -1308,7 +1312,7 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
             const bool have = (uint32_t)lane < per && li < nl;
             const uint64_t b = __ballot(have);
             const uint32_t qc = qcnt_of(c);
-            if (have) s_q[wv][c][(qhead_of(c) + qc + (uint32_t)lane) & (MQ_CAP - 1)] = a.miss_list[(size_t)c * a.miss_cap + li];
+            if (have) q_at((uint32_t)c, qhead_of(c) + qc + (uint32_t)lane) = a.miss_list[(size_t)c * a.miss_cap + li];
             qset(qcnts, c, qc + (uint32_t)__popcll((unsigned long long)b));
             wave_sync();
             list_row += nwaves_all;
@@ -1373,7 +1377,7 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
                     if (b) {
                         const uint32_t qc = qcnt_of(c);
                         if (miss && cls == (uint32_t)c)
-                            s_q[wv][c][(qhead_of(c) + qc + (uint32_t)__popcll((unsigned long long)(b & lt))) & (MQ_CAP - 1)] = rec;
+                            q_at((uint32_t)c, qhead_of(c) + qc + (uint32_t)__popcll((unsigned long long)(b & lt))) = rec;
                         qset(qcnts, c, qc + (uint32_t)__popcll((unsigned long long)b));
                     }
                 }
