@@ -86,6 +86,37 @@ def test_corpora_vs_oracle(tok, gen, size):
         _check_batch(tok, O, x.tobytes(), td_corpus.chunk_offsets(len(x), 80))
 
 
+def test_sparse_and_dense_misses_per_tile(tok):
+    """Tiles with 0..K missed pieces (pieces that are no token and get merged): up to six go through the global miss lists
+    (collected in LDS over tiles, appended in bursts), more flag the tile for a scan — both routes, the boundary between
+    them, pieces of every length class, and list rows that mix tiles, against the restatement."""
+    O = H.port_tokenizer()
+    rng = random.Random(77)
+    filler = ("the quick brown fox jumps over the lazy dog and then some more of the same words again " * 60).encode()
+    rare = [b"qzxjv", b"Zqxwvk", b"xqzjkvbwpfm", b"qxzvjkwqxzvjkwqxzvjk", b"zqjxkvwzqjxkvwzqjxkvwzqjxkvwzqjxkvw",
+            b"qjzxvkqjzxvkqjzxvkqjzxvkqjzxvkqjzxvkqjzxvkqjzxvkqjzx", "\u4e2d\u6587\u5b57\u7b26".encode(), b"0x7fE3a9Qz"]
+    docs = []
+    for k in list(range(0, 10)) * 6 + [40, 100, 0, 1, 6, 7]:
+        # about one 4 KiB tile of common words with k rare strings spliced in at word boundaries
+        words = filler[:4096 - 8].split(b" ")
+        for _ in range(k):
+            words.insert(rng.randrange(1, len(words)), rng.choice(rare))
+        docs.append(b" ".join(words))
+    rng.shuffle(docs)
+    text, offs = H.pack_docs(docs)
+    _check_batch(tok, O, text, offs)
+    _check_batch(tok, O, text, np.asarray([0, len(text)], dtype=np.int64))     # the same bytes as one document
+    # > 64 sparsely hit tiles in a row: the LDS collection is appended several times within one workgroup's tiles
+    docs = []
+    for i in range(400):
+        words = filler[:4096 - 8].split(b" ")
+        for _ in range(1 + i % 3):
+            words.insert(rng.randrange(1, len(words)), rare[i % len(rare)])
+        docs.append(b" ".join(words))
+    text, offs = H.pack_docs(docs)
+    _check_batch(tok, O, text, offs)
+
+
 def test_tile_boundary_sweep(tok):
     # slide document boundaries and piece kinds across the 4096-byte tile edge
     O = H.port_tokenizer()
