@@ -135,7 +135,7 @@ struct Ctl {  // small control block in device memory
     uint32_t scan_done;
     uint32_t merge_next;   // td_merge_pieces: next tile nobody has taken yet
     uint32_t miss_count[6];  // entries on the miss lists (K_MISS_CLASSES of them)
-    uint32_t any_flagged;    // some tile is flagged TILE_HAS_MISS (td_merge_pieces has tiles to scan)
+    uint32_t flagged_count;  // tiles flagged TILE_HAS_MISS (on flagged_list: td_merge_pieces draws them from there)
     uint32_t pad2;
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
@@ -150,7 +150,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -266,6 +266,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->stage2, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;  // ids of merged pieces
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->flagged_list, (size_t)(n_tiles + 64) * 4))) return rc;
     if ((rc = ensure(t, t->miss_list, (size_t)(n_tiles + 1) * K_MISS_LISTED_MAX * K_MISS_CLASSES * 8))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
     if ((rc = ensure(t, t->doc_slot, (size_t)(n_docs + 1) * 4))) return rc;
@@ -325,7 +326,8 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.merge_next = &ctl->merge_next;
     a.miss_list = (unsigned long long*)t->miss_list.p;
     a.miss_count = ctl->miss_count;
-    a.any_flagged = &ctl->any_flagged;
+    a.flagged_count = &ctl->flagged_count;
+    a.flagged_list = (uint32_t*)t->flagged_list.p;
     a.miss_cap = (uint32_t)((n_tiles + 1) * K_MISS_LISTED_MAX);
     a.chunk_pref = (int64_t*)t->chunk_pref.p;
     a.ctl_reset = &ctl->long_count;  // keep a sticky error (err / err_pos) but reset the per-call counters
@@ -480,7 +482,7 @@ void td_destroy(td_tokenizer* t) {
         for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h}) if (st) (void)hipStreamDestroy(st);
         if (t->small_in) (void)hipHostFree(t->small_in);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)

@@ -47,7 +47,8 @@ struct EncodeArgs {
                                     // one list per length class, miss_cap entries apart
     uint32_t* miss_count;       // [K_MISS_CLASSES] entries on them
     uint32_t miss_cap;          // (room for K_MISS_LISTED_MAX per tile on every list)
-    uint32_t* any_flagged;      // set by td_probe_tiles when it flags a tile TILE_HAS_MISS
+    uint32_t* flagged_list;     // the tiles td_probe_tiles flagged TILE_HAS_MISS, in the order its workgroups appended them
+    uint32_t* flagged_count;    // entries on it
     int64_t* chunk_pref;        // [n_tiles/4096 + 2] token base of every 4096-tile chunk (exclusive scan of the chunk totals)
     uint32_t* ctl_reset; uint32_t ctl_reset_words;  // per-call counters td_prepare clears
     int32_t* out_tokens;        // [out_cap]

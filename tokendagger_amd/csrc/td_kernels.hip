@@ -864,13 +864,15 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
     __shared__ uint32_t s_rec[K_MISS_LISTED_MAX];  // the first few: slot << 19 | tile position << 7 | length
     __shared__ unsigned long long s_pend[64];      // miss-list entries of the last tiles, not appended yet
     __shared__ uint32_t s_npend;
+    __shared__ uint32_t s_flagl[32];               // flagged tiles of this workgroup, not appended yet
+    __shared__ uint32_t s_nflagl;
     __shared__ uint32_t s_ncold;                   // pieces put aside for the long route
     __shared__ uint16_t s_coldk[K_THREADS];        // their indices in the piece list
 
     const int tid = threadIdx.x;
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
-    if (tid == 0) s_npend = 0;
+    if (tid == 0) { s_npend = 0; s_nflagl = 0; }
     if (tid < (int)(P12_MAXLEN + 1) * 4) {
         const int len = tid >> 2, w = tid & 3, nb = len - 4 * w;  // bytes of dword w that belong to a len-byte key
         s_kmask[tid] = w == 3 || nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
@@ -878,7 +880,6 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
 
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
     uint32_t pfs = 0;  // START bits of window word `tid`
-    bool told_flagged = false;
     const uint32_t list_max = a.stop_after == 70 ? 0u : (uint32_t)K_MISS_LISTED_MAX;  // (70: tuning aid, no miss lists)
     // first wavefront: the np entries waiting in s_pend go to their class's global list; ONE atomic per class (same-address
     // atomics are served one after the other, tens of nanoseconds each: one per entry was +50 % on the whole kernel)
@@ -1080,8 +1081,18 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
             uint32_t fl = s_flags;
             const uint32_t nr = s_nrec;
             if (nr > list_max) {
+                // flagged: td_merge_pieces scans the tile.  It draws the flagged tiles from a list (two at a time: runs of
+                // consecutive tiles, grown while they were light, sent whole heavy stretches to single wavefronts: 2.7 ms
+                // instead of 1.2 on the reference's code file set), appended 32 at a time per workgroup
                 fl |= TILE_HAS_MISS;
-                if (!told_flagged) { *a.any_flagged = 1u; told_flagged = true; }  // (once per workgroup: stores to one address queue up)
+                uint32_t nf = s_nflagl;
+                s_flagl[nf++] = (uint32_t)tile;
+                if (nf == 32u) {
+                    const uint32_t at = atomicAdd(a.flagged_count, 32u);
+                    for (uint32_t q = 0; q < 32u; ++q) a.flagged_list[at + q] = s_flagl[q];
+                    nf = 0;
+                }
+                s_nflagl = nf;
             }
             else if (nr) fl |= TILE_MISS_LISTED;
             a.tile_count[tile] = np_total | fl;
@@ -1100,6 +1111,10 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
         __syncthreads();
     }
     if (tid < 64) append_pending(s_npend);  // (what is still waiting in LDS)
+    if (tid == 0 && s_nflagl) {
+        const uint32_t nf = s_nflagl, at = atomicAdd(a.flagged_count, nf);
+        for (uint32_t q = 0; q < nf; ++q) a.flagged_list[at + q] = s_flagl[q];
+    }
 }
 
 // ------------------------------------------------------------------ byte-pair merge, one lane per piece ----
@@ -1271,18 +1286,18 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
         TD_TICK(t_out)
     };
 
-    // Wavefronts DRAW their tiles (runs of a few consecutive ones from a counter): dealt round-robin, a corpus whose heavy
-    // stretches repeat with a period (a file set read again and again) sent them all to the same wavefronts, and the kernel
-    // lasted as long as the unluckiest one (2.8 ms for 3 workgroups per CU, 2.3 ms for 2, 3.0 ms for 1: the stride decided).
-    // The tile one past the last is a virtual one: no rows, it drains the partial batches through the same single call
+    // Wavefronts DRAW their tiles, two at a time, from the list of flagged tiles td_probe_tiles made.  History: dealt
+    // round-robin, a corpus whose heavy stretches repeat with a period (a file set read again and again) sent them all to the
+    // same wavefronts (2.8 ms with 3 workgroups per CU, 2.3 with 2, 3.0 with 1: the stride decided); drawn as runs of
+    // consecutive tiles that grew while the tiles were light (same-address atomics are served one after the other, tens of
+    // nanoseconds each, so light tiles must not be drawn one by one), whole heavy stretches went to single wavefronts
+    // (2.7 ms instead of 1.2 on the reference's code file set).  With the list, light tiles are not drawn at all.
+    // The draw one past the last is a virtual tile: no rows, it drains the partial batches through the same single call
     // site of run_batch.
-    // (run length: same-address atomics are served one after the other, ~10 ns each, so wavefronts that race through tiles
-    // without missed pieces must not draw them one by one: a run that needed no batch doubles the next one (up to 32), one with batches
-    // halves it, a busy one goes back to single tiles)
-    const int run_min = (a.stop_after >= 50 && a.stop_after < 60) ? 1 << (a.stop_after - 50) : 2;  // (50..59: tuning aid)
-    int run = 4, tile = 0, run_end = 0;
-    uint32_t batches_in_run = 0, run_counts = 0;
-    int run_first = 0;
+    const int run = 2;
+    const int n_flagged = (int)*a.flagged_count;
+    int fpos = 0, run_end = 0, run_first = 0;  // position on the flagged list
+    uint32_t run_counts = 0, run_tiles = 0;
     // first the global miss lists (the few missed pieces of sparsely hit tiles, one list per length class): a "row" is one
     // batch's worth of records of one class, dealt round-robin; then the flagged tiles.  list_row >= 0: the next draw is a row.
     uint32_t n_listed[MQ_CLASSES], rows_before[MQ_CLASSES + 1];
@@ -1316,29 +1331,28 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
             qset(qcnts, c, qc + (uint32_t)__popcll((unsigned long long)b));
             wave_sync();
             list_row += nwaves_all;
-            tile = 0; run_end = 0;      // (not a tile: falls through to the batch loop below with no rows)
+            fpos = 0; run_end = 0;      // (not a tile: falls through to the batch loop below with no rows)
         } else if (list_row >= 0) {
             list_row = -1;              // lists done: tiles from here on
-            if (!*a.any_flagged) { tile = a.n_tiles; run_end = a.n_tiles + 1; }  // (no tile to scan: straight to the drain; drawing tiles costs an atomic per run)
+            if (n_flagged == 0) { fpos = 0; run_end = 1; }  // (no tile to scan: straight to the drain)
             continue;
         }
         const bool from_list = list_row >= 0;
-        if (!from_list && tile >= run_end) {
-            run = batches_in_run == 0 ? (run < 32 ? run * 2 : 32) : (run / 2 > run_min ? run / 2 : run_min);
-            batches_in_run = 0;
+        if (!from_list && fpos >= run_end) {
             uint32_t t0 = 0;
             if (lane == 0) t0 = atomicAdd(a.merge_next, (uint32_t)run);
-            tile = (int)uni32(t0);
-            run_end = tile + run;
-            run_counts = (lane < run && tile + lane < a.n_tiles) ? a.tile_count[tile + lane] : 0u;  // the run's tile_count words: one load
-            run_first = tile;
+            fpos = (int)uni32(t0);
+            run_end = fpos + run;
+            run_first = fpos;
+            run_tiles = (lane < run && fpos + lane < n_flagged) ? a.flagged_list[fpos + lane] : 0u;
+            run_counts = (lane < run && fpos + lane < n_flagged) ? a.tile_count[run_tiles] : 0u;
         }
-        const bool drain = !from_list && tile >= a.n_tiles;
+        const bool drain = !from_list && fpos >= n_flagged;
         uint32_t cnt = 0;
+        int tile = 0;
         if (!drain && !from_list) {
-            const uint32_t tc = (uint32_t)__builtin_amdgcn_readlane((int)run_counts, tile - run_first);
-            if (!(tc & TILE_HAS_MISS)) { ++tile; continue; }  // (uniform per wavefront)
-            cnt = tc & TILE_COUNT_MASK;
+            tile = (int)(uint32_t)__builtin_amdgcn_readlane((int)run_tiles, fpos - run_first);
+            cnt = (uint32_t)__builtin_amdgcn_readlane((int)run_counts, fpos - run_first) & TILE_COUNT_MASK;
         }
         const uint32_t* slots = a.stage + (size_t)((drain || from_list) ? 0 : tile) * K_STAGE;
         const uint32_t rows = (drain || from_list) ? 1u : (cnt + 63u) >> 6;
@@ -1390,11 +1404,10 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
                     if (drain ? qcnt_of(q) != 0u : qcnt_of(q) >= 64u / mq_units((uint32_t)q)) c = q;
                 if (c < 0) break;
                 run_batch(c);
-                ++batches_in_run;
             }
         }
         if (drain) break;
-        if (!from_list) ++tile;
+        if (!from_list) ++fpos;
     }
 #ifdef TD_MERGE_TIMING
     if (lane == 0 && (blockIdx.x % 97) == 0 && wv == 0)
