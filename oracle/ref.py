@@ -42,6 +42,9 @@ def _lib():
     lib.tdref_split.restype = ctypes.c_int64
     lib.tdref_split.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
                                 ctypes.c_int64]
+    lib.tdref_split_bytes.restype = ctypes.c_int64
+    lib.tdref_split_bytes.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,
+                                      ctypes.c_void_p, ctypes.c_int64]
     lib.tdref_decode.restype = ctypes.c_int64
     lib.tdref_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                  ctypes.c_int64]
@@ -124,6 +127,19 @@ class RefTokenizer:
         if n < 0:
             raise self._err()
         return out[:n].copy()
+
+    def split_pieces(self, data: bytes) -> list[bytes]:
+        """The pieces of split_text themselves (a pattern may skip text: their lengths need not add up to offsets)."""
+        lens = np.empty(max(len(data), 1), dtype=np.int64)
+        buf = ctypes.create_string_buffer(max(len(data), 1))
+        n = self._lib.tdref_split_bytes(self._h, data, len(data), buf, len(data), lens.ctypes.data, lens.size)
+        if n < 0:
+            raise self._err()
+        raw, out, pos = buf.raw, [], 0
+        for k in range(n):
+            out.append(raw[pos:pos + int(lens[k])])
+            pos += int(lens[k])
+        return out
 
     def decode_bytes(self, tokens) -> bytes:
         t = np.ascontiguousarray(tokens, dtype=np.int32)

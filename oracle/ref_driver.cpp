@@ -142,6 +142,26 @@ int64_t tdref_split(void* h, const uint8_t* text, int64_t len, int64_t* ends, in
     }
 }
 
+// the pieces themselves (split_text returns strings: with a pattern that skips text, their lengths do not add up to offsets)
+int64_t tdref_split_bytes(void* h, const uint8_t* text, int64_t len, uint8_t* out, int64_t cap_bytes, int64_t* lens, int64_t cap) {
+    try {
+        std::string s((const char*)text, len);
+        auto pieces = ((Ref*)h)->bpe->split_text(s, 0, s.size());
+        if ((int64_t)pieces.size() > cap) { g_err = "output capacity too small"; return -2; }
+        int64_t pos = 0;
+        for (size_t i = 0; i < pieces.size(); ++i) {
+            if (pos + (int64_t)pieces[i].size() > cap_bytes) { g_err = "output capacity too small"; return -2; }
+            memcpy(out + pos, pieces[i].data(), pieces[i].size());
+            pos += (int64_t)pieces[i].size();
+            lens[i] = (int64_t)pieces[i].size();
+        }
+        return (int64_t)pieces.size();
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 int64_t tdref_decode(void* h, const int32_t* toks, int64_t n, uint8_t* out, int64_t cap) {
     try {
         std::vector<int> v(toks, toks + n);

@@ -132,13 +132,32 @@ TWIN_SO = ROOT / "tests" / "twin" / "_build" / "libtdtwin.so"
 
 def build_twin():
     TWIN_SO.parent.mkdir(parents=True, exist_ok=True)
-    srcs = [ROOT / "tests/twin/td_twin.cpp", ROOT / "tokendagger_amd/csrc/td_tables.cpp"]
+    srcs = [ROOT / "tests/twin/td_twin.cpp", ROOT / "tokendagger_amd/csrc/td_tables.cpp", ROOT / "tokendagger_amd/csrc/td_regex.cpp"]
     deps = srcs + [ROOT / "tokendagger_amd/csrc/td_common.h", ROOT / "tokendagger_amd/csrc/td_tables.h",
-                   ROOT / "tokendagger_amd/csrc/generated/unicode_classes.inc"]
+                   ROOT / "tokendagger_amd/csrc/td_regex.h", ROOT / "tokendagger_amd/csrc/generated/unicode_classes.inc",
+                   ROOT / "tokendagger_amd/csrc/generated/unicode_gc.inc"]
     if TWIN_SO.exists() and all(TWIN_SO.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
                            *map(str, srcs), "-o", str(TWIN_SO)])
+
+
+def rx_split(pattern: str, data: bytes):
+    """Generic split pattern through td_regex.cpp (compile) + td_regex.h (the matcher the device runs), one document.
+    -> list of (start, end), or raises ValueError with the compiler's message when the pattern is not supported."""
+    build_twin()
+    lib = ctypes.CDLL(str(TWIN_SO))
+    lib.twin_rx_split.restype = ctypes.c_int64
+    lib.twin_rx_split.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_int64, ctypes.c_char_p, ctypes.c_int]
+    cap = len(data) + 1
+    st = np.empty(cap, dtype=np.int64); en = np.empty(cap, dtype=np.int64)
+    err = ctypes.create_string_buffer(512)
+    n = lib.twin_rx_split(pattern.encode("utf-8"), data, len(data), st.ctypes.data, en.ctypes.data, cap, err, 512)
+    if n == -1:
+        raise ValueError(err.value.decode())
+    assert n >= 0, n
+    return list(zip(st[:n].tolist(), en[:n].tolist()))
 
 
 class Twin:

@@ -1,0 +1,92 @@
+"""Generic split patterns: td_regex.cpp compiles the backtracking subset of PCRE2 syntax tokenizer patterns are
+written in, td_regex.h matches it — on the device one lane per document (td_generic.hip).  Pinned against PCRE2 itself: the
+compiled reference runs ANY pattern (tiktoken.cpp:47-128), so pieces (with the text a pattern skips) and ids are compared
+with it directly.  CPU: compiler + matcher (the same header the kernel compiles); GPU: ids through the C ABI."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import ref
+from tokendagger_amd import vocab_io
+
+AUTOGEN = r"[a-zA-Z]+|\s+|[0-9]+|[^\w\s]"          # the reference's tests/autogenned_test.py:66 (skips '_' and 'é')
+PATTERNS = {
+    "autogen": AUTOGEN,
+    # every member of the family through the GENERIC compiler (the product runs them on their own kernels)
+    "llama4": vocab_io.LLAMA4_PAT_STR, "tekken": vocab_io.TEKKEN_PAT_STR, "cl100k": vocab_io.CL100K_PAT_STR,
+    "cl100k_possessive": vocab_io.CL100K_PAT_STR_POSSESSIVE, "cl100k_current": vocab_io.CL100K_PAT_STR_CURRENT,
+    "qwen2": vocab_io.QWEN2_PAT_STR, "gpt2": vocab_io.GPT2_PAT_STR, "gpt2_possessive": vocab_io.GPT2_PAT_STR_POSSESSIVE,
+    # other shapes: \w \d classes, bounded repeats, ranges, dots, look-aheads, literals, skipped text, a tail that never matches
+    "words": r"\w+|[^\w\s]+|\s+", "digits": r"\d{1,3}|\D+", "camel": r"[A-Z][a-z]*|\s|.", "cats": r"\p{Lu}\p{Ll}*|\p{Nd}+|\.{2,}|.",
+    "look": r"[a-z]+(?=[0-9])|[0-9]+|\s+(?!\S)|\S", "letters_only": r"\p{L}+", "lit": r"(?i:the|an|a|k|s)| ?\pL+|\PL",
+    "hex": r"0x[0-9a-fA-F]{1,8}|\x41+|[\x{4e00}-\x{9fff}]+|[^\S\n]*\n|.", "opt": r"(?:ab|a)?c|[ab]+|\s*+x|.",
+}
+REJECTED = [r"(\w+)\s+\1", r"\S+?", r"^abc", r"\bword\b", r"(?<=a)b", r"[[:alpha:]]+", r"(a|b)+", r"\p{Han}+", r"(?i)abc", r"a|", r"(?:a|b)*"]
+
+
+def _strings(n, seed):
+    rng = random.Random(seed)
+    for i in range(n):
+        k = i % 4
+        if k == 0:
+            yield "".join(rng.choice(" \t\n\r_aAbBtThHeExX09zZ.,'\"(){}-+=é中ſK😀/") for _ in range(rng.randrange(0, 60)))
+        elif k == 1:
+            yield H.fuzz_string(rng, 60)
+        elif k == 2:
+            yield H.random_unicode_string(rng, 40)
+        else:
+            yield "".join(rng.choice(["the ", "An", " a", "0x1F", "ab", "abc", "c", " x", "12345", "\n\n", "  ", "HelloWorld", "...", "中文"]) for _ in range(rng.randrange(1, 12)))
+
+
+def test_unsupported_syntax_is_rejected_with_a_reason():
+    for pat in REJECTED:
+        with pytest.raises(ValueError) as e:
+            H.rx_split(pat, b"abc")
+        assert "split pattern" in str(e.value) or "support" in str(e.value), (pat, str(e.value))
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+@pytest.mark.parametrize("name", sorted(PATTERNS))
+def test_pieces_equal_pcre2(name, golden):
+    pat = PATTERNS[name]
+    _, mr, special = H.llama4()
+    R = ref.RefTokenizer(pat, mr, special)
+    for s in _strings(2500, hash(name) & 0xFFFF):
+        b = s.encode("utf-8")
+        assert [b[a:e] for a, e in H.rx_split(pat, b)] == R.split_pieces(b), (name, s)
+    text, offs = golden["text"].tobytes(), golden["offsets"]
+    for d in range(0, len(offs) - 1, 41):
+        doc = text[offs[d]:offs[d + 1]]
+        if len(doc) > 20000:
+            continue
+        assert [doc[a:e] for a, e in H.rx_split(pat, doc)] == R.split_pieces(doc), (name, golden["names"][d])
+
+
+def test_the_reference_tests_own_pattern_skips_text():
+    spans = H.rx_split(AUTOGEN, "snake_case é 42!".encode())
+    assert [(a, e) for a, e in spans] == [(0, 5), (6, 10), (10, 11), (13, 14), (14, 16), (16, 17)]  # '_' and 'é' are skipped
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_gpu_generic_patterns_equal_the_reference():
+    import td_corpus
+    from tokendagger_amd import capi
+    _, mr, special = H.llama4()
+    for name in ("autogen", "words", "look", "letters_only", "opt"):
+        pat = PATTERNS[name]
+        tok = capi.HipTokenizer(pat, mr, special, device=0)
+        R = ref.RefTokenizer(pat, mr, special)
+        docs = [s.encode("utf-8") for s in _strings(600, 7 + len(name))]
+        docs += [b"", b"_", b"___", "é".encode(), b"a_b", b"snake_case_name = 42", ("word_" * 3000).encode(), ("x" * 5000 + "_").encode()]
+        x, o = td_corpus.code(1 << 20, seed=3)
+        docs += [x[o[d]:o[d + 1]].tobytes() for d in range(0, len(o) - 1, 3)][:300]
+        text, offs = H.pack_docs(docs)
+        toks, toffs = tok.encode_batch(text, offs)
+        _, etoks, eoffs = R.encode_batch(np.frombuffer(text, dtype=np.uint8), offs, n_threads=8, want_tokens=True)
+        assert np.array_equal(toffs, eoffs), name
+        assert np.array_equal(toks, etoks), name
+        assert list(tok.encode_batch(b"snake_case", np.asarray([0, 10], dtype=np.int64))[0]) == list(R.encode(b"snake_case"))
+        tok.close()

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../tokendagger_amd/csrc/td_common.h"
+#include "../../tokendagger_amd/csrc/td_regex.h"
 #include "../../tokendagger_amd/csrc/td_tables.h"
 
 using namespace td;
@@ -91,6 +92,10 @@ void* twin_create(const char* pat, int64_t n_vocab, const uint8_t* bytes, const 
                   int64_t n_special, const uint8_t* sbytes, const int64_t* soffs, const int32_t* sranks, int* rc_out) {
     Twin* t = new Twin;
     int rc = build_tables(pat, n_vocab, bytes, offs, ranks, n_special, sbytes, soffs, sranks, t->H, t->err);
+    if (rc == TD_OK && t->H.pattern_kind == PATTERN_GENERIC) {  // (the twin models the family's kernels; generic patterns: twin_rx_split)
+        rc = TD_E_PATTERN;
+        t->err = "the CPU twin models the pattern family only";
+    }
     if (rc_out) *rc_out = rc;
     if (rc != TD_OK) {
         static thread_local std::string keep;
@@ -481,6 +486,28 @@ int64_t twin_word_rules_check(void* h, const uint8_t* text, int64_t n, const int
     }
     if (stats) { stats[0] = heads; stats[1] = unres; stats[2] = pieces; stats[3] = upieces; }
     return bad;
+}
+
+// generic split patterns: compile `pattern` (td_regex.cpp) and run the reference's piece loop (rx_next_piece) over one
+// document.  -> number of pieces (their [start, end) in starts / ends), -1 when the pattern is not supported (err says why)
+int64_t twin_rx_split(const char* pattern, const uint8_t* text, int64_t n, int64_t* starts, int64_t* ends, int64_t cap, char* err, int errcap) {
+    static thread_local RxProgram P;
+    std::string e;
+    if (!rx_compile(pattern, P, e)) {
+        if (err && errcap > 0) { strncpy(err, e.c_str(), (size_t)errcap - 1); err[errcap - 1] = 0; }
+        return -1;
+    }
+    struct Acc { const uint8_t* t; uint32_t byte(int64_t i) const { return t[i]; } } acc{text};
+    const RxTables T = rx_host_tables();
+    int64_t k = 0;
+    for (int64_t pos = 0; pos < n;) {
+        int64_t ms, me;
+        rx_next_piece(P, T, acc, pos, n, ms, me);
+        if (k >= cap) return -2;
+        starts[k] = ms; ends[k] = me; ++k;
+        pos = me;
+    }
+    return k;
 }
 
 }  // extern "C"

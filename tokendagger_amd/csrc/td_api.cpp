@@ -17,6 +17,7 @@
 
 #include "../../include/tokendagger_hip.h"
 #include "td_kernels.h"
+#include "td_regex.h"
 #include "td_tables.h"
 #include "td_vocab.h"
 
@@ -136,7 +137,7 @@ struct Ctl {  // small control block in device memory
     uint32_t merge_next;   // td_merge_pieces: next tile nobody has taken yet
     uint32_t miss_count[6];  // entries on the miss lists (K_MISS_CLASSES of them)
     uint32_t flagged_count;  // tiles flagged TILE_HAS_MISS (on flagged_list: td_merge_pieces draws them from there)
-    uint32_t pad2;
+    uint32_t gap_count;      // generic split patterns: stretches of text the pattern skipped
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 }  // namespace
@@ -150,7 +151,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, gap_list, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -159,6 +160,9 @@ struct td_tokenizer {
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
     std::vector<Ev3> ev_pending, ev_free;
     int64_t last_long = 0, last_far = 0;
+    const RxProgram* d_rx = nullptr;      // generic split pattern: the compiled program and its tables in HBM
+    const uint16_t* d_rx_s1 = nullptr;
+    const uint8_t* d_rx_s2 = nullptr;
     size_t ws_bytes = 0;
     // One workspace per handle: work of this handle may be in flight on one stream at a time.  A call on another
     // stream first waits (on the device, not the host) for the previous call's last kernel.
@@ -267,6 +271,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->flagged_list, (size_t)(n_tiles + 64) * 4))) return rc;
+    if (t->H.pattern_kind == PATTERN_GENERIC && (rc = ensure(t, t->gap_list, (size_t)(n / 2 + 4096) * 8))) return rc;  // (a skipped stretch and the piece behind it take two bytes at least)
     if ((rc = ensure(t, t->miss_list, (size_t)(n_tiles + 1) * K_MISS_LISTED_MAX * K_MISS_CLASSES * 8))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
     if ((rc = ensure(t, t->doc_slot, (size_t)(n_docs + 1) * 4))) return rc;
@@ -327,6 +332,12 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.miss_list = (unsigned long long*)t->miss_list.p;
     a.miss_count = ctl->miss_count;
     a.flagged_count = &ctl->flagged_count;
+    a.rx = t->d_rx;
+    a.rx_stage1 = t->d_rx_s1;
+    a.rx_stage2 = t->d_rx_s2;
+    a.gap_list = (int64_t*)t->gap_list.p;
+    a.gap_cap = (uint32_t)std::min<size_t>(t->gap_list.cap / 8, 0x7FFFFFF0u);
+    a.gap_count = &ctl->gap_count;
     a.flagged_list = (uint32_t*)t->flagged_list.p;
     a.miss_cap = (uint32_t)((n_tiles + 1) * K_MISS_LISTED_MAX);
     a.chunk_pref = (int64_t*)t->chunk_pref.p;
@@ -456,6 +467,14 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if ((rc = upload(t, H.pair_slots.data(), H.pair_slots.size(), &d.pair_slots))) return fail(rc);
     if ((rc = upload(t, H.tok_off.data(), H.tok_off.size(), &d.tok_off))) return fail(rc);
     if ((rc = upload(t, H.tok_bytes.data(), H.tok_bytes.size(), &d.tok_bytes))) return fail(rc);
+    if (H.pattern_kind == PATTERN_GENERIC) {
+        size_t n1 = 0, n2 = 0;
+        const uint16_t* s1 = rx_stage1(&n1);
+        const uint8_t* s2 = rx_stage2(&n2);
+        if ((rc = upload(t, reinterpret_cast<const RxProgram*>(H.rx_program.data()), 1, &t->d_rx))) return fail(rc);
+        if ((rc = upload(t, s1, n1, &t->d_rx_s1))) return fail(rc);
+        if ((rc = upload(t, s2, n2, &t->d_rx_s2))) return fail(rc);
+    }
     t->dT = d;
     if ((rc = upload(t, &t->dT, 1, &t->dTp))) return fail(rc);
     if ((rc = ensure(t, t->ctl, sizeof(Ctl)))) return fail(rc);
@@ -482,7 +501,7 @@ void td_destroy(td_tokenizer* t) {
         for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h}) if (st) (void)hipStreamDestroy(st);
         if (t->small_in) (void)hipHostFree(t->small_in);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->gap_list, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)
@@ -746,7 +765,7 @@ int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc
     int rc;
     if ((rc = check_offsets(t, "doc_offsets", doc_offsets, n_docs, text))) return rc;
     const int64_t n = doc_offsets[n_docs];
-    if (n > 0 && n <= SMALL_MAX_BYTES && n_docs <= SMALL_MAX_DOCS && t->small_enabled) {
+    if (n > 0 && n <= SMALL_MAX_BYTES && n_docs <= SMALL_MAX_DOCS && t->small_enabled && t->H.pattern_kind != PATTERN_GENERIC) {  // (the one-launch kernel knows the family's scanners only)
         rc = encode_batch_small(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
         if (rc != -1) return rc;  // (-1: a piece above 64 bytes; the general path below handles it)
     }
@@ -1130,6 +1149,21 @@ int32_t last_piece_token_len_host(td_tokenizer* t, const uint8_t* text, int64_t 
         }
     };
     const Tables hv = t->H.view();
+    if (t->H.pattern_kind == PATTERN_GENERIC) {
+        // the compiled pattern over the whole segment (no provable restart points): its last piece
+        struct SegAcc { const uint8_t* p; uint32_t byte(int64_t i) const { return p[i]; } } S{text + s_lo};
+        const RxProgram& P = *reinterpret_cast<const RxProgram*>(t->H.rx_program.data());
+        const RxTables RT = rx_host_tables();
+        const int64_t n = s_hi - s_lo;
+        int64_t ms = 0, me = 0;
+        for (int64_t pos = 0; pos < n; pos = me) rx_next_piece(P, RT, S, pos, n, ms, me);
+        const uint32_t len = (uint32_t)(me - ms);
+        const uint8_t* pb = text + s_lo + ms;
+        std::vector<int32_t> tmp;
+        const int32_t whole = (len == 1) ? t->H.byte_id[pb[0]] : piece_lookup(hv, piece_key_host(pb, len), len, [pb](uint32_t i) { return (uint32_t)pb[i]; });
+        if (whole != NO_RANK) return 1;
+        return merge_piece_host(hv, pb, len, tmp) == TD_OK ? (int32_t)tmp.size() : 0;
+    }
     HostAcc A{&hv, text, s_lo, s_hi, s_hi + 4};
     // the last piece starts at or behind the last provable sync point of the segment: walk back to it instead of scanning
     // the whole segment (this runs on the host for every CoreBPE.encode call)

@@ -121,7 +121,8 @@ struct Tables {
 // by PV_GPT2, and the same two class remaps as cl100k.
 // PV_WS_EOS_FIRST: current tiktoken releases spell cl100k_base with `\s++$` IN FRONT of `\s*[\r\n]`: a whitespace run that
 // reaches the end of the subject is one piece even when it contains CR/LF ("\r\t" at the end: one piece, not two).
-enum : uint32_t { PV_NO_CONTRACTION = 1, PV_SINGLE_DIGIT = 2, PV_LEADING_CONTRACTION = 4, PV_PLAIN_LETTERS = 8, PV_GPT2 = 16, PV_WS_EOS_FIRST = 32 };
+enum : uint32_t { PV_NO_CONTRACTION = 1, PV_SINGLE_DIGIT = 2, PV_LEADING_CONTRACTION = 4, PV_PLAIN_LETTERS = 8, PV_GPT2 = 16, PV_WS_EOS_FIRST = 32,
+                  PV_GENERIC = 64 };  // PV_GENERIC: not a member of the family: the compiled pattern (td_regex.h) is matched document by document (td_generic.hip)
 
 // ------------------------------------------------------------------ hashing -----------------
 TD_HD uint32_t hash_piece(uint64_t key, uint32_t len) {

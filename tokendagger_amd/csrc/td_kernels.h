@@ -7,6 +7,8 @@
 
 namespace td {
 
+struct RxProgram;       // td_regex.h: a compiled generic split pattern
+
 struct LongEntry {      // a piece longer than K_MAXSHORT bytes, merged by td_long_pieces
     int64_t gs;         // global byte offset of the piece
     uint32_t len;       // bytes
@@ -47,6 +49,13 @@ struct EncodeArgs {
                                     // one list per length class, miss_cap entries apart
     uint32_t* miss_count;       // [K_MISS_CLASSES] entries on them
     uint32_t miss_cap;          // (room for K_MISS_LISTED_MAX per tile on every list)
+    // generic split patterns (PV_GENERIC; td_generic.hip)
+    const RxProgram* rx;        // the compiled pattern
+    const uint16_t* rx_stage1;  // general-category table (generated/unicode_gc.inc)
+    const uint8_t* rx_stage2;
+    int64_t* gap_list;          // global byte positions of the stretches the pattern skips (they get no tokens)
+    uint32_t* gap_count;
+    uint32_t gap_cap;
     uint32_t* flagged_list;     // the tiles td_probe_tiles flagged TILE_HAS_MISS, in the order its workgroups appended them
     uint32_t* flagged_count;    // entries on it
     int64_t* chunk_pref;        // [n_tiles/4096 + 2] token base of every 4096-tile chunk (exclusive scan of the chunk totals)
@@ -107,6 +116,9 @@ hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream);
 // ev[3] | td_long_pieces, td_scan_tiles, td_pack_tokens | ev[4]
 constexpr int TD_PROF_EVENTS = 5;
 hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev = nullptr);
+// generic split patterns (td_generic.hip), called by launch_encode in place of td_split_tiles / ahead of td_scan_tiles
+hipError_t launch_generic_split(const EncodeArgs& a, hipStream_t stream);
+hipError_t launch_generic_gaps(const EncodeArgs& a, hipStream_t stream);
 // phases: 1 = lengths + offsets (td_decode_len, td_decode_chunks, document byte offsets), 2 = gather (td_decode_copy), 3 = both
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, int phases = 3);
 int encode_grid_blocks();  // persistent grid size of td_probe_tiles

@@ -2416,6 +2416,10 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     if (ev) (void)hipEventRecord(ev[0], stream);
     constexpr uint32_t PV_TEKKEN = PV_NO_CONTRACTION | PV_SINGLE_DIGIT;
     constexpr uint32_t PV_CL100K = PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS;
+    if (a.pat_flags & PV_GENERIC) {  // not a member of the family: the compiled pattern, document by document (td_generic.hip)
+        const hipError_t ge = launch_generic_split(a, stream);
+        if (ge != hipSuccess) return ge;
+    } else
     switch (a.pat_flags) {
         case PV_GPT2: hipLaunchKernelGGL(td_split_tiles<PV_GPT2>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
         case 0u: hipLaunchKernelGGL(td_split_tiles<0u>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
@@ -2444,6 +2448,10 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     if (tokens) {
         hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(td_giant_pieces, dim3(128), dim3(GP_THREADS), 0, stream, a);
+        if (a.pat_flags & PV_GENERIC) {  // text the pattern skips gets no tokens
+            const hipError_t ge = launch_generic_gaps(a, stream);
+            if (ge != hipSuccess) return ge;
+        }
         hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
         hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
     }

@@ -1,0 +1,418 @@
+// Host side of the generic split patterns: pat_str -> RxProgram (td_regex.h).  A recursive-descent reader for the subset
+// of PCRE2 syntax listed there; anything else is an error message for TD_E_PATTERN (there is no CPU regex fallback and no
+// silent approximation: what the reader accepts, the matcher runs with PCRE2's semantics, pinned against PCRE2 itself by
+// tests/test_generic_pattern.py).
+#include "td_regex.h"
+
+#include <string>
+#include <vector>
+
+#include "generated/unicode_gc.inc"
+#include "td_tables.h"
+
+namespace td {
+
+RxTables rx_host_tables() { return RxTables{td_ugc_stage1, td_ugc_stage2}; }
+const uint16_t* rx_stage1(size_t* n) { *n = sizeof td_ugc_stage1 / sizeof td_ugc_stage1[0]; return td_ugc_stage1; }
+const uint8_t* rx_stage2(size_t* n) { *n = sizeof td_ugc_stage2; return td_ugc_stage2; }
+
+namespace {
+
+// general category ids of generated/unicode_gc.inc
+const char* const kGc[30] = {"Cn", "Lu", "Ll", "Lt", "Lm", "Lo", "Mn", "Mc", "Me", "Nd", "Nl", "No", "Pc", "Pd", "Ps",
+                             "Pe", "Pi", "Pf", "Po", "Sm", "Sc", "Sk", "So", "Zs", "Zl", "Zp", "Cc", "Cf", "Cs", "Co"};
+
+struct Reader {
+    const std::string& s;
+    size_t i = 0;
+    RxProgram& P;
+    std::string err;
+    Reader(const std::string& s_, RxProgram& P_) : s(s_), P(P_) {}
+
+    bool fail(const std::string& what) {
+        if (err.empty()) err = what + " (at offset " + std::to_string(i) + " of the split pattern)";
+        return false;
+    }
+    bool eof() const { return i >= s.size(); }
+    int peek(size_t k = 0) const { return i + k < s.size() ? (unsigned char)s[i + k] : -1; }
+
+    // ---- program building ----
+    bool new_item(const RxItem& it, uint16_t& idx) {
+        if (P.n_items >= (uint32_t)RX_MAX_ITEMS) return fail("split pattern too large (class items)");
+        idx = (uint16_t)P.n_items;
+        P.items[P.n_items++] = it;
+        return true;
+    }
+    bool new_class(uint16_t first_item, uint16_t n_items, bool negate, uint16_t& cls) {
+        if (P.n_classes >= (uint32_t)RX_MAX_CLASSES) return fail("split pattern too large (classes)");
+        cls = (uint16_t)P.n_classes;
+        RxClass c{};
+        c.first_item = first_item; c.n_items = n_items; c.negate = negate ? 1 : 0;
+        P.classes[P.n_classes++] = c;
+        return true;
+    }
+    static RxItem range_item(uint32_t lo, uint32_t hi) {
+        RxItem it{};
+        it.lo = lo; it.hi = hi;
+        return it;
+    }
+    static RxItem none_item() { return range_item(1, 0); }
+    bool single_class(const RxItem& it, uint16_t& cls) {
+        uint16_t idx = 0;
+        return new_item(it, idx) && new_class(idx, 1, false, cls);
+    }
+
+    // ---- lexical pieces ----
+    bool read_codepoint_literal(uint32_t& cp) {  // one (possibly multi-byte) character of the pattern text
+        const uint32_t b = (uint32_t)peek();
+        if (b < 0x80u) { cp = b; ++i; return true; }
+        const uint32_t need = utf8_declared_len(b) - 1u;
+        if (need == 0 || i + need >= s.size()) return fail("split pattern is not valid UTF-8");
+        cp = b & (0xFFu >> (need + 2u));
+        for (uint32_t k = 1; k <= need; ++k) {
+            const uint32_t c = (unsigned char)s[i + k];
+            if ((c & 0xC0u) != 0x80u) return fail("split pattern is not valid UTF-8");
+            cp = (cp << 6) | (c & 0x3Fu);
+        }
+        i += need + 1;
+        return true;
+    }
+    bool read_hex(uint32_t& v) {  // behind "\x": HH or {H..}
+        v = 0;
+        auto hexv = [](int c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; };
+        if (peek() == '{') {
+            ++i;
+            int nd = 0;
+            while (!eof() && peek() != '}') {
+                const int h = hexv(peek());
+                if (h < 0 || ++nd > 6) return fail("bad \\x{...} escape");
+                v = v * 16 + (uint32_t)h;
+                ++i;
+            }
+            if (eof() || nd == 0) return fail("bad \\x{...} escape");
+            ++i;
+            return v <= 0x10FFFFu ? true : fail("\\x{...} beyond U+10FFFF");
+        }
+        for (int k = 0; k < 2; ++k) {
+            const int h = hexv(peek());
+            if (h < 0) break;
+            v = v * 16 + (uint32_t)h;
+            ++i;
+        }
+        return true;
+    }
+    bool read_property(bool upper_p, RxItem& it) {  // behind "\p" / "\P"
+        std::string name;
+        bool neg = upper_p;
+        if (peek() == '{') {
+            ++i;
+            if (peek() == '^') { neg = !neg; ++i; }
+            while (!eof() && peek() != '}') name.push_back((char)s[i++]);
+            if (eof()) return fail("unterminated \\p{");
+            ++i;
+        } else if (!eof()) {
+            name.push_back((char)s[i++]);
+        }
+        uint32_t mask = 0;
+        if (name.size() == 1 || name == "L&") {
+            const char c0 = name[0];
+            for (int g = 0; g < 30; ++g)
+                if (kGc[g][0] == c0 && (name.size() == 1 || g == 1 || g == 2 || g == 3)) mask |= 1u << g;
+            if (name == "L&") mask &= (1u << 1) | (1u << 2) | (1u << 3);
+        } else {
+            for (int g = 0; g < 30; ++g)
+                if (name == kGc[g]) mask |= 1u << g;
+        }
+        if (!mask) return fail("unsupported Unicode property \\p{" + name + "} (general categories only)");
+        it = none_item();
+        it.gc_mask = mask;
+        it.negate = neg ? 1 : 0;
+        return true;
+    }
+    // behind a backslash: a class escape (-> item, is_class = true) or a literal character (-> cp)
+    bool read_escape(bool& is_class, RxItem& it, uint32_t& cp) {
+        if (eof()) return fail("pattern ends in a backslash");
+        const int c = peek();
+        ++i;
+        is_class = true;
+        it = none_item();
+        switch (c) {
+            case 's': it.flags = RX_F_S; return true;
+            case 'S': it.flags = RX_F_S; it.negate = 1; return true;
+            case 'w': it.flags = RX_F_W; return true;
+            case 'W': it.flags = RX_F_W; it.negate = 1; return true;
+            case 'd': it.flags = RX_F_D; return true;
+            case 'D': it.flags = RX_F_D; it.negate = 1; return true;
+            case 'p': return read_property(false, it);
+            case 'P': return read_property(true, it);
+            default: break;
+        }
+        is_class = false;
+        switch (c) {
+            case 'n': cp = '\n'; return true;
+            case 'r': cp = '\r'; return true;
+            case 't': cp = '\t'; return true;
+            case 'f': cp = '\f'; return true;
+            case 'a': cp = 0x07; return true;
+            case 'e': cp = 0x1B; return true;
+            case '0': cp = 0; return true;
+            case 'x': return read_hex(cp);
+            default: break;
+        }
+        if (c == 'v' || c == 'h' || c == 'H' || c == 'V' || c == 'R' || c == 'N' || c == 'X' || c == 'b' || c == 'B' || c == 'A' || c == 'Z' ||
+            c == 'z' || c == 'G' || c == 'K' || c == 'Q' || c == 'E' || c == 'k' || c == 'g' || c == 'c' || c == 'o' || c == 'u' || (c >= '1' && c <= '9'))
+            return fail(std::string("unsupported escape \\") + (char)c);
+        if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) return fail(std::string("unsupported escape \\") + (char)c);
+        if (c >= 0x80) { --i; return read_codepoint_literal(cp); }
+        cp = (uint32_t)c;  // escaped punctuation
+        return true;
+    }
+
+    // "[...]" (the '[' is consumed): the class; when `chars` is given and the class is a plain positive set of ASCII
+    // characters, they are listed there too (for the expansion inside literal groups)
+    bool read_bracket(uint16_t& cls, std::vector<uint32_t>* chars) {
+        bool neg = false, plain = true;
+        if (peek() == '^') { neg = true; ++i; }
+        const uint16_t first = (uint16_t)P.n_items;
+        uint16_t n = 0, idx;
+        bool first_char = true;
+        for (;;) {
+            if (eof()) return fail("unterminated character class");
+            int c = peek();
+            if (c == ']' && !first_char) { ++i; break; }
+            first_char = false;
+            if (c == '[' && peek(1) == ':') return fail("POSIX classes [:name:] are not supported");
+            uint32_t lo;
+            RxItem it;
+            bool is_class = false;
+            if (c == '\\') {
+                ++i;
+                if (peek() == 'v') return fail("unsupported escape \\v");
+                if (!read_escape(is_class, it, lo)) return false;
+            } else if (!read_codepoint_literal(lo)) {
+                return false;
+            }
+            if (is_class) {
+                plain = false;
+                if (!new_item(it, idx)) return false;
+                ++n;
+                continue;
+            }
+            uint32_t hi = lo;
+            if (peek() == '-' && peek(1) != ']' && peek(1) != -1) {
+                ++i;
+                bool hc = false;
+                RxItem dummy;
+                if (peek() == '\\') {
+                    ++i;
+                    if (!read_escape(hc, dummy, hi)) return false;
+                    if (hc) return fail("a class escape cannot end a range");
+                } else if (!read_codepoint_literal(hi)) {
+                    return false;
+                }
+                if (hi < lo) return fail("range out of order in character class");
+            }
+            if (!new_item(range_item(lo, hi), idx)) return false;
+            ++n;
+            if (chars) {
+                if (hi - lo > 16 || hi >= 0x80u) plain = false;
+                else for (uint32_t v = lo; v <= hi; ++v) chars->push_back(v);
+            }
+        }
+        if (n == 0) return fail("empty character class");
+        if (chars && (!plain || neg)) chars->clear();
+        return new_class(first, n, neg, cls);
+    }
+
+    // quantifier behind a class atom
+    bool read_quantifier(RxNode& nd) {
+        nd.min = 1; nd.max = 1; nd.possessive = 0;
+        const int c = peek();
+        if (c == '?') { nd.min = 0; nd.max = 1; ++i; }
+        else if (c == '*') { nd.min = 0; nd.max = (uint16_t)RX_INF; ++i; }
+        else if (c == '+') { nd.min = 1; nd.max = (uint16_t)RX_INF; ++i; }
+        else if (c == '{' && peek(1) >= '0' && peek(1) <= '9') {
+            size_t j = i + 1;
+            uint32_t a = 0, b = 0;
+            bool comma = false, have_b = false;
+            while (j < s.size() && s[j] >= '0' && s[j] <= '9') { a = a * 10 + (uint32_t)(s[j] - '0'); if (a > 60000) return fail("repeat count too large"); ++j; }
+            if (j < s.size() && s[j] == ',') {
+                comma = true; ++j;
+                while (j < s.size() && s[j] >= '0' && s[j] <= '9') { b = b * 10 + (uint32_t)(s[j] - '0'); have_b = true; if (b > 60000) return fail("repeat count too large"); ++j; }
+            }
+            if (j >= s.size() || s[j] != '}') return fail("malformed {m,n} quantifier");
+            i = j + 1;
+            nd.min = (uint16_t)a;
+            nd.max = (uint16_t)(!comma ? a : have_b ? b : RX_INF);
+            if (nd.max < nd.min) return fail("{m,n} with n < m");
+        } else {
+            return true;
+        }
+        if (peek() == '+') { nd.possessive = 1; ++i; }
+        else if (peek() == '?') return fail("lazy quantifiers are not supported");
+        return true;
+    }
+
+    bool push_node(const RxNode& nd, uint32_t alt_first) {
+        if (P.n_nodes >= (uint32_t)RX_MAX_NODES) return fail("split pattern too large (nodes)");
+        if (P.n_nodes - alt_first >= (uint32_t)RX_MAX_SEQ) return fail("an alternative of the split pattern has too many elements");
+        P.nodes[P.n_nodes++] = nd;
+        return true;
+    }
+    static void utf8_append(std::string& o, uint32_t cp) {
+        if (cp < 0x80) o.push_back((char)cp);
+        else if (cp < 0x800) { o.push_back((char)(0xC0 | (cp >> 6))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+        else if (cp < 0x10000) { o.push_back((char)(0xE0 | (cp >> 12))); o.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+        else { o.push_back((char)(0xF0 | (cp >> 18))); o.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); o.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+    }
+
+    // "(?:" / "(?i:" group of literal alternatives (the opening is consumed) -> one RX_LITSET node
+    bool read_literal_group(bool caseless, uint32_t alt_first) {
+        std::vector<std::string> alts(1);  // the alternatives in order; a bracket of plain ASCII characters multiplies the current one
+        std::vector<std::string> done;
+        for (;;) {
+            if (eof()) return fail("unterminated group");
+            const int c = peek();
+            if (c == ')') { ++i; break; }
+            if (c == '|') { ++i; for (auto& a : alts) done.push_back(a); alts.assign(1, std::string()); continue; }
+            if (c == '(' || c == '*' || c == '+' || c == '?' || c == '{' || c == '.' || c == '^' || c == '$')
+                return fail("only literal alternatives are supported inside a group");
+            if (c == '[') {
+                ++i;
+                std::vector<uint32_t> chars;
+                uint16_t cls;
+                const uint32_t items0 = P.n_items, classes0 = P.n_classes;
+                if (!read_bracket(cls, &chars)) return false;
+                P.n_items = items0; P.n_classes = classes0;  // (only its characters are used)
+                if (chars.empty()) return fail("inside a group only classes of a few ASCII characters are supported");
+                std::vector<std::string> next;
+                for (auto& a : alts)
+                    for (uint32_t ch : chars) { next.push_back(a); utf8_append(next.back(), ch); }
+                if (next.size() > 64) return fail("group expands to too many literals");
+                alts.swap(next);
+                continue;
+            }
+            uint32_t cp;
+            if (c == '\\') {
+                ++i;
+                bool is_class;
+                RxItem it;
+                if (!read_escape(is_class, it, cp)) return false;
+                if (is_class) return fail("only literal alternatives are supported inside a group");
+            } else if (!read_codepoint_literal(cp)) {
+                return false;
+            }
+            for (auto& a : alts) utf8_append(a, cp);
+        }
+        for (auto& a : alts) done.push_back(a);
+        RxNode nd{};
+        nd.kind = RX_LITSET;
+        nd.caseless = caseless ? 1 : 0;
+        nd.a = (uint16_t)P.n_lits;
+        nd.b = (uint16_t)done.size();
+        nd.min = 1; nd.max = 1;
+        for (auto& a : done) {
+            if (a.empty()) return fail("empty alternative inside a group");
+            if (P.n_lits >= (uint32_t)RX_MAX_LITS || P.n_litbytes + a.size() > (size_t)RX_MAX_LITBYTES) return fail("split pattern too large (literals)");
+            if (caseless)
+                for (unsigned char ch : a)
+                    if (ch >= 0x80) return fail("case-insensitive groups support ASCII literals only");
+            RxLit l;
+            l.off = (uint16_t)P.n_litbytes; l.len = (uint16_t)a.size();
+            for (unsigned char ch : a) P.litbytes[P.n_litbytes++] = ch;
+            P.lits[P.n_lits++] = l;
+        }
+        if (peek() == '?') {
+            nd.min = 0; ++i;
+            if (peek() == '+') ++i;  // (possessive: nothing follows that could make it back out... handled as greedy; see below)
+            else if (peek() == '?') return fail("lazy quantifiers are not supported");
+        } else if (peek() == '*' || peek() == '+' || peek() == '{') {
+            return fail("repeated groups are not supported");
+        }
+        return push_node(nd, alt_first);
+    }
+
+    // one class atom at the cursor -> class id (for look-aheads and sequences)
+    bool read_class_atom(uint16_t& cls) {
+        const int c = peek();
+        if (c == '[') { ++i; return read_bracket(cls, nullptr); }
+        if (c == '.') {
+            ++i;
+            uint16_t idx = 0;
+            return new_item(range_item('\n', '\n'), idx) && new_class(idx, 1, true, cls);
+        }
+        uint32_t cp;
+        if (c == '\\') {
+            ++i;
+            if (peek() == 'v') return fail("unsupported escape \\v");
+            bool is_class;
+            RxItem it;
+            if (!read_escape(is_class, it, cp)) return false;
+            return single_class(is_class ? it : range_item(cp, cp), cls);
+        }
+        if (!read_codepoint_literal(cp)) return false;
+        return single_class(range_item(cp, cp), cls);
+    }
+
+    bool read_alternative() {
+        if (P.n_alts >= (uint32_t)RX_MAX_ALTS) return fail("split pattern has too many alternatives");
+        const uint32_t first = P.n_nodes;
+        while (!eof() && peek() != '|') {
+            const int c = peek();
+            if (c == ')') return fail("unbalanced parenthesis");
+            if (c == '^') return fail("anchors other than $ are not supported");
+            if (c == '*' || c == '+' || c == '?' || (c == '{' && peek(1) >= '0' && peek(1) <= '9')) return fail("quantifier without an atom");
+            if (c == '$') {
+                ++i;
+                RxNode nd{};
+                nd.kind = RX_EOS;
+                if (!push_node(nd, first)) return false;
+                continue;
+            }
+            if (c == '(') {
+                if (peek(1) != '?') return fail("capturing groups are not supported");
+                if (peek(2) == ':' ) { i += 3; if (!read_literal_group(false, first)) return false; continue; }
+                if (peek(2) == 'i' && peek(3) == ':') { i += 4; if (!read_literal_group(true, first)) return false; continue; }
+                if (peek(2) == '!' || peek(2) == '=') {
+                    const bool negative = peek(2) == '!';
+                    i += 3;
+                    RxNode nd{};
+                    nd.kind = negative ? RX_NLOOK : RX_PLOOK;
+                    if (!read_class_atom(nd.a)) return false;
+                    if (peek() != ')') return fail("a look-ahead may hold one character class only");
+                    ++i;
+                    if (!push_node(nd, first)) return false;
+                    continue;
+                }
+                return fail("unsupported group syntax");
+            }
+            RxNode nd{};
+            nd.kind = RX_CLASS;
+            if (!read_class_atom(nd.a)) return false;
+            if (!read_quantifier(nd)) return false;
+            if (!push_node(nd, first)) return false;
+        }
+        if (P.n_nodes == first) return fail("empty alternative in the split pattern");
+        RxAlt a;
+        a.first_node = (uint16_t)first; a.n_nodes = (uint16_t)(P.n_nodes - first);
+        P.alts[P.n_alts++] = a;
+        return true;
+    }
+};
+
+}  // namespace
+
+bool rx_compile(const std::string& pattern, RxProgram& P, std::string& err) {
+    P = RxProgram();
+    Reader R(pattern, P);
+    if (pattern.empty()) { err = "empty split pattern"; return false; }
+    for (;;) {
+        if (!R.read_alternative()) { err = R.err; return false; }
+        if (R.eof()) break;
+        ++R.i;  // '|'
+        if (R.eof()) { err = "split pattern ends in '|'"; return false; }
+    }
+    return true;
+}
+
+}  // namespace td

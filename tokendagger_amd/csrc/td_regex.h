@@ -1,0 +1,255 @@
+// Generic split patterns: a compiled form of the backtracking subset of PCRE2 patterns that tokenizer split
+// patterns are written in, and the matcher that runs it — the SAME code on the device (td_generic.hip: one lane per
+// document), on the host (td_regex.cpp compiles; td_api.cpp's last-piece helper) and in the CPU twin of the test-suite.
+//
+// What the reference does with a pattern (tiktoken.cpp:47-128): pcre2_compile(pattern, PCRE2_UTF | PCRE2_UCP), then a
+// loop of pcre2_match(subject = the document, start_offset, PCRE2_NOTEMPTY): the leftmost match at or behind start_offset
+// is a piece, the bytes it skipped over are NOT tokenized, and when nothing matches any more the rest of the text is one
+// last piece.  rx_next_piece() is that loop's body.
+//
+// Supported syntax (td_regex.cpp rejects everything else with TD_E_PATTERN — there is no CPU regex fallback):
+//   top-level alternation  A1|A2|...  of sequences of
+//     character classes   [...]  [^...]  \s \S \d \D \w \W \p{Xx} \P{Xx} (general categories, one- and two-letter)  .
+//                         literal and escaped characters, \r \n \t \f \v \xHH \x{H..}, ranges a-z
+//     quantifiers         ? * + {m} {m,} {m,n}   and their possessive forms ?+ *+ ++ {m,n}+
+//     groups of literals  (?:ab|c|[de])  (?i:'s|'t|ll)  optionally followed by ?   (case-insensitive: ASCII + U+017F / U+212A)
+//     look-ahead          (?!X)  (?=X)   with X one character class
+//     $                   end of the subject (or in front of its final newline)
+// Semantics are PCRE2's: ordered alternation, greedy quantifiers that give back one character at a time, possessive ones
+// that do not, a match may not be empty.  Invalid UTF-8 (which PCRE2_NO_UTF_CHECK leaves undefined in the reference) is
+// read as one character per byte that belongs to no category.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+
+#include "td_common.h"
+
+namespace td {
+
+constexpr int RX_MAX_ALTS = 32, RX_MAX_NODES = 128, RX_MAX_CLASSES = 48, RX_MAX_ITEMS = 192, RX_MAX_LITS = 96, RX_MAX_LITBYTES = 768;
+constexpr int RX_MAX_SEQ = 16;          // nodes of one alternative (the matcher's backtracking state is that deep)
+constexpr uint32_t RX_INF = 0xFFFFu;    // no upper bound
+constexpr uint32_t RX_F_S = 1u, RX_F_W = 2u, RX_F_D = 4u;  // item flags: \s \w \d (bits 5..7 of the table byte >> 5)
+
+enum RxKind : uint8_t { RX_CLASS = 0, RX_LITSET = 1, RX_NLOOK = 2, RX_PLOOK = 3, RX_EOS = 4 };
+
+struct RxItem {        // one member of a character class
+    uint32_t gc_mask;  // general categories (bit = category id of generated/unicode_gc.inc)
+    uint32_t lo, hi;   // code point range (lo > hi: none)
+    uint8_t flags;     // RX_F_*
+    uint8_t negate;    // \S \W \D \P{..}
+    uint8_t pad[2];
+};
+struct RxClass { uint16_t first_item, n_items; uint8_t negate; uint8_t pad[3]; };
+struct RxLit { uint16_t off, len; };
+struct RxNode {
+    uint8_t kind;        // RxKind
+    uint8_t possessive;  // RX_CLASS: does not give characters back
+    uint8_t caseless;    // RX_LITSET
+    uint8_t pad;
+    uint16_t a, b;       // RX_CLASS / RX_*LOOK: a = class; RX_LITSET: a = first literal, b = number of literals
+    uint16_t min, max;   // RX_CLASS: repeat bounds; RX_LITSET: min 0 (optional) or 1, max 1
+};
+struct RxAlt { uint16_t first_node, n_nodes; };
+struct RxProgram {
+    uint32_t n_alts, n_nodes, n_classes, n_items, n_lits, n_litbytes;
+    RxAlt alts[RX_MAX_ALTS];
+    RxNode nodes[RX_MAX_NODES];
+    RxClass classes[RX_MAX_CLASSES];
+    RxItem items[RX_MAX_ITEMS];
+    RxLit lits[RX_MAX_LITS];
+    uint8_t litbytes[RX_MAX_LITBYTES];
+};
+struct RxTables {  // generated/unicode_gc.inc (host arrays, or their copies in HBM)
+    const uint16_t* stage1;
+    const uint8_t* stage2;
+};
+
+// the character that starts at byte i of the subject (i < n): code point (or 0x110000 | byte for a byte that is not the
+// start of a well-formed sequence) and its length in bytes
+template <class A>
+TD_HD uint32_t rx_char_at(const A& s, int64_t i, int64_t n, uint32_t& len) {
+    const uint32_t b = s.byte(i);
+    len = 1;
+    if (b < 0x80u) return b;
+    const uint32_t need = utf8_declared_len(b) - 1u;
+    if (need == 0u || i + (int64_t)need >= n) return 0x110000u | b;  // not a lead byte, or the sequence leaves the subject
+    uint32_t cp = b & (0xFFu >> (need + 2u));
+    for (uint32_t k = 1; k <= need; ++k) {
+        const uint32_t c = s.byte(i + k);
+        if ((c & 0xC0u) != 0x80u) return 0x110000u | b;
+        cp = (cp << 6) | (c & 0x3Fu);
+    }
+    if (cp > 0x10FFFFu || (cp >= 0xD800u && cp <= 0xDFFFu)) return 0x110000u | b;
+    len = need + 1u;
+    return cp;
+}
+// start of the character that ends at byte e (exclusive), not in front of `lo`: the inverse step of rx_char_at for what it
+// accepted (a well-formed sequence) and one byte otherwise
+template <class A>
+TD_HD int64_t rx_prev_char(const A& s, int64_t lo, int64_t e, int64_t n) {
+    int64_t p = e - 1;
+    for (int k = 0; k < 3 && p > lo && (s.byte(p) & 0xC0u) == 0x80u; ++k) --p;
+    uint32_t len;
+    (void)rx_char_at(s, p, n, len);
+    return (p + (int64_t)len == e) ? p : e - 1;
+}
+
+TD_HD bool rx_in_class(const RxProgram& P, const RxTables& T, uint32_t cls, uint32_t cp) {
+    const RxClass c = P.classes[cls];
+    uint32_t props = 28u;  // (category Cs: nothing) for bytes outside UTF-8
+    if (cp < 0x110000u) props = T.stage2[(uint32_t)T.stage1[cp >> 8] * 256u + (cp & 255u)];
+    const uint32_t gc = props & 31u, fl = props >> 5;
+    bool in = false;
+    for (uint32_t k = 0; k < c.n_items; ++k) {
+        const RxItem it = P.items[c.first_item + k];
+        bool m = cp < 0x110000u && (((it.gc_mask >> gc) & 1u) || (it.flags & fl) || (cp >= it.lo && cp <= it.hi));
+        if (cp >= 0x110000u) m = false;
+        in = in || (m != (it.negate != 0));
+    }
+    return in != (c.negate != 0);
+}
+
+// does literal `l` of the program stand at byte p of the subject?  -> bytes it takes there, or -1
+template <class A>
+TD_HD int rx_lit_at(const RxProgram& P, const RxLit l, bool caseless, const A& s, int64_t p, int64_t n) {
+    int64_t q = p;
+    for (uint32_t k = 0; k < l.len; ++k) {
+        const uint32_t c = P.litbytes[l.off + k];
+        if (q >= n) return -1;
+        const uint32_t b = s.byte(q);
+        if (b == c) { ++q; continue; }
+        if (!caseless) return -1;
+        const uint32_t lc = c | 0x20u;
+        const bool letter = lc >= 'a' && lc <= 'z';
+        if (letter && (b | 0x20u) == lc && b < 0x80u) { ++q; continue; }
+        if (lc == 's' && b == 0xC5u && q + 1 < n && s.byte(q + 1) == 0xBFu) { q += 2; continue; }                                    // U+017F
+        if (lc == 'k' && b == 0xE2u && q + 2 < n && s.byte(q + 1) == 0x84u && s.byte(q + 2) == 0xAAu) { q += 3; continue; }         // U+212A
+        return -1;
+    }
+    return (int)(q - p);
+}
+
+// one alternative, anchored at `start`: end of its (non-empty) match, or -1
+template <class A>
+TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt alt, const A& s, int64_t start, int64_t n) {
+    int64_t beg[RX_MAX_SEQ], end[RX_MAX_SEQ];
+    uint32_t cnt[RX_MAX_SEQ];  // RX_CLASS: characters taken; RX_LITSET: literal chosen (b = skipped)
+    const int nn = (int)alt.n_nodes;
+    int i = 0;
+    int64_t pos = start;
+    bool forward = true;
+    for (;;) {
+        if (forward) {
+            if (i == nn) {
+                if (pos > start) return pos;  // (PCRE2_NOTEMPTY: an empty match is a failure to back out of)
+                forward = false;
+                continue;
+            }
+            const RxNode nd = P.nodes[alt.first_node + i];
+            bool ok = true;
+            beg[i] = pos;
+            if (nd.kind == RX_CLASS) {
+                uint32_t c = 0;
+                int64_t p = pos;
+                while (c < nd.max && p < n) {
+                    uint32_t len;
+                    const uint32_t cp = rx_char_at(s, p, n, len);
+                    if (!rx_in_class(P, T, nd.a, cp)) break;
+                    p += len;
+                    ++c;
+                }
+                ok = c >= nd.min;
+                cnt[i] = c;
+                end[i] = p;
+                pos = p;
+            } else if (nd.kind == RX_LITSET) {
+                uint32_t k = 0;
+                int len = -1;
+                for (; k < nd.b; ++k) {
+                    len = rx_lit_at(P, P.lits[nd.a + k], nd.caseless != 0, s, pos, n);
+                    if (len >= 0) break;
+                }
+                if (k < nd.b) { cnt[i] = k; pos += len; }
+                else if (nd.min == 0) cnt[i] = nd.b;
+                else ok = false;
+                end[i] = pos;
+            } else if (nd.kind == RX_EOS) {
+                ok = pos == n || (pos == n - 1 && s.byte(pos) == '\n');
+                end[i] = pos;
+            } else {  // look-ahead on one character
+                bool in = false;
+                if (pos < n) {
+                    uint32_t len;
+                    in = rx_in_class(P, T, nd.a, rx_char_at(s, pos, n, len));
+                }
+                ok = (nd.kind == RX_PLOOK) ? in : !in;
+                end[i] = pos;
+            }
+            if (ok) ++i; else forward = false;
+            continue;
+        }
+        // back out: the nearest node in front of i that has another way to match
+        bool resumed = false;
+        while (--i >= 0) {
+            const RxNode nd = P.nodes[alt.first_node + i];
+            if (nd.kind == RX_CLASS) {
+                if (nd.possessive || cnt[i] <= nd.min) continue;
+                end[i] = rx_prev_char(s, beg[i], end[i], n);
+                --cnt[i];
+                pos = end[i];
+                resumed = true;
+                break;
+            }
+            if (nd.kind == RX_LITSET) {
+                if (cnt[i] >= nd.b) continue;  // (already skipped)
+                uint32_t k = cnt[i] + 1;
+                int len = -1;
+                for (; k < nd.b; ++k) {
+                    len = rx_lit_at(P, P.lits[nd.a + k], nd.caseless != 0, s, beg[i], n);
+                    if (len >= 0) break;
+                }
+                if (k < nd.b) { cnt[i] = k; pos = beg[i] + len; end[i] = pos; resumed = true; break; }
+                if (nd.min == 0) { cnt[i] = nd.b; pos = beg[i]; end[i] = pos; resumed = true; break; }
+                continue;
+            }
+        }
+        if (!resumed) return -1;
+        ++i;
+        forward = true;
+    }
+}
+
+// the pattern anchored at `start`: end of the match of the first alternative that matches, or -1
+template <class A>
+TD_HD int64_t rx_match_at(const RxProgram& P, const RxTables& T, const A& s, int64_t start, int64_t n) {
+    for (uint32_t a = 0; a < P.n_alts; ++a) {
+        const int64_t e = rx_match_alt(P, T, P.alts[a], s, start, n);
+        if (e >= 0) return e;
+    }
+    return -1;
+}
+
+// The reference's loop body (tiktoken.cpp:86-122) from byte `pos` of the subject [0, n): the next piece is [ms, me).
+// Bytes [pos, ms) are skipped (no tokens).  When nothing matches any more, the rest [pos, n) is the last piece.
+template <class A>
+TD_HD void rx_next_piece(const RxProgram& P, const RxTables& T, const A& s, int64_t pos, int64_t n, int64_t& ms, int64_t& me) {
+    for (int64_t p = pos; p < n;) {
+        const int64_t e = rx_match_at(P, T, s, p, n);
+        if (e >= 0) { ms = p; me = e; return; }
+        uint32_t len;
+        (void)rx_char_at(s, p, n, len);
+        p += len;
+    }
+    ms = pos;
+    me = n;
+}
+
+// ---- host side (td_regex.cpp) ----
+bool rx_compile(const std::string& pattern, RxProgram& P, std::string& err);  // false: err says what is not supported
+RxTables rx_host_tables();
+const uint16_t* rx_stage1(size_t* n);
+const uint8_t* rx_stage2(size_t* n);
+
+}  // namespace td

@@ -1,5 +1,6 @@
 // Host-side table construction.  See td_tables.h.
 #include "td_tables.h"
+#include "td_regex.h"
 
 #include <string.h>
 
@@ -60,6 +61,7 @@ uint32_t pattern_flags(PatternKind k) {
     if (k == PATTERN_CL100K_EOS) return PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS | PV_WS_EOS_FIRST;
     if (k == PATTERN_QWEN2) return PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS | PV_SINGLE_DIGIT;
     if (k == PATTERN_GPT2) return PV_GPT2;
+    if (k == PATTERN_GENERIC) return PV_GENERIC;
     return 0u;
 }
 
@@ -133,10 +135,20 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
     H.pattern = pattern ? pattern : "";
     H.pattern_kind = classify_pattern(H.pattern);
     if (H.pattern_kind == PATTERN_UNSUPPORTED) {
-        err = "split pattern is not supported by the device pre-tokenizer (supported: the o200k/Llama-4 pattern, the "
-              "Mistral tekken pattern, the cl100k_base/Llama-3 pattern, the Qwen2 pattern and the GPT-2 pattern); "
-              "there is no CPU regex fallback";
-        return TD_E_PATTERN;
+        // not a member of the family with a scanner of its own: the generic engine, if the pattern is within its subset
+        static_assert(std::is_trivially_copyable<RxProgram>::value, "the compiled pattern is uploaded as bytes");
+        H.rx_program.resize(sizeof(RxProgram));
+        std::string why;
+        RxProgram* P = reinterpret_cast<RxProgram*>(H.rx_program.data());
+        if (rx_compile(H.pattern, *P, why)) {
+            H.pattern_kind = PATTERN_GENERIC;
+        } else {
+            H.rx_program.clear();
+            err = "split pattern is not supported by the device pre-tokenizer: " + why +
+                  " (supported: the o200k/Llama-4, Mistral tekken, cl100k_base/Llama-3, Qwen2 and GPT-2 patterns, and patterns within the "
+                  "subset td_regex.h lists); there is no CPU regex fallback";
+            return TD_E_PATTERN;
+        }
     }
     if (n_vocab <= 0) { err = "empty vocabulary"; return TD_E_VOCAB; }
 

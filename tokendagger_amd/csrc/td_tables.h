@@ -20,6 +20,7 @@ enum PatternKind : int {
     PATTERN_GPT2 = 3,   // r50k_base / p50k_base (GPT-2)
     PATTERN_CL100K_EOS = 4,  // cl100k_base as current tiktoken releases spell it: `\s++$` ahead of `\s*[\r\n]` (a different language
                              // on trailing whitespace that contains CR/LF)
+    PATTERN_GENERIC = 6,  // any other pattern td_regex.cpp can compile: matched by the generic engine, td_regex.h
     PATTERN_QWEN2 = 5,  // Qwen2 / Qwen2.5 / Qwen3 (tokenizer.json pre_tokenizer): the cl100k_base pattern with single-digit number pieces (`\p{N}`)
 };
 const char* cl100k_pattern();
@@ -31,6 +32,7 @@ const char* o200k_pattern();
 struct HostTables {
     PatternKind pattern_kind = PATTERN_UNSUPPORTED;
     std::string pattern;
+    std::vector<uint8_t> rx_program;  // PATTERN_GENERIC: the compiled pattern (one RxProgram, td_regex.h)
     std::vector<uint8_t> ascii_cls;
     std::vector<uint8_t> ucls2_remap;  // stage-2 class table with the pattern's class remaps applied (empty: the static one)
     std::vector<int32_t> byte_id;
