@@ -26,7 +26,7 @@ extern "C" {
 
 #define TD_OK 0
 #define TD_E_INVALID 1      /* bad argument */
-#define TD_E_PATTERN 2      /* pat_str is not a split pattern the device scanner implements */
+#define TD_E_PATTERN 2      /* pat_str uses regex syntax outside what the device pre-tokenizer implements (td_last_error says which) */
 #define TD_E_VOCAB 3        /* vocabulary cannot be represented */
 #define TD_E_UNKNOWN_BYTE 4 /* input contains a byte / part that is not in the vocabulary
                                (reference: TiktokenError "No value found for pair", tiktoken.cpp:364) */
@@ -47,6 +47,10 @@ typedef struct td_tokenizer td_tokenizer;
  * The vocabulary is passed as concatenated token bytes + n+1 offsets + n ranks (what a list of
  * VocabItem{rank, token_bytes} holds, tiktoken.hpp:12-16); specials likewise (token_string, rank).
  * Builds the device tables and uploads them to HIP device `device` (-1: current device).
+ * pat_str (init_regex, tiktoken.cpp:47-68): the known tokenizer patterns (o200k / Llama-4, tekken, cl100k_base / Llama-3, Qwen2, GPT-2)
+ * have kernels of their own; any other pattern within the backtracking subset listed in tokendagger_amd/csrc/td_regex.h is
+ * compiled and matched one lane per document with PCRE2's semantics (text it skips gets no tokens, tiktoken.cpp:86-122);
+ * anything else is TD_E_PATTERN.  There is no CPU regex fallback.
  */
 int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, const int64_t* token_offsets,
               const int32_t* ranks, int64_t n_special, const uint8_t* special_bytes,
