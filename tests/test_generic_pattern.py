@@ -90,3 +90,18 @@ def test_gpu_generic_patterns_equal_the_reference():
         assert np.array_equal(toks, etoks), name
         assert list(tok.encode_batch(b"snake_case", np.asarray([0, 10], dtype=np.int64))[0]) == list(R.encode(b"snake_case"))
         tok.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_gpu_python_surface_with_the_reference_tests_pattern():
+    """tests/autogenned_test.py:58-70 of the reference: Encoding(pat_str=r"[a-zA-Z]+|\\s+|[0-9]+|[^\\w\\s]", ...).encode(prompt)."""
+    import tokendagger as tiktoken
+    _, mr, special = H.llama4()
+    enc = tiktoken.Encoding(name="test_tokenizer", pat_str=AUTOGEN, mergeable_ranks=mr, special_tokens=special)
+    R = ref.RefTokenizer(AUTOGEN, mr, special)
+    for s in ["This is a test prompt for tokenization.", "snake_case_name = 42", "é", "", "a", "naïve café_1", "x" * 5000 + " _ " + "y" * 70]:
+        assert enc.encode(s) == list(R.encode(s.encode("utf-8"))), s
+        assert enc.decode(enc.encode(s)) == b"".join(R.split_pieces(s.encode("utf-8"))).decode("utf-8"), s  # (skipped text is gone)
+    batch = ["one two", "three_four", "5 six!"]
+    assert enc.encode_batch(batch) == [list(R.encode(b.encode())) for b in batch]
