@@ -64,6 +64,17 @@ def test_pieces_equal_pcre2(name, golden):
         assert [doc[a:e] for a, e in H.rx_split(pat, doc)] == R.split_pieces(doc), (name, golden["names"][d])
 
 
+def test_patterns_beyond_the_program_limits_are_rejected_not_truncated():
+    for pat in ("|".join("a%d" % i for i in range(40)),              # alternatives
+                "".join("[a-%c]" % chr(ord("b") + i % 20) for i in range(20)),  # elements of one alternative
+                "(?:" + "|".join("w%03d" % i for i in range(120)) + ")"):      # literals of a group
+        with pytest.raises(ValueError) as e:
+            H.rx_split(pat, b"abc")
+        assert "too" in str(e.value), (pat[:30], str(e.value))
+    # 31 alternatives are fine; ordered alternation: "a2" stands in front of "a29"
+    assert H.rx_split("|".join("a%d" % i for i in range(30)) + "|.", b"a7a29x") == [(0, 2), (2, 4), (4, 5), (5, 6)]
+
+
 def test_the_reference_tests_own_pattern_skips_text():
     spans = H.rx_split(AUTOGEN, "snake_case é 42!".encode())
     assert [(a, e) for a, e in spans] == [(0, 5), (6, 10), (10, 11), (13, 14), (14, 16), (16, 17)]  # '_' and 'é' are skipped

@@ -354,14 +354,34 @@ struct Reader {
         return single_class(range_item(cp, cp), cls);
     }
 
+    bool flush_literal(std::string& lit, uint32_t alt_first) {
+        if (lit.empty()) return true;
+        if (P.n_lits >= (uint32_t)RX_MAX_LITS || P.n_litbytes + lit.size() > (size_t)RX_MAX_LITBYTES) return fail("split pattern too large (literals)");
+        RxNode nd{};
+        nd.kind = RX_LITSET;
+        nd.a = (uint16_t)P.n_lits;
+        nd.b = 1;
+        nd.min = 1; nd.max = 1;
+        RxLit l;
+        l.off = (uint16_t)P.n_litbytes; l.len = (uint16_t)lit.size();
+        for (unsigned char ch : lit) P.litbytes[P.n_litbytes++] = ch;
+        P.lits[P.n_lits++] = l;
+        lit.clear();
+        return push_node(nd, alt_first);
+    }
+
     bool read_alternative() {
         if (P.n_alts >= (uint32_t)RX_MAX_ALTS) return fail("split pattern has too many alternatives");
         const uint32_t first = P.n_nodes;
+        std::string pending;  // literal characters read so far that no node holds yet
         while (!eof() && peek() != '|') {
             const int c = peek();
             if (c == ')') return fail("unbalanced parenthesis");
             if (c == '^') return fail("anchors other than $ are not supported");
             if (c == '*' || c == '+' || c == '?' || (c == '{' && peek(1) >= '0' && peek(1) <= '9')) return fail("quantifier without an atom");
+            if (c == '$' || c == '(') {
+                if (!flush_literal(pending, first)) return false;
+            }
             if (c == '$') {
                 ++i;
                 RxNode nd{};
@@ -386,12 +406,35 @@ struct Reader {
                 }
                 return fail("unsupported group syntax");
             }
+            // a literal character without a quantifier joins the literal run in front of it (one node for "0x", not a class per
+            // character)
+            if (c != '[' && c != '.') {
+                const size_t i0 = i;
+                const uint32_t items0 = P.n_items, classes0 = P.n_classes;
+                uint32_t cp = 0;
+                bool is_class = false, ok = true;
+                if (c == '\\') {
+                    ++i;
+                    RxItem it;
+                    if (peek() == 'v') return fail("unsupported escape \\v");
+                    ok = read_escape(is_class, it, cp);
+                } else {
+                    ok = read_codepoint_literal(cp);
+                }
+                if (!ok) return false;
+                const int q = peek();
+                const bool quantified = q == '?' || q == '*' || q == '+' || (q == '{' && peek(1) >= '0' && peek(1) <= '9');
+                if (!is_class && !quantified) { utf8_append(pending, cp); continue; }
+                i = i0; P.n_items = items0; P.n_classes = classes0;  // (read again below as a class atom)
+            }
+            if (!flush_literal(pending, first)) return false;
             RxNode nd{};
             nd.kind = RX_CLASS;
             if (!read_class_atom(nd.a)) return false;
             if (!read_quantifier(nd)) return false;
             if (!push_node(nd, first)) return false;
         }
+        if (!flush_literal(pending, first)) return false;
         if (P.n_nodes == first) return fail("empty alternative in the split pattern");
         RxAlt a;
         a.first_node = (uint16_t)first; a.n_nodes = (uint16_t)(P.n_nodes - first);
