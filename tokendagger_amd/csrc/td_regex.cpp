@@ -377,7 +377,27 @@ struct Reader {
         while (!eof() && peek() != '|') {
             const int c = peek();
             if (c == ')') return fail("unbalanced parenthesis");
-            if (c == '^') return fail("anchors other than $ are not supported");
+            {   // zero-width assertions: ^ \A \z \Z \b \B
+                int zk = -1;
+                size_t adv = 0;
+                if (c == '^') { zk = RX_BOS; adv = 1; }
+                else if (c == '\\') {
+                    const int e1 = peek(1);
+                    if (e1 == 'A') zk = RX_BOS; else if (e1 == 'z') zk = RX_EOS_STRICT; else if (e1 == 'Z') zk = RX_EOS;
+                    else if (e1 == 'b') zk = RX_WORDB; else if (e1 == 'B') zk = RX_NWORDB;
+                    adv = 2;
+                }
+                if (zk >= 0) {
+                    if (!flush_literal(pending, first)) return false;
+                    i += adv;
+                    const int q = peek();
+                    if (q == '?' || q == '*' || q == '+' || (q == '{' && peek(1) >= '0' && peek(1) <= '9')) return fail("a quantifier on an assertion is not supported");
+                    RxNode nd{};
+                    nd.kind = (uint8_t)zk;
+                    if (!push_node(nd, first)) return false;
+                    continue;
+                }
+            }
             if (c == '*' || c == '+' || c == '?' || (c == '{' && peek(1) >= '0' && peek(1) <= '9')) return fail("quantifier without an atom");
             if (c == '$' || c == '(') {
                 if (!flush_literal(pending, first)) return false;

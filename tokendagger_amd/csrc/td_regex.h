@@ -14,7 +14,8 @@
 //     quantifiers         ? * + {m} {m,} {m,n}   and their possessive forms ?+ *+ ++ {m,n}+
 //     groups of literals  (?:ab|c|[de])  (?i:'s|'t|ll)  optionally followed by ?   (case-insensitive: ASCII + U+017F / U+212A)
 //     look-ahead          (?!X)  (?=X)   with X one character class
-//     $                   end of the subject (or in front of its final newline)
+//     $ \Z                end of the subject (or in front of its final newline);  \z  the very end;  ^ \A  its start
+//     \b \B               word boundary (\w as PCRE2_UCP defines it) / not one
 // Semantics are PCRE2's: ordered alternation, greedy quantifiers that give back one character at a time, possessive ones
 // that do not, a match may not be empty.  Invalid UTF-8 (which PCRE2_NO_UTF_CHECK leaves undefined in the reference) is
 // read as one character per byte that belongs to no category.
@@ -32,7 +33,7 @@ constexpr int RX_MAX_SEQ = 16;          // nodes of one alternative (the matcher
 constexpr uint32_t RX_INF = 0xFFFFu;    // no upper bound
 constexpr uint32_t RX_F_S = 1u, RX_F_W = 2u, RX_F_D = 4u;  // item flags: \s \w \d (bits 5..7 of the table byte >> 5)
 
-enum RxKind : uint8_t { RX_CLASS = 0, RX_LITSET = 1, RX_NLOOK = 2, RX_PLOOK = 3, RX_EOS = 4 };
+enum RxKind : uint8_t { RX_CLASS = 0, RX_LITSET = 1, RX_NLOOK = 2, RX_PLOOK = 3, RX_EOS = 4, RX_EOS_STRICT = 5, RX_BOS = 6, RX_WORDB = 7, RX_NWORDB = 8 };
 
 struct RxItem {        // one member of a character class
     uint32_t gc_mask;  // general categories (bit = category id of generated/unicode_gc.inc)
@@ -177,6 +178,22 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
                 end[i] = pos;
             } else if (nd.kind == RX_EOS) {
                 ok = pos == n || (pos == n - 1 && s.byte(pos) == '\n');
+                end[i] = pos;
+            } else if (nd.kind == RX_EOS_STRICT || nd.kind == RX_BOS) {
+                ok = nd.kind == RX_BOS ? pos == 0 : pos == n;
+                end[i] = pos;
+            } else if (nd.kind == RX_WORDB || nd.kind == RX_NWORDB) {
+                bool wl = false, wr = false;
+                uint32_t len;
+                if (pos > 0) {
+                    const uint32_t cp = rx_char_at(s, rx_prev_char(s, 0, pos, n), n, len);
+                    wl = cp < 0x110000u && ((T.stage2[(uint32_t)T.stage1[cp >> 8] * 256u + (cp & 255u)] >> 5) & RX_F_W);
+                }
+                if (pos < n) {
+                    const uint32_t cp = rx_char_at(s, pos, n, len);
+                    wr = cp < 0x110000u && ((T.stage2[(uint32_t)T.stage1[cp >> 8] * 256u + (cp & 255u)] >> 5) & RX_F_W);
+                }
+                ok = (wl != wr) == (nd.kind == RX_WORDB);
                 end[i] = pos;
             } else {  // look-ahead on one character
                 bool in = false;
