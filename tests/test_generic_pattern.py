@@ -92,10 +92,10 @@ def test_gpu_generic_patterns_equal_the_reference():
         pat = PATTERNS[name]
         tok = capi.HipTokenizer(pat, mr, special, device=0)
         R = ref.RefTokenizer(pat, mr, special)
-        docs = [s.encode("utf-8") for s in _strings(600, 7 + len(name))]
+        docs = [s.encode("utf-8") for s in _strings(400, 7 + len(name))]
         docs += [b"", b"_", b"___", "é".encode(), b"a_b", b"snake_case_name = 42", ("word_" * 3000).encode(), ("x" * 5000 + "_").encode()]
         x, o = td_corpus.code(1 << 20, seed=3)
-        docs += [x[o[d]:o[d + 1]].tobytes() for d in range(0, len(o) - 1, 3)][:300]
+        docs += [x[o[d]:o[d + 1]].tobytes() for d in range(0, len(o) - 1, 3)][:150]
         text, offs = H.pack_docs(docs)
         toks, toffs = tok.encode_batch(text, offs)
         _, etoks, eoffs = R.encode_batch(np.frombuffer(text, dtype=np.uint8), offs, n_threads=8, want_tokens=True)
