@@ -135,7 +135,7 @@ def build_twin():
     srcs = [ROOT / "tests/twin/td_twin.cpp", ROOT / "tokendagger_amd/csrc/td_tables.cpp", ROOT / "tokendagger_amd/csrc/td_regex.cpp"]
     deps = srcs + [ROOT / "tokendagger_amd/csrc/td_common.h", ROOT / "tokendagger_amd/csrc/td_tables.h",
                    ROOT / "tokendagger_amd/csrc/td_regex.h", ROOT / "tokendagger_amd/csrc/generated/unicode_classes.inc",
-                   ROOT / "tokendagger_amd/csrc/generated/unicode_gc.inc"]
+                   ROOT / "tokendagger_amd/csrc/generated/unicode_gc.inc", ROOT / "tokendagger_amd/csrc/generated/unicode_scripts.inc"]
     if TWIN_SO.exists() and all(TWIN_SO.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",

@@ -23,9 +23,10 @@ PATTERNS = {
     "words": r"\w+|[^\w\s]+|\s+", "digits": r"\d{1,3}|\D+", "camel": r"[A-Z][a-z]*|\s|.", "cats": r"\p{Lu}\p{Ll}*|\p{Nd}+|\.{2,}|.",
     "look": r"[a-z]+(?=[0-9])|[0-9]+|\s+(?!\S)|\S", "letters_only": r"\p{L}+", "lit": r"(?i:the|an|a|k|s)| ?\pL+|\PL",
     "wordb": r"\b\w+\b|\B[-_]+\B|\S", "anchors": r"^\s+|\A[#]+|\w+\z|\w+|\s+\Z|\W", "bnd2": r"\Bs\b|[a-z]+?"[:-1] + r"|.",
+    "scripts": r"\p{Han}+|[\p{Hiragana}\p{Katakana}ー]+|\p{Hangul}+|\p{Latin}+|\P{Thai}|\s+|.", "cyr": r"[\p{Cyrillic}\p{Greek}]+\d*|\p{Any}",
     "hex": r"0x[0-9a-fA-F]{1,8}|\x41+|[\x{4e00}-\x{9fff}]+|[^\S\n]*\n|.", "opt": r"(?:ab|a)?c|[ab]+|\s*+x|.",
 }
-REJECTED = [r"(\w+)\s+\1", r"\S+?", r"\b+x", r"\Gabc", r"(?<=a)b", r"[[:alpha:]]+", r"(a|b)+", r"\p{Han}+", r"(?i)abc", r"a|", r"(?:a|b)*"]
+REJECTED = [r"(\w+)\s+\1", r"\S+?", r"\b+x", r"\Gabc", r"(?<=a)b", r"[[:alpha:]]+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:a|b)*"]
 
 
 def _strings(n, seed):

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "generated/unicode_gc.inc"
+#include "generated/unicode_scripts.inc"
 #include "td_tables.h"
 
 namespace td {
@@ -101,7 +102,8 @@ struct Reader {
         }
         return true;
     }
-    bool read_property(bool upper_p, RxItem& it) {  // behind "\p" / "\P"
+    // behind "\\p" / "\\P": a general category (-> it) or a script (-> its ranges in `multi`, `multi_neg` when negated)
+    bool read_property(bool upper_p, RxItem& it, std::vector<RxItem>* multi, bool* multi_neg) {
         std::string name;
         bool neg = upper_p;
         if (peek() == '{') {
@@ -123,14 +125,24 @@ struct Reader {
             for (int g = 0; g < 30; ++g)
                 if (name == kGc[g]) mask |= 1u << g;
         }
-        if (!mask) return fail("unsupported Unicode property \\p{" + name + "} (general categories only)");
         it = none_item();
-        it.gc_mask = mask;
-        it.negate = neg ? 1 : 0;
-        return true;
+        if (mask) {
+            it.gc_mask = mask;
+            it.negate = neg ? 1 : 0;
+            return true;
+        }
+        if (name == "Any") { it = range_item(0, 0x10FFFF); it.negate = neg ? 1 : 0; return true; }
+        for (const TdScript& sc : td_scripts) {
+            if (name != sc.name) continue;
+            if (!multi) return fail("script property \\p{" + name + "} is not supported here");
+            for (unsigned k = 0; k < sc.n; ++k) multi->push_back(range_item(sc.ranges[k].lo, sc.ranges[k].hi));
+            if (multi_neg) *multi_neg = neg;
+            return true;
+        }
+        return fail("unsupported Unicode property \\p{" + name + "} (general categories and the scripts of generated/unicode_scripts.inc)");
     }
     // behind a backslash: a class escape (-> item, is_class = true) or a literal character (-> cp)
-    bool read_escape(bool& is_class, RxItem& it, uint32_t& cp) {
+    bool read_escape(bool& is_class, RxItem& it, uint32_t& cp, std::vector<RxItem>* multi = nullptr, bool* multi_neg = nullptr) {
         if (eof()) return fail("pattern ends in a backslash");
         const int c = peek();
         ++i;
@@ -143,8 +155,8 @@ struct Reader {
             case 'W': it.flags = RX_F_W; it.negate = 1; return true;
             case 'd': it.flags = RX_F_D; return true;
             case 'D': it.flags = RX_F_D; it.negate = 1; return true;
-            case 'p': return read_property(false, it);
-            case 'P': return read_property(true, it);
+            case 'p': return read_property(false, it, multi, multi_neg);
+            case 'P': return read_property(true, it, multi, multi_neg);
             default: break;
         }
         is_class = false;
@@ -185,15 +197,22 @@ struct Reader {
             uint32_t lo;
             RxItem it;
             bool is_class = false;
+            std::vector<RxItem> multi;
+            bool multi_neg = false;
             if (c == '\\') {
                 ++i;
                 if (peek() == 'v') return fail("unsupported escape \\v");
-                if (!read_escape(is_class, it, lo)) return false;
+                if (!read_escape(is_class, it, lo, &multi, &multi_neg)) return false;
             } else if (!read_codepoint_literal(lo)) {
                 return false;
             }
             if (is_class) {
                 plain = false;
+                if (!multi.empty()) {  // a script: its ranges
+                    if (multi_neg) return fail("a negated script property inside a character class is not supported");
+                    for (const RxItem& m : multi) { if (!new_item(m, idx)) return false; ++n; }
+                    continue;
+                }
                 if (!new_item(it, idx)) return false;
                 ++n;
                 continue;
@@ -345,9 +364,17 @@ struct Reader {
         if (c == '\\') {
             ++i;
             if (peek() == 'v') return fail("unsupported escape \\v");
-            bool is_class;
+            bool is_class, multi_neg = false;
             RxItem it;
-            if (!read_escape(is_class, it, cp)) return false;
+            std::vector<RxItem> multi;
+            if (!read_escape(is_class, it, cp, &multi, &multi_neg)) return false;
+            if (!multi.empty()) {  // a script on its own: a class of its ranges
+                const uint16_t first = (uint16_t)P.n_items;
+                uint16_t idx = 0;
+                for (const RxItem& m : multi)
+                    if (!new_item(m, idx)) return false;
+                return new_class(first, (uint16_t)multi.size(), multi_neg, cls);
+            }
             return single_class(is_class ? it : range_item(cp, cp), cls);
         }
         if (!read_codepoint_literal(cp)) return false;
@@ -437,7 +464,9 @@ struct Reader {
                     ++i;
                     RxItem it;
                     if (peek() == 'v') return fail("unsupported escape \\v");
-                    ok = read_escape(is_class, it, cp);
+                    std::vector<RxItem> multi;
+                    bool multi_neg = false;
+                    ok = read_escape(is_class, it, cp, &multi, &multi_neg);
                 } else {
                     ok = read_codepoint_literal(cp);
                 }
