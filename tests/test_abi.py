@@ -6,6 +6,7 @@ from pathlib import Path
 
 import pytest
 
+import cases
 import helpers as H
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -44,8 +45,30 @@ def test_no_cpu_fallback_without_gpu():
 def test_unsupported_pattern_rejected_before_touching_the_gpu():
     from tokendagger_amd import capi
     with pytest.raises(capi.TokenDaggerHipError) as e:
-        capi.HipTokenizer(r"(\w+)\s+\1|\S+?", {b"a": 0}, {}, device=0)  # (back-reference, lazy quantifier: outside the generic subset)
+        capi.HipTokenizer(cases.UNSUPPORTED_PATTERN, {b"a": 0}, {}, device=0)  # (back-reference, lazy quantifier: outside the generic subset)
     assert e.value.code == 2 and "not supported" in str(e.value)
+
+
+def test_encoding_constructor_rejects_unsupported_pattern_on_cpu():
+    """The construction-time contract the GPU test test_python_api.py::test_attributes_and_errors relies on, checked without
+    a GPU: the pattern is compiled before any device is touched, so the failure is TD_E_PATTERN (2) here as well, through the
+    Python surface (TokenDaggerError) and through the C ABI; and the patterns the generic compiler accepts do NOT fail with
+    TD_E_PATTERN (on a CPU box they get as far as the missing device)."""
+    import cases
+    import tokendagger
+    from tokendagger_amd import capi
+    with pytest.raises(tokendagger.TokenDaggerError):
+        tokendagger.Encoding(name="bad", pat_str=cases.UNSUPPORTED_PATTERN, mergeable_ranks={b"a": 0})
+    with pytest.raises(capi.TokenDaggerHipError) as e:
+        capi.HipTokenizer(cases.UNSUPPORTED_PATTERN, {b"a": 0}, {}, device=0)
+    assert e.value.code == 2
+    import torch
+    if torch.cuda.is_available():
+        return
+    for pat in cases.SUPPORTED_GENERIC_PATTERNS:
+        with pytest.raises(capi.TokenDaggerHipError) as e:
+            capi.HipTokenizer(pat, {bytes([b]): b for b in range(256)}, {}, device=0)
+        assert e.value.code != 2, (pat, str(e.value))
 
 
 def test_product_does_not_reference_the_oracle():

@@ -25,8 +25,10 @@ PATTERNS = {
     "wordb": r"\b\w+\b|\B[-_]+\B|\S", "anchors": r"^\s+|\A[#]+|\w+\z|\w+|\s+\Z|\W", "bnd2": r"\Bs\b|[a-z]+?"[:-1] + r"|.",
     "scripts": r"\p{Han}+|[\p{Hiragana}\p{Katakana}ー]+|\p{Hangul}+|\p{Latin}+|\P{Thai}|\s+|.", "cyr": r"[\p{Cyrillic}\p{Greek}]+\d*|\p{Any}",
     "hex": r"0x[0-9a-fA-F]{1,8}|\x41+|[\x{4e00}-\x{9fff}]+|[^\S\n]*\n|.", "opt": r"(?:ab|a)?c|[ab]+|\s*+x|.",
+    # atomic optional groups: once a literal is chosen the matcher never comes back for the next one or the skip
+    "atomic1": r"(?:a|ab)?+c|.", "atomic2": r"(?:ab|a)?+bc|.", "atomic3": r" ?(?:the|a|an)?+[a-z]+|\s+|.",
 }
-REJECTED = [r"(\w+)\s+\1", r"\S+?", r"\b+x", r"\Gabc", r"(?<=a)b", r"[[:alpha:]]+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:a|b)*"]
+REJECTED = [r"\012|.", r"[\d-z]", r"[\p{Han}-z]", r"\x{D800}", r"[\x{DFFF}]", r"(\w+)\s+\1", r"\S+?", r"\b+x", r"\Gabc", r"(?<=a)b", r"[[:alpha:]]+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:a|b)*"]
 
 
 def _strings(n, seed):
@@ -67,6 +69,18 @@ def test_pieces_equal_pcre2(name, golden):
         assert [doc[a:e] for a, e in H.rx_split(pat, doc)] == R.split_pieces(doc), (name, golden["names"][d])
 
 
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_unbounded_quantifiers_have_no_65535_limit():
+    """'*', '+' and '{m,}' stopped after 65535 characters (the bound was stored in 16 bits and used as a real one)."""
+    _, mr, special = H.llama4()
+    for pat, doc in ((r"[a-z]+|\s+", b"a" * 70000 + b" b"), (r"\s*[a-z]|\S", b" " * 66000 + b"x."), (r"[a-z]{2,}|.", b"q" * 131075 + b"!"),
+                     (r"\p{L}+|.", "é".encode() * 66001 + b"1")):
+        R = ref.RefTokenizer(pat, mr, special)
+        assert [doc[a:e] for a, e in H.rx_split(pat, doc)] == R.split_pieces(doc), pat
+    assert H.rx_split(r"(?:a|ab)?+c|.", b"abc") == [(0, 1), (1, 2), (2, 3)]
+    assert H.rx_split(r"(?:ab|a)?+bc|.", b"abc") == [(0, 1), (1, 3)]
+
+
 def test_patterns_beyond_the_program_limits_are_rejected_not_truncated():
     for pat in ("|".join("a%d" % i for i in range(40)),              # alternatives
                 "".join("[a-%c]" % chr(ord("b") + i % 20) for i in range(20)),  # elements of one alternative
@@ -89,12 +103,13 @@ def test_gpu_generic_patterns_equal_the_reference():
     import td_corpus
     from tokendagger_amd import capi
     _, mr, special = H.llama4()
-    for name in ("autogen", "words", "look", "letters_only", "opt"):
+    for name in ("autogen", "words", "look", "letters_only", "opt", "atomic3"):
         pat = PATTERNS[name]
         tok = capi.HipTokenizer(pat, mr, special, device=0)
         R = ref.RefTokenizer(pat, mr, special)
         docs = [s.encode("utf-8") for s in _strings(400, 7 + len(name))]
         docs += [b"", b"_", b"___", "é".encode(), b"a_b", b"snake_case_name = 42", ("word_" * 3000).encode(), ("x" * 5000 + "_").encode()]
+        docs += [b"a" * 70000 + b" b", b" " * 66000 + b"x."]  # runs longer than 65535 characters
         x, o = td_corpus.code(1 << 20, seed=3)
         docs += [x[o[d]:o[d + 1]].tobytes() for d in range(0, len(o) - 1, 3)][:150]
         text, offs = H.pack_docs(docs)

@@ -7,6 +7,11 @@ import helpers as H
 
 pytestmark = pytest.mark.gpu
 
+# a pattern that is really outside the generic subset (back-reference + lazy quantifier), shared with the CPU-side contract
+# test (tests/test_abi.py::test_encoding_constructor_rejects_unsupported_pattern_on_cpu): the reference's constructor cannot
+# build a usable tokenizer from a pattern it cannot compile either (tiktoken.cpp:59-62)
+BAD_PATTERN = cases.UNSUPPORTED_PATTERN
+
 
 @pytest.fixture(scope="module")
 def enc():
@@ -83,7 +88,7 @@ def test_attributes_and_errors(enc):
     assert "<|begin_of_text|>" in enc.special_tokens_set and len(enc.special_tokens()) == 1134
     assert repr(enc) == "<TokenDagger 'llama4'>"
     with pytest.raises(tokendagger.TokenDaggerError):
-        tokendagger.Encoding(name="bad", pat_str=r"\w+|\s+", mergeable_ranks={b"a": 0})
+        tokendagger.Encoding(name="bad", pat_str=BAD_PATTERN, mergeable_ranks={b"a": 0})
     t = tokendagger.create_tokenizer("toy", enc.pattern, [{"rank": 0, "token_bytes": [97]}, {"rank": 1, "token_bytes": [98]},
                                                            {"rank": 2, "token_bytes": [97, 98], "token_string": "ab"}])
     assert t.encode("ab") == [2] and t.encode("ba") == [1, 0]

@@ -92,6 +92,7 @@ struct Reader {
             }
             if (eof() || nd == 0) return fail("bad \\x{...} escape");
             ++i;
+            if (v >= 0xD800u && v <= 0xDFFFu) return fail("\\x{...} names a surrogate (PCRE2 error 173 in UTF mode)");
             return v <= 0x10FFFFu ? true : fail("\\x{...} beyond U+10FFFF");
         }
         for (int k = 0; k < 2; ++k) {
@@ -167,7 +168,9 @@ struct Reader {
             case 'f': cp = '\f'; return true;
             case 'a': cp = 0x07; return true;
             case 'e': cp = 0x1B; return true;
-            case '0': cp = 0; return true;
+            case '0':  // PCRE2 reads up to two more octal digits (\012 = newline): not supported, and never NUL + literal digits
+                if (peek() >= '0' && peek() <= '9') return fail("octal escapes (\\0 followed by a digit) are not supported");
+                cp = 0; return true;
             case 'x': return read_hex(cp);
             default: break;
         }
@@ -211,10 +214,13 @@ struct Reader {
                 if (!multi.empty()) {  // a script: its ranges
                     if (multi_neg) return fail("a negated script property inside a character class is not supported");
                     for (const RxItem& m : multi) { if (!new_item(m, idx)) return false; ++n; }
+                    if (peek() == '-' && peek(1) != ']' && peek(1) != -1) return fail("a class escape cannot start a range");
                     continue;
                 }
                 if (!new_item(it, idx)) return false;
                 ++n;
+                // PCRE2 refuses "[\\d-z]" (error 150: invalid range in character class), so the reference cannot be built from it
+                if (peek() == '-' && peek(1) != ']' && peek(1) != -1) return fail("a class escape cannot start a range");
                 continue;
             }
             uint32_t hi = lo;
@@ -343,7 +349,7 @@ struct Reader {
         }
         if (peek() == '?') {
             nd.min = 0; ++i;
-            if (peek() == '+') ++i;  // (possessive: nothing follows that could make it back out... handled as greedy; see below)
+            if (peek() == '+') { nd.possessive = 1; ++i; }  // atomic: once a literal (or the skip) is chosen the matcher never comes back for another
             else if (peek() == '?') return fail("lazy quantifiers are not supported");
         } else if (peek() == '*' || peek() == '+' || peek() == '{') {
             return fail("repeated groups are not supported");

@@ -155,7 +155,7 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
             if (nd.kind == RX_CLASS) {
                 uint32_t c = 0;
                 int64_t p = pos;
-                while (c < nd.max && p < n) {
+                while ((nd.max == RX_INF || c < nd.max) && p < n) {  // (RX_INF = no upper bound, not 65535: cnt[] is 32-bit)
                     uint32_t len;
                     const uint32_t cp = rx_char_at(s, p, n, len);
                     if (!rx_in_class(P, T, nd.a, cp)) break;
@@ -221,7 +221,7 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
                 break;
             }
             if (nd.kind == RX_LITSET) {
-                if (cnt[i] >= nd.b) continue;  // (already skipped)
+                if (nd.possessive || cnt[i] >= nd.b) continue;  // (atomic group "(?:..)?+": no second choice; or already skipped)
                 uint32_t k = cnt[i] + 1;
                 int len = -1;
                 for (; k < nd.b; ++k) {
