@@ -155,6 +155,8 @@ int64_t td_info(const td_tokenizer* t, int what);
 #define TD_OPT_PIPE_CHUNK_BYTES 3 /* td_encode_batch cuts inputs of at least two chunks into chunks of whole documents of about
                                     this many bytes (default 32 MiB) and overlaps host copies, PCIe transfers and kernels */
 #define TD_OPT_SMALL_PATH 5       /* 0: never take the one-launch path for inputs of at most 4 KiB (default 1: on) */
+#define TD_OPT_FUSED 6            /* 0: pre-tokenizer and lookup as two kernels, two passes over the text (default 1: one fused pass;
+                                    TD_FUSED=0 in the environment at td_create time also turns it off).  Same results either way. */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 8) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 

@@ -109,7 +109,10 @@ def test_gpu_generic_patterns_equal_the_reference():
         R = ref.RefTokenizer(pat, mr, special)
         docs = [s.encode("utf-8") for s in _strings(400, 7 + len(name))]
         docs += [b"", b"_", b"___", "é".encode(), b"a_b", b"snake_case_name = 42", ("word_" * 3000).encode(), ("x" * 5000 + "_").encode()]
-        docs += [b"a" * 70000 + b" b", b" " * 66000 + b"x."]  # runs longer than 65535 characters
+        if name in ("autogen", "words", "letters_only"):
+            # runs longer than 65535 characters.  Only for patterns that match such a run in one go: "look" backs
+            # out of [a-z]+(?=[0-9]) one character at a time at every start, quadratic for PCRE2 and for one GPU lane alike
+            docs += [b"a" * 70000 + b" b", b" " * 66000 + b"x."]
         x, o = td_corpus.code(1 << 20, seed=3)
         docs += [x[o[d]:o[d + 1]].tobytes() for d in range(0, len(o) - 1, 3)][:150]
         text, offs = H.pack_docs(docs)

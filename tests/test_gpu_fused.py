@@ -1,0 +1,166 @@
+"""The fused tile loop (td_split_tiles<.., true>: pre-tokenizer + whole-piece lookup + in-place merge of the few pieces
+that are no token, one pass over the text) against the compiled reference AND against the two-kernel form it replaces
+(TD_OPT_FUSED = 0), on the inputs that take each of its branches:
+
+  plain halves (every piece a token)                      synthetic English
+  halves with 1..16 missed pieces (merged in place)       English with rare words sprinkled in
+  halves with more (handed to td_merge_pieces)            mixed-script text, emoji, random bytes
+  pieces above 64 bytes (TOK_LONGREF)                     long runs, CJK sentences
+  deferred token tiles: more than 2048 pieces in 4 KiB    "a.b.c." / "1 2 3 "
+                        pieces longer than the window      runs of 300 .. 100 000 bytes, across tile boundaries
+                        a tile that starts inside one
+  tile geometry                                           sizes around multiples of 4096 / 8192, documents cut everywhere
+
+Reference behaviour: CoreBPE::encode, /root/reference/src/tiktoken/tiktoken.cpp:169-234 (through oracle/_ref, the checker).
+"""
+from __future__ import annotations
+
+import os
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+import td_corpus
+from oracle import ref
+from tokendagger_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+TD_OPT_FUSED = capi.TD_OPT_FUSED
+
+
+@pytest.fixture(scope="module")
+def tok():
+    pat, mr, special = H.llama4()
+    t = capi.HipTokenizer(pat, mr, special, device=0)
+    t.set_option(capi.TD_OPT_SMALL_PATH, 0)  # (the one-launch path for tiny inputs is not what is tested here)
+    yield t
+    t.close()
+
+
+def _both(tok, text: bytes, offs):
+    offs = np.asarray(offs, dtype=np.int64)
+    tok.set_option(TD_OPT_FUSED, 1)
+    ft, fo = tok.encode_batch(text, offs)
+    tok.set_option(TD_OPT_FUSED, 0)
+    ut, uo = tok.encode_batch(text, offs)
+    tok.set_option(TD_OPT_FUSED, 1)
+    return (ft, fo), (ut, uo)
+
+
+def _check(tok, text: bytes, offs, what: str):
+    (ft, fo), (ut, uo) = _both(tok, text, offs)
+    assert np.array_equal(fo, uo), f"{what}: document offsets differ between the fused and the two-kernel form"
+    assert np.array_equal(ft, ut), f"{what}: ids differ between the fused and the two-kernel form"
+    if ref.available():
+        R = H.ref_tokenizer()
+        _, et, eo = R.encode_batch(np.frombuffer(text, dtype=np.uint8), np.asarray(offs, dtype=np.int64), n_threads=os.cpu_count() or 1,
+                                   want_tokens=True)
+        assert np.array_equal(fo, eo), f"{what}: document offsets differ from the reference"
+        bad = np.flatnonzero(ft != et)
+        assert bad.size == 0, f"{what}: ids differ from the reference, first at token {bad[:1]}"
+    return ft, fo
+
+
+def _rare_words(n: int, seed: int, every: int) -> bytes:
+    """English text with a word that is no token about every `every` bytes: halves with a handful of missed pieces."""
+    rng = random.Random(seed)
+    x, _ = td_corpus.english(n, seed=seed)
+    b = bytearray(x.tobytes())
+    out = bytearray()
+    pos = 0
+    while pos < len(b):
+        step = rng.randrange(every // 2, every * 3 // 2)
+        out += b[pos:pos + step]
+        pos += step
+        k = rng.randrange(3)
+        if k == 0:
+            out += (" " + "".join(rng.choice("qxzjkvw") for _ in range(rng.randrange(5, 40)))).encode()
+        elif k == 1:
+            out += (" " + rng.choice(["zxqvbn", "Xylophonyx", "qwrtzp", "ĉapelo", "żółć", "naïveté", "ǆǆǆ"]) + " ").encode()
+        else:
+            out += (" x" + "".join(rng.choice("0123456789abcdef") for _ in range(rng.randrange(8, 60)))).encode()
+    return bytes(out)
+
+
+def test_plain_text_and_tile_geometry(tok):
+    x, o = td_corpus.english(3 << 20, seed=11)
+    _check(tok, x.tobytes(), o, "english 3 MiB")
+    base = x.tobytes()
+    for n in (1, 15, 16, 17, 4095, 4096, 4097, 8191, 8192, 8193, 8192 + 127, 8192 + 129, 8192 + 191, 8192 + 193, 16384, 16385, 3 * 8192 - 1,
+              65536 + 5):
+        _check(tok, base[:n], [0, n], f"english, {n} bytes, one document")
+    # documents cut everywhere (mid-word): every token tile sees document starts at odd places
+    rng = random.Random(5)
+    cuts = sorted(set(rng.randrange(0, 300000) for _ in range(4000)) | {0, 300000})
+    _check(tok, base[:300000], cuts, "english, 4000 random document cuts")
+    cuts = list(range(0, 40001))  # one-byte documents, including across tile boundaries
+    _check(tok, base[:40000], cuts, "english, one-byte documents")
+    _check(tok, base[:20000], [0, 0, 0, 5, 5, 8192, 8192, 8192 + 128, 20000, 20000], "empty documents")
+
+
+def test_halves_with_a_few_missed_pieces_are_merged_in_place(tok):
+    for every, seed in ((300, 1), (1200, 2), (4000, 3), (150, 4)):
+        t = _rare_words(1 << 20, seed, every)
+        _check(tok, t, [0, len(t)], f"rare words every ~{every} bytes")
+        offs = sorted(set([0, len(t)] + [random.Random(seed).randrange(len(t)) for _ in range(500)]))
+        _check(tok, t, offs, f"rare words every ~{every} bytes, 500 documents")
+
+
+def test_heavy_halves_go_to_the_merge_kernel(tok, golden):
+    x, o = td_corpus.mixed(2 << 20, seed=7)
+    _check(tok, x.tobytes(), o, "mixed-script 2 MiB")
+    x, o = td_corpus.code(2 << 20, seed=7)
+    _check(tok, x.tobytes(), o, "synthetic code 2 MiB")
+    rng = random.Random(9)
+    emoji = "".join(rng.choice("😀🎉👨‍💻🇩🇪✨🔥 aé中") for _ in range(40000)).encode()
+    _check(tok, emoji, [0, len(emoji)], "emoji")
+    _check(tok, golden["text"].tobytes(), golden["offsets"], "golden documents")
+
+
+def test_long_pieces_and_deferred_tiles(tok):
+    rng = random.Random(3)
+    filler, _ = td_corpus.english(1 << 18, seed=2)
+    filler = filler.tobytes()
+    cases = {
+        "dense punctuation (> 2048 pieces per half)": b"a.b.c.d.e.f.g.h." * 4000,
+        "digits and blanks": b"1 2 3 4 5 6 7 8 9 0 " * 3000,
+        "every byte a piece": b".,;:!?()[]{}" * 5000,
+        "run of 300": filler[:5000] + b"a" * 300 + filler[:5000],
+        "runs around the halo sizes": b"".join(filler[i * 700:(i + 1) * 700] + bytes([97 + i % 26]) * L for i, L in
+                                              enumerate([63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 1023, 1024, 1025])),
+        "blanks 5000": filler[:9000] + b" " * 5000 + filler[:3000],
+        "piece over several tiles": filler[:8000] + b"z" * 30000 + filler[:100] + b"=" * 20000 + b"\n" * 9000 + filler[:8000],
+        "100 KB of one letter": b"q" * 100000,
+        "cjk sentences": ("".join(rng.choice("的一是不了人我在有他这为之大来以个中上们") for _ in range(60000))).encode(),
+        "cjk with punctuation": "".join("".join(rng.choice("的一是不了人我在有他这为之大来以个中上们") for _ in range(rng.randrange(1, 90))) + rng.choice("，。！？ \n")
+                                        for _ in range(2500)).encode(),
+    }
+    for name, t in cases.items():
+        _check(tok, t, [0, len(t)], name)
+        # the same text at every alignment of the interesting stretch relative to the tile grid
+    t = filler[:8192 - 200]
+    for shift in (0, 1, 63, 64, 100, 127, 128, 129, 190, 200, 250):
+        u = t + b" " * shift + b"x" * 400 + filler[:9000]
+        _check(tok, u, [0, len(u)], f"run of 400 at tile offset -200+{shift}")
+
+
+def test_random_bytes_and_unknown_bytes(tok):
+    rng = random.Random(21)
+    junk = bytes(rng.randrange(256) for _ in range(200000))
+    # (the Llama-4 vocabulary holds every single byte: no TD_E_UNKNOWN_BYTE here)
+    _check(tok, junk, sorted(set([0, len(junk)] + [rng.randrange(len(junk)) for _ in range(300)])), "random bytes")
+    ascii_junk = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789 \n\t.,'") for _ in range(300000))
+    _check(tok, ascii_junk, [0, len(ascii_junk)], "random ASCII")
+
+
+def test_encode_ordinary_mode_takes_the_same_path(tok):
+    x, o = td_corpus.english(1 << 19, seed=4)
+    tok.set_option(TD_OPT_FUSED, 1)
+    a = tok.encode_batch(x.tobytes(), o, mode=capi.TD_MODE_ORDINARY)
+    tok.set_option(TD_OPT_FUSED, 0)
+    b = tok.encode_batch(x.tobytes(), o, mode=capi.TD_MODE_ORDINARY)
+    tok.set_option(TD_OPT_FUSED, 1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -25,6 +25,7 @@ TD_OPT_PROFILE = 2
 TD_OPT_PIPE_CHUNK_BYTES = 3
 TD_OPT_PIPE_THREADS = 4
 TD_OPT_SMALL_PATH = 5
+TD_OPT_FUSED = 6
 
 EXPORTS = [
     "td_create", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",

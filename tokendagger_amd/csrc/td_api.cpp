@@ -138,6 +138,7 @@ struct Ctl {  // small control block in device memory
     uint32_t miss_count[6];  // entries on the miss lists (K_MISS_CLASSES of them)
     uint32_t flagged_count;  // tiles flagged TILE_HAS_MISS (on flagged_list: td_merge_pieces draws them from there)
     uint32_t gap_count;      // generic split patterns: stretches of text the pattern skipped
+    uint32_t deferred_count; // fused tile loop: token tiles left to td_probe_tiles
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 }  // namespace
@@ -151,12 +152,13 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, gap_list, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
     bool profile = false;
     int stop_after = 0;
+    bool fused = true;  // pre-tokenizer and lookup in one pass over the text (TD_OPT_FUSED; TD_FUSED=0 in the environment turns it off)
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
     std::vector<Ev3> ev_pending, ev_free;
     int64_t last_long = 0, last_far = 0;
@@ -271,6 +273,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->flagged_list, (size_t)(n_tiles + 64) * 4))) return rc;
+    if ((rc = ensure(t, t->deferred_list, (size_t)(n_tiles + 64) * 4))) return rc;
     if (t->H.pattern_kind == PATTERN_GENERIC && (rc = ensure(t, t->gap_list, (size_t)(n / 2 + 4096) * 8))) return rc;  // (a skipped stretch and the piece behind it take two bytes at least)
     if ((rc = ensure(t, t->miss_list, (size_t)(n_tiles + 1) * K_MISS_LISTED_MAX * K_MISS_CLASSES * 8))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
@@ -339,6 +342,10 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.gap_cap = (uint32_t)std::min<size_t>(t->gap_list.cap / 8, 0x7FFFFFF0u);
     a.gap_count = &ctl->gap_count;
     a.flagged_list = (uint32_t*)t->flagged_list.p;
+    a.deferred_list = (uint32_t*)t->deferred_list.p;
+    a.deferred_count = &ctl->deferred_count;
+    a.fused = t->fused ? 1 : 0;
+    a.probe_deferred = 0;
     a.miss_cap = (uint32_t)((n_tiles + 1) * K_MISS_LISTED_MAX);
     a.chunk_pref = (int64_t*)t->chunk_pref.p;
     a.ctl_reset = &ctl->long_count;  // keep a sticky error (err / err_pos) but reset the per-call counters
@@ -412,6 +419,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
         return TD_E_INVALID;
     }
     td_tokenizer* t = new td_tokenizer;
+    if (const char* e = getenv("TD_FUSED")) t->fused = atoi(e) != 0;
     std::string err;
     int rc = build_tables(pat_str, n_vocab, token_bytes, token_offsets, ranks, n_special, special_bytes, special_offsets,
                           special_ids, t->H, err);
@@ -1260,8 +1268,14 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
         t->pool_bytes_opt = value;
         return TD_OK;
     }
-    if (what == 99) {  // undocumented: phase ablation for kernel tuning (results are garbage when != 0)
+#ifdef TD_ABLATE
+    if (what == 99) {  // tuning builds only (tools/build_variant.sh -DTD_ABLATE): phase ablation, results are garbage when != 0
         t->stop_after = (int)value;
+        return TD_OK;
+    }
+#endif
+    if (what == TD_OPT_FUSED) {
+        t->fused = value != 0;
         return TD_OK;
     }
     if (what == TD_OPT_PROFILE) {

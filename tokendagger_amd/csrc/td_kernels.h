@@ -56,6 +56,10 @@ struct EncodeArgs {
     int64_t* gap_list;          // global byte positions of the stretches the pattern skips (they get no tokens)
     uint32_t* gap_count;
     uint32_t gap_cap;
+    uint32_t* deferred_list;    // fused tile loop (td_split_tiles<.., true>): the token tiles it left to td_probe_tiles
+    uint32_t* deferred_count;   // entries on it
+    int fused;                  // launch the fused tile loop (pre-tokenizer + lookup in one pass over the text)
+    int probe_deferred;         // td_probe_tiles: only the tiles on deferred_list (set by launch_encode)
     uint32_t* flagged_list;     // the tiles td_probe_tiles flagged TILE_HAS_MISS, in the order its workgroups appended them
     uint32_t* flagged_count;    // entries on it
     int64_t* chunk_pref;        // [n_tiles/4096 + 2] token base of every 4096-tile chunk (exclusive scan of the chunk totals)
@@ -70,7 +74,7 @@ struct EncodeArgs {
     uint32_t pat_flags;         // PV_* scanner flags of the split pattern (selects the td_split_tiles instantiation)
     int use_fastpath;           // whole-piece lookup before the merge loop (CoreBPE::encode) or not
     int text_aligned;           // text pointer is 16-byte aligned
-    int stop_after;             // debug/ablation: leave the tile loop after phase N (0 = run everything)
+    int stop_after;             // ablation (only in -DTD_ABLATE builds): leave the tile loop after phase N (0 = run everything)
 };
 
 struct DecodeArgs {

@@ -23,6 +23,14 @@
 
 namespace td {
 
+// Ablation hook (tools/gpu_ablate.py: "leave the tile loop after phase N"): compiled in only with -DTD_ABLATE (tools/build_variant.sh);
+// release builds carry no trace of it in the hot loops.
+#ifdef TD_ABLATE
+#define TD_STOP(n) (a.stop_after == (n))
+#else
+#define TD_STOP(n) false
+#endif
+
 // ------------------------------------------------------------------ accessors ---------------
 struct LdsSrc {
     const uint8_t* txt;
@@ -216,6 +224,27 @@ __device__ __forceinline__ uint4 load_text16(const EncodeArgs& a, int64_t g) {
     return make_uint4(0, 0, 0, 0);
 }
 
+// Edge windows of the tile loops (the first and the last windows of the text, an unaligned text pointer): staged straight
+// into LDS by an out-of-line routine, byte by byte, zeros outside [0, n).  Interior windows are prefetched into registers
+// with plain 16-byte loads and no call anywhere near them: as a per-load "aligned and inside? else call" the out-of-line
+// edge path made the compiler keep the prefetch addresses alive across the calls in scratch memory — six 8-byte spill
+// stores and five reloads per lane and tile, more bytes than the tile's text (the "2 GB of scratch traffic per GiB" of
+// round 2's split kernel).  Returns the OR of the bytes the lane staged.
+__device__ __noinline__ uint32_t stage_window_edge(uint8_t* s_txt, const uint8_t* text, int64_t n, int64_t w0, int tid, int n16) {
+    uint32_t hib = 0;
+    for (int v = tid; v < n16; v += K_THREADS) {
+        const int64_t g = w0 + (int64_t)v * 16;
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 16; ++k) {
+            const int64_t gg = g + k;
+            if (gg >= 0 && gg < n) w[k >> 2] |= (uint32_t)text[gg] << ((k & 3) * 8);
+        }
+        reinterpret_cast<uint4*>(s_txt)[v] = make_uint4(w[0], w[1], w[2], w[3]);
+        hib |= w[0] | w[1] | w[2] | w[3];
+    }
+    return hib;
+}
+
 // LDS traffic between the lanes of ONE wavefront: program order is execution order, the fence keeps the compiler from
 // moving the accesses and waits for the outstanding LDS operations
 __device__ __forceinline__ void wave_sync() {
@@ -242,6 +271,52 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int /*lane*/) {
     return x;
 }
 
+// ------------------------------------------------------------------ probe helpers (td_probe_tiles and the fused tile loop) ----
+constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per tile by this kernel
+
+// length classes of the missed pieces (<= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units of 16 key slots in td_merge_pieces)
+__device__ __forceinline__ uint32_t mq_class(uint32_t len) { return len <= 8u ? 0u : len <= 16u ? 1u : len <= 32u ? 2u : len <= 48u ? 3u : 4u; }
+__device__ __forceinline__ uint32_t mq_units(uint32_t cls) { return cls < 2u ? 1u : cls; }
+
+#ifndef TD_PROBE_MIN_WAVES
+#define TD_PROBE_MIN_WAVES 8  // (measured on 256 MiB of English: 0.49 ms at 8 waves/SIMD, 0.66 ms at 5..7)
+#endif
+
+// everything the hot probe path leaves out: keys longer than 16 bytes (hashed + verified against the token bytes), probe
+// sequences longer than one slot, pieces longer than K_MAXSHORT (handed to td_long_pieces).  Returns the piece's slot.
+__device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const Tables& T, const uint8_t* s_txt, const int32_t* s_byteid,
+                                                     uint32_t* s_flags, int64_t wg0, int i, uint32_t len) {
+    if (len > (uint32_t)K_MAXSHORT) {
+        if (len == 0xFFFFFFFFu) { raise(a, TD_E_SCRATCH, wg0 + i); return 0u; }
+        const uint32_t idx = atomicAdd(a.long_count, 1u);
+        if (idx >= a.long_cap) { raise(a, TD_E_SCRATCH, wg0 + i); return 0u; }
+        LongEntry le;
+        le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
+        a.long_list[idx] = le;
+        atomicOr(s_flags, TILE_HAS_LONG);
+        return TOK_LONGREF | idx;
+    }
+    const uint8_t* pb = s_txt + i;
+    if (len == 1) {
+        const int32_t id = s_byteid[pb[0]];
+        if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
+        return (uint32_t)id;
+    }
+    if (a.use_fastpath) {
+        auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
+        uint64_t key;
+        if (len <= 8) {
+            key = 0;
+            for (uint32_t q = 0; q < len; ++q) key |= (uint64_t)pb[q] << (8 * q);
+        } else {
+            key = hash_bytes(get, len);
+        }
+        const int32_t r = piece_lookup(T, key, len, get);
+        if (r != NO_RANK) return (uint32_t)r;
+    }
+    return TOK_MISS | ((uint32_t)i << 7) | len;  // (the caller notes it: note_miss)
+}
+
 // ------------------------------------------------------------------ td_split_tiles ----------
 // Pre-tokenizer: the regex split of the reference (CoreBPE::split_text, tiktoken.cpp:70-128) as a
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
@@ -253,18 +328,54 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int /*lane*/) {
 // the hot scan loop of the Llama-4 pattern carries no trace of the others (as run-time flags they cost 5 % of it).
 constexpr int KS_HCAP = 1024;  // heads the list holds per tile (what does not fit is matched by the lane that found it)
 constexpr int KS_CCAP = 256;
-template <uint32_t PV>
-__global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
+
+// ---- the fused form (FUSED = true): td_encode_tiles ---------------------------------------------------------------
+// The pre-tokenizer's tile loop goes on where td_split_tiles stops: the text of the tile is in LDS and so are its START bits,
+// so the pieces are looked up right there (td_probe_tiles' loop) and the tile's slots go to the staging region in the layout
+// td_pack_tokens reads — the text is read from HBM ONCE, the START bitmap is not read back, and the split phases (bound by
+// instruction issue) of one workgroup overlap the probe phases (bound by the latency of one scattered load per piece) of
+// the others on the same CU.  A tile of KS_TILE bytes is two token tiles of K_TILE bytes ("halves"), handled one after the
+// other with the same LDS:
+//   - dense piece list of the half from the START bits (block scan), piece k -> lane k mod 256, one slot per piece in LDS;
+//   - pieces that are no token (2..64 bytes): a half with at most FZ_INLINE_MAX of them merges them right here, one lane per
+//     piece (mg_round_t), and writes their ids in place: the tile stays PLAIN for td_pack_tokens (running text: one or two
+//     such pieces in every other tile).  A half with more hands them to td_merge_pieces the way td_probe_tiles does
+//     (TOK_MISS markers, TILE_HAS_MISS, the list of flagged tiles);
+//   - pieces above K_MAXSHORT bytes: TOK_LONGREF + an entry for td_long_pieces / td_giant_pieces, as before.
+// What the window cannot decide (a tile that starts inside a piece longer than the left halo, a piece that leaves the
+// window: the td_split_far_* cases) or hold (more than FZ_NPC pieces in a half) is DEFERRED: the token tile goes on a list,
+// and td_probe_tiles — which otherwise finds nothing to do — looks its pieces up after the far kernels have completed the
+// START bits.  Results are the same slots either way.
+constexpr int FZ_NPC = 2048;         // pieces per half the LDS list holds (a half with more: deferred)
+constexpr int FZ_INLINE_MAX = 16;    // missed pieces of a half that are merged in place
+constexpr int FZ_MG_UNITS = 16;      // 16-slot units of merge state per wavefront (4 pieces of up to 64 bytes)
+constexpr int FZ_R_MASK = (K_MWORDS + 1) * MK_COUNT * 8;  // bytes of the class masks
+constexpr int FZ_R_HEADS = FZ_R_MASK;                     // s_heads behind them
+constexpr int FZ_R_COLD = FZ_R_HEADS + (KS_HCAP + 2) * 2;
+constexpr int FZ_R_SPLIT_END = FZ_R_COLD + KS_CCAP * 2;
+// the same bytes during the token phases
+constexpr int FZ_R_PLIST = 0;                              // u16[FZ_NPC + 8] piece starts; later u32[16 * 64] ids of the merged pieces
+constexpr int FZ_R_TOK = ((FZ_NPC + 8) * 2 + 15) & ~15;    // u32[FZ_NPC] one slot per piece
+constexpr int FZ_R_TOK_END = FZ_R_TOK + FZ_NPC * 4;
+constexpr int FZ_R_BYTES = FZ_R_SPLIT_END > FZ_R_TOK_END ? ((FZ_R_SPLIT_END + 15) & ~15) : FZ_R_TOK_END;
+static_assert(FZ_R_TOK >= FZ_INLINE_MAX * 64 * 4, "the merged pieces' ids take the place of the piece list");
+constexpr int FZ_MG_BYTES = (K_THREADS / 64) * FZ_MG_UNITS * MG_UNIT * 4 * 2;  // keys + ids of every wavefront
+
+template <uint32_t PV, bool FUSED>
+__global__ __launch_bounds__(K_THREADS, FUSED ? 4 : TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
-    __shared__ __attribute__((aligned(16))) uint64_t s_mask[(K_MWORDS + 1) * MK_COUNT];  // class masks, word-major
+    __shared__ __attribute__((aligned(16))) uint8_t s_R[FZ_R_BYTES];  // class masks | heads | cold list; FUSED: then piece list | slots
+    uint64_t* const s_mask = reinterpret_cast<uint64_t*>(s_R);       // [(K_MWORDS + 1) * MK_COUNT] class masks, word-major
+    uint16_t* const s_heads = reinterpret_cast<uint16_t*>(s_R + FZ_R_HEADS);  // [KS_HCAP + 2] unresolved heads (window positions)
+    uint16_t* const s_cold = reinterpret_cast<uint16_t*>(s_R + FZ_R_COLD);    // [KS_CCAP] piece starts the branch-free matcher left open
     __shared__ uint32_t s_start[K_WIN / 32 + 3];  // bit i: a piece starts at window byte i
     __shared__ uint32_t s_doc[K_WIN / 32 + 2];
     __shared__ uint8_t s_lut[128];                // ASCII byte -> feature byte
     __shared__ uint8_t s_fcls[16];                // class -> feature byte
-    __shared__ uint16_t s_heads[KS_HCAP + 2];     // unresolved heads (window positions)
-    __shared__ uint16_t s_cold[KS_CCAP];          // piece starts the branch-free matcher left open
     __shared__ uint32_t s_nh, s_cur, s_ncold, s_nonascii;
     __shared__ int s_last;
+    __shared__ int s_cross;                       // FUSED: window position of the first piece start at/after the tile end (-1: unknown)
+    __shared__ uint32_t s_defer;                  // FUSED: the window cannot decide this tile (td_split_far_* will)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -272,15 +383,40 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
     for (int q = tid; q < 128; q += K_THREADS) s_lut[q] = (uint8_t)feature_of_class(T.ascii_cls[q]);
     if (tid < 16) s_fcls[tid] = (uint8_t)feature_of_class((uint32_t)tid);
     if (tid == 0) s_nonascii = 0;
+    // FUSED: state of the token phases (declared unconditionally; the plain instantiation never touches it and the
+    // compiler drops it)
+    __shared__ __attribute__((aligned(16))) uint32_t s_mg[FUSED ? FZ_MG_BYTES / 4 : 4];  // merge state (keys | ids per wavefront); the probe's cold list
+    __shared__ int32_t s_byteid[FUSED ? 256 : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_kmask[FUSED ? (P12_MAXLEN + 1) * 4 : 4];  // row len: byte masks of a len-byte key
+    __shared__ uint16_t s_pb[FUSED ? K_THREADS : 4], s_sm[FUSED ? K_THREADS : 4];  // pieces before each lane's 16 bytes of the half / their START bits
+    __shared__ uint32_t s_wave[8];
+    __shared__ uint32_t s_hflags, s_nmiss, s_ncoldp;
+    __shared__ uint16_t s_missk[FUSED ? FZ_INLINE_MAX : 4];  // piece indices of the missed pieces that are merged in place
+    __shared__ uint32_t s_mnt[FUSED ? FZ_INLINE_MAX : 4];    // ... and how many ids each became
+    __shared__ uint32_t s_flagl[32];                         // flagged token tiles of this workgroup, not appended yet
+    __shared__ uint32_t s_nflagl;
+    if constexpr (FUSED) {
+        for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
+        if (tid < (int)(P12_MAXLEN + 1) * 4) {
+            const int len = tid >> 2, w = tid & 3, nb = len - 4 * w;  // bytes of dword w that belong to a len-byte key
+            s_kmask[tid] = w == 3 || nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
+        }
+        if (tid == 0) s_nflagl = 0;
+    }
     __syncthreads();
 
     constexpr int NPF = (K_WIN / 16 + K_THREADS - 1) / K_THREADS;  // 16-byte prefetch registers per lane for one window
     uint4 pf[NPF];
     const int64_t nwords = (a.n + 31) >> 5;
+    // (uniform) the whole window lies inside the text and 16-byte loads are aligned: prefetched into registers; the others
+    // (first / last windows, unaligned text) are staged by stage_window_edge when their turn comes
+    auto interior = [&](int64_t w0) { return a.text_aligned && w0 >= 0 && w0 + K_WIN <= a.n; };
     auto load_window = [&](int64_t w0) {
+        if (!interior(w0)) return;
+        const uint4* src16 = reinterpret_cast<const uint4*>(a.text + w0);
 #pragma unroll
         for (int q = 0; q < NPF; ++q)
-            if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = load_text16(a, w0 + (int64_t)(q * K_THREADS + tid) * 16);
+            if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = src16[q * K_THREADS + tid];
     };
 #pragma unroll
     for (int q = 0; q < NPF; ++q) pf[q] = make_uint4(0, 0, 0, 0);
@@ -294,12 +430,16 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         // ---- phase 0: stage the text window and the document bits.  The text of this tile was requested one
         //      iteration ago (registers pf[]), so its HBM latency is hidden behind the previous tile --------------
         uint32_t hib = 0;  // (any byte >= 0x80 in what this lane stages?)
+        if (interior(wg0)) {
 #pragma unroll
-        for (int q = 0; q < NPF; ++q)
-            if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) {
-                reinterpret_cast<uint4*>(s_txt)[q * K_THREADS + tid] = pf[q];
-                hib |= pf[q].x | pf[q].y | pf[q].z | pf[q].w;
-            }
+            for (int q = 0; q < NPF; ++q)
+                if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) {
+                    reinterpret_cast<uint4*>(s_txt)[q * K_THREADS + tid] = pf[q];
+                    hib |= pf[q].x | pf[q].y | pf[q].z | pf[q].w;
+                }
+        } else {
+            hib = stage_window_edge(s_txt, a.text, a.n, wg0, tid, K_WIN / 16);
+        }
         for (int w = tid; w < K_WIN / 32; w += K_THREADS) {
             const int64_t gw = (wg0 >> 5) + w;
             uint32_t dw = (gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
@@ -309,7 +449,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         }
         if (tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);  // next tile of this workgroup
         for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
-        if (tid == 0) { s_nh = 0; s_cur = 0; s_ncold = 0; s_last = -1; }
+        if (tid == 0) { s_nh = 0; s_cur = 0; s_ncold = 0; s_last = -1; s_cross = -1; s_defer = 0; }
         if (__ballot((hib & 0x80808080u) != 0) && lane == 0) s_nonascii = 1;  // (reset behind phase 1; __syncthreads_or costs extra barriers)
         __syncthreads();
         const bool tile_ascii = !s_nonascii;
@@ -487,7 +627,7 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
         }
         __syncthreads();
         if (tid == 0) s_nonascii = 0;
-        if (a.stop_after == 12) continue;
+        if (TD_STOP(12)) continue;
 
         // ---- phase 2: piece boundaries.
         //  (a) whole-word rules: every lane takes the 32 bytes of its stride + 32 bytes of look-ahead as 64-bit masks and
@@ -507,13 +647,17 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
             const uint32_t* s_mask32 = reinterpret_cast<const uint32_t*>(s_mask);
             auto dword_at = [](int j) { return (j >> 1) * (MK_COUNT * 2) + (j & 1); };  // mask 0 of dword j; mask k: + 2 k
             auto defer = [&](int64_t g) {
+                if (FUSED) s_defer = 1;
                 const uint32_t q = atomicAdd(a.slow_count, 1u);
                 if (q < a.slow_cap) a.slow_list[q] = g;
                 else raise(a, TD_E_SCRATCH, g);
             };
             auto mark = [&](int q) { atomicOr(&s_start[q >> 5], 1u << (q & 31)); };
             auto sync_at = [&](int q) { return (s_mask32[dword_at(q >> 5) + 2 * MK_SYNC] >> (q & 31)) & 1u; };
-            auto crossed = [&](int e) { if (tile + 1 < a.n_stiles) a.tile_carry[tile + 1] = wg0 + e; };  // first piece start of the next tile
+            auto crossed = [&](int e) {  // first piece start of the next tile
+                if (FUSED) s_cross = e;
+                if (tile + 1 < a.n_stiles) a.tile_carry[tile + 1] = wg0 + e;
+            };
             // general matcher from the piece start p (marked) to the end of its chain
             auto walk = [&](int p) {
                 for (;;) {
@@ -565,14 +709,14 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                         if (w == 0) m &= ~0xFull;
                         if (m) s = w * 64 + td_top64(m) - 1;
                     }
-                    if (s < 0) a.tile_flag[tile] = 1;
+                    if (s < 0) { a.tile_flag[tile] = 1; if (FUSED) s_defer = 1; }
                     else s_heads[nh++] = (uint16_t)s;
                 }
                 if (s_last >= 0) s_heads[nh++] = (uint16_t)s_last;
                 s_nh = nh;
             }
             __syncthreads();
-            if (a.stop_after == 13) continue;
+            if (TD_STOP(13)) continue;
             // (b)
             {
                 const uint32_t nh = s_nh;
@@ -639,7 +783,224 @@ __global__ __launch_bounds__(K_THREADS, TD_SPLIT_MIN_WAVES) void td_split_tiles(
                 a.startbits[(tile_g0 >> 5) + tid] = v;
             }
         }
+        if constexpr (FUSED) {
+            // ================= token phases: the tile's pieces -> slots of the staging region (see the note above) =========
+            const int cross = s_cross;
+            const bool tile_deferred = s_defer != 0 || cross < 0;  // (uniform: both are final since the barrier above)
+            uint16_t* const s_plist = reinterpret_cast<uint16_t*>(s_R + FZ_R_PLIST);
+            uint32_t* const s_tok = reinterpret_cast<uint32_t*>(s_R + FZ_R_TOK);
+            uint32_t* const s_mres = reinterpret_cast<uint32_t*>(s_R + FZ_R_PLIST);  // ids of the merged pieces, 64 slots each (the piece list is dead by then)
+            uint16_t* const s_coldk = reinterpret_cast<uint16_t*>(s_mg);
+            const int wv = tid >> 6;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef const u32x4 __attribute__((address_space(1)))* gslot_t;  // (global loads, not flat ones)
+            gslot_t const p12 = (gslot_t)(uintptr_t)T.piece12_slots;
+            for (int h = 0; h < KS_TILE / K_TILE; ++h) {
+                const int hb = K_HL + h * K_TILE;  // the half owns window bytes [hb, he)
+                if (hb >= tile_hi) break;
+                const int he = hb + K_TILE < tile_hi ? hb + K_TILE : tile_hi;
+                const int tile4 = tile * (KS_TILE / K_TILE) + h;
+                __syncthreads();  // (the region is free: phase 2 / the half before are done with it)
+                // ---- dense list of the half's piece starts ----
+                const int c0 = hb + tid * K_CHUNK;
+                uint32_t smask = 0;  // START bits of my 16 bytes
+                if (c0 < he) {
+                    smask = (s_start[c0 >> 5] >> (c0 & 31)) & 0xFFFFu;
+                    if (c0 + K_CHUNK > he) smask &= (1u << (he - c0)) - 1u;
+                }
+                const uint32_t smask0 = smask;
+                uint32_t np;
+                const uint32_t pbase = block_excl_scan(__popc(smask), s_wave, np);
+                if (tile_deferred || np > (uint32_t)FZ_NPC) {  // (uniform) td_probe_tiles takes this token tile, behind the far kernels
+                    if (tid == 0) {
+                        const uint32_t at = atomicAdd(a.deferred_count, 1u);
+                        a.deferred_list[at] = (uint32_t)tile4;
+                    }
+                    continue;
+                }
+                {
+                    uint32_t k = pbase;
+                    while (smask) {
+                        const int b = __ffs(smask) - 1;
+                        smask &= smask - 1;
+                        s_plist[k++] = (uint16_t)(c0 + b);
+                    }
+                }
+                s_pb[tid] = (uint16_t)pbase;
+                s_sm[tid] = (uint16_t)smask0;
+                if (tid == 0) {
+                    // end of the half's last piece: the next START bit (bits at and behind the tile end are zero), else where
+                    // the boundary scan crossed the tile end
+                    int e = cross;
+                    for (int w = he >> 5; w < K_WIN / 32 + 3; ++w) {
+                        uint32_t m = s_start[w];
+                        if (w == (he >> 5)) m &= ~((1u << (he & 31)) - 1u);
+                        if (m) { e = w * 32 + (__ffs(m) - 1); break; }
+                    }
+                    s_plist[np] = (uint16_t)e;
+                    s_hflags = 0; s_nmiss = 0; s_ncoldp = 0;
+                }
+                __syncthreads();
+                // ---- probe (td_probe_tiles' loop): piece k -> lane k mod 256; the slot stays in LDS ----
+                auto note_miss = [&](uint32_t k) {
+                    const uint32_t mi = atomicAdd(&s_nmiss, 1u);
+                    if (mi < (uint32_t)FZ_INLINE_MAX) s_missk[mi] = (uint16_t)k;
+                };
+                for (uint32_t k = tid; k < np; k += K_THREADS) {
+                    const int i = s_plist[k];
+                    const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
+                    const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
+                    const uint32_t sh = (i & 3) * 8;
+                    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                    const uint4 km = reinterpret_cast<const uint4*>(s_kmask)[len < P12_MAXLEN ? len : P12_MAXLEN];
+                    const uint32_t k0 = __funnelshift_r(w0, w1, sh) & km.x, k1 = __funnelshift_r(w1, w2, sh) & km.y,
+                                   k2 = __funnelshift_r(w2, w3, sh) & km.z;
+                    const u32x4 sl = p12[hash_piece12(k0, k1, k2, len) & T.piece12_mask];
+                    uint32_t res;
+                    if (len <= P12_MAXLEN && a.use_fastpath && (sl.w == 0u || (sl.x == k0 && sl.y == k1 && sl.z == k2 && (sl.w >> 24) == (0x80u | len)))) {
+                        const bool miss = sl.w == 0u;  // empty slot: not a token (a single byte that is no token is an error, not a merge)
+                        res = miss ? (TOK_MISS | ((uint32_t)i << 7) | len) : (sl.w & 0x1FFFFFu);
+                        if (miss) {
+                            if (len == 1) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
+                            note_miss(k);
+                        }
+                    } else {
+                        // longer keys, an occupied home slot, long pieces: put aside and handled densely behind the loop
+                        const uint32_t j = atomicAdd(&s_ncoldp, 1u);
+                        if (j < (uint32_t)K_THREADS) { s_coldk[j] = (uint16_t)k; continue; }
+                        res = probe_piece_cold(a, T, s_txt, s_byteid, &s_hflags, wg0, i, len);  // (more than 256 of them in one half)
+                        if ((res & 0xC0000000u) == TOK_MISS) note_miss(k);
+                    }
+                    s_tok[k] = res;
+                }
+                __syncthreads();
+                {
+                    const uint32_t nc = s_ncoldp < (uint32_t)K_THREADS ? s_ncoldp : (uint32_t)K_THREADS;
+                    if ((uint32_t)tid < nc) {
+                        const uint32_t k = s_coldk[tid];
+                        const int i = s_plist[k];
+                        const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
+                        const uint32_t res = probe_piece_cold(a, T, s_txt, s_byteid, &s_hflags, wg0, i, len);
+                        if ((res & 0xC0000000u) == TOK_MISS) note_miss(k);
+                        s_tok[k] = res;
+                    }
+                }
+                __syncthreads();
+                // ---- pieces that are no token ----
+                const uint32_t nm = s_nmiss;
+                const bool inl = nm >= 1u && nm <= (uint32_t)FZ_INLINE_MAX;  // (uniform) merged here; more: td_merge_pieces
+                if (inl) {
+                    // wavefront wv takes the pieces j = wv, wv + 4, ...: four of them at most, four units (64 bytes) each; the parts
+                    // of a piece are set up by the whole wavefront (a lane per byte: the byte-pair ranks are independent
+                    // loads), then lane q runs piece q's merge chain (mg_round_t, td_common.h)
+                    uint32_t* const keys = s_mg + wv * (FZ_MG_UNITS * MG_UNIT * 2);
+                    uint32_t* const ids = keys + FZ_MG_UNITS * MG_UNIT;
+                    MergeState st;
+                    st.alive = 0; st.t = 0; st.len = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        const uint32_t j = (uint32_t)wv + 4u * q;
+                        if (j < nm) {  // (uniform in the wavefront)
+                            const uint32_t v = s_tok[s_missk[j]];
+                            const uint32_t pos = (v >> 7) & 0x3FFFu, len = v & 127u;
+                            MergeState sq;
+                            sq.alive = 0; sq.t = 4u * q; sq.len = len;
+                            if ((uint32_t)lane < len) mg_put(T, s_byteid, keys, ids, sq, (uint32_t)lane, s_txt[pos + lane], s_txt[pos + lane + 1]);
+                            if ((uint32_t)lane == q) {
+                                st.t = 4u * q; st.len = len;
+                                st.alive = len >= 64u ? ~0ull : ((1ull << len) - 1ull);
+                            }
+                        }
+                    }
+                    if (st.len) mg_pad(keys, st);
+                    wave_sync_lds();
+                    for (;;) {
+                        const bool more = mg_round_t<uint64_t>(T, keys, ids, st);
+                        if (!__any(more)) break;
+                    }
+                    if (st.len) {
+                        const uint32_t j = (uint32_t)wv + 4u * (uint32_t)lane;
+                        const uint32_t gpos = (s_tok[s_missk[j]] >> 7) & 0x3FFFu;
+                        uint32_t nt = 0;
+                        for (uint64_t al = st.alive; al; al &= al - 1ull) {
+                            const uint32_t jj = (uint32_t)td_ctz64(al);
+                            const uint32_t id = ids[mg_slot(st.t, jj)];
+                            if ((int32_t)id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + gpos + jj);
+                            s_mres[j * 64u + nt++] = id;
+                        }
+                        s_mnt[j] = nt;
+                    }
+                    __syncthreads();
+                }
+                // ---- the half's slots -> its staging region ----
+                uint32_t* const dst = a.stage + (size_t)tile4 * K_STAGE;
+                uint32_t total = np;
+                auto extras_before = [&](uint32_t k) {  // ids the merged pieces in front of slot k add
+                    uint32_t x = 0;
+                    for (uint32_t j = 0; j < nm; ++j) x += ((uint32_t)s_missk[j] < k) ? s_mnt[j] - 1u : 0u;
+                    return x;
+                };
+                if (!inl) {
+                    // one slot per piece, 16 bytes per lane (slots behind the last one are never read).  A half with many
+                    // missed pieces hands them to td_merge_pieces: the marker's position is the token tile's, not the window's
+                    const uint32_t fix = nm ? ((uint32_t)hb << 7) : 0u;
+                    for (uint32_t v = tid; v * 4u < np; v += K_THREADS) {
+                        uint4 x = reinterpret_cast<const uint4*>(s_tok)[v];
+                        if (fix) {
+                            if ((x.x & 0xC0000000u) == TOK_MISS) x.x -= fix;
+                            if ((x.y & 0xC0000000u) == TOK_MISS) x.y -= fix;
+                            if ((x.z & 0xC0000000u) == TOK_MISS) x.z -= fix;
+                            if ((x.w & 0xC0000000u) == TOK_MISS) x.w -= fix;
+                        }
+                        reinterpret_cast<uint4*>(dst)[v] = x;
+                    }
+                } else {
+                    for (uint32_t k = tid; k < np; k += K_THREADS) {
+                        const uint32_t v = s_tok[k];
+                        if ((v & 0xC0000000u) != TOK_MISS) dst[k + extras_before(k)] = v;
+                    }
+                    for (uint32_t j = (uint32_t)wv; j < nm; j += K_THREADS / 64) {
+                        const uint32_t kj = s_missk[j], nt = s_mnt[j];
+                        const uint32_t off = kj + extras_before(kj);
+                        if ((uint32_t)lane < nt) dst[off + lane] = s_mres[j * 64u + lane];
+                    }
+                    total = np + extras_before(0xFFFFFFFFu);
+                }
+                if (tid == 0) {
+                    uint32_t fl = s_hflags;
+                    if (nm > (uint32_t)FZ_INLINE_MAX) {  // td_merge_pieces draws the flagged tiles from a list (appended 32 at a time per workgroup)
+                        fl |= TILE_HAS_MISS;
+                        uint32_t nf = s_nflagl;
+                        s_flagl[nf++] = (uint32_t)tile4;
+                        if (nf == 32u) {
+                            const uint32_t at = atomicAdd(a.flagged_count, 32u);
+                            for (uint32_t q = 0; q < 32u; ++q) a.flagged_list[at + q] = s_flagl[q];
+                            nf = 0;
+                        }
+                        s_nflagl = nf;
+                    }
+                    a.tile_count[tile4] = total | fl;
+                }
+                {   // the slot of every document that starts in this half (consecutive from the half's first one)
+                    const int64_t half_g0 = wg0 + hb, half_end_g = wg0 + he;
+                    const int64_t fd = (int64_t)a.tile_first_doc[tile4];
+                    for (int64_t d = fd + tid; d < a.n_docs; d += K_THREADS) {
+                        const int64_t p = a.doc_offsets[d];
+                        if (p >= half_end_g) break;
+                        const int lp = (int)(p - half_g0);
+                        const uint32_t k = (uint32_t)s_pb[lp >> 4] + __popc((uint32_t)s_sm[lp >> 4] & ((1u << (lp & 15)) - 1u));
+                        a.doc_slot[d] = inl ? k + extras_before(k) : k;
+                    }
+                }
+            }
+        }
         __syncthreads();
+    }
+    if constexpr (FUSED) {
+        if (tid == 0 && s_nflagl) {
+            const uint32_t nf = s_nflagl, at = atomicAdd(a.flagged_count, nf);
+            for (uint32_t q = 0; q < nf; ++q) a.flagged_list[at + q] = s_flagl[q];
+        }
     }
 }
 
@@ -803,51 +1164,6 @@ __global__ __launch_bounds__(256) void td_split_far_tiles(const EncodeArgs a) {
 // single bytes through the 256-entry table), TOK_MISS | position | length when it is not (td_merge_tiles expands those),
 // TOK_LONGREF | index for pieces above 64 bytes (td_long_pieces).  No per-byte token array and no compaction: slot k is
 // piece k, lane k mod 256 stores it, the stores of a wavefront are consecutive.
-constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per tile by this kernel
-
-// length classes of the missed pieces (<= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units of 16 key slots in td_merge_pieces)
-__device__ __forceinline__ uint32_t mq_class(uint32_t len) { return len <= 8u ? 0u : len <= 16u ? 1u : len <= 32u ? 2u : len <= 48u ? 3u : 4u; }
-__device__ __forceinline__ uint32_t mq_units(uint32_t cls) { return cls < 2u ? 1u : cls; }
-
-#ifndef TD_PROBE_MIN_WAVES
-#define TD_PROBE_MIN_WAVES 8  // (measured on 256 MiB of English: 0.49 ms at 8 waves/SIMD, 0.66 ms at 5..7)
-#endif
-
-// everything the hot probe path leaves out: keys longer than 16 bytes (hashed + verified against the token bytes), probe
-// sequences longer than one slot, pieces longer than K_MAXSHORT (handed to td_long_pieces).  Returns the piece's slot.
-__device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const Tables& T, const uint8_t* s_txt, const int32_t* s_byteid,
-                                                     uint32_t* s_flags, int64_t wg0, int i, uint32_t len) {
-    if (len > (uint32_t)K_MAXSHORT) {
-        if (len == 0xFFFFFFFFu) { raise(a, TD_E_SCRATCH, wg0 + i); return 0u; }
-        const uint32_t idx = atomicAdd(a.long_count, 1u);
-        if (idx >= a.long_cap) { raise(a, TD_E_SCRATCH, wg0 + i); return 0u; }
-        LongEntry le;
-        le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
-        a.long_list[idx] = le;
-        atomicOr(s_flags, TILE_HAS_LONG);
-        return TOK_LONGREF | idx;
-    }
-    const uint8_t* pb = s_txt + i;
-    if (len == 1) {
-        const int32_t id = s_byteid[pb[0]];
-        if (id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
-        return (uint32_t)id;
-    }
-    if (a.use_fastpath) {
-        auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
-        uint64_t key;
-        if (len <= 8) {
-            key = 0;
-            for (uint32_t q = 0; q < len; ++q) key |= (uint64_t)pb[q] << (8 * q);
-        } else {
-            key = hash_bytes(get, len);
-        }
-        const int32_t r = piece_lookup(T, key, len, get);
-        if (r != NO_RANK) return (uint32_t)r;
-    }
-    return TOK_MISS | ((uint32_t)i << 7) | len;  // (the caller notes it: note_miss)
-}
-
 __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_BWIN + 16];
     __shared__ uint32_t s_start[K_BWIN / 32 + 3];  // bit i: a piece starts at tile byte i
@@ -880,7 +1196,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
 
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
     uint32_t pfs = 0;  // START bits of window word `tid`
-    const uint32_t list_max = a.stop_after == 70 ? 0u : (uint32_t)K_MISS_LISTED_MAX;  // (70: tuning aid, no miss lists)
+    const uint32_t list_max = TD_STOP(70) ? 0u : (uint32_t)K_MISS_LISTED_MAX;  // (70: tuning aid, no miss lists)
     // first wavefront: the np entries waiting in s_pend go to their class's global list; ONE atomic per class (same-address
     // atomics are served one after the other, tens of nanoseconds each: one per entry was +50 % on the whole kernel)
     auto append_pending = [&](uint32_t np) {
@@ -906,13 +1222,18 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
         const int64_t gw = (wg0_ >> 5) + tid;
         return (tid < K_BWIN / 32 + 3 && gw < nwords) ? a.startbits[gw] : 0u;
     };
-    if ((int)blockIdx.x < a.n_tiles) {
-        const int64_t w0 = (int64_t)blockIdx.x * K_TILE;
+    // the token tiles this launch looks up: all of them, or (behind the fused tile loop) the ones it deferred
+    const uint32_t* const tlist = a.probe_deferred ? a.deferred_list : nullptr;
+    const int n_items = tlist ? (int)*a.deferred_count : a.n_tiles;
+    auto tile_of = [&](int it) { return tlist ? (int)tlist[it] : it; };
+    if ((int)blockIdx.x < n_items) {
+        const int64_t w0 = (int64_t)tile_of((int)blockIdx.x) * K_TILE;
         pf0 = load_text16(a, w0 + (int64_t)tid * 16);
         if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, w0 + (int64_t)(K_THREADS + tid) * 16);
         pfs = load_startword(w0);
     }
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int tile = tile_of(item);
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
         const int64_t wg0 = tile_g0;                 // window index 0 == first byte of the tile
         const int tile_hi = (int)((a.n - tile_g0 < K_TILE) ? (a.n - tile_g0) : K_TILE);
@@ -927,9 +1248,9 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
             if (a.n >= g && a.n < g + 32) sw |= 1u << (int)(a.n - g);  // the end of the text delimits the last piece
             s_start[tid] = sw;
         }
-        {
-            const int64_t nwg0 = wg0 + (int64_t)gridDim.x * K_TILE;
-            if (tile + (int)gridDim.x < a.n_tiles) {
+        if (item + (int)gridDim.x < n_items) {
+            const int64_t nwg0 = (int64_t)tile_of(item + (int)gridDim.x) * K_TILE;
+            {
                 pf0 = load_text16(a, nwg0 + (int64_t)tid * 16);
                 if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, nwg0 + (int64_t)(K_THREADS + tid) * 16);
                 pfs = load_startword(nwg0);
@@ -937,7 +1258,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
         }
         if (tid == 0) { s_ext_end = 0; s_flags = 0; s_ncold = 0; s_nrec = 0; }
         __syncthreads();
-        if (a.stop_after == 30) continue;
+        if (TD_STOP(30)) continue;
 
         // ---- dense list of the tile's piece starts (so that every lane has a piece to look up) ----
         uint32_t np_total, pbase, smask0;
@@ -983,7 +1304,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
             }
         }
         __syncthreads();
-        if (a.stop_after == 31) continue;
+        if (TD_STOP(31)) continue;
         const long long ext_end = s_ext_end;
         // ---- probe: piece k -> lane k mod 256, one piece per lane at a time (more in flight cost registers, and registers
         //      cost resident wavefronts: both round 1 and round 2 measured 2 and 4 in flight slower).  Hot path = pieces of
@@ -1008,7 +1329,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
             const uint4 km = reinterpret_cast<const uint4*>(s_kmask)[len < P12_MAXLEN ? len : P12_MAXLEN];
             const uint32_t k0 = __funnelshift_r(w0, w1, sh) & km.x, k1 = __funnelshift_r(w1, w2, sh) & km.y,
                            k2 = __funnelshift_r(w2, w3, sh) & km.z;
-            const u32x4 sl = p12[hash_piece12(k0, k1, k2, len) & (a.stop_after == 32 ? 0xFu : T.piece12_mask)];  // (32: tuning aid, 16 slots only)
+            const u32x4 sl = p12[hash_piece12(k0, k1, k2, len) & (TD_STOP(32) ? 0xFu : T.piece12_mask)];  // (32: tuning aid, 16 slots only)
             const bool last_ext = ext_end && k == np_total - 1;
             uint32_t res;
             if (len <= P12_MAXLEN && a.use_fastpath && !last_ext && (sl.w == 0u || (sl.x == k0 && sl.y == k1 && sl.z == k2 && (sl.w >> 24) == (0x80u | len)))) {
@@ -1050,7 +1371,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
             }
         }
         __syncthreads();
-        if (a.stop_after == 3) continue;
+        if (TD_STOP(3)) continue;
         // ---- per-tile results: slot count + flags; the slot of every document that starts in this tile (documents are
         //      consecutive from the tile's first one, recorded by td_mark_docs; empty documents share a position) ----
         s_off[tid] = pbase;
@@ -1248,7 +1569,7 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
         if (st.len) mg_init_piece(a, T, s_byteid, keys, ids, st, gpos);
         TD_TICK(t_init)
         for (;;) {  // (pieces of at most 32 bytes: the part mask is one register)
-            if (a.stop_after == 41) break;
+            if (TD_STOP(41)) break;
 #ifdef TD_MERGE_TIMING
             ++n_rounds;
 #endif
@@ -1966,7 +2287,7 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         const int64_t g_lo = (int64_t)tile * K_TILE;
         const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
         PK_TICK(t_meta)
-        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_MISS_LISTED)) || a.stop_after == 60) {  // (60: tuning aid, every tile down the plain path)
+        if (!(tc & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_MISS_LISTED)) || TD_STOP(60)) {  // (60: tuning aid, every tile down the plain path)
             // the first 64 documents of the tile (nearly always all of them): offsets and slots are loaded with the ids
             const int64_t dm = dfirst + lane;
             int64_t dpos = a.n;
@@ -2387,8 +2708,15 @@ static int long_grid_blocks() {  // (work is dealt round-robin to the wavefronts
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_long;
 }
+static int g_blocks_fused = 0;
+static int fused_grid_blocks() {
+    if (!g_blocks_fused) g_blocks_fused = resident_blocks((const void*)td_split_tiles<0u, true>, 3);
+    const char* e = getenv("TD_FUSED_BLOCKS_PER_CU");
+    if (e && atoi(e) > 0) return 256 * atoi(e);
+    return g_blocks_fused;
+}
 static int split_grid_blocks() {
-    if (!g_blocks_split) g_blocks_split = resident_blocks((const void*)td_split_tiles<0u>, 3);
+    if (!g_blocks_split) g_blocks_split = resident_blocks((const void*)td_split_tiles<0u, false>, 3);
     const char* e = getenv("TD_SPLIT_BLOCKS_PER_CU");
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_split;
@@ -2416,30 +2744,50 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     if (ev) (void)hipEventRecord(ev[0], stream);
     constexpr uint32_t PV_TEKKEN = PV_NO_CONTRACTION | PV_SINGLE_DIGIT;
     constexpr uint32_t PV_CL100K = PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS;
+    bool fused = false;
     if (a.pat_flags & PV_GENERIC) {  // not a member of the family: the compiled pattern, document by document (td_generic.hip)
         const hipError_t ge = launch_generic_split(a, stream);
         if (ge != hipSuccess) return ge;
-    } else
-    switch (a.pat_flags) {
-        case PV_GPT2: hipLaunchKernelGGL(td_split_tiles<PV_GPT2>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
-        case 0u: hipLaunchKernelGGL(td_split_tiles<0u>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
-        case PV_TEKKEN: hipLaunchKernelGGL(td_split_tiles<PV_TEKKEN>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
-        case PV_CL100K: hipLaunchKernelGGL(td_split_tiles<PV_CL100K>, dim3(sblocks), dim3(K_THREADS), 0, stream, a); break;
-        case PV_CL100K | PV_WS_EOS_FIRST:
-            hipLaunchKernelGGL(td_split_tiles<(PV_CL100K | PV_WS_EOS_FIRST)>, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
-            break;
-        case PV_CL100K | PV_SINGLE_DIGIT:
-            hipLaunchKernelGGL(td_split_tiles<(PV_CL100K | PV_SINGLE_DIGIT)>, dim3(sblocks), dim3(K_THREADS), 0, stream, a);
-            break;
-        default: return hipErrorInvalidValue;
+    } else {
+        fused = a.fused != 0;
+#ifdef TD_ABLATE
+        if (a.stop_after) fused = false;  // (the phase numbers are the unfused kernels')
+#endif
+        const int fblocks = a.n_stiles < fused_grid_blocks() ? a.n_stiles : fused_grid_blocks();
+#define TD_LAUNCH_SPLIT(PVX)                                                                                          \
+    if (fused) hipLaunchKernelGGL((td_split_tiles<(PVX), true>), dim3(fblocks), dim3(K_THREADS), 0, stream, a);       \
+    else hipLaunchKernelGGL((td_split_tiles<(PVX), false>), dim3(sblocks), dim3(K_THREADS), 0, stream, a)
+        switch (a.pat_flags) {
+            case PV_GPT2: TD_LAUNCH_SPLIT(PV_GPT2); break;
+            case 0u: TD_LAUNCH_SPLIT(0u); break;
+            case PV_TEKKEN: TD_LAUNCH_SPLIT(PV_TEKKEN); break;
+            case PV_CL100K: TD_LAUNCH_SPLIT(PV_CL100K); break;
+            case PV_CL100K | PV_WS_EOS_FIRST: TD_LAUNCH_SPLIT(PV_CL100K | PV_WS_EOS_FIRST); break;
+            case PV_CL100K | PV_SINGLE_DIGIT: TD_LAUNCH_SPLIT(PV_CL100K | PV_SINGLE_DIGIT); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef TD_LAUNCH_SPLIT
     }
     hipLaunchKernelGGL(td_split_far_pieces, dim3(64), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(td_split_far_tiles, dim3(256), dim3(256), 0, stream, a);
     if (ev) (void)hipEventRecord(ev[1], stream);
+#ifdef TD_ABLATE
     const bool tokens = a.stop_after != 2 && a.stop_after != 11 && a.stop_after != 12;
-    if (tokens) hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+    const bool merges = a.stop_after != 3 && a.stop_after != 30 && a.stop_after != 31 && a.stop_after != 32;
+#else
+    const bool tokens = true, merges = true;
+#endif
+    if (tokens) {
+        if (fused) {  // only the token tiles the fused loop deferred (normally none)
+            EncodeArgs ad = a;
+            ad.probe_deferred = 1;
+            hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks < 512 ? pblocks : 512), dim3(K_THREADS), 0, stream, ad);
+        } else {
+            hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+        }
+    }
     if (ev) (void)hipEventRecord(ev[2], stream);
-    if (tokens && a.stop_after != 3 && a.stop_after != 30 && a.stop_after != 31 && a.stop_after != 32) {
+    if (tokens && merges) {
         const int wtiles = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
         const int mblocks = wtiles < merge_grid_blocks() ? wtiles : merge_grid_blocks();
         hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(K_THREADS), 0, stream, a);
