@@ -146,6 +146,8 @@ int td_encode_batch_with_special_strs(td_tokenizer* t, const uint8_t* text, cons
 #define TD_INFO_N_SPECIAL 6
 #define TD_INFO_LONG_PIECES 7    /* long pieces seen by the last td_encode_batch call */
 #define TD_INFO_FAR_PIECES 8     /* pieces whose end the pre-tokenizer's window could not see (td_split_far_pieces), last call */
+#define TD_INFO_DEFERRED_TILES 9 /* token tiles (4 KiB) the fused tile loop left to td_probe_tiles, last call (as of the last td_device_status) */
+#define TD_INFO_FLAGGED_TILES 10 /* token tiles whose missed pieces went to td_merge_pieces, last call */
 int64_t td_info(const td_tokenizer* t, int what);
 
 /* Options. */

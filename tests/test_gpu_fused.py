@@ -147,13 +147,20 @@ def test_long_pieces_and_deferred_tiles(tok):
         _check(tok, u, [0, len(u)], f"run of 400 at tile offset -200+{shift}")
 
 
-def test_random_bytes_and_unknown_bytes(tok):
+def test_random_text_and_invalid_utf8(tok):
     rng = random.Random(21)
-    junk = bytes(rng.randrange(256) for _ in range(200000))
-    # (the Llama-4 vocabulary holds every single byte: no TD_E_UNKNOWN_BYTE here)
-    _check(tok, junk, sorted(set([0, len(junk)] + [rng.randrange(len(junk)) for _ in range(300)])), "random bytes")
+    # valid UTF-8 from all over the code space (the reference runs PCRE2 with NO_UTF_CHECK: invalid UTF-8 is undefined
+    # behaviour there — it crashes on random bytes — so only valid text is compared with it)
+    uni = "".join(H.random_unicode_string(rng, 40) for _ in range(8000)).encode("utf-8")
+    cuts = sorted(set([0, len(uni)]))
+    _check(tok, uni, cuts, "random code points")
     ascii_junk = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789 \n\t.,'") for _ in range(300000))
     _check(tok, ascii_junk, [0, len(ascii_junk)], "random ASCII")
+    # random bytes: the fused and the two-kernel form must still agree with each other
+    junk = bytes(rng.randrange(256) for _ in range(200000))
+    offs = sorted(set([0, len(junk)] + [rng.randrange(len(junk)) for _ in range(300)]))
+    (ft, fo), (ut, uo) = _both(tok, junk, offs)
+    assert np.array_equal(fo, uo) and np.array_equal(ft, ut), "random bytes: fused and two-kernel ids differ"
 
 
 def test_encode_ordinary_mode_takes_the_same_path(tok):

@@ -161,7 +161,7 @@ struct td_tokenizer {
     bool fused = true;  // pre-tokenizer and lookup in one pass over the text (TD_OPT_FUSED; TD_FUSED=0 in the environment turns it off)
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
     std::vector<Ev3> ev_pending, ev_free;
-    int64_t last_long = 0, last_far = 0;
+    int64_t last_long = 0, last_far = 0, last_deferred = 0, last_flagged = 0;
     const RxProgram* d_rx = nullptr;      // generic split pattern: the compiled program and its tables in HBM
     const uint16_t* d_rx_s1 = nullptr;
     const uint8_t* d_rx_s2 = nullptr;
@@ -381,6 +381,8 @@ int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) 
     HIP_TRY(t, hipMemcpy(&c, t->ctl.p, sizeof c, hipMemcpyDeviceToHost));
     t->last_long = c.long_count;
     t->last_far = c.slow_count;
+    t->last_deferred = c.deferred_count;
+    t->last_flagged = c.flagged_count;
     if (err_pos) *err_pos = c.err_pos;
     if (c.err != 0) {
         HIP_TRY(t, hipMemset(t->ctl.p, 0, sizeof(Ctl)));
@@ -1257,6 +1259,8 @@ int64_t td_info(const td_tokenizer* t, int what) {
         case TD_INFO_N_SPECIAL: return (int64_t)t->H.special_ids.size();
         case TD_INFO_LONG_PIECES: return t->last_long;
         case TD_INFO_FAR_PIECES: return t->last_far;
+        case TD_INFO_DEFERRED_TILES: return t->last_deferred;
+        case TD_INFO_FLAGGED_TILES: return t->last_flagged;
     }
     return -1;
 }

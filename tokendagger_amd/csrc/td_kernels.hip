@@ -326,43 +326,49 @@ __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const 
 #endif
 // PV = the pattern's scanner flags as a compile-time constant: one instantiation per member of the pattern family, so
 // the hot scan loop of the Llama-4 pattern carries no trace of the others (as run-time flags they cost 5 % of it).
-constexpr int KS_HCAP = 1024;  // heads the list holds per tile (what does not fit is matched by the lane that found it)
-constexpr int KS_CCAP = 256;
+constexpr int KS_HCAP = 768;   // heads the list holds per tile (what does not fit is matched by the lane that found it)
+constexpr int KS_CCAP = 128;
 
-// ---- the fused form (FUSED = true): td_encode_tiles ---------------------------------------------------------------
+// ---- the fused form (FUSED = true) ---------------------------------------------------------------------------------
 // The pre-tokenizer's tile loop goes on where td_split_tiles stops: the text of the tile is in LDS and so are its START bits,
-// so the pieces are looked up right there (td_probe_tiles' loop) and the tile's slots go to the staging region in the layout
-// td_pack_tokens reads — the text is read from HBM ONCE, the START bitmap is not read back, and the split phases (bound by
-// instruction issue) of one workgroup overlap the probe phases (bound by the latency of one scattered load per piece) of
-// the others on the same CU.  A tile of KS_TILE bytes is two token tiles of K_TILE bytes ("halves"), handled one after the
-// other with the same LDS:
-//   - dense piece list of the half from the START bits (block scan), piece k -> lane k mod 256, one slot per piece in LDS;
-//   - pieces that are no token (2..64 bytes): a half with at most FZ_INLINE_MAX of them merges them right here, one lane per
-//     piece (mg_round_t), and writes their ids in place: the tile stays PLAIN for td_pack_tokens (running text: one or two
-//     such pieces in every other tile).  A half with more hands them to td_merge_pieces the way td_probe_tiles does
-//     (TOK_MISS markers, TILE_HAS_MISS, the list of flagged tiles);
+// so the pieces are looked up right there and their slots go to the staging regions in the layout td_probe_tiles writes —
+// the text is read from HBM ONCE, the START bitmap is not read back, and the split phases (bound by instruction issue) of
+// one workgroup overlap the lookups (bound by the latency of one scattered load per piece) of the others on the same CU.
+//   - dense piece list of the whole tile from the START bits (DPP scan), piece k -> lane k mod 256;
+//   - the lookups of a lane go out TOGETHER, FZ_PB at a time (a lane has 6-7 pieces in running text): one round trip to
+//     the exact-key table instead of one per piece — the workgroup has nothing else to overlap them with;
+//   - slot k is stored straight to the token tile's staging region (a tile of KS_TILE bytes is two token tiles of K_TILE
+//     bytes: pieces that start in the first half are the first tile's slots);
+//   - pieces that are no token (2..64 bytes) are handed to td_merge_pieces exactly as td_probe_tiles hands them over: a token
+//     tile with at most K_MISS_LISTED_MAX of them puts their records on the global lists, one with more is flagged;
 //   - pieces above K_MAXSHORT bytes: TOK_LONGREF + an entry for td_long_pieces / td_giant_pieces, as before.
 // What the window cannot decide (a tile that starts inside a piece longer than the left halo, a piece that leaves the
-// window: the td_split_far_* cases) or hold (more than FZ_NPC pieces in a half) is DEFERRED: the token tile goes on a list,
-// and td_probe_tiles — which otherwise finds nothing to do — looks its pieces up after the far kernels have completed the
+// window: the td_split_far_* cases) or hold (more than FZ_NPC pieces) is DEFERRED: its token tiles go on a list, and
+// td_probe_tiles — which otherwise finds nothing to do — looks their pieces up after the far kernels have completed the
 // START bits.  Results are the same slots either way.
-constexpr int FZ_NPC = 2048;         // pieces per half the LDS list holds (a half with more: deferred)
-constexpr int FZ_INLINE_MAX = 16;    // missed pieces of a half that are merged in place
-constexpr int FZ_MG_UNITS = 16;      // 16-slot units of merge state per wavefront (4 pieces of up to 64 bytes)
+constexpr int FZ_NPC = 5120;         // pieces per tile the LDS list holds (a tile with more: deferred)
+#ifndef TD_FZ_PB
+#define TD_FZ_PB 1
+#endif
+constexpr int FZ_PB = TD_FZ_PB;      // lookups a lane has in flight
 constexpr int FZ_R_MASK = (K_MWORDS + 1) * MK_COUNT * 8;  // bytes of the class masks
 constexpr int FZ_R_HEADS = FZ_R_MASK;                     // s_heads behind them
 constexpr int FZ_R_COLD = FZ_R_HEADS + (KS_HCAP + 2) * 2;
 constexpr int FZ_R_SPLIT_END = FZ_R_COLD + KS_CCAP * 2;
 // the same bytes during the token phases
-constexpr int FZ_R_PLIST = 0;                              // u16[FZ_NPC + 8] piece starts; later u32[16 * 64] ids of the merged pieces
-constexpr int FZ_R_TOK = ((FZ_NPC + 8) * 2 + 15) & ~15;    // u32[FZ_NPC] one slot per piece
-constexpr int FZ_R_TOK_END = FZ_R_TOK + FZ_NPC * 4;
-constexpr int FZ_R_BYTES = FZ_R_SPLIT_END > FZ_R_TOK_END ? ((FZ_R_SPLIT_END + 15) & ~15) : FZ_R_TOK_END;
-static_assert(FZ_R_TOK >= FZ_INLINE_MAX * 64 * 4, "the merged pieces' ids take the place of the piece list");
-constexpr int FZ_MG_BYTES = (K_THREADS / 64) * FZ_MG_UNITS * MG_UNIT * 4 * 2;  // keys + ids of every wavefront
+constexpr int FZ_R_PLIST = 0;                                 // u16[FZ_NPC + 8] piece starts (window positions) + end delimiter
+constexpr int FZ_CCAP = 768;                                  // pieces a tile can put aside for the long route (more: deferred)
+constexpr int FZ_R_COLDK = ((FZ_NPC + 8) * 2 + 15) & ~15;     // u16[FZ_CCAP] pieces put aside for the long route
+constexpr int FZ_R_PB = FZ_R_COLDK + FZ_CCAP * 2;             // u16[K_THREADS] pieces before each lane's 32 bytes
+constexpr int FZ_R_SM = FZ_R_PB + K_THREADS * 2;              // u32[K_THREADS] START bits of each lane's 32 bytes
+constexpr int FZ_R_TOK_END = FZ_R_SM + K_THREADS * 4;
+constexpr int FZ_R_BYTES = ((FZ_R_SPLIT_END > FZ_R_TOK_END ? FZ_R_SPLIT_END : FZ_R_TOK_END) + 15) & ~15;
+#ifndef TD_FUSED_MIN_WAVES
+#define TD_FUSED_MIN_WAVES 6  // (256 MiB: English 0.66 ms at 5 and at 6, 0.71 at 4; source code 0.98 / 0.96 / 1.09; mixed-script 1.63 / 1.56 / 1.87)
+#endif
 
 template <uint32_t PV, bool FUSED>
-__global__ __launch_bounds__(K_THREADS, FUSED ? 4 : TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
+__global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
     __shared__ __attribute__((aligned(16))) uint8_t s_R[FZ_R_BYTES];  // class masks | heads | cold list; FUSED: then piece list | slots
     uint64_t* const s_mask = reinterpret_cast<uint64_t*>(s_R);       // [(K_MWORDS + 1) * MK_COUNT] class masks, word-major
@@ -379,29 +385,50 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? 4 : TD_SPLIT_MIN_WAVES) void td_
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+#ifdef TD_FUSED_TIMING
+    unsigned long long tt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_readcyclecounter(), t_total0 = t_last, n_tiles_done = 0;
+#define FZ_TICK(i) { const unsigned long long t_now = __builtin_readcyclecounter(); tt[i] += t_now - t_last; t_last = t_now; }
+#else
+#define FZ_TICK(i)
+#endif
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 128; q += K_THREADS) s_lut[q] = (uint8_t)feature_of_class(T.ascii_cls[q]);
     if (tid < 16) s_fcls[tid] = (uint8_t)feature_of_class((uint32_t)tid);
     if (tid == 0) s_nonascii = 0;
     // FUSED: state of the token phases (declared unconditionally; the plain instantiation never touches it and the
     // compiler drops it)
-    __shared__ __attribute__((aligned(16))) uint32_t s_mg[FUSED ? FZ_MG_BYTES / 4 : 4];  // merge state (keys | ids per wavefront); the probe's cold list
-    __shared__ int32_t s_byteid[FUSED ? 256 : 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_kmask[FUSED ? (P12_MAXLEN + 1) * 4 : 4];  // row len: byte masks of a len-byte key
-    __shared__ uint16_t s_pb[FUSED ? K_THREADS : 4], s_sm[FUSED ? K_THREADS : 4];  // pieces before each lane's 16 bytes of the half / their START bits
     __shared__ uint32_t s_wave[8];
-    __shared__ uint32_t s_hflags, s_nmiss, s_ncoldp;
-    __shared__ uint16_t s_missk[FUSED ? FZ_INLINE_MAX : 4];  // piece indices of the missed pieces that are merged in place
-    __shared__ uint32_t s_mnt[FUSED ? FZ_INLINE_MAX : 4];    // ... and how many ids each became
-    __shared__ uint32_t s_flagl[32];                         // flagged token tiles of this workgroup, not appended yet
+    __shared__ uint32_t s_hflags[2], s_nrec[2], s_ncoldp;          // per token tile of the pair: TILE_HAS_LONG; missed pieces
+    __shared__ uint32_t s_rec[2][K_MISS_LISTED_MAX];               // the first few: slot << 19 | tile position << 7 | length
+    __shared__ unsigned long long s_pend[64];                      // miss-list entries of the last tiles, not appended yet
+    __shared__ uint32_t s_npend;
+    __shared__ uint32_t s_flagl[32];                               // flagged token tiles of this workgroup, not appended yet
     __shared__ uint32_t s_nflagl;
+    // first wavefront: the np entries waiting in s_pend go to their class's global list; ONE atomic per class (td_probe_tiles)
+    auto append_pending = [&](uint32_t npd) {
+        const int ln = tid & 63;
+        const bool have = (uint32_t)ln < npd;
+        const unsigned long long rec = have ? s_pend[ln] : 0ull;
+        const uint32_t c = mq_class((uint32_t)rec & 127u);
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)K_MISS_CLASSES; ++q) {
+            const uint64_t b = __ballot(have && c == q);
+            if (b) {
+                const int leader = (int)td_ctz64(b);
+                uint32_t at = 0;
+                if (ln == leader) at = atomicAdd(&a.miss_count[q], (uint32_t)__popcll((unsigned long long)b));
+                at = (uint32_t)__shfl((int)at, leader);
+                if (have && c == q) a.miss_list[(size_t)q * a.miss_cap + at + (uint32_t)__popcll((unsigned long long)(b & ((1ull << ln) - 1ull)))] = rec;
+            }
+        }
+    };
     if constexpr (FUSED) {
-        for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
         if (tid < (int)(P12_MAXLEN + 1) * 4) {
             const int len = tid >> 2, w = tid & 3, nb = len - 4 * w;  // bytes of dword w that belong to a len-byte key
             s_kmask[tid] = w == 3 || nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
         }
-        if (tid == 0) s_nflagl = 0;
+        if (tid == 0) { s_nflagl = 0; s_npend = 0; }
     }
     __syncthreads();
 
@@ -447,11 +474,14 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? 4 : TD_SPLIT_MIN_WAVES) void td_
             if (g + 32 > a.n) dw |= (g >= a.n) ? 0xFFFFFFFFu : ~((1u << (int)(a.n - g)) - 1u);
             s_doc[w] = dw;
         }
-        if (tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);  // next tile of this workgroup
+        // next tile of this workgroup.  (FUSED: requested behind the boundary phases instead — the token phases are long
+        // enough to hide the latency, and the prefetch registers are free while the register-hungry phases run)
+        if (!FUSED && tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);
         for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
         if (tid == 0) { s_nh = 0; s_cur = 0; s_ncold = 0; s_last = -1; s_cross = -1; s_defer = 0; }
         if (__ballot((hib & 0x80808080u) != 0) && lane == 0) s_nonascii = 1;  // (reset behind phase 1; __syncthreads_or costs extra barriers)
         __syncthreads();
+        FZ_TICK(0)
         const bool tile_ascii = !s_nonascii;
 
         // ---- phase 1: class masks.  Every lane takes 8 text bytes: feature byte per byte (ASCII: 128-B LUT in LDS;
@@ -626,6 +656,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? 4 : TD_SPLIT_MIN_WAVES) void td_
         }
         }
         __syncthreads();
+        FZ_TICK(1)
         if (tid == 0) s_nonascii = 0;
         if (TD_STOP(12)) continue;
 
@@ -716,6 +747,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? 4 : TD_SPLIT_MIN_WAVES) void td_
                 s_nh = nh;
             }
             __syncthreads();
+            FZ_TICK(2)
             if (TD_STOP(13)) continue;
             // (b)
             {
@@ -774,6 +806,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? 4 : TD_SPLIT_MIN_WAVES) void td_
             }
         }
         __syncthreads();
+        FZ_TICK(3)
         // ---- publish the tile's own START bits (tile-aligned words: no other workgroup writes them) ----
         if (tid < KS_TILE / 32) {
             const int64_t g = tile_g0 + (int64_t)tid * 32;
@@ -783,220 +816,214 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? 4 : TD_SPLIT_MIN_WAVES) void td_
                 a.startbits[(tile_g0 >> 5) + tid] = v;
             }
         }
+        if (FUSED && tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);
         if constexpr (FUSED) {
-            // ================= token phases: the tile's pieces -> slots of the staging region (see the note above) =========
+            // ================= token phases: the tile's pieces -> slots of the staging regions (see the note above) =========
+            constexpr int NT4 = KS_TILE / K_TILE;  // token tiles per pre-tokenizer tile
+            static_assert(NT4 == 2 && KS_CHUNK == 32, "two token tiles, a 32-bit START word per lane");
             const int cross = s_cross;
             const bool tile_deferred = s_defer != 0 || cross < 0;  // (uniform: both are final since the barrier above)
             uint16_t* const s_plist = reinterpret_cast<uint16_t*>(s_R + FZ_R_PLIST);
-            uint32_t* const s_tok = reinterpret_cast<uint32_t*>(s_R + FZ_R_TOK);
-            uint32_t* const s_mres = reinterpret_cast<uint32_t*>(s_R + FZ_R_PLIST);  // ids of the merged pieces, 64 slots each (the piece list is dead by then)
-            uint16_t* const s_coldk = reinterpret_cast<uint16_t*>(s_mg);
+            uint16_t* const s_coldk = reinterpret_cast<uint16_t*>(s_R + FZ_R_COLDK);
+            uint16_t* const s_pb = reinterpret_cast<uint16_t*>(s_R + FZ_R_PB);
+            uint32_t* const s_sm = reinterpret_cast<uint32_t*>(s_R + FZ_R_SM);
             const int wv = tid >> 6;
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            typedef const u32x4 __attribute__((address_space(1)))* gslot_t;  // (global loads, not flat ones)
-            gslot_t const p12 = (gslot_t)(uintptr_t)T.piece12_slots;
-            for (int h = 0; h < KS_TILE / K_TILE; ++h) {
-                const int hb = K_HL + h * K_TILE;  // the half owns window bytes [hb, he)
-                if (hb >= tile_hi) break;
-                const int he = hb + K_TILE < tile_hi ? hb + K_TILE : tile_hi;
-                const int tile4 = tile * (KS_TILE / K_TILE) + h;
-                __syncthreads();  // (the region is free: phase 2 / the half before are done with it)
-                // ---- dense list of the half's piece starts ----
-                const int c0 = hb + tid * K_CHUNK;
-                uint32_t smask = 0;  // START bits of my 16 bytes
-                if (c0 < he) {
-                    smask = (s_start[c0 >> 5] >> (c0 & 31)) & 0xFFFFu;
-                    if (c0 + K_CHUNK > he) smask &= (1u << (he - c0)) - 1u;
+            const int tile4 = tile * NT4;            // first token tile of the pair
+            const bool two = K_HL + K_TILE < tile_hi;  // the second one exists
+            // the documents that start in the tile are consecutive from its first one: the loads go out now, they are used last
+            const uint32_t fd0 = a.tile_first_doc[tile4], fd1 = two ? a.tile_first_doc[tile4 + 1] : 0xFFFFFFFFu;
+            // ---- dense list of the tile's piece starts ----
+            const int b0 = K_HL + tid * KS_CHUNK;
+            const uint32_t smask0 = s_start[b0 >> 5];  // START bits of my 32 bytes (bits at and behind the tile end are zero)
+            __syncthreads();  // (the region is free: phase 2 is done with the masks and the lists)
+            const uint32_t cnt = __popc(smask0);
+            const uint32_t incl = wave_incl_scan(cnt, lane);
+            if (lane == 63) s_wave[wv] = incl;
+            if (tid == 0) { s_hflags[0] = 0; s_hflags[1] = 0; s_nrec[0] = 0; s_nrec[1] = 0; s_ncoldp = 0; }
+            __syncthreads();
+            const uint32_t w0s = s_wave[0], w1s = s_wave[1], w2s = s_wave[2], w3s = s_wave[3];
+            const uint32_t np = w0s + w1s + w2s + w3s, n0 = w0s + w1s;  // pieces of the tile / of its first token tile (lanes 0..127)
+            const uint32_t pbase = (wv > 0 ? w0s : 0u) + (wv > 1 ? w1s : 0u) + (wv > 2 ? w2s : 0u) + incl - cnt;
+            if (tile_deferred || np > (uint32_t)FZ_NPC) {  // (uniform) td_probe_tiles takes these token tiles, behind the far kernels
+                if (tid == 0) {
+                    const uint32_t at = atomicAdd(a.deferred_count, two ? 2u : 1u);
+                    a.deferred_list[at] = (uint32_t)tile4;
+                    if (two) a.deferred_list[at + 1] = (uint32_t)tile4 + 1u;
                 }
-                const uint32_t smask0 = smask;
-                uint32_t np;
-                const uint32_t pbase = block_excl_scan(__popc(smask), s_wave, np);
-                if (tile_deferred || np > (uint32_t)FZ_NPC) {  // (uniform) td_probe_tiles takes this token tile, behind the far kernels
-                    if (tid == 0) {
-                        const uint32_t at = atomicAdd(a.deferred_count, 1u);
-                        a.deferred_list[at] = (uint32_t)tile4;
-                    }
-                    continue;
-                }
+            } else {
                 {
-                    uint32_t k = pbase;
-                    while (smask) {
-                        const int b = __ffs(smask) - 1;
-                        smask &= smask - 1;
-                        s_plist[k++] = (uint16_t)(c0 + b);
+                    uint32_t k = pbase, m = smask0;
+                    while (m) {
+                        const int b = __ffs(m) - 1;
+                        m &= m - 1;
+                        s_plist[k++] = (uint16_t)(b0 + b);
                     }
                 }
                 s_pb[tid] = (uint16_t)pbase;
-                s_sm[tid] = (uint16_t)smask0;
-                if (tid == 0) {
-                    // end of the half's last piece: the next START bit (bits at and behind the tile end are zero), else where
-                    // the boundary scan crossed the tile end
-                    int e = cross;
-                    for (int w = he >> 5; w < K_WIN / 32 + 3; ++w) {
-                        uint32_t m = s_start[w];
-                        if (w == (he >> 5)) m &= ~((1u << (he & 31)) - 1u);
-                        if (m) { e = w * 32 + (__ffs(m) - 1); break; }
-                    }
-                    s_plist[np] = (uint16_t)e;
-                    s_hflags = 0; s_nmiss = 0; s_ncoldp = 0;
-                }
+                s_sm[tid] = smask0;
+                if (tid == 0) s_plist[np] = (uint16_t)cross;  // end of the tile's last piece: where the boundary scan crossed the tile end
+                const uint64_t fdd = fd0 != 0xFFFFFFFFu ? fd0 : fd1;
+                const int64_t dmine = (int64_t)fdd + tid;
+                const int64_t dpos = (fdd != 0xFFFFFFFFu && dmine < a.n_docs) ? a.doc_offsets[dmine] : a.n;  // (used in the last phase)
                 __syncthreads();
-                // ---- probe (td_probe_tiles' loop): piece k -> lane k mod 256; the slot stays in LDS ----
-                auto note_miss = [&](uint32_t k) {
-                    const uint32_t mi = atomicAdd(&s_nmiss, 1u);
-                    if (mi < (uint32_t)FZ_INLINE_MAX) s_missk[mi] = (uint16_t)k;
+                FZ_TICK(4)
+                // ---- lookups.  Piece k -> lane k mod 256, FZ_PB pieces of a lane at a time: first all their keys and loads
+                //      (three dwords cut out of LDS with funnel shifts, masked by length; ONE 16-byte load of the first slot of
+                //      the exact-key table each), then the compares and the slot stores.  An empty slot is a miss; a slot held
+                //      by another key and longer pieces are put aside (probe_piece_cold behind the loop). ----
+                uint32_t* const dst0 = a.stage + (size_t)tile4 * K_STAGE;
+                uint32_t* const dst1 = dst0 + K_STAGE - n0;  // (slot k >= n0 is slot k - n0 of the second token tile)
+                auto note_miss = [&](uint32_t k, uint32_t res) {  // res: TOK_MISS | position in ITS token tile << 7 | length
+                    const uint32_t h = k >= n0 ? 1u : 0u;
+                    const uint32_t mi = atomicAdd(&s_nrec[h], 1u);
+                    if (mi < (uint32_t)K_MISS_LISTED_MAX) s_rec[h][mi] = ((k - (h ? n0 : 0u)) << 19) | (res & 0x7FFFFu);
                 };
-                for (uint32_t k = tid; k < np; k += K_THREADS) {
-                    const int i = s_plist[k];
-                    const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
-                    const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
-                    const uint32_t sh = (i & 3) * 8;
-                    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
-                    const uint4 km = reinterpret_cast<const uint4*>(s_kmask)[len < P12_MAXLEN ? len : P12_MAXLEN];
-                    const uint32_t k0 = __funnelshift_r(w0, w1, sh) & km.x, k1 = __funnelshift_r(w1, w2, sh) & km.y,
-                                   k2 = __funnelshift_r(w2, w3, sh) & km.z;
-                    const u32x4 sl = p12[hash_piece12(k0, k1, k2, len) & T.piece12_mask];
-                    uint32_t res;
-                    if (len <= P12_MAXLEN && a.use_fastpath && (sl.w == 0u || (sl.x == k0 && sl.y == k1 && sl.z == k2 && (sl.w >> 24) == (0x80u | len)))) {
-                        const bool miss = sl.w == 0u;  // empty slot: not a token (a single byte that is no token is an error, not a merge)
-                        res = miss ? (TOK_MISS | ((uint32_t)i << 7) | len) : (sl.w & 0x1FFFFFu);
-                        if (miss) {
-                            if (len == 1) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
-                            note_miss(k);
-                        }
-                    } else {
-                        // longer keys, an occupied home slot, long pieces: put aside and handled densely behind the loop
-                        const uint32_t j = atomicAdd(&s_ncoldp, 1u);
-                        if (j < (uint32_t)K_THREADS) { s_coldk[j] = (uint16_t)k; continue; }
-                        res = probe_piece_cold(a, T, s_txt, s_byteid, &s_hflags, wg0, i, len);  // (more than 256 of them in one half)
-                        if ((res & 0xC0000000u) == TOK_MISS) note_miss(k);
-                    }
-                    s_tok[k] = res;
-                }
-                __syncthreads();
-                {
-                    const uint32_t nc = s_ncoldp < (uint32_t)K_THREADS ? s_ncoldp : (uint32_t)K_THREADS;
-                    if ((uint32_t)tid < nc) {
-                        const uint32_t k = s_coldk[tid];
-                        const int i = s_plist[k];
-                        const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
-                        const uint32_t res = probe_piece_cold(a, T, s_txt, s_byteid, &s_hflags, wg0, i, len);
-                        if ((res & 0xC0000000u) == TOK_MISS) note_miss(k);
-                        s_tok[k] = res;
-                    }
-                }
-                __syncthreads();
-                // ---- pieces that are no token ----
-                const uint32_t nm = s_nmiss;
-                const bool inl = nm >= 1u && nm <= (uint32_t)FZ_INLINE_MAX;  // (uniform) merged here; more: td_merge_pieces
-                if (inl) {
-                    // wavefront wv takes the pieces j = wv, wv + 4, ...: four of them at most, four units (64 bytes) each; the parts
-                    // of a piece are set up by the whole wavefront (a lane per byte: the byte-pair ranks are independent
-                    // loads), then lane q runs piece q's merge chain (mg_round_t, td_common.h)
-                    uint32_t* const keys = s_mg + wv * (FZ_MG_UNITS * MG_UNIT * 2);
-                    uint32_t* const ids = keys + FZ_MG_UNITS * MG_UNIT;
-                    MergeState st;
-                    st.alive = 0; st.t = 0; st.len = 0;
+                auto miss_marker = [&](int i, uint32_t len) { return TOK_MISS | ((uint32_t)((i - K_HL) & (K_TILE - 1)) << 7) | len; };
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef const u32x4 __attribute__((address_space(1)))* gslot_t;  // (global loads, not flat ones)
+                gslot_t const p12 = (gslot_t)(uintptr_t)T.piece12_slots;
+                for (uint32_t kb = tid; kb < np; kb += K_THREADS * FZ_PB) {
+                    u32x4 sl[FZ_PB];
+                    uint32_t kk0[FZ_PB], kk1[FZ_PB], kk2[FZ_PB], il[FZ_PB];
 #pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) {
-                        const uint32_t j = (uint32_t)wv + 4u * q;
-                        if (j < nm) {  // (uniform in the wavefront)
-                            const uint32_t v = s_tok[s_missk[j]];
-                            const uint32_t pos = (v >> 7) & 0x3FFFu, len = v & 127u;
-                            MergeState sq;
-                            sq.alive = 0; sq.t = 4u * q; sq.len = len;
-                            if ((uint32_t)lane < len) mg_put(T, s_byteid, keys, ids, sq, (uint32_t)lane, s_txt[pos + lane], s_txt[pos + lane + 1]);
-                            if ((uint32_t)lane == q) {
-                                st.t = 4u * q; st.len = len;
-                                st.alive = len >= 64u ? ~0ull : ((1ull << len) - 1ull);
+                    for (int q = 0; q < FZ_PB; ++q) {
+                        const uint32_t k = kb + (uint32_t)q * K_THREADS;
+                        const bool on = k < np;
+                        const int i = on ? s_plist[k] : K_HL;
+                        const uint32_t len = on ? (uint32_t)s_plist[k + 1] - (uint32_t)i : 0u;
+                        const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2);
+                        const uint32_t sh = (i & 3) * 8;
+                        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                        const uint4 km = reinterpret_cast<const uint4*>(s_kmask)[len < P12_MAXLEN ? len : P12_MAXLEN];
+                        kk0[q] = __funnelshift_r(w0, w1, sh) & km.x;
+                        kk1[q] = __funnelshift_r(w1, w2, sh) & km.y;
+                        kk2[q] = __funnelshift_r(w2, w3, sh) & km.z;
+                        il[q] = ((uint32_t)i << 16) | (len < 0xFFFFu ? len : 0xFFFFu);
+                        if (on) sl[q] = p12[hash_piece12(kk0[q], kk1[q], kk2[q], len) & T.piece12_mask];
+                    }
+#pragma unroll
+                    for (int q = 0; q < FZ_PB; ++q) {
+                        const uint32_t k = kb + (uint32_t)q * K_THREADS;
+                        if (k < np) {
+                            const int i = (int)(il[q] >> 16);
+                            const uint32_t len = il[q] & 0xFFFFu;
+                            const u32x4 e = sl[q];
+                            if (len <= P12_MAXLEN && a.use_fastpath &&
+                                (e.w == 0u || (e.x == kk0[q] && e.y == kk1[q] && e.z == kk2[q] && (e.w >> 24) == (0x80u | len)))) {
+                                const bool miss = e.w == 0u;  // empty slot: not a token (a single byte that is no token is an error, not a merge)
+                                const uint32_t res = miss ? miss_marker(i, len) : (e.w & 0x1FFFFFu);
+                                if (miss) {
+                                    if (len == 1) raise(a, TD_E_UNKNOWN_BYTE, wg0 + i);
+                                    note_miss(k, res);
+                                }
+                                (k < n0 ? dst0 : dst1)[k] = res;
+                            } else {
+                                const uint32_t j = atomicAdd(&s_ncoldp, 1u);
+                                if (j < (uint32_t)FZ_CCAP) s_coldk[j] = (uint16_t)k;  // (more: the tile is deferred after all, below)
                             }
                         }
                     }
-                    if (st.len) mg_pad(keys, st);
-                    wave_sync_lds();
-                    for (;;) {
-                        const bool more = mg_round_t<uint64_t>(T, keys, ids, st);
-                        if (!__any(more)) break;
-                    }
-                    if (st.len) {
-                        const uint32_t j = (uint32_t)wv + 4u * (uint32_t)lane;
-                        const uint32_t gpos = (s_tok[s_missk[j]] >> 7) & 0x3FFFu;
-                        uint32_t nt = 0;
-                        for (uint64_t al = st.alive; al; al &= al - 1ull) {
-                            const uint32_t jj = (uint32_t)td_ctz64(al);
-                            const uint32_t id = ids[mg_slot(st.t, jj)];
-                            if ((int32_t)id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, wg0 + gpos + jj);
-                            s_mres[j * 64u + nt++] = id;
-                        }
-                        s_mnt[j] = nt;
-                    }
-                    __syncthreads();
                 }
-                // ---- the half's slots -> its staging region ----
-                uint32_t* const dst = a.stage + (size_t)tile4 * K_STAGE;
-                uint32_t total = np;
-                auto extras_before = [&](uint32_t k) {  // ids the merged pieces in front of slot k add
-                    uint32_t x = 0;
-                    for (uint32_t j = 0; j < nm; ++j) x += ((uint32_t)s_missk[j] < k) ? s_mnt[j] - 1u : 0u;
-                    return x;
-                };
-                if (!inl) {
-                    // one slot per piece, 16 bytes per lane (slots behind the last one are never read).  A half with many
-                    // missed pieces hands them to td_merge_pieces: the marker's position is the token tile's, not the window's
-                    const uint32_t fix = nm ? ((uint32_t)hb << 7) : 0u;
-                    for (uint32_t v = tid; v * 4u < np; v += K_THREADS) {
-                        uint4 x = reinterpret_cast<const uint4*>(s_tok)[v];
-                        if (fix) {
-                            if ((x.x & 0xC0000000u) == TOK_MISS) x.x -= fix;
-                            if ((x.y & 0xC0000000u) == TOK_MISS) x.y -= fix;
-                            if ((x.z & 0xC0000000u) == TOK_MISS) x.z -= fix;
-                            if ((x.w & 0xC0000000u) == TOK_MISS) x.w -= fix;
-                        }
-                        reinterpret_cast<uint4*>(dst)[v] = x;
+                __syncthreads();
+                FZ_TICK(5)
+                const uint32_t ncold = s_ncoldp;
+                const bool cold_overflow = ncold > (uint32_t)FZ_CCAP;  // (uniform)
+                if (!cold_overflow) {
+                    for (uint32_t c = tid; c < ncold; c += K_THREADS) {
+                        const uint32_t k = s_coldk[c];
+                        const int i = s_plist[k];
+                        const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
+                        const uint32_t h = k >= n0 ? 1u : 0u;
+                        uint32_t res = probe_piece_cold(a, T, s_txt, T.byte_id, &s_hflags[h], wg0, i, len);
+                        if ((res & 0xC0000000u) == TOK_MISS) { res = miss_marker(i, len); note_miss(k, res); }
+                        (h ? dst1 : dst0)[k] = res;
+                    }
+                }
+                __syncthreads();
+                FZ_TICK(6)
+                if (cold_overflow) {  // more pieces for the long route than the list holds: td_probe_tiles does the tile over
+                    if (tid == 0) {
+                        const uint32_t at = atomicAdd(a.deferred_count, two ? 2u : 1u);
+                        a.deferred_list[at] = (uint32_t)tile4;
+                        if (two) a.deferred_list[at + 1] = (uint32_t)tile4 + 1u;
                     }
                 } else {
-                    for (uint32_t k = tid; k < np; k += K_THREADS) {
-                        const uint32_t v = s_tok[k];
-                        if ((v & 0xC0000000u) != TOK_MISS) dst[k + extras_before(k)] = v;
-                    }
-                    for (uint32_t j = (uint32_t)wv; j < nm; j += K_THREADS / 64) {
-                        const uint32_t kj = s_missk[j], nt = s_mnt[j];
-                        const uint32_t off = kj + extras_before(kj);
-                        if ((uint32_t)lane < nt) dst[off + lane] = s_mres[j * 64u + lane];
-                    }
-                    total = np + extras_before(0xFFFFFFFFu);
-                }
-                if (tid == 0) {
-                    uint32_t fl = s_hflags;
-                    if (nm > (uint32_t)FZ_INLINE_MAX) {  // td_merge_pieces draws the flagged tiles from a list (appended 32 at a time per workgroup)
-                        fl |= TILE_HAS_MISS;
-                        uint32_t nf = s_nflagl;
-                        s_flagl[nf++] = (uint32_t)tile4;
-                        if (nf == 32u) {
-                            const uint32_t at = atomicAdd(a.flagged_count, 32u);
-                            for (uint32_t q = 0; q < 32u; ++q) a.flagged_list[at + q] = s_flagl[q];
-                            nf = 0;
+                // ---- per token tile: slot count + flags; its missed pieces to the global lists (few) or the tile flagged (many) ----
+                if (tid < 64) {  // (first wavefront: program order between its lanes' LDS accesses; td_probe_tiles has the notes)
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; ++h) {
+                        const uint32_t nr = s_nrec[h], np0 = s_npend;
+                        const bool listed = nr && nr <= (uint32_t)K_MISS_LISTED_MAX;
+                        if (listed && (uint32_t)tid < nr) s_pend[np0 + tid] = ((unsigned long long)((uint32_t)tile4 + h) << 32) | s_rec[h][tid];
+                        const uint32_t np1 = listed ? np0 + nr : np0;
+                        wave_sync_lds();
+                        if (np1 > 64u - (uint32_t)K_MISS_LISTED_MAX) {
+                            append_pending(np1);
+                            wave_sync_lds();
+                            if (tid == 0) s_npend = 0;
+                        } else if (tid == 0) {
+                            s_npend = np1;
                         }
-                        s_nflagl = nf;
+                        wave_sync_lds();
                     }
-                    a.tile_count[tile4] = total | fl;
+                    if (tid == 0) {
+#pragma unroll
+                        for (uint32_t h = 0; h < 2; ++h) {
+                            if (h == 1 && !two) break;
+                            uint32_t fl = s_hflags[h];
+                            const uint32_t nr = s_nrec[h];
+                            if (nr > (uint32_t)K_MISS_LISTED_MAX) {
+                                fl |= TILE_HAS_MISS;
+                                uint32_t nf = s_nflagl;
+                                s_flagl[nf++] = (uint32_t)tile4 + h;
+                                if (nf == 32u) {
+                                    const uint32_t at = atomicAdd(a.flagged_count, 32u);
+                                    for (uint32_t q = 0; q < 32u; ++q) a.flagged_list[at + q] = s_flagl[q];
+                                    nf = 0;
+                                }
+                                s_nflagl = nf;
+                            } else if (nr) {
+                                fl |= TILE_MISS_LISTED;
+                            }
+                            a.tile_count[tile4 + h] = (h ? np - n0 : n0) | fl;
+                        }
+                    }
                 }
-                {   // the slot of every document that starts in this half (consecutive from the half's first one)
-                    const int64_t half_g0 = wg0 + hb, half_end_g = wg0 + he;
-                    const int64_t fd = (int64_t)a.tile_first_doc[tile4];
-                    for (int64_t d = fd + tid; d < a.n_docs; d += K_THREADS) {
-                        const int64_t p = a.doc_offsets[d];
-                        if (p >= half_end_g) break;
-                        const int lp = (int)(p - half_g0);
-                        const uint32_t k = (uint32_t)s_pb[lp >> 4] + __popc((uint32_t)s_sm[lp >> 4] & ((1u << (lp & 15)) - 1u));
-                        a.doc_slot[d] = inl ? k + extras_before(k) : k;
+                FZ_TICK(7)
+                {   // the slot of every document that starts in this tile
+                    const int64_t tile_end_g = wg0 + tile_hi;
+                    auto slot_of = [&](int64_t p) {
+                        const int lp = (int)(p - tile_g0);
+                        const uint32_t k = (uint32_t)s_pb[lp >> 5] + __popc(s_sm[lp >> 5] & ((1u << (lp & 31)) - 1u));
+                        return k >= n0 ? k - n0 : k;
+                    };
+                    if (dpos < tile_end_g) a.doc_slot[dmine] = slot_of(dpos);
+                    if (__syncthreads_and(dpos < tile_end_g)) {  // more than 256 documents start in this tile
+                        for (int64_t d = (int64_t)fdd + K_THREADS + tid; d < a.n_docs; d += K_THREADS) {
+                            const int64_t p = a.doc_offsets[d];
+                            if (p >= tile_end_g) break;
+                            a.doc_slot[d] = slot_of(p);
+                        }
                     }
+                }
+                FZ_TICK(9)
                 }
             }
         }
         __syncthreads();
+        FZ_TICK(10)
+#ifdef TD_FUSED_TIMING
+        ++n_tiles_done;
+#endif
     }
+#ifdef TD_FUSED_TIMING
+    if (FUSED && tid == 0 && (blockIdx.x % 211) == 0)
+        printf("fused wg %d: %llu tiles, total %llu cycles | stage %llu masks %llu rules %llu heads %llu | list %llu probe %llu cold %llu merge %llu write %llu docs %llu tail %llu\n",
+               (int)blockIdx.x, n_tiles_done, (unsigned long long)(__builtin_readcyclecounter() - t_total0), tt[0], tt[1], tt[2], tt[3], tt[4], tt[5], tt[6], tt[7],
+               tt[8], tt[9], tt[10]);
+#endif
     if constexpr (FUSED) {
+        if (tid < 64) append_pending(s_npend);  // (what is still waiting in LDS)
         if (tid == 0 && s_nflagl) {
             const uint32_t nf = s_nflagl, at = atomicAdd(a.flagged_count, nf);
             for (uint32_t q = 0; q < nf; ++q) a.flagged_list[at + q] = s_flagl[q];
