@@ -129,7 +129,7 @@ def test_from_files_matches_in_memory_construction(enc, tmp_path):
     with pytest.raises(FileNotFoundError):
         tiktoken.load_tokenizer("none", tmp_path / "missing.json", pat)
     with pytest.raises(tiktoken.TokenDaggerError):
-        tiktoken.Tokenizer.from_files("bad", pat_str="[a-z]+", tiktoken_model=tmp_path / "tokenizer.model")
+        tiktoken.Tokenizer.from_files("bad", pat_str=BAD_PATTERN, tiktoken_model=tmp_path / "tokenizer.model")
 
 
 def test_single_token_accessors(enc):
