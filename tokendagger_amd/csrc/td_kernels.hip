@@ -438,7 +438,23 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     // (uniform) the whole window lies inside the text and 16-byte loads are aligned: prefetched into registers; the others
     // (first / last windows, unaligned text) are staged by stage_window_edge when their turn comes
     auto interior = [&](int64_t w0) { return a.text_aligned && w0 >= 0 && w0 + K_WIN <= a.n; };
+    // what a tile needs besides its text is requested with it: the document bits of the window (266 words: one per lane and
+    // ten more) and, FUSED, the first documents of its two token tiles.  (Loaded when the tile's turn came they were a
+    // global-memory round trip at the top of every tile and another one in front of the document slots: 13 % + 5 % of the
+    // fused loop.)
+    uint32_t pfd0 = 0, pfd1 = 0, pffd0 = 0xFFFFFFFFu, pffd1 = 0xFFFFFFFFu;
+    static_assert(K_WIN / 32 <= 2 * K_THREADS, "two prefetched document words per lane cover the window");
     auto load_window = [&](int64_t w0) {
+        {
+            const int64_t gw0 = (w0 >> 5) + tid, gw1 = gw0 + K_THREADS;
+            pfd0 = (gw0 >= 0 && gw0 < nwords) ? a.docbits[gw0] : 0u;
+            pfd1 = (tid < K_WIN / 32 - K_THREADS && gw1 >= 0 && gw1 < nwords) ? a.docbits[gw1] : 0u;
+            if (FUSED) {
+                const int64_t t4 = (w0 + K_HL) / K_TILE;  // first token tile of the window's tile
+                pffd0 = t4 < a.n_tiles ? a.tile_first_doc[t4] : 0xFFFFFFFFu;
+                pffd1 = t4 + 1 < a.n_tiles ? a.tile_first_doc[t4 + 1] : 0xFFFFFFFFu;
+            }
+        }
         if (!interior(w0)) return;
         const uint4* src16 = reinterpret_cast<const uint4*>(a.text + w0);
 #pragma unroll
@@ -448,7 +464,14 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
 #pragma unroll
     for (int q = 0; q < NPF; ++q) pf[q] = make_uint4(0, 0, 0, 0);
     if ((int)blockIdx.x < a.n_stiles) load_window((int64_t)blockIdx.x * KS_TILE - K_HL);
+    const int tid_outer = tid;
     for (int tile = blockIdx.x; tile < a.n_stiles; tile += gridDim.x) {
+        // The lane index is made opaque once per tile: everything derived from it is then recomputed inside the iteration (a
+        // few integer operations) instead of being hoisted out of the tile loop — the compiler hoisted dozens of such per-lane
+        // values, ran out of registers and parked them in scratch memory, reloading them in the hot loops.
+        int tid_opaque = tid_outer;
+        asm volatile("" : "+v"(tid_opaque));
+        const int tid = tid_opaque, lane = tid & 63;
         const int64_t tile_g0 = (int64_t)tile * KS_TILE;
         const int64_t wg0 = tile_g0 - K_HL;  // global offset of window index 0 (multiple of 64)
         const int tile_hi = K_HL + (int)((a.n - tile_g0 < KS_TILE) ? (a.n - tile_g0) : KS_TILE);
@@ -467,13 +490,17 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         } else {
             hib = stage_window_edge(s_txt, a.text, a.n, wg0, tid, K_WIN / 16);
         }
-        for (int w = tid; w < K_WIN / 32; w += K_THREADS) {
-            const int64_t gw = (wg0 >> 5) + w;
-            uint32_t dw = (gw >= 0 && gw < nwords) ? a.docbits[gw] : 0u;
-            const int64_t g = wg0 + (int64_t)w * 32;  // bytes past the end of the text: "end of subject" sentinels
-            if (g + 32 > a.n) dw |= (g >= a.n) ? 0xFFFFFFFFu : ~((1u << (int)(a.n - g)) - 1u);
-            s_doc[w] = dw;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int w = tid + q * K_THREADS;
+            if (w < K_WIN / 32) {
+                uint32_t dw = q ? pfd1 : pfd0;
+                const int64_t g = wg0 + (int64_t)w * 32;  // bytes past the end of the text: "end of subject" sentinels
+                if (g + 32 > a.n) dw |= (g >= a.n) ? 0xFFFFFFFFu : ~((1u << (int)(a.n - g)) - 1u);
+                s_doc[w] = dw;
+            }
         }
+        const uint32_t fd0 = pffd0, fd1 = pffd1;  // (FUSED) first documents of this tile's token tiles
         // next tile of this workgroup.  (FUSED: requested behind the boundary phases instead — the token phases are long
         // enough to hide the latency, and the prefetch registers are free while the register-hungry phases run)
         if (!FUSED && tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);
@@ -830,8 +857,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             const int wv = tid >> 6;
             const int tile4 = tile * NT4;            // first token tile of the pair
             const bool two = K_HL + K_TILE < tile_hi;  // the second one exists
-            // the documents that start in the tile are consecutive from its first one: the loads go out now, they are used last
-            const uint32_t fd0 = a.tile_first_doc[tile4], fd1 = two ? a.tile_first_doc[tile4 + 1] : 0xFFFFFFFFu;
+            // (the documents that start in the tile are consecutive from its first one, fd0 / fd1: prefetched with the window)
             // ---- dense list of the tile's piece starts ----
             const int b0 = K_HL + tid * KS_CHUNK;
             const uint32_t smask0 = s_start[b0 >> 5];  // START bits of my 32 bytes (bits at and behind the tile end are zero)
