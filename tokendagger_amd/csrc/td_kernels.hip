@@ -756,30 +756,29 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 }
             }
             __syncthreads();
-            if (tid == 0) {
-                uint32_t nh = s_nh < (uint32_t)KS_HCAP ? s_nh : (uint32_t)KS_HCAP;
-                // last provable sync point before the tile start (window bytes 4..K_HL), unless the tile starts on one
-                static_assert(K_HL % 64 == 0 && K_HL >= 64, "left halo = whole mask words");
-                if (!(s_mask[(K_HL / 64) * MK_COUNT + MK_SYNC] & 1ull)) {
-                    int s = -1;
-                    for (int w = K_HL / 64 - 1; w >= 0 && s < 0; --w) {
-                        uint64_t m = s_mask[w * MK_COUNT + MK_SYNC];
-                        if (w == 0) m &= ~0xFull;
-                        if (m) s = w * 64 + td_top64(m) - 1;
-                    }
-                    if (s < 0) { a.tile_flag[tile] = 1; if (FUSED) s_defer = 1; }
-                    else s_heads[nh++] = (uint16_t)s;
-                }
-                if (s_last >= 0) s_heads[nh++] = (uint16_t)s_last;
-                s_nh = nh;
-            }
-            __syncthreads();
             FZ_TICK(2)
             if (TD_STOP(13)) continue;
             // (b)
             {
-                const uint32_t nh = s_nh;
+                const uint32_t nh = s_nh < (uint32_t)KS_HCAP ? s_nh : (uint32_t)KS_HCAP;
                 int p = -1;
+                // two heads are not on the list (a second barrier and a serial stretch of lane 0 put them there): lane 0 starts
+                // with the last provable sync point before the tile start (window bytes 4..K_HL) unless the tile starts on one,
+                // lane 1 with the tile's last head
+                if (tid == 0) {
+                    static_assert(K_HL % 64 == 0 && K_HL >= 64, "left halo = whole mask words");
+                    if (!(s_mask[(K_HL / 64) * MK_COUNT + MK_SYNC] & 1ull)) {
+                        int sp = -1;
+                        for (int w = K_HL / 64 - 1; w >= 0 && sp < 0; --w) {
+                            uint64_t m = s_mask[w * MK_COUNT + MK_SYNC];
+                            if (w == 0) m &= ~0xFull;
+                            if (m) sp = w * 64 + td_top64(m) - 1;
+                        }
+                        if (sp < 0) { a.tile_flag[tile] = 1; if (FUSED) s_defer = 1; }
+                        else p = sp;
+                    }
+                }
+                if (tid == 1 && s_last >= 0) p = s_last;
                 bool more = true;  // (uniform) the list may still hold heads
                 for (;;) {
                     const uint64_t nb = __ballot(p < 0);
@@ -861,7 +860,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             // ---- dense list of the tile's piece starts ----
             const int b0 = K_HL + tid * KS_CHUNK;
             const uint32_t smask0 = s_start[b0 >> 5];  // START bits of my 32 bytes (bits at and behind the tile end are zero)
-            __syncthreads();  // (the region is free: phase 2 is done with the masks and the lists)
+            // (the region is free: nobody has touched the masks and the lists since the barrier in front of the START bits' way out)
             const uint32_t cnt = __popc(smask0);
             const uint32_t incl = wave_incl_scan(cnt, lane);
             if (lane == 63) s_wave[wv] = incl;
@@ -1023,9 +1022,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                         const uint32_t k = (uint32_t)s_pb[lp >> 5] + __popc(s_sm[lp >> 5] & ((1u << (lp & 31)) - 1u));
                         return k >= n0 ? k - n0 : k;
                     };
-                    if (dpos < tile_end_g) a.doc_slot[dmine] = slot_of(dpos);
-                    if (__syncthreads_and(dpos < tile_end_g)) {  // more than 256 documents start in this tile
-                        for (int64_t d = (int64_t)fdd + K_THREADS + tid; d < a.n_docs; d += K_THREADS) {
+                    if (dpos < tile_end_g) {
+                        a.doc_slot[dmine] = slot_of(dpos);
+                        for (int64_t d = dmine + K_THREADS; d < a.n_docs; d += K_THREADS) {  // more than 256 documents start in this tile
                             const int64_t p = a.doc_offsets[d];
                             if (p >= tile_end_g) break;
                             a.doc_slot[d] = slot_of(p);
