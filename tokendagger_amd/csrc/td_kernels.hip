@@ -384,7 +384,6 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     __shared__ uint32_t s_defer;                  // FUSED: the window cannot decide this tile (td_split_far_* will)
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
 #ifdef TD_FUSED_TIMING
     unsigned long long tt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_readcyclecounter(), t_total0 = t_last, n_tiles_done = 0;
 #define FZ_TICK(i) { const unsigned long long t_now = __builtin_readcyclecounter(); tt[i] += t_now - t_last; t_last = t_now; }
@@ -2329,11 +2328,87 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
     const int64_t total = a.tile_base[a.n_tiles];
     const int nwaves = gridDim.x * (K_THREADS / 64);
     auto base_of = [&](int tile) { return a.tile_base[tile] + a.chunk_pref[tile / K_SCAN_CHUNK]; };
-    for (int tile = blockIdx.x * (K_THREADS / 64) + wv; tile < a.n_tiles; tile += nwaves) {
-        // everything that depends on the tile index only goes out together (one round trip, not four in a row)
-        const uint32_t tc = a.tile_count[tile];
-        const int64_t base = base_of(tile);
-        const int64_t dfirst = (int64_t)a.tile_first_doc[tile];
+    // Software pipeline over the wavefront's tiles.  Loads and stores share one in-order counter on this hardware: waiting
+    // for a load also waits for every store issued BEFORE it, so "load tile t, store tile t, load tile t+1 ..." exposes a
+    // store round trip per tile (the kernel ran at 2.6 TB/s).  Here the loads of tile t+1 are issued in front of the stores
+    // of tile t, and what depends on the tile index only (count, base, first document: wave-uniform scalar loads) is
+    // requested two tiles ahead.  The pipelined form covers plain tiles of up to 1024 ids (every slot an id: one pass of four
+    // 16-byte loads per lane); the others take the general path below.  (Plain variables and macros, no structs handed to
+    // lambdas: as a struct by reference the tile's data lived in scratch memory, every load followed by a wait.)
+    typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16 bytes at a dword-aligned address
+    (void)base_of;
+    const int tile_first = (int)uni32((uint32_t)(blockIdx.x * (K_THREADS / 64) + wv));
+    uint32_t tcA = 0, dfA = 0, tcB = 0, dfB = 0, tcC = 0, dfC = 0;          // A = this tile, B = the next one, C = the one after
+    int64_t baseA = 0, baseB = 0, baseC = 0;
+#define PK_FETCH(t, X) { tc##X = a.tile_count[t]; base##X = a.tile_base[t] + a.chunk_pref[(t) / K_SCAN_CHUNK]; df##X = a.tile_first_doc[t]; }
+#define PK_FAST(X) (!(tc##X & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_MISS_LISTED)) && (tc##X & TILE_COUNT_MASK) <= 1024u && \
+                    base##X + (int64_t)(tc##X & TILE_COUNT_MASK) <= a.out_cap)
+    uint4 cx0 = make_uint4(0, 0, 0, 0), cx1 = cx0, cx2 = cx0, cx3 = cx0, nx0 = cx0, nx1 = cx0, nx2 = cx0, nx3 = cx0;
+    uint32_t ch0 = 0, ctl = 0, cdsl = 0, nh0 = 0, ntl = 0, ndsl = 0;
+    int64_t cdpos = 0, ndpos = 0;
+    // the tile's ids as 16-byte pieces aligned to the DESTINATION (single ids up to its next 16-byte boundary and behind the
+    // last piece), its first 64 documents
+#define PK_GEOM(X) const uint32_t g_c = tc##X & TILE_COUNT_MASK;                                                     \
+                   uint32_t g_head = (uint32_t)((16u - ((uint32_t)(uintptr_t)(a.out_tokens + base##X) & 15u)) & 15u) >> 2; \
+                   if (g_head > g_c) g_head = g_c;                                                                   \
+                   const uint32_t g_nv = (g_c - g_head) >> 2, g_done = g_head + 4 * g_nv;
+#define PK_LOAD(t, X, P) { PK_GEOM(X)                                                                                 \
+        const uint32_t* g_src = a.stage + (size_t)(t) * K_STAGE;                                                      \
+        P##h0 = 0; P##tl = 0; P##dsl = 0; P##dpos = a.n;                                                              \
+        if ((uint32_t)lane < g_head) P##h0 = g_src[lane];                                                             \
+        if (g_done + (uint32_t)lane < g_c) P##tl = g_src[g_done + lane];                                              \
+        if ((uint32_t)lane < g_nv) { const u32x4a4 v = *reinterpret_cast<const u32x4a4*>(g_src + g_head + 4 * lane); P##x0 = make_uint4(v.x, v.y, v.z, v.w); } \
+        if ((uint32_t)lane + 64 < g_nv) { const u32x4a4 v = *reinterpret_cast<const u32x4a4*>(g_src + g_head + 4 * (lane + 64)); P##x1 = make_uint4(v.x, v.y, v.z, v.w); } \
+        if ((uint32_t)lane + 128 < g_nv) { const u32x4a4 v = *reinterpret_cast<const u32x4a4*>(g_src + g_head + 4 * (lane + 128)); P##x2 = make_uint4(v.x, v.y, v.z, v.w); } \
+        if ((uint32_t)lane + 192 < g_nv) { const u32x4a4 v = *reinterpret_cast<const u32x4a4*>(g_src + g_head + 4 * (lane + 192)); P##x3 = make_uint4(v.x, v.y, v.z, v.w); } \
+        const int64_t g_dm = (int64_t)df##X + lane;                                                                   \
+        if (g_dm < a.n_docs) { P##dpos = a.doc_offsets[g_dm]; P##dsl = a.doc_slot[g_dm]; } }
+    if (tile_first < a.n_tiles) PK_FETCH(tile_first, A)
+    if (tile_first + nwaves < a.n_tiles) PK_FETCH(tile_first + nwaves, B)
+    bool fast_cur = tile_first < a.n_tiles && PK_FAST(A);
+    if (fast_cur) PK_LOAD(tile_first, A, c)
+    for (int tile = tile_first; tile < a.n_tiles; tile += nwaves) {
+        if (tile + 2 * nwaves < a.n_tiles) PK_FETCH(tile + 2 * nwaves, C)
+        const bool fast_next = tile + nwaves < a.n_tiles && PK_FAST(B);
+        if (fast_next) PK_LOAD(tile + nwaves, B, n)  // (in front of this tile's stores)
+        const uint32_t tc = tcA;
+        const int64_t base = baseA;
+        const int64_t dfirst = (int64_t)dfA;
+        const bool fast_this = fast_cur;
+        const uint4 sx0 = cx0, sx1 = cx1, sx2 = cx2, sx3 = cx3;
+        const uint32_t sh0 = ch0, stl = ctl, sdsl = cdsl;
+        const int64_t sdpos = cdpos;
+        tcA = tcB; baseA = baseB; dfA = dfB; tcB = tcC; baseB = baseC; dfB = dfC;
+        fast_cur = fast_next;
+        cx0 = nx0; cx1 = nx1; cx2 = nx2; cx3 = nx3; ch0 = nh0; ctl = ntl; cdsl = ndsl; cdpos = ndpos;
+        if (fast_this && !TD_STOP(61)) {
+            const uint32_t g_c = tc & TILE_COUNT_MASK;
+            int32_t* dst = a.out_tokens + base;
+            uint32_t g_head = (uint32_t)((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2;
+            if (g_head > g_c) g_head = g_c;
+            const uint32_t g_nv = (g_c - g_head) >> 2, g_done = g_head + 4 * g_nv;
+            if ((uint32_t)lane < g_nv) *reinterpret_cast<uint4*>(dst + g_head + 4 * lane) = sx0;
+            if ((uint32_t)lane + 64 < g_nv) *reinterpret_cast<uint4*>(dst + g_head + 4 * (lane + 64)) = sx1;
+            if ((uint32_t)lane + 128 < g_nv) *reinterpret_cast<uint4*>(dst + g_head + 4 * (lane + 128)) = sx2;
+            if ((uint32_t)lane + 192 < g_nv) *reinterpret_cast<uint4*>(dst + g_head + 4 * (lane + 192)) = sx3;
+            if ((uint32_t)lane < g_head) dst[lane] = (int32_t)sh0;
+            if (g_done + (uint32_t)lane < g_c) dst[g_done + lane] = (int32_t)stl;
+            const int64_t g_lo = (int64_t)tile * K_TILE;
+            const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
+            const int64_t dm = dfirst + lane;
+            if (sdpos < g_hi) a.out_offsets[dm] = base + sdsl;
+            if (__all(sdpos < g_hi)) {  // more than 64 documents start in this tile
+                for (int64_t d = dfirst + 64 + lane; d < a.n_docs; d += 64) {
+                    if (a.doc_offsets[d] >= g_hi) break;
+                    a.out_offsets[d] = base + a.doc_slot[d];
+                }
+            }
+            if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
+                const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
+                for (int64_t d = d_end + lane; d <= a.n_docs; d += 64) a.out_offsets[d] = total;
+            }
+            continue;
+        }
         const uint32_t cnt = tc & TILE_COUNT_MASK;
         const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
         const int64_t g_lo = (int64_t)tile * K_TILE;
