@@ -139,6 +139,7 @@ struct Ctl {  // small control block in device memory
     uint32_t flagged_count;  // tiles flagged TILE_HAS_MISS (on flagged_list: td_merge_pieces draws them from there)
     uint32_t gap_count;      // generic split patterns: stretches of text the pattern skipped
     uint32_t deferred_count; // fused tile loop: token tiles left to td_probe_tiles
+    uint32_t giant_count;    // long pieces above 1 KiB
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 }  // namespace
@@ -326,6 +327,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.long_cap = (uint32_t)std::min<size_t>(t->long_list.cap / sizeof(LongEntry), 0x7FFFFFF0u);
     Ctl* ctl = (Ctl*)t->ctl.p;
     a.long_count = &ctl->long_count;
+    a.giant_count = &ctl->giant_count;
     a.slow_count = &ctl->slow_count;
     a.pool = (uint32_t*)t->pool.p;
     a.pool_cap = t->pool.cap / 4;

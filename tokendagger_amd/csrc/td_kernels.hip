@@ -149,15 +149,19 @@ __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* a, int64_t n, 
 // ------------------------------------------------------------------ td_mark_docs ------------
 __global__ void td_mark_docs(const int64_t* doc_offsets, int64_t n_docs, int64_t n, uint32_t* docbits,
                              uint32_t* tile_first_doc) {
+    // Document offsets are non-decreasing, so a document knows from its two neighbours whether it shares its word of the
+    // bitmap or is the first one of its tile: the common case (alone in its 32 bytes, the bitmap is zeroed by td_prepare) is
+    // a plain store, and the first document of a tile is exactly one thread's plain store.  (One atomicOr + one atomicMin per
+    // document were 62 us per GiB of short paragraphs: 1.7 M atomics.)
     for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < n_docs; d += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = doc_offsets[d];
         if (p >= 0 && p < n) {
-            atomicOr(&docbits[p >> 5], 1u << (p & 31));
-            // first document of each tile (tile_first_doc is preset to 0xFFFFFFFF); only documents whose
-            // predecessor lies in an earlier tile can be the first one
-            const int64_t tile = p / K_TILE;
-            if (d == 0 || doc_offsets[d - 1] / K_TILE != tile || doc_offsets[d - 1] < 0)
-                atomicMin(&tile_first_doc[tile], (uint32_t)d);
+            const int64_t pp = d > 0 ? doc_offsets[d - 1] : -1, pn = d + 1 < n_docs ? doc_offsets[d + 1] : -1;
+            const bool shared = (pp >= 0 && (pp >> 5) == (p >> 5)) || (pn >= 0 && pn < n && (pn >> 5) == (p >> 5));
+            if (shared) atomicOr(&docbits[p >> 5], 1u << (p & 31));
+            else docbits[p >> 5] = 1u << (p & 31);
+            // first document of each tile (tile_first_doc is preset to 0xFFFFFFFF)
+            if (pp < 0 || pp / K_TILE != p / K_TILE) tile_first_doc[p / K_TILE] = (uint32_t)d;
         }
     }
 }
@@ -272,6 +276,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int /*lane*/) {
 }
 
 // ------------------------------------------------------------------ probe helpers (td_probe_tiles and the fused tile loop) ----
+constexpr int K_GIANT_MIN = 1024;  // pieces above this many bytes: td_giant_pieces (= LP_MEDIUM)
 constexpr int K_BWIN = K_TILE + 2 * K_MAXSHORT;  // text / START bits staged per tile by this kernel
 
 // length classes of the missed pieces (<= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units of 16 key slots in td_merge_pieces)
@@ -293,6 +298,7 @@ __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const 
         LongEntry le;
         le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
         a.long_list[idx] = le;
+        if (len > (uint32_t)K_GIANT_MIN) atomicAdd(a.giant_count, 1u);  // (td_giant_pieces looks at the list only when there is one)
         atomicOr(s_flags, TILE_HAS_LONG);
         return TOK_LONGREF | idx;
     }
@@ -2096,6 +2102,10 @@ __global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a
     __shared__ uint32_t s_viol;
     const Tables T = uniform_tables(a.Tp);
     const int tid = threadIdx.x;
+    static_assert(K_GIANT_MIN == LP_MEDIUM, "what td_long_pieces leaves");
+    // (without a piece above LP_MEDIUM bytes there is nothing to look for: walking the list of 132 000 long pieces of 256 MiB
+    // of mixed-script text, 128 workgroups with a dependent load per entry, was 0.27 ms for nothing)
+    if (*a.giant_count == 0u) return;
     const uint32_t nlong = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
     for (uint32_t j = blockIdx.x; j < nlong; j += gridDim.x) {
         const uint32_t len = a.long_list[j].len;
