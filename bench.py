@@ -138,6 +138,11 @@ def cpu_baseline(x: np.ndarray, offs: np.ndarray, ranks: dict, special: dict, pa
         b_all, c_all, s_all, runs_all = timed(R, 1 << 30, cores)
         # T = 1: 48 MiB (about a second per run at the reference's single-thread rate)
         b_1, c_1, s_1, runs_1 = timed(R, 48 << 20, 1)
+        # the same work list the GPU is timed on (identical document boundaries): every document of
+        # the corpus its own CoreBPE::encode call, dealt to T std::threads; 1 warm-up + 3 runs, median
+        R.encode_batch(x, offs, n_threads=cores, want_tokens=False)
+        runs_docs = [R.encode_batch(x, offs, n_threads=cores, want_tokens=False)[0] for _ in range(3)]
+        s_docs = statistics.median(runs_docs)
         return {
             "value": round(b_all / s_all / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "reference",
             "mib_per_s": round(b_all / s_all / 2**20, 1),
@@ -147,8 +152,12 @@ def cpu_baseline(x: np.ndarray, offs: np.ndarray, ranks: dict, special: dict, pa
             "single_thread": {"value": round(b_1 / s_1 / 1e9, 4), "unit": "GB/s", "mib_per_s": round(b_1 / s_1 / 2**20, 1),
                               "sample": f"first {b_1 / 2**20:.0f} MiB as {c_1} slices, 1 thread, median of 3",
                               "runs_s": [round(v, 4) for v in runs_1]},
+            "same_documents": {"value": round(n / s_docs / 1e9, 4), "unit": "GB/s", "mib_per_s": round(n / s_docs / 2**20, 1),
+                               "sample": f"the whole corpus on the GPU's own document boundaries ({len(offs) - 1} documents, one CoreBPE::encode "
+                                         f"call each), {cores} std::threads, 1 warm-up + 3 runs, median",
+                               "runs_s": [round(v, 4) for v in runs_docs]},
             "nproc": cores, "cpu_model": _cpu_model(),
-            "python_encode_batch": None,  # the reference's pybind module is not built on the GPU box: not measured
+            "python_encode_batch": python_encode_batch_baseline(x, n, cores) if ascii_only else None,
         }
     except Exception as e:  # compiled reference unusable here: time the single-threaded C restatement instead
         from oracle import port
@@ -165,6 +174,38 @@ def cpu_baseline(x: np.ndarray, offs: np.ndarray, ranks: dict, special: dict, pa
         return {"value": round(s_bytes / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
                 "sample": f"first {s_bytes / 2**20:.0f} MiB ({sample_docs} documents), oracle/td_oracle.c, one thread, one run",
                 "nproc": cores, "cpu_model": _cpu_model()}
+
+
+def python_encode_batch_baseline(x: np.ndarray, n: int, cores: int):
+    """The reference's benchmark METHOD (tests/throughput_test.py:399-422): Tokenizer.encode_batch(T x 10 slices, num_threads=T)
+    through the reference's own pybind module, in a process of its own (oracle/ref_pybench.py).  None when that module was not
+    prebuilt (oracle/build_ref.sh needs /root/reference)."""
+    import tempfile
+    mod = list((ROOT / "oracle" / "_ref" / "refmod").glob("_tokendagger_core*.so")) if (ROOT / "oracle" / "_ref" / "refmod").exists() else []
+    if not mod:
+        return None
+    sample = min(n, 256 << 20)
+    out = {}
+    try:
+        with tempfile.NamedTemporaryFile(suffix=".bin", dir="/tmp") as f:
+            x[:sample].tofile(f)
+            f.flush()
+            for threads in sorted({cores, 8}):
+                r = subprocess.run([sys.executable, str(ROOT / "oracle" / "ref_pybench.py"), f.name, str(sample), str(threads), "3"],
+                                   capture_output=True, text=True, timeout=600)
+                if r.returncode != 0:
+                    sys.stderr.write(f"[bench] ref_pybench failed: {r.stderr[-300:]}\n")
+                    return None
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                sec = statistics.median(j["seconds"])
+                out[f"threads_{threads}"] = {"value": round(j["bytes"] / sec / 1e9, 4), "unit": "GB/s", "mib_per_s": round(j["bytes"] / sec / 2**20, 1),
+                                             "runs_s": [round(v, 4) for v in j["seconds"]], "chunks": j["chunks"]}
+        out["sample"] = (f"first {sample >> 20} MiB, T x 10 equal slices, ONE encode_batch(chunks, num_threads=T) call through the reference's own "
+                         f"_tokendagger_core (py_binding.cpp + tiktoken.cpp unmodified): Python threads, list[list[int]] out; 1 warm-up + 3 runs, median")
+        return out
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write(f"[bench] python_encode_batch baseline unavailable: {e}\n")
+        return None
 
 
 def _port_variant(pat: str):
@@ -218,8 +259,8 @@ def _free_port() -> int:
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--corpus", default="english", choices=["english", "mixed", "code", "code_files"])
     ap.add_argument("--size-mb", type=int, default=1024, help="MiB of text (whole job for strong scaling, per GPU for weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
@@ -341,6 +382,23 @@ def main():
         elapsed = float(tmax.item())
 
     n_tok = int(d_toff[n_docs].item())
+    # ---- what a step costs before it has touched any text: the same launches on ONE tile (8 KiB, one document) -------
+    fixed_us = None
+    if rank == 0 and n > 8192 and not a.no_cpu_baseline:  # (profiling runs pass --no-cpu-baseline: only the timed steps' launches then)
+        tok.set_option(capi.TD_OPT_PROFILE, 0)
+        one = torch.tensor([0, 8192], dtype=torch.int64, device=dev)
+        t_one = torch.empty(8192 + 1024, dtype=torch.int32, device=dev)
+        o_one = torch.empty(2, dtype=torch.int64, device=dev)
+        for _ in range(20):
+            tok.encode_device(d_text.data_ptr(), 8192, one.data_ptr(), 1, t_one.data_ptr(), 8192 + 1024, o_one.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(200):
+            tok.encode_device(d_text.data_ptr(), 8192, one.data_ptr(), 1, t_one.data_ptr(), 8192 + 1024, o_one.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        fixed_us = round((time.perf_counter() - t1) / 200 * 1e6, 1)
+        tok.device_status(stream.cuda_stream)
+        # (the last full step's outputs are still in d_tok / d_toff: the tile went to buffers of its own)
     # ---- parity of what was just timed: EVERY document of this rank's shard vs the compiled reference -----------
     verified, vdetail = None, ""
     if not a.no_verify:
@@ -378,6 +436,16 @@ def main():
         k_avg_ms = avg[k_name] if k_name else None
         achieved = b_alg / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms else None
         step_achieved = (job_bytes + 4 * job_tok + 8 * (g_docs + 1)) / (ms_step * 1e-3) / 1e9 / world
+        # every kernel segment against the bytes IT has to move (its own inputs read once, its own outputs written once;
+        # DESIGN.md section 5 lists them), from the HIP events around the segments of the timed steps
+        own = {
+            "td_prepare+td_mark_docs": n // 8 + 12 * n_docs,                     # zero the document bitmap; offsets in, bits + first documents out
+            "td_split_tiles": n + n // 8 + n // 8 + 4 * n_tok + 12 * n_docs,      # text + document bits in; START bits, one slot per piece, document slots out
+            "td_pack_tokens": 8 * n_tok + 20 * n_docs,                            # slots in, ids out; per document: offset + slot in, token offset out
+        }
+        per_kernel = {k: {"ms": round(v, 4), "necessary_bytes": own.get(k), "gbs": round(own[k] / (v * 1e-3) / 1e9, 1) if own.get(k) and v > 0 else None,
+                          "frac_of_hbm_peak": round(own[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if own.get(k) and v > 0 else None}
+                      for k, v in ({k: s_ / max(k_n, 1) for k, s_ in sums.items()}).items()}
         traffic, traffic_note = None, "no PMC pass recorded for this workload"
         tfile = ROOT / "profiles" / "hbm_traffic.json"
         if tfile.exists():
@@ -405,14 +473,17 @@ def main():
                                    f"CoreBPE::encode semantics, input resident in HBM",
                        "bytes": job_bytes, "tokens": job_tok, "docs": g_docs,
                        "bytes_rank0": n, "tokens_rank0": n_tok, "docs_rank0": n_docs,
-                       "parallelism": (f"dp{world}: contiguous byte-balanced document shards, RCCL all-gather of "
-                                       f"{{tokens, documents}} every step" if world > 1 else "single GPU"),
+                       "parallelism": (f"dp{world}: contiguous byte-balanced document shards, "
+                                       f"{'RCCL' if a.dist_backend == 'nccl' else 'gloo (host)'} all-gather of "
+                                       f"{{tokens, documents}} every step" if world > 1 else
+                                       ("single GPU + the RCCL all-gather at world size 1" if use_dist and a.dist_backend == "nccl" else "single GPU")),
                        "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "kernel": k_name, "achieved": round(achieved, 2) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                          "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": b_alg,
                          "kernel_ms_avg": round(k_avg_ms, 4) if k_avg_ms else None, "launches_timed": k_n,
                          "all_kernels_ms_avg": {k: round(v, 4) for k, v in avg.items()},
+                         "per_kernel": per_kernel, "fixed_overhead_us": fixed_us,
                          "whole_step": {"achieved": round(step_achieved, 2), "frac": round(step_achieved / HBM_PEAK_GBS, 5),
                                         "note": "algorithmic bytes of the job / ms_per_step / GPUs: every kernel and gap of a step"}},
         }

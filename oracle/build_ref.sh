@@ -20,3 +20,18 @@ g++ -std=c++17 -O2 -fPIC -w -pthread -shared \
     "$ref/src/tiktoken/tiktoken.cpp" "$here/ref_driver.cpp" \
     "$pcre" -o "$out/libtdref.so"
 echo "built $out/libtdref.so"
+# The reference's own Python extension (src/py_binding.cpp, unmodified, compiled where it lies) for the cpu_baseline leg that
+# follows the reference's benchmark METHOD (Tokenizer.encode_batch: Python threads over the pybind CoreBPE.encode,
+# tests/throughput_test.py:413-422).  extern/pybind11 is an empty submodule in the checkout: the installed pybind11 headers
+# are used.  Lives in a directory of its own: its module name is the same as the product's extension.
+pyinc="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])' 2>/dev/null || true)"
+pbinc="$(python3 -c 'import pybind11; print(pybind11.get_include())' 2>/dev/null || true)"
+ext="$(python3 -c 'import sysconfig; print(sysconfig.get_config_var("EXT_SUFFIX"))' 2>/dev/null || true)"
+if [ -n "$pyinc" ] && [ -n "$pbinc" ] && [ -f "$ref/src/py_binding.cpp" ]; then
+    mkdir -p "$out/refmod"
+    g++ -std=c++17 -O2 -fPIC -w -pthread -shared \
+        -I"$here/shim" -I"$ref/src/tiktoken" -I"$ref/src" -I"$pyinc" -I"$pbinc" \
+        "$ref/src/py_binding.cpp" "$ref/src/tiktoken/tiktoken.cpp" \
+        "$pcre" -o "$out/refmod/_tokendagger_core$ext"
+    echo "built $out/refmod/_tokendagger_core$ext"
+fi

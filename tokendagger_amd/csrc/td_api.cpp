@@ -1303,7 +1303,8 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     return TD_E_INVALID;
 }
 
-static const char* const kProfSegments[TD_PROF_EVENTS - 1] = {"td_split_tiles", "td_probe_tiles", "td_merge_pieces", "td_long_pieces+td_scan_tiles+td_pack_tokens"};
+static const char* const kProfSegments[TD_PROF_EVENTS - 1] = {"td_prepare+td_mark_docs", "td_split_tiles", "td_probe_tiles", "td_merge_pieces",
+                                                              "td_long_pieces+td_giant_pieces+td_scan_tiles", "td_pack_tokens"};
 
 int td_profile_read_ex(td_tokenizer* t, double* ms_sums, int n_segments, int64_t* launches) {
     if (!t || n_segments < 0 || (n_segments > 0 && !ms_sums)) return TD_E_INVALID;
@@ -1332,8 +1333,8 @@ const char* td_profile_segment_name(int i) { return (i >= 0 && i + 1 < TD_PROF_E
 int td_profile_read(td_tokenizer* t, double* split_ms_sum, double* encode_ms_sum, int64_t* launches) {
     double s[TD_PROF_EVENTS - 1] = {};
     const int rc = td_profile_read_ex(t, s, TD_PROF_EVENTS - 1, launches);
-    if (split_ms_sum) *split_ms_sum = s[0];
-    if (encode_ms_sum) *encode_ms_sum = s[1] + s[2];
+    if (split_ms_sum) *split_ms_sum = s[1];
+    if (encode_ms_sum) *encode_ms_sum = s[2] + s[3];
     return rc;
 }
 

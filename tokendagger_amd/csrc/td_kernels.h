@@ -117,9 +117,10 @@ struct SmallArgs {
 hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream);
 
 // All launches are asynchronous on `stream`; none of them synchronises or allocates.
-// ev (optional, TD_PROF_EVENTS events): ev[0] | td_split_tiles, td_split_slow | ev[1] | td_probe_tiles | ev[2] | td_merge_pieces |
-// ev[3] | td_long_pieces, td_scan_tiles, td_pack_tokens | ev[4]
-constexpr int TD_PROF_EVENTS = 5;
+// ev (optional, TD_PROF_EVENTS events): ev[0] | td_prepare, td_mark_docs | ev[1] | td_split_tiles (fused: + lookups), td_split_far_* |
+// ev[2] | td_probe_tiles (fused: the deferred tiles only) | ev[3] | td_merge_pieces | ev[4] | td_long_pieces, td_giant_pieces,
+// td_scan_tiles | ev[5] | td_pack_tokens | ev[6]
+constexpr int TD_PROF_EVENTS = 7;
 hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev = nullptr);
 // generic split patterns (td_generic.hip), called by launch_encode in place of td_split_tiles / ahead of td_scan_tiles
 hipError_t launch_generic_split(const EncodeArgs& a, hipStream_t stream);

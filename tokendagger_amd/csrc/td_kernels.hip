@@ -2861,6 +2861,7 @@ static int split_grid_blocks() {
 
 hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev) {
     if (a.n_tiles <= 0) return hipSuccess;
+    if (ev) (void)hipEventRecord(ev[0], stream);
     {   // one launch clears what was seven memsets: document bits, per-tile long-piece counts, first-document
         // indices (0xFFFFFFFF = none) and the per-call counters
         const int64_t words = (a.n + 31) / 32 + 2;
@@ -2878,7 +2879,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     }
     const int sblocks = a.n_stiles < split_grid_blocks() ? a.n_stiles : split_grid_blocks();
     const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
-    if (ev) (void)hipEventRecord(ev[0], stream);
+    if (ev) (void)hipEventRecord(ev[1], stream);
     constexpr uint32_t PV_TEKKEN = PV_NO_CONTRACTION | PV_SINGLE_DIGIT;
     constexpr uint32_t PV_CL100K = PV_NO_CONTRACTION | PV_LEADING_CONTRACTION | PV_PLAIN_LETTERS;
     bool fused = false;
@@ -2907,7 +2908,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     }
     hipLaunchKernelGGL(td_split_far_pieces, dim3(64), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(td_split_far_tiles, dim3(256), dim3(256), 0, stream, a);
-    if (ev) (void)hipEventRecord(ev[1], stream);
+    if (ev) (void)hipEventRecord(ev[2], stream);
 #ifdef TD_ABLATE
     const bool tokens = a.stop_after != 2 && a.stop_after != 11 && a.stop_after != 12;
     const bool merges = a.stop_after != 3 && a.stop_after != 30 && a.stop_after != 31 && a.stop_after != 32;
@@ -2923,13 +2924,13 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
             hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
         }
     }
-    if (ev) (void)hipEventRecord(ev[2], stream);
+    if (ev) (void)hipEventRecord(ev[3], stream);
     if (tokens && merges) {
         const int wtiles = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
         const int mblocks = wtiles < merge_grid_blocks() ? wtiles : merge_grid_blocks();
         hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(K_THREADS), 0, stream, a);
     }
-    if (ev) (void)hipEventRecord(ev[3], stream);
+    if (ev) (void)hipEventRecord(ev[4], stream);
     if (tokens) {
         hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(td_giant_pieces, dim3(128), dim3(GP_THREADS), 0, stream, a);
@@ -2938,9 +2939,12 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
             if (ge != hipSuccess) return ge;
         }
         hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
+        if (ev) (void)hipEventRecord(ev[5], stream);
         hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
+    } else if (ev) {
+        (void)hipEventRecord(ev[5], stream);
     }
-    if (ev) (void)hipEventRecord(ev[4], stream);
+    if (ev) (void)hipEventRecord(ev[6], stream);
     return hipGetLastError();
 }
 
