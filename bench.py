@@ -269,6 +269,9 @@ def parse_args(argv=None):
                          "surrogate for BASELINE config 4 (tekken.json is absent from the reference checkout)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only for exercising the multi-rank path with several ranks on ONE GPU (RCCL refuses that)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "capi"],
+                    help="who issues the step's all-gather of {tokens, documents}: torch.distributed (default) or the C ABI's "
+                         "td_comm_gather_counts (RCCL opened by the tokenizer library itself; needs --dist-backend nccl)")
     ap.add_argument("--same-gpu", action="store_true", help="all ranks use cuda:0 (multi-rank logic test on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -343,15 +346,26 @@ def main():
     d_toff = torch.zeros(n_docs + 2, dtype=torch.int64, device=dev)
     d_toff[n_docs + 1] = n_docs
     tok.reserve(max(n, 1), n_docs + 1)
-    tok.set_option(capi.TD_OPT_PROFILE, 1)
     stream = torch.cuda.current_stream(dev)
     mine = d_toff[n_docs:n_docs + 2]
     gathered = torch.zeros(2 * world, dtype=torch.int64, device=gdev) if use_dist else None
 
+    comm = None
+    if use_dist and a.collective == "capi":
+        if a.dist_backend != "nccl":
+            raise SystemExit("bench: --collective capi is the RCCL entry of the C ABI: use --dist-backend nccl")
+        idt = torch.zeros(capi.TD_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        comm = capi.RcclComm(bytes(idt.cpu().numpy().tobytes()), world, rank, dev.index)
+
     def step():
         tok.encode_device(d_text.data_ptr(), n, d_offs.data_ptr(), n_docs, d_tok.data_ptr(), cap, d_toff.data_ptr(),
                           stream.cuda_stream)
-        if use_dist:  # the path's only exchange: per-rank {tokens, documents} -> global bases
+        if comm is not None:  # the same exchange through the C ABI (td_comm_gather_counts), on the step's own stream
+            comm.gather_counts(mine.data_ptr(), gathered.data_ptr(), stream.cuda_stream)
+        elif use_dist:  # the path's only exchange: per-rank {tokens, documents} -> global bases
             dist.all_gather_into_tensor(gathered, mine if gdev is dev else mine.cpu())
 
     def fence():
@@ -360,11 +374,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
+    # the timed region runs WITHOUT the per-kernel events (a repeated step is then one hipGraph launch, captured during the
+    # warm-up); the kernel segments are timed afterwards on a few more steps of the same work with the events on
+    tok.set_option(capi.TD_OPT_PROFILE, 0)
+    for _ in range(max(a.warmup, 0)):
         step()
     torch.cuda.synchronize(dev)
     tok.device_status(stream.cuda_stream)
-    tok.profile_read()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -372,10 +388,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     tok.device_status(stream.cuda_stream)
-    prof = tok.profile_read_all() if hasattr(tok, "profile_read_all") else None
-    if prof is None:
-        sp_ms, en_ms, k_n = tok.profile_read()
-        prof = ({"td_split_tiles": sp_ms, "td_encode_tiles": en_ms}, k_n)
+    tok.set_option(capi.TD_OPT_PROFILE, 1)
+    tok.profile_read()
+    for _ in range(min(max(a.steps, 1), 20)):
+        step()
+    torch.cuda.synchronize(dev)
+    tok.device_status(stream.cuda_stream)
+    prof = tok.profile_read_all()
+    tok.set_option(capi.TD_OPT_PROFILE, 0)
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -474,14 +494,15 @@ def main():
                        "bytes": job_bytes, "tokens": job_tok, "docs": g_docs,
                        "bytes_rank0": n, "tokens_rank0": n_tok, "docs_rank0": n_docs,
                        "parallelism": (f"dp{world}: contiguous byte-balanced document shards, "
-                                       f"{'RCCL' if a.dist_backend == 'nccl' else 'gloo (host)'} all-gather of "
+                                       f"{('RCCL (C ABI td_comm_gather_counts)' if a.collective == 'capi' else 'RCCL (torch.distributed)') if a.dist_backend == 'nccl' else 'gloo (host)'} all-gather of "
                                        f"{{tokens, documents}} every step" if world > 1 else
-                                       ("single GPU + the RCCL all-gather at world size 1" if use_dist and a.dist_backend == "nccl" else "single GPU")),
+                                       (f"single GPU + the RCCL all-gather at world size 1 ({'C ABI td_comm_gather_counts' if a.collective == 'capi' else 'torch.distributed'})" if use_dist and a.dist_backend == "nccl" else "single GPU")),
                        "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "kernel": k_name, "achieved": round(achieved, 2) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                          "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": b_alg,
                          "kernel_ms_avg": round(k_avg_ms, 4) if k_avg_ms else None, "launches_timed": k_n,
+                         "kernel_timing_note": "HIP events on the launch stream around every kernel segment, on steps of the same work run right behind the timed region (the timed region itself runs without them)",
                          "all_kernels_ms_avg": {k: round(v, 4) for k, v in avg.items()},
                          "per_kernel": per_kernel, "fixed_overhead_us": fixed_us,
                          "whole_step": {"achieved": round(step_achieved, 2), "frac": round(step_achieved / HBM_PEAK_GBS, 5),

@@ -159,6 +159,9 @@ int64_t td_info(const td_tokenizer* t, int what);
 #define TD_OPT_SMALL_PATH 5       /* 0: never take the one-launch path for inputs of at most 4 KiB (default 1: on) */
 #define TD_OPT_FUSED 6            /* 0: pre-tokenizer and lookup as two kernels, two passes over the text (default 1: one fused pass;
                                     TD_FUSED=0 in the environment at td_create time also turns it off).  Same results either way. */
+#define TD_OPT_GRAPH 7            /* 0: never replay a repeated td_encode_device call as a hipGraph (default 1: the second identical call in a
+                                    row captures the step's launches, the following ones are one graph launch; TD_GRAPH=0 in the
+                                    environment at td_create time also turns it off) */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 8) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 
@@ -221,6 +224,32 @@ int td_vocab_arrays(const td_vocab* v, int which, const uint8_t** bytes, const i
                     int64_t* n);
 /* td_create over a loaded vocabulary (pattern = td_vocab_pattern) */
 int td_create_from_vocab(const td_vocab* v, int device, td_tokenizer** out);
+
+/*
+ * Multi-GPU epilogue (one process per GPU, documents sharded across ranks).  The reference parallelises over
+ * independent texts on a thread pool (tokendagger/wrapper.py:231-235) and needs no exchange; across GPUs the only one is
+ * the gather of every rank's {tokens, documents} -> global token / document bases, and optionally of the ids to one rank.
+ * RCCL (over xGMI on an MI355X node) is opened at run time; the tokenizer library links against HIP only.
+ *   td_comm_unique_id      rank 0 makes the id (ncclGetUniqueId); the caller carries its 128 bytes to the other ranks
+ *   td_comm_create         ncclCommInitRank on `device` (-1: the current device); collective over all ranks
+ *   td_comm_gather_counts  ncclAllGather of d_counts[2] = {tokens, documents} (device memory: e.g. elements n_docs and
+ *                          n_docs + 1 of the offsets buffer td_encode_device wrote, with the document count stored behind the
+ *                          total) into d_table[2 * world] on every rank; asynchronous on `stream`
+ *   td_comm_bases          host: exclusive prefix sums of a gathered table -> this rank's token / document base and the totals
+ *   td_comm_gather_tokens  grouped ncclSend / ncclRecv: every rank's ids (table[2 r] of them) end up contiguous, in rank order,
+ *                          in d_root_tokens on `root`; `table` is the gathered table on the HOST; asynchronous on `stream`
+ */
+#define TD_COMM_ID_BYTES 128
+typedef struct td_comm td_comm;
+int td_comm_unique_id(uint8_t id[TD_COMM_ID_BYTES]);
+int td_comm_create(const uint8_t id[TD_COMM_ID_BYTES], int world, int rank, int device, td_comm** out);
+void td_comm_destroy(td_comm* c);
+int td_comm_gather_counts(td_comm* c, const int64_t* d_counts, int64_t* d_table, void* stream);
+int td_comm_bases(const int64_t* table, int world, int rank, int64_t* token_base, int64_t* doc_base, int64_t* token_total,
+                  int64_t* doc_total);
+int td_comm_gather_tokens(td_comm* c, const int32_t* d_tokens, const int64_t* table, int root, int32_t* d_root_tokens,
+                          int64_t root_capacity, void* stream);
+const char* td_comm_last_error(void);
 
 #ifdef __cplusplus
 }

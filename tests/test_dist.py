@@ -71,3 +71,15 @@ def test_shard_documents_edge_cases():
     assert parts[0][0] == 0 and parts[-1][1] == 4
     assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
     assert shard_documents(np.asarray([0], dtype=np.int64), 2, 1) == (0, 0)
+
+
+def test_bases_from_a_gathered_table_c_entry():
+    """td_comm_bases (the host half of the C ABI's multi-GPU epilogue): exclusive prefix sums over {tokens, documents}."""
+    from tokendagger_amd import capi
+    table = np.asarray([[10, 2], [0, 0], [7, 5], [3, 1]], dtype=np.int64)
+    assert [capi.comm_bases(table, r) for r in range(4)] == [(0, 0, 20, 8), (10, 2, 20, 8), (10, 2, 20, 8), (17, 7, 20, 8)]
+    assert capi.comm_bases(np.asarray([5, 1], dtype=np.int64), 0) == (0, 0, 5, 1)
+    with pytest.raises(capi.TokenDaggerHipError):
+        capi.comm_bases(np.asarray([5, -1], dtype=np.int64), 0)
+    with pytest.raises(capi.TokenDaggerHipError):
+        capi.comm_bases(table, 4)

@@ -171,3 +171,40 @@ def test_encode_ordinary_mode_takes_the_same_path(tok):
     b = tok.encode_batch(x.tobytes(), o, mode=capi.TD_MODE_ORDINARY)
     tok.set_option(TD_OPT_FUSED, 1)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_repeated_device_calls_replay_a_graph_with_the_same_results(tok):
+    """td_encode_device: the second identical call in a row captures the step as a hipGraph, later ones replay it
+    (TD_OPT_GRAPH).  Results must not depend on which way a call was launched, and a change of any argument must not
+    replay the old graph."""
+    import torch
+    x, o = td_corpus.mixed(3 << 20, seed=5)
+    y, p = td_corpus.english(2 << 20, seed=6)
+    R = H.ref_tokenizer() if ref.available() else None
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(text, offs, times):
+        n, nd = len(text), len(offs) - 1
+        dt, do = torch.from_numpy(text).cuda(), torch.from_numpy(offs).cuda()
+        dk = torch.empty(n + 1024, dtype=torch.int32, device="cuda")
+        dto = torch.empty(nd + 1, dtype=torch.int64, device="cuda")
+        outs = []
+        for _ in range(times):
+            dk.zero_()
+            dto.zero_()
+            tok.encode_device(dt.data_ptr(), n, do.data_ptr(), nd, dk.data_ptr(), n + 1024, dto.data_ptr(), s)
+            tok.device_status(s)
+            toff = dto.cpu().numpy()
+            outs.append((dk[:int(toff[-1])].cpu().numpy(), toff))
+        return outs
+
+    for g in (1, 0):
+        tok.set_option(capi.TD_OPT_GRAPH, g)
+        for text, offs in ((x, o), (y, p), (x, o)):
+            outs = run(text, offs, 5)
+            for t_, o_ in outs[1:]:
+                assert np.array_equal(t_, outs[0][0]) and np.array_equal(o_, outs[0][1]), "a replayed step gave different ids"
+            if R is not None:
+                _, et, eo = R.encode_batch(text, offs, n_threads=os.cpu_count() or 1, want_tokens=True)
+                assert np.array_equal(outs[-1][1], eo) and np.array_equal(outs[-1][0], et)
+    tok.set_option(capi.TD_OPT_GRAPH, 1)

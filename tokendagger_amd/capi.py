@@ -26,6 +26,7 @@ TD_OPT_PIPE_CHUNK_BYTES = 3
 TD_OPT_PIPE_THREADS = 4
 TD_OPT_SMALL_PATH = 5
 TD_OPT_FUSED = 6
+TD_OPT_GRAPH = 7
 
 EXPORTS = [
     "td_create", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",
@@ -35,6 +36,8 @@ EXPORTS = [
     "td_vocab_load_tekken", "td_vocab_load_json", "td_vocab_set_pattern", "td_vocab_pattern", "td_vocab_arrays",
     "td_create_from_vocab", "td_token_bytes", "td_single_token", "td_decode_device", "td_decode_batch", "td_encode_batch_with_special",
     "td_encode_with_special_strs", "td_encode_batch_with_special_strs", "td_profile_read_ex", "td_profile_segment_name",
+    "td_comm_unique_id", "td_comm_create", "td_comm_destroy", "td_comm_gather_counts", "td_comm_bases", "td_comm_gather_tokens",
+    "td_comm_last_error",
 ]
 
 
@@ -81,6 +84,18 @@ def load_library():
     _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(str(lib_path), mode=ctypes.RTLD_GLOBAL)
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    lib.td_comm_unique_id.restype = i32
+    lib.td_comm_unique_id.argtypes = [vp]
+    lib.td_comm_create.restype = i32
+    lib.td_comm_create.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
+    lib.td_comm_destroy.argtypes = [vp]
+    lib.td_comm_gather_counts.restype = i32
+    lib.td_comm_gather_counts.argtypes = [vp, vp, vp, vp]
+    lib.td_comm_bases.restype = i32
+    lib.td_comm_bases.argtypes = [vp, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    lib.td_comm_gather_tokens.restype = i32
+    lib.td_comm_gather_tokens.argtypes = [vp, vp, vp, i32, vp, i64, vp]
+    lib.td_comm_last_error.restype = ctypes.c_char_p
     lib.td_create.restype = i32
     lib.td_create.argtypes = [ctypes.c_char_p, i64, vp, vp, vp, i64, vp, vp, vp, i32, ctypes.POINTER(vp)]
     lib.td_destroy.argtypes = [vp]
@@ -474,3 +489,65 @@ class HipTokenizer:
             self._lib.td_special_get(self._h, i, ctypes.byref(s), ctypes.byref(n), ctypes.byref(tid))
             out[ctypes.string_at(s, n.value).decode("utf-8")] = tid.value
         return out
+
+
+# ---------------------------------------------------------------------------------------------- multi-GPU epilogue
+TD_COMM_ID_BYTES = 128
+
+
+def comm_bases(table, rank: int) -> tuple[int, int, int, int]:
+    """td_comm_bases: gathered {tokens, documents} per rank (host array of 2 * world int64) -> (token_base, doc_base,
+    token_total, doc_total) of `rank`.  Host only: no device, no RCCL."""
+    lib = load_library()
+    t = np.ascontiguousarray(np.asarray(table, dtype=np.int64).reshape(-1))
+    world = len(t) // 2
+    tb, db, tt, dt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    rc = lib.td_comm_bases(t.ctypes.data_as(ctypes.c_void_p), world, rank, ctypes.byref(tb), ctypes.byref(db), ctypes.byref(tt), ctypes.byref(dt))
+    if rc != 0:
+        raise TokenDaggerHipError(rc, (lib.td_comm_last_error() or b"").decode("utf-8", "replace"))
+    return tb.value, db.value, tt.value, dt.value
+
+
+def comm_unique_id() -> bytes:
+    """td_comm_unique_id (rank 0): the 128 bytes every rank hands to RcclComm."""
+    lib = load_library()
+    buf = (ctypes.c_uint8 * TD_COMM_ID_BYTES)()
+    rc = lib.td_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+    if rc != 0:
+        raise TokenDaggerHipError(rc, (lib.td_comm_last_error() or b"").decode("utf-8", "replace"))
+    return bytes(buf)
+
+
+class RcclComm:
+    """The path's only exchange behind the C ABI (td_comm_*): RCCL all-gather of {tokens, documents}, optional gather of the
+    ids to one rank.  Pointers are raw device addresses (e.g. torch.Tensor.data_ptr())."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int = -1):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self.world, self.rank = world, rank
+        idb = (ctypes.c_uint8 * TD_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._lib.td_comm_create(ctypes.cast(idb, ctypes.c_void_p), world, rank, device, ctypes.byref(self._h)))
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise TokenDaggerHipError(rc, (self._lib.td_comm_last_error() or b"").decode("utf-8", "replace"))
+
+    def gather_counts(self, d_counts: int, d_table: int, stream: int = 0):
+        self._check(self._lib.td_comm_gather_counts(self._h, ctypes.c_void_p(d_counts), ctypes.c_void_p(d_table), ctypes.c_void_p(stream)))
+
+    def gather_tokens(self, d_tokens: int, table, root: int, d_root_tokens: int, root_capacity: int, stream: int = 0):
+        t = np.ascontiguousarray(np.asarray(table, dtype=np.int64).reshape(-1))
+        self._check(self._lib.td_comm_gather_tokens(self._h, ctypes.c_void_p(d_tokens), t.ctypes.data_as(ctypes.c_void_p), root,
+                                                    ctypes.c_void_p(d_root_tokens), root_capacity, ctypes.c_void_p(stream)))
+
+    def close(self):
+        if self._h:
+            self._lib.td_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -159,6 +159,12 @@ struct td_tokenizer {
     int64_t pool_bytes_opt = 0;
     bool profile = false;
     int stop_after = 0;
+    // the last step as a hipGraph (encode_device_locked)
+    bool graphs = true;
+    hipGraphExec_t graph_exec = nullptr;
+    EncodeArgs graph_key, last_key;
+    hipStream_t graph_stream = nullptr, last_key_stream = nullptr;
+    bool has_last_key = false;
     bool fused = true;  // pre-tokenizer and lookup in one pass over the text (TD_OPT_FUSED; TD_FUSED=0 in the environment turns it off)
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
     std::vector<Ev3> ev_pending, ev_free;
@@ -196,6 +202,11 @@ struct td_tokenizer {
 };
 
 namespace {
+
+void drop_graph(td_tokenizer* t) {
+    if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
+    t->graph_exec = nullptr;
+}
 
 int ensure(td_tokenizer* t, DevBuf& b, size_t bytes) {
     if (b.cap >= bytes && b.p) return TD_OK;
@@ -371,6 +382,42 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
         else for (auto& e : ev.e) HIP_TRY(t, hipEventCreate(&e));
         t->ev_pending.push_back(ev);
     }
+    // A call that repeats the previous one exactly (same buffers, sizes, stream: a loop over a resident batch, one rank's step
+    // of a multi-GPU job) replays the step as ONE hipGraph launch instead of its dozen kernel launches: the second such call
+    // captures the launches, the following ones replay them.  Anything else is launched kernel by kernel.  (The fixed cost
+    // of a step — what a one-tile input takes — is what bends strong scaling at eight GPUs, not what a GiB on one GPU sees.)
+    if (t->graphs && !t->profile && !t->stop_after) {
+        const bool same_as_graph = t->graph_exec && t->graph_stream == stream && memcmp(&a, &t->graph_key, sizeof a) == 0;
+        if (same_as_graph) {
+            HIP_TRY(t, hipGraphLaunch(t->graph_exec, stream));
+            return order_after(t, stream);
+        }
+        const bool repeats = t->has_last_key && t->last_key_stream == stream && memcmp(&a, &t->last_key, sizeof a) == 0;
+        if (repeats) {
+            drop_graph(t);
+            hipGraph_t g = nullptr;
+            hipError_t ce = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+            if (ce == hipSuccess) {
+                const hipError_t le = launch_encode(a, stream, nullptr);
+                ce = hipStreamEndCapture(stream, &g);
+                if (le != hipSuccess) ce = le;
+            }
+            if (ce == hipSuccess && g && hipGraphInstantiate(&t->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                (void)hipGraphDestroy(g);
+                t->graph_key = a;
+                t->graph_stream = stream;
+                HIP_TRY(t, hipGraphLaunch(t->graph_exec, stream));
+                return order_after(t, stream);
+            }
+            if (g) (void)hipGraphDestroy(g);
+            t->graph_exec = nullptr;
+            t->graphs = false;  // capture is not available here: plain launches from now on
+            (void)hipGetLastError();
+        }
+        t->last_key = a;
+        t->last_key_stream = stream;
+        t->has_last_key = true;
+    }
     HIP_TRY(t, launch_encode(a, stream, t->profile ? ev.e : nullptr));
     return order_after(t, stream);
 }
@@ -424,6 +471,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     }
     td_tokenizer* t = new td_tokenizer;
     if (const char* e = getenv("TD_FUSED")) t->fused = atoi(e) != 0;
+    if (const char* e = getenv("TD_GRAPH")) t->graphs = atoi(e) != 0;
     std::string err;
     int rc = build_tables(pat_str, n_vocab, token_bytes, token_offsets, ranks, n_special, special_bytes, special_offsets,
                           special_ids, t->H, err);
@@ -501,6 +549,7 @@ void td_destroy(td_tokenizer* t) {
         DeviceGuard dg(t->device);  // reached from finalisers at arbitrary points: the caller's device must survive
         (void)hipDeviceSynchronize();
         bury(t);
+        drop_graph(t);
         for (void* p : t->table_allocs) (void)hipFree(p);
         for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
         for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
@@ -1282,6 +1331,11 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
 #endif
     if (what == TD_OPT_FUSED) {
         t->fused = value != 0;
+        return TD_OK;
+    }
+    if (what == TD_OPT_GRAPH) {
+        t->graphs = value != 0;
+        if (!t->graphs) { drop_graph(t); t->has_last_key = false; }
         return TD_OK;
     }
     if (what == TD_OPT_PROFILE) {

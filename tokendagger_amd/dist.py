@@ -22,22 +22,24 @@ def shard_documents(doc_offsets: np.ndarray, world: int, rank: int) -> tuple[int
 
 
 def gather_counts(n_docs_local: int, n_tokens_local, device=None, group=None):
-    """all-gather of {documents, tokens} per rank.  -> (doc_base, token_base, total_docs, total_tokens, table)
-    where *_base are this rank's exclusive prefix sums.  `n_tokens_local` may be an int or a 0-d/1-element
-    tensor that already lives on `device` (no host sync needed before the collective)."""
+    """all-gather of {tokens, documents} per rank (the layout of the C ABI's td_comm_gather_counts).
+    -> (doc_base, token_base, total_docs, total_tokens, table) where *_base are this rank's exclusive prefix sums, computed
+    by the C entry td_comm_bases.  `n_tokens_local` may be an int or a 0-d/1-element tensor that already lives on `device`
+    (no host sync needed before the collective).  The collective itself is torch.distributed's here (RCCL with the "nccl"
+    backend, gloo on CPU); tokendagger_amd.capi.RcclComm is the same exchange without torch."""
     import torch
     import torch.distributed as dist
+    from . import capi
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     mine = torch.zeros(2, dtype=torch.int64, device=device)
-    mine[0] = n_docs_local
     if torch.is_tensor(n_tokens_local):
-        mine[1:2] = n_tokens_local.reshape(-1)[:1].to(torch.int64)
+        mine[0:1] = n_tokens_local.reshape(-1)[:1].to(torch.int64)
     else:
-        mine[1] = int(n_tokens_local)
+        mine[0] = int(n_tokens_local)
+    mine[1] = n_docs_local
     table = torch.zeros(2 * world, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(table, mine, group=group)
     t = table.view(world, 2).cpu().numpy()
-    doc_base = int(t[:rank, 0].sum())
-    tok_base = int(t[:rank, 1].sum())
-    return doc_base, tok_base, int(t[:, 0].sum()), int(t[:, 1].sum()), t
+    tok_base, doc_base, tok_total, doc_total = capi.comm_bases(t, rank)
+    return doc_base, tok_base, doc_total, tok_total, t
