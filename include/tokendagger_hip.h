@@ -75,7 +75,7 @@ const char* td_last_error(const td_tokenizer* t);
  * tokendagger/wrapper.py:212-235).  out_tokens (capacity out_capacity ids) receives all ids,
  * out_offsets[n_docs+1] the per-document token offsets, *n_tokens the total.  If the capacity is
  * too small the call fails with TD_E_CAPACITY and *n_tokens holds the required size.
- * Copies text to the device, runs the kernels, copies ids back; synchronous.  Inputs of 64 MiB and more go through a
+ * Copies text to the device, runs the kernels, copies ids back; synchronous.  Inputs of two chunks (2 x 16 MiB) and more go through a
  * three-stage pipeline of pinned bounce buffers (host copy || H2D || kernels || D2H || host copy, TD_OPT_PIPE_*);
  * inputs of at most 4 KiB (and 1024 documents) take ONE kernel launch that reads and writes pinned host memory directly.
  */
@@ -155,14 +155,14 @@ int64_t td_info(const td_tokenizer* t, int what);
 #define TD_OPT_PROFILE 2         /* 1: bracket the kernels of every td_encode_device call with HIP events on the
                                     call's stream (td_profile_read_ex) */
 #define TD_OPT_PIPE_CHUNK_BYTES 3 /* td_encode_batch cuts inputs of at least two chunks into chunks of whole documents of about
-                                    this many bytes (default 32 MiB) and overlaps host copies, PCIe transfers and kernels */
+                                    this many bytes (default 16 MiB) and overlaps host copies, PCIe transfers and kernels */
 #define TD_OPT_SMALL_PATH 5       /* 0: never take the one-launch path for inputs of at most 4 KiB (default 1: on) */
 #define TD_OPT_FUSED 6            /* 0: pre-tokenizer and lookup as two kernels, two passes over the text (default 1: one fused pass;
                                     TD_FUSED=0 in the environment at td_create time also turns it off).  Same results either way. */
 #define TD_OPT_GRAPH 7            /* 0: never replay a repeated td_encode_device call as a hipGraph (default 1: the second identical call in a
                                     row captures the step's launches, the following ones are one graph launch; TD_GRAPH=0 in the
                                     environment at td_create time also turns it off) */
-#define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 8) */
+#define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 16) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 
 /* Sums (ms) of the pre-tokenizer kernel and token kernel (probe + merge) durations and the number of calls recorded

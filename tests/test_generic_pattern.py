@@ -137,3 +137,19 @@ def test_gpu_python_surface_with_the_reference_tests_pattern():
         assert enc.decode(enc.encode(s)) == b"".join(R.split_pieces(s.encode("utf-8"))).decode("utf-8"), s  # (skipped text is gone)
     batch = ["one two", "three_four", "5 six!"]
     assert enc.encode_batch(batch) == [list(R.encode(b.encode())) for b in batch]
+
+
+@pytest.mark.gpu
+def test_gpu_left_context_assertions_refuse_special_cuts():
+    """the reference matches a segment behind a special token with the text in front as left context
+    (tiktoken.cpp:86-93); segments are subjects of their own here, so a pattern with ^ \\A \\b \\B refuses the cut instead of
+    approximating it.  Without a cut (no allowed special in the text) the pattern works as ever."""
+    import tokendagger as tiktoken
+    _, mr, special = H.llama4()
+    enc = tiktoken.Encoding(name="wb", pat_str=PATTERNS["wordb"], mergeable_ranks=mr, special_tokens=special)
+    plain = tiktoken.Encoding(name="w", pat_str=PATTERNS["words"], mergeable_ranks=mr, special_tokens=special)
+    s = "one two<|begin_of_text|>three"
+    assert enc.encode("one two three") == enc.encode("one two three", allowed_special="all")  # (nothing to cut)
+    with pytest.raises(tiktoken.TokenDaggerError):
+        enc.encode(s, allowed_special="all")
+    assert plain.encode(s, allowed_special="all")[2] == special["<|begin_of_text|>"]

@@ -739,11 +739,20 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
     for (int i = 0; i < nchunks + 2; ++i) {
         // slot i % 3 was chunk i - 3's: its ids left the pinned buffer (out_job), its kernels were done long before
         if (out_job[i % 3]) { t->pool_threads->wait(out_job[i % 3]); out_job[i % 3].reset(); }
-        if (i < nchunks && (rc = submit(i))) return rc;
-        if (i - 1 >= 0 && i - 1 < nchunks && (rc = fetch(i - 1))) return rc;
-        if (i - 2 >= 0 && i - 2 < nchunks && (rc = deliver(i - 2))) return rc;
+        if (i < nchunks && (rc = submit(i))) break;
+        if (i - 1 >= 0 && i - 1 < nchunks && (rc = fetch(i - 1))) break;
+        if (i - 2 >= 0 && i - 2 < nchunks && (rc = deliver(i - 2))) break;
     }
     for (auto& j : out_job) if (j) t->pool_threads->wait(j);
+    if (rc != TD_OK) {
+        // a chunk failed on the host side (allocation, a HIP call): nothing of this call may still be reading the caller's
+        // text or writing its output buffers when the error is returned — the copy jobs are done (above), the three streams
+        // are drained here
+        (void)hipStreamSynchronize(t->s_h2d);
+        (void)hipStreamSynchronize(t->s_k);
+        (void)hipStreamSynchronize(t->s_d2h);
+        return rc;
+    }
     out_offsets[n_docs] = tok_base;
     if (n_tokens) *n_tokens = tok_base;
     HIP_TRY(t, hipStreamSynchronize(t->s_k));
@@ -1158,6 +1167,14 @@ int encode_special_locked(td_tokenizer* t, const uint8_t* text, const int64_t* d
         rc = encode_batch_locked(t, text, doc_offsets, n_docs, TD_MODE_ENCODE, out_tokens, out_capacity, out_offsets, &ntok);
         if (n_tokens) *n_tokens = ntok;
         return rc;
+    }
+    if (t->H.rx_left_context) {
+        // The reference matches every segment with the text in front of it as left context (pcre2_match on text[0, end) from
+        // start_offset, tiktoken.cpp:86-93): behind a special token \\A and ^ cannot match and \\b sees the special's last
+        // character.  The segments go to the device as subjects of their own, so for a pattern with these assertions the
+        // cut would be a silent approximation: refused instead.
+        t->err = "the split pattern uses ^, \\A, \\b or \\B: cutting allowed special tokens out of the text is not supported with it";
+        return TD_E_PATTERN;
     }
     std::vector<uint8_t> seg_text;
     std::vector<int64_t> seg_offs((size_t)nseg + 1, 0);

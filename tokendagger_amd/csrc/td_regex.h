@@ -17,6 +17,11 @@
 //     look-ahead          (?!X)  (?=X)   with X one character class
 //     $ \Z                end of the subject (or in front of its final newline);  \z  the very end;  ^ \A  its start
 //     \b \B               word boundary (\w as PCRE2_UCP defines it) / not one
+//                         (^ \A \b \B look at what stands in FRONT of the subject: with them a call that cuts allowed special
+//                         tokens out of the text is refused, TD_E_PATTERN — the reference would match the text behind a special
+//                         with the special as left context, tiktoken.cpp:86-93)
+//     a group followed by ?+ is atomic (the literal chosen, or the skip, is final); \0 followed by a digit (octal), a class
+//     escape as the start of a range ([\d-z]) and surrogates in \x{..} are rejected as PCRE2 rejects or reads them differently
 // Semantics are PCRE2's: ordered alternation, greedy quantifiers that give back one character at a time, possessive ones
 // that do not, a match may not be empty.  Invalid UTF-8 (which PCRE2_NO_UTF_CHECK leaves undefined in the reference) is
 // read as one character per byte that belongs to no category.

@@ -33,6 +33,7 @@ struct HostTables {
     PatternKind pattern_kind = PATTERN_UNSUPPORTED;
     std::string pattern;
     std::vector<uint8_t> rx_program;  // PATTERN_GENERIC: the compiled pattern (one RxProgram, td_regex.h)
+    bool rx_left_context = false;     // ... uses ^ \\A \\b \\B: a match depends on what stands in front of its subject
     std::vector<uint8_t> ascii_cls;
     std::vector<uint8_t> ucls2_remap;  // stage-2 class table with the pattern's class remaps applied (empty: the static one)
     std::vector<int32_t> byte_id;
