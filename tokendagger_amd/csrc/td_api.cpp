@@ -197,6 +197,8 @@ struct td_tokenizer {
     // one-launch path for inputs of at most 4 KiB: pinned host buffers the kernel reads and writes directly
     void* small_in = nullptr;
     void* small_out = nullptr;
+    void* small_dec_in = nullptr;   // td_small_decode: ids in, status + bytes out
+    void* small_dec_out = nullptr;
     unsigned long long small_seq = 0;
     bool small_enabled = true;
 };
@@ -561,6 +563,8 @@ void td_destroy(td_tokenizer* t) {
         }
         for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h}) if (st) (void)hipStreamDestroy(st);
         if (t->small_in) (void)hipHostFree(t->small_in);
+        if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
+        if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
         if (t->small_out) (void)hipHostFree(t->small_out);
         DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->gap_list, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
@@ -919,6 +923,52 @@ int td_decode_device(td_tokenizer* t, const void* d_tokens, int64_t n_tokens, vo
     });
 }
 
+// decode_bytes on at most SMALL_DEC_MAX_TOKENS ids: ONE launch over pinned host buffers (td_small_decode).  Returns TD_OK, a
+// TD_E_* code, or -1: more bytes than the kernel's window holds (the general path takes the call).
+static int decode_bytes_small(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, uint8_t* out, int64_t out_capacity, int64_t* n_bytes) {
+    if (!t->small_dec_in) {
+        HIP_TRY(t, hipHostMalloc(&t->small_dec_in, SMALL_DEC_MAX_TOKENS * 4 + 64, hipHostMallocDefault));
+        HIP_TRY(t, hipHostMalloc(&t->small_dec_out, 64 + SMALL_DEC_MAX_BYTES, hipHostMallocDefault));
+        memset(t->small_dec_out, 0, 64 + SMALL_DEC_MAX_BYTES);
+    }
+    int rc;
+    hipStream_t s = nullptr;
+    if ((rc = order_before(t, s))) return rc;
+    memcpy(t->small_dec_in, tokens, (size_t)n_tokens * 4);
+    SmallDecArgs a;
+    a.Tp = t->dTp;
+    a.tokens = (const int32_t*)t->small_dec_in;
+    a.status = (SmallStatus*)t->small_dec_out;
+    a.out = (uint8_t*)t->small_dec_out + 64;
+    a.seq = ++t->small_seq;
+    a.n = (int)n_tokens;
+    HIP_TRY(t, launch_small_decode(a, s));
+    volatile unsigned long long* seqp = &a.status->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == a.seq) break;
+        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            HIP_TRY(t, hipStreamSynchronize(s));  // (a launch failure surfaces here)
+            if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == a.seq) break;
+            t->err = "td_small_decode did not complete";
+            return TD_E_HIP;
+        }
+    }
+    const SmallStatus st = *a.status;
+    if (st.err == TD_E_BAD_TOKEN) {
+        const long long ep = st.err_pos;
+        t->err = "Invalid token for decoding: " + std::to_string(ep >= 0 && ep < n_tokens ? tokens[ep] : -1);  // reference: tiktoken.cpp:249
+        return TD_E_BAD_TOKEN;
+    }
+    if (st.err) { t->err = "device error " + std::to_string(st.err); return st.err; }
+    if (st.fallback) return -1;
+    if (n_bytes) *n_bytes = st.n_tokens;
+    if ((int64_t)st.n_tokens > out_capacity) { t->err = "decode capacity too small"; return TD_E_CAPACITY; }
+    if (st.n_tokens > 0 && !out) { t->err = "null out"; return TD_E_INVALID; }
+    if (st.n_tokens) memcpy(out, a.out, st.n_tokens);
+    return TD_OK;
+}
+
 int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, uint8_t* out, int64_t out_capacity,
                     int64_t* n_bytes) {
     if (!t || n_tokens < 0 || (n_tokens > 0 && !tokens)) return TD_E_INVALID;
@@ -926,6 +976,10 @@ int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, ui
     if (n_tokens == 0) return TD_OK;
     return locked(t, [&] {
         int rc;
+        if (n_tokens <= SMALL_DEC_MAX_TOKENS && t->small_enabled) {
+            rc = decode_bytes_small(t, tokens, n_tokens, out, out_capacity, n_bytes);
+            if (rc != -1) return rc;
+        }
         if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4 + 16))) return rc;
         if ((rc = order_before(t, nullptr))) return rc;
         HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));

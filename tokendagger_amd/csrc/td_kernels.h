@@ -115,6 +115,17 @@ struct SmallArgs {
     int n, n_docs, use_fastpath;
 };
 hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream);
+// The same for decode_bytes on at most SMALL_DEC_MAX_TOKENS ids (td_small_decode): ids in, bytes + status out, pinned host memory.
+constexpr int SMALL_DEC_MAX_TOKENS = 1024, SMALL_DEC_MAX_BYTES = 16384;
+struct SmallDecArgs {
+    const Tables* Tp;
+    const int32_t* tokens;   // [n] (pinned host memory)
+    uint8_t* out;            // [SMALL_DEC_MAX_BYTES]
+    SmallStatus* status;     // n_tokens = bytes written; err_pos = index of the first id that is no token; fallback = 1: more bytes than the buffer holds
+    unsigned long long seq;
+    int n;
+};
+hipError_t launch_small_decode(const SmallDecArgs& a, hipStream_t stream);
 
 // All launches are asynchronous on `stream`; none of them synchronises or allocates.
 // ev (optional, TD_PROF_EVENTS events): ev[0] | td_prepare, td_mark_docs | ev[1] | td_split_tiles (fused: + lookups), td_split_far_* |

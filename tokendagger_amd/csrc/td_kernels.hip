@@ -2808,6 +2808,70 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
     }
 }
 
+// ------------------------------------------------------------------ td_small_decode ---------
+// decode_bytes (CoreBPE::decode_bytes, tiktoken.cpp:236-255) for at most 1024 ids in ONE launch: the ids come straight out of
+// a pinned host buffer, the bytes go to one through an LDS window (16-byte stores), a sequence number the host spins on is
+// released last.  (The general path is three launches and four copies: ~110 us for a chat message's worth of ids.)
+__global__ __launch_bounds__(K_THREADS) void td_small_decode(const SmallDecArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[SMALL_DEC_MAX_BYTES];
+    __shared__ uint32_t s_wave[8];
+    __shared__ uint32_t s_err, s_errpos;
+    const Tables T = uniform_tables(a.Tp);
+    const int tid = threadIdx.x;
+    constexpr int PER = SMALL_DEC_MAX_TOKENS / K_THREADS;  // ids per lane (consecutive: the scan is over lanes)
+    if (tid == 0) { s_err = 0; s_errpos = 0; }
+    __syncthreads();
+    int32_t ids[PER];
+    uint32_t so[PER], ln[PER];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid * PER + k;
+        ids[k] = i < a.n ? a.tokens[i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid * PER + k;
+        so[k] = 0; ln[k] = 0;
+        if (i < a.n) {
+            if (ids[k] >= 0 && ids[k] <= T.max_id) {
+                so[k] = T.tok_off[ids[k]];
+                ln[k] = T.tok_off[ids[k] + 1] - so[k];
+            }
+            if (ln[k] == 0 && atomicCAS(&s_err, 0u, (uint32_t)TD_E_BAD_TOKEN) == 0u) s_errpos = (uint32_t)i;  // (no token is empty)
+        }
+        mine += ln[k];
+    }
+    uint32_t total;
+    uint32_t off = block_excl_scan(mine, s_wave, total);
+    const bool fits = total <= (uint32_t)SMALL_DEC_MAX_BYTES;
+    if (fits && !s_err) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint8_t* src = T.tok_bytes + so[k];
+            for (uint32_t q = 0; q < ln[k]; ++q) s_out[off + q] = src[q];
+            off += ln[k];
+        }
+    }
+    __syncthreads();
+    if (fits && !s_err)
+        for (uint32_t v = tid; v * 16u < total; v += K_THREADS) reinterpret_cast<uint4*>(a.out)[v] = reinterpret_cast<const uint4*>(s_out)[v];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        a.status->n_tokens = total;
+        a.status->err = (int)s_err;
+        a.status->err_pos = (long long)s_errpos;
+        a.status->fallback = fits ? 0 : 1;
+        __hip_atomic_store(&a.status->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_small_decode(const SmallDecArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(td_small_decode, dim3(1), dim3(K_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(td_small_encode, dim3(1), dim3(K_THREADS), 0, stream, a);
     return hipGetLastError();
