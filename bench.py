@@ -264,7 +264,7 @@ def parse_args(argv=None):
     ap.add_argument("--corpus", default="english", choices=["english", "mixed", "code", "code_files"])
     ap.add_argument("--size-mb", type=int, default=1024, help="MiB of text (whole job for strong scaling, per GPU for weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
-    ap.add_argument("--pattern", default="llama4", choices=["llama4", "tekken"],
+    ap.add_argument("--pattern", default="llama4", choices=["llama4", "tekken", "generic:autogen", "generic:words"],
                     help="split pattern; 'tekken' = the Mistral tekken pattern over the Llama-4 vocabulary, the labelled "
                          "surrogate for BASELINE config 4 (tekken.json is absent from the reference checkout)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -324,6 +324,10 @@ def main():
     name, pat, ranks, special = vocab_io.load_tdv(vocab_io.default_vocab_path())
     if a.pattern == "tekken":
         pat = vocab_io.TEKKEN_PAT_STR
+    elif a.pattern == "generic:autogen":  # the reference's tests/autogenned_test.py:66 (skips '_' and non-ASCII letters): the generic engine
+        pat = r"[a-zA-Z]+|\s+|[0-9]+|[^\w\s]"
+    elif a.pattern == "generic:words":
+        pat = r"\w+|[^\w\s]+|\s+"
     tok = capi.HipTokenizer(pat, ranks, special, device=dev.index)
 
     # ---- the corpus and this rank's share of it -------------------------------------------------------------
@@ -488,7 +492,7 @@ def main():
             "vs_baseline": None, "dtype": "u8",
             "data": f"synthetic (seeded td_corpus.{a.corpus}, 32 MiB generator block tiled)" if a.corpus != "code_files" else
                     "the reference's code_performance_benchmark file set (tests/golden/code_corpus.npz), tiled",
-            "config": {"workload": f"Llama-4-Scout vocab{' + tekken split pattern (config 4 surrogate: tekken.json missing)' if a.pattern == 'tekken' else ''}, "
+            "config": {"workload": f"Llama-4-Scout vocab{' + tekken split pattern (config 4 surrogate: tekken.json missing)' if a.pattern == 'tekken' else (' + generic split pattern ' + pat if a.pattern.startswith('generic') else '')}, "
                                    f"{job_bytes >> 20} MiB {'of the code_performance_benchmark file set' if a.corpus == 'code_files' else 'synthetic ' + a.corpus + ' text'}, {g_docs} documents, "
                                    f"CoreBPE::encode semantics, input resident in HBM",
                        "bytes": job_bytes, "tokens": job_tok, "docs": g_docs,

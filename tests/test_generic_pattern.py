@@ -152,4 +152,4 @@ def test_gpu_left_context_assertions_refuse_special_cuts():
     assert enc.encode("one two three") == enc.encode("one two three", allowed_special="all")  # (nothing to cut)
     with pytest.raises(tiktoken.TokenDaggerError):
         enc.encode(s, allowed_special="all")
-    assert plain.encode(s, allowed_special="all")[2] == special["<|begin_of_text|>"]
+    assert special["<|begin_of_text|>"] in plain.encode(s, allowed_special="all")

@@ -26,7 +26,14 @@ __device__ __forceinline__ void raise_g(const EncodeArgs& a, int code, int64_t p
 
 __global__ __launch_bounds__(256) void td_split_generic(const EncodeArgs a) {
     const RxTables T{a.rx_stage1, a.rx_stage2};
-    const RxProgram& P = *a.rx;
+    // the compiled pattern in LDS: the matcher reads a node, a class or a literal at every step, and out of HBM each of
+    // those was a cache round trip in the middle of a dependent chain
+    __shared__ RxProgram sP;
+    static_assert(sizeof(RxProgram) % 4 == 0, "copied as dwords");
+    for (uint32_t w = threadIdx.x; w < sizeof(RxProgram) / 4; w += blockDim.x)
+        reinterpret_cast<uint32_t*>(&sP)[w] = reinterpret_cast<const uint32_t*>(a.rx)[w];
+    __syncthreads();
+    const RxProgram& P = sP;
     for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < a.n_docs; d += (int64_t)gridDim.x * blockDim.x) {
         const int64_t o0 = a.doc_offsets[d], o1 = a.doc_offsets[d + 1];
         if (o0 < 0 || o1 > a.n || o1 <= o0) continue;

@@ -510,6 +510,14 @@ bool rx_compile(const std::string& pattern, RxProgram& P, std::string& err) {
         ++R.i;  // '|'
         if (R.eof()) { err = "split pattern ends in '|'"; return false; }
     }
+    // membership of the ASCII code points, once (the matcher tests one bit for them)
+    const RxTables T = rx_host_tables();
+    for (uint32_t c = 0; c < P.n_classes; ++c) {
+        uint32_t m[4] = {0, 0, 0, 0};
+        for (uint32_t cp = 0; cp < 128u; ++cp)
+            if (rx_in_class_slow(P, T, c, cp)) m[cp >> 5] |= 1u << (cp & 31u);
+        for (int k = 0; k < 4; ++k) P.classes[c].ascii[k] = m[k];
+    }
     return true;
 }
 

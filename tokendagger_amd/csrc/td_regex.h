@@ -48,7 +48,12 @@ struct RxItem {        // one member of a character class
     uint8_t negate;    // \S \W \D \P{..}
     uint8_t pad[2];
 };
-struct RxClass { uint16_t first_item, n_items; uint8_t negate; uint8_t pad[3]; };
+struct RxClass {
+    uint16_t first_item, n_items;
+    uint8_t negate;
+    uint8_t pad[3];
+    uint32_t ascii[4];  // membership of the code points 0..127, filled in by rx_compile: ASCII text never walks the items
+};
 struct RxLit { uint16_t off, len; };
 struct RxNode {
     uint8_t kind;        // RxKind
@@ -103,7 +108,12 @@ TD_HD int64_t rx_prev_char(const A& s, int64_t lo, int64_t e, int64_t n) {
     return (p + (int64_t)len == e) ? p : e - 1;
 }
 
+TD_HD bool rx_in_class_slow(const RxProgram& P, const RxTables& T, uint32_t cls, uint32_t cp);
 TD_HD bool rx_in_class(const RxProgram& P, const RxTables& T, uint32_t cls, uint32_t cp) {
+    if (cp < 128u) return (P.classes[cls].ascii[cp >> 5] >> (cp & 31u)) & 1u;
+    return rx_in_class_slow(P, T, cls, cp);
+}
+TD_HD bool rx_in_class_slow(const RxProgram& P, const RxTables& T, uint32_t cls, uint32_t cp) {
     const RxClass c = P.classes[cls];
     uint32_t props = 28u;  // (category Cs: nothing) for bytes outside UTF-8
     if (cp < 0x110000u) props = T.stage2[(uint32_t)T.stage1[cp >> 8] * 256u + (cp & 255u)];
