@@ -153,3 +153,41 @@ def test_gpu_left_context_assertions_refuse_special_cuts():
     with pytest.raises(tiktoken.TokenDaggerError):
         enc.encode(s, allowed_special="all")
     assert special["<|begin_of_text|>"] in plain.encode(s, allowed_special="all")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_gpu_generic_chunks_inside_large_documents():
+    """The generic engine matches 1 KiB chunks speculatively and checks them against their predecessors (td_generic.hip): one
+    document of megabytes, documents that start and end anywhere relative to the chunk grid, multi-byte characters and skipped
+    text across chunk boundaries, pieces longer than a chunk (every chunk inside leaves with the same exit), and patterns whose
+    matches depend on look-ahead — all against PCRE2 running the very pattern."""
+    import td_corpus
+    from tokendagger_amd import capi
+    _, mr, special = H.llama4()
+    rng = random.Random(12)
+    eng, _ = td_corpus.english(3 << 20, seed=8)
+    mix, _ = td_corpus.mixed(2 << 20, seed=8)
+    code, _ = td_corpus.code(1 << 20, seed=8)
+    eng, mix, code = eng.tobytes(), mix.tobytes(), code.tobytes()
+    snake = ("snake_case_name = naïve_café_%d; " * 40000 % tuple(range(40000))).encode()
+    longrun = eng[:3000] + b"a" * 5000 + b" " * 3000 + b"_" * 2500 + eng[:3000] + "é".encode() * 2000 + eng[:5000]
+    for name in ("autogen", "words", "look", "cats", "lit", "wordb", "scripts"):
+        pat = PATTERNS[name]
+        tok = capi.HipTokenizer(pat, mr, special, device=0)
+        R = ref.RefTokenizer(pat, mr, special)
+        for what, text, offs in (
+                ("english, one document", eng, [0, len(eng)]),
+                ("mixed-script, one document", mix, [0, len(mix)]),
+                ("code + snake_case (skipped text), one document", code + snake, [0, len(code) + len(snake)]),
+                ("long runs", longrun, [0, len(longrun)]),
+                ("documents cut anywhere", eng[:1 << 20], sorted(set([0, 1 << 20] + [rng.randrange(1 << 20) for _ in range(700)]))),
+                ("documents around the chunk grid", eng[:40000], sorted(set([0, 40000, 1023, 1024, 1025, 2047, 2048, 2049, 3072, 5000, 5001, 9216])))):
+            if name in ("look", "lit") and what == "long runs":
+                continue  # (these back out of a long run one character at a time at every start: quadratic for PCRE2 and for a lane alike)
+            offs = np.asarray(offs, dtype=np.int64)
+            toks, toffs = tok.encode_batch(text, offs)
+            _, etoks, eoffs = R.encode_batch(np.frombuffer(text, dtype=np.uint8), offs, n_threads=8, want_tokens=True)
+            assert np.array_equal(toffs, eoffs), (name, what)
+            assert np.array_equal(toks, etoks), (name, what)
+        tok.close()

@@ -153,7 +153,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, gapbits, gx_exit, gx_state, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -288,7 +288,12 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->flagged_list, (size_t)(n_tiles + 64) * 4))) return rc;
     if ((rc = ensure(t, t->deferred_list, (size_t)(n_tiles + 64) * 4))) return rc;
-    if (t->H.pattern_kind == PATTERN_GENERIC && (rc = ensure(t, t->gap_list, (size_t)(n / 2 + 4096) * 8))) return rc;  // (a skipped stretch and the piece behind it take two bytes at least)
+    if (t->H.pattern_kind == PATTERN_GENERIC) {
+        if ((rc = ensure(t, t->gap_list, (size_t)(n / 1024 + 64) * 4))) return rc;   // chunks that failed the check
+        if ((rc = ensure(t, t->gapbits, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
+        if ((rc = ensure(t, t->gx_exit, (size_t)(n / 1024 + 2) * 8))) return rc;
+        if ((rc = ensure(t, t->gx_state, (size_t)(n / 1024 + 2) * 4))) return rc;
+    }
     if ((rc = ensure(t, t->miss_list, (size_t)(n_tiles + 1) * K_MISS_LISTED_MAX * K_MISS_CLASSES * 8))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
     if ((rc = ensure(t, t->doc_slot, (size_t)(n_docs + 1) * 4))) return rc;
@@ -354,7 +359,10 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.rx_stage1 = t->d_rx_s1;
     a.rx_stage2 = t->d_rx_s2;
     a.gap_list = (int64_t*)t->gap_list.p;
-    a.gap_cap = (uint32_t)std::min<size_t>(t->gap_list.cap / 8, 0x7FFFFFF0u);
+    a.gap_cap = (uint32_t)std::min<size_t>(t->gap_list.cap / 4, 0x7FFFFFF0u);
+    a.gapbits = (uint32_t*)t->gapbits.p;
+    a.gx_exit = (int64_t*)t->gx_exit.p;
+    a.gx_state = (uint32_t*)t->gx_state.p;
     a.gap_count = &ctl->gap_count;
     a.flagged_list = (uint32_t*)t->flagged_list.p;
     a.deferred_list = (uint32_t*)t->deferred_list.p;
@@ -566,7 +574,7 @@ void td_destroy(td_tokenizer* t) {
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
         if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->gap_list, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)

@@ -1,12 +1,12 @@
 // Generic split patterns on the device: what td_regex.cpp compiled is matched by the backtracking matcher of
-// td_regex.h, ONE LANE PER DOCUMENT (documents are independent subjects, tiktoken.cpp:86-122; without pattern-specific
-// synchronisation rules there is nothing provable inside one).  The kernel writes the same START bitmap the family's
-// td_split_tiles writes, so td_probe_tiles and everything behind it run unchanged.
+// td_regex.h, ONE LANE PER 1 KiB CHUNK of the text, speculatively inside a document and checked afterwards (below; round 2
+// ran one lane per document: as fast as its longest document was long).  The kernels write the same START bitmap the
+// family's td_split_tiles writes, so td_probe_tiles and everything behind it run unchanged.
 //
-// Text the pattern SKIPS (the reference tokenizes only what matches) becomes a piece of its own in the bitmap and is noted on
-// a list; after the merge kernels td_generic_gaps turns such a piece's slot into a marker with zero ids and takes the ids it
-// had been given out of the tile's count, so td_pack_tokens (which already expands markers of any size) leaves it out.
-// This first form is as fast as its longest document is long; the members of the family keep their own kernels.
+// Text the pattern SKIPS (the reference tokenizes only what matches) becomes a piece of its own in the bitmap and is noted in
+// a second bitmap; after the merge kernels td_generic_gaps turns such a piece's slot into a marker with zero ids and takes
+// the ids it had been given out of the tile's count, so td_pack_tokens (which already expands markers of any size) leaves it
+// out.  The members of the family keep their own kernels.
 #include <hip/hip_runtime.h>
 
 #include "td_kernels.h"
@@ -19,75 +19,251 @@ struct GlobalDoc {  // the subject: one document of the batch
     const uint8_t* p;
     __device__ __forceinline__ uint32_t byte(int64_t i) const { return p[i]; }
 };
+// The same with the 16 bytes around the last position read kept in registers: the matcher walks its subject a character at
+// a time, and a byte load per character was a cache round trip per character in a dependent chain (64 different cache
+// lines per wavefront load).  `text` is the whole batch (16-byte aligned), o0 the document's offset in it, n_text its size.
+struct WindowDoc {
+    const uint8_t* text;
+    int64_t o0, n_text;
+    mutable int64_t blk;
+    mutable uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ uint32_t byte(int64_t i) const {
+        const int64_t g = o0 + i, b = g >> 4;
+        if (b != blk) {
+            blk = b;
+            if (16 * b + 16 <= n_text) {
+                const uint4 v = *reinterpret_cast<const uint4*>(text + 16 * b);
+                w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
+            } else {  // (the last, partial block of the text)
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16 && 16 * b + k < n_text; ++k) t[k >> 2] |= (uint32_t)text[16 * b + k] << (8 * (k & 3));
+                w0 = t[0]; w1 = t[1]; w2 = t[2]; w3 = t[3];
+            }
+        }
+        const uint32_t k = (uint32_t)g & 15u;
+        const uint32_t lo = (k & 4u) ? w1 : w0, hi = (k & 4u) ? w3 : w2;
+        return (((k & 8u) ? hi : lo) >> (8u * (k & 3u))) & 0xFFu;
+    }
+};
 __device__ __forceinline__ void raise_g(const EncodeArgs& a, int code, int64_t pos) {
     if (atomicCAS(a.err, 0, code) == 0) *a.err_pos = pos;
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void td_split_generic(const EncodeArgs a) {
+// ---- inside a document: speculative chunks ---------------------------------------------------------------------------
+// The next piece from a position depends on the position and the subject only (rx_next_piece has no other state), so a
+// document can be matched in CHUNKS in parallel: every lane starts at the first character boundary of its 1 KiB chunk as if
+// a piece started there, marks the piece starts it finds and notes where it left the chunk (its EXIT: the first piece start
+// at or behind the chunk end).  td_generic_commit then checks every chunk against its predecessor: the predecessor's exit
+// is this chunk's true ENTRY; if the chunk's own run marked a piece start exactly there, everything it found from there on
+// is what a sequential run finds (induction from the document start, which is a true start), and what it marked in front
+// of it was speculation and is cleared.  A chunk that lies inside one long piece must have left with the same exit.
+// Matchers of tokenizer patterns resynchronise within a piece or two, so nearly every chunk passes; the documents of the
+// others are redone from their first failing chunk by one lane (td_generic_redo).  Documents that start inside a chunk
+// start with a true piece start and need no check.
+constexpr int GX_CHUNK = 1024;  // bytes per lane (a multiple of 32: a lane owns whole words of the bitmaps)
+
+struct GxWords {  // the lane's words of the START / gap bitmaps, written in increasing order
+    uint32_t* sb;
+    uint32_t* gb;
+    int64_t cw;       // word being filled
+    uint32_t s, g;
+    __device__ __forceinline__ void upto(int64_t w) {  // words below w are complete
+        while (cw < w) { sb[cw] = s; gb[cw] = g; ++cw; s = 0; g = 0; }
+    }
+    __device__ __forceinline__ void mark(int64_t p, bool gap) {
+        upto(p >> 5);
+        s |= 1u << (p & 31);
+        if (gap) g |= 1u << (p & 31);
+    }
+};
+
+// piece starts of text[from, lim) inside document [o0, o1), matching from `from`; returns the first piece start >= lim (or o1)
+template <class W>
+__device__ __forceinline__ int64_t gx_run(const RxProgram& P, const RxTables& T, const uint8_t* text, int64_t n_text, bool aligned, int64_t o0,
+                                          int64_t o1, int64_t from, int64_t lim, W& out) {
+    const int64_t n = o1 - o0;
+    int64_t pos = from - o0;
+    if (!aligned) {  // (a text pointer that is not 16-byte aligned: plain byte loads)
+        const GlobalDoc s{text + o0};
+        while (pos < n) {
+            if (o0 + pos >= lim) return o0 + pos;
+            int64_t ms, me;
+            rx_next_piece(P, T, s, pos, n, ms, me);
+            if (ms > pos) {
+                out.mark(o0 + pos, true);
+                if (o0 + ms >= lim) return o0 + ms;
+            }
+            out.mark(o0 + ms, false);
+            pos = me;
+        }
+        return o1;
+    }
+    const WindowDoc s{text, o0, n_text, -1, 0u, 0u, 0u, 0u};
+    while (pos < n) {
+        if (o0 + pos >= lim) return o0 + pos;
+        int64_t ms, me;
+        rx_next_piece(P, T, s, pos, n, ms, me);
+        if (ms > pos) {  // skipped text: a piece of its own, without tokens
+            out.mark(o0 + pos, true);
+            if (o0 + ms >= lim) return o0 + ms;
+        }
+        out.mark(o0 + ms, false);
+        pos = me;
+    }
+    return o1;
+}
+
+#ifndef TD_GX_WAVES
+#define TD_GX_WAVES 2
+#endif
+__global__ __launch_bounds__(256, TD_GX_WAVES) void td_generic_chunks(const EncodeArgs a) {
     const RxTables T{a.rx_stage1, a.rx_stage2};
-    // the compiled pattern in LDS: the matcher reads a node, a class or a literal at every step, and out of HBM each of
-    // those was a cache round trip in the middle of a dependent chain
-    __shared__ RxProgram sP;
+    __shared__ RxProgram sP;  // (the matcher reads a node, a class or a literal at every step: out of HBM each was a cache round trip)
     static_assert(sizeof(RxProgram) % 4 == 0, "copied as dwords");
     for (uint32_t w = threadIdx.x; w < sizeof(RxProgram) / 4; w += blockDim.x)
         reinterpret_cast<uint32_t*>(&sP)[w] = reinterpret_cast<const uint32_t*>(a.rx)[w];
     __syncthreads();
     const RxProgram& P = sP;
-    for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < a.n_docs; d += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t o0 = a.doc_offsets[d], o1 = a.doc_offsets[d + 1];
-        if (o0 < 0 || o1 > a.n || o1 <= o0) continue;
-        const GlobalDoc s{a.text + o0};
-        const int64_t n = o1 - o0;
-        for (int64_t pos = 0; pos < n;) {
-            int64_t ms, me;
-            rx_next_piece(P, T, s, pos, n, ms, me);
-            if (ms > pos) {  // skipped text: a piece of its own, without tokens
-                const uint32_t gi = atomicAdd(a.gap_count, 1u);
-                if (gi < a.gap_cap) a.gap_list[gi] = o0 + pos;
-                else raise_g(a, TD_E_SCRATCH, o0 + pos);
-                atomicOr(&a.startbits[(o0 + pos) >> 5], 1u << ((o0 + pos) & 31));
+    const int64_t n_chunks = (a.n + GX_CHUNK - 1) / GX_CHUNK;
+    for (int64_t ch = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ch < n_chunks; ch += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c0 = ch * GX_CHUNK, c1 = (c0 + GX_CHUNK < a.n) ? c0 + GX_CHUNK : a.n;
+        // the document that holds c0: the last one with offset <= c0 (behind empty ones at the same offset)
+        int64_t lo = 0, hi = a.n_docs;  // doc_offsets[lo] <= c0 < doc_offsets[hi]
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.doc_offsets[mid] <= c0) lo = mid; else hi = mid;
+        }
+        GxWords W{a.startbits, a.gapbits, c0 >> 5, 0u, 0u};
+        int64_t exit_at = -1;
+        for (int64_t d = lo; d < a.n_docs; ++d) {
+            const int64_t o0 = a.doc_offsets[d], o1 = a.doc_offsets[d + 1];
+            if (o0 >= c1) break;
+            if (o1 <= o0) continue;
+            int64_t from = o0;
+            if (o0 < c0) {  // the chunk starts inside this document: speculate from its first character boundary
+                from = c0;
+                for (int k = 0; k < 3 && from < o1 && (a.text[from] & 0xC0u) == 0x80u; ++k) ++from;
             }
-            atomicOr(&a.startbits[(o0 + ms) >> 5], 1u << ((o0 + ms) & 31));
-            pos = me;
+            const int64_t e = gx_run(P, T, a.text, a.n, a.text_aligned != 0, o0, o1, from, c1, W);
+            if (e >= c1) { exit_at = e; break; }
+        }
+        if (exit_at < 0) exit_at = c1;
+        W.upto((c1 + 31) >> 5);
+        if (c1 == a.n) {  // the words behind the text (td_probe_tiles reads a few of them)
+            const int64_t wend = ((a.n + 31) >> 5) + 8;
+            for (int64_t w = (c1 + 31) >> 5; w < wend; ++w) { a.startbits[w] = 0; a.gapbits[w] = 0; }
+        }
+        a.gx_exit[ch] = exit_at;
+    }
+}
+
+__device__ __forceinline__ void gx_clear_below(uint32_t* bits, int64_t c0, int64_t upto) {  // clear bits [c0, upto), c0 word-aligned
+    for (int64_t w = c0 >> 5; w < (upto >> 5); ++w) bits[w] = 0;
+    if (upto & 31) bits[upto >> 5] &= ~((1u << (upto & 31)) - 1u);
+}
+
+__global__ __launch_bounds__(256) void td_generic_commit(const EncodeArgs a) {
+    const int64_t n_chunks = (a.n + GX_CHUNK - 1) / GX_CHUNK;
+    for (int64_t ch = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ch < n_chunks; ch += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c0 = ch * GX_CHUNK, c1 = (c0 + GX_CHUNK < a.n) ? c0 + GX_CHUNK : a.n;
+        bool valid = true;
+        if (!((a.docbits[c0 >> 5] >> (c0 & 31)) & 1u)) {  // the chunk starts inside a document: its head [c0, h) was speculation
+            int64_t h = c1;  // first document start inside the chunk
+            for (int64_t w = c0 >> 5; w < ((c1 + 31) >> 5) && h == c1; ++w) {
+                uint32_t m = a.docbits[w];
+                if (w == (c1 >> 5) && (c1 & 31)) m &= (1u << (c1 & 31)) - 1u;
+                if (m) h = w * 32 + (__ffs(m) - 1);
+            }
+            const int64_t t = a.gx_exit[ch - 1];  // the true entry: where the chunk in front left off
+            if (t >= h) {  // no piece of that document starts in the head
+                gx_clear_below(a.startbits, c0, h);
+                gx_clear_below(a.gapbits, c0, h);
+                valid = h < c1 || a.gx_exit[ch] == t;  // (inside one long piece: the exit carries over)
+            } else {
+                valid = (a.startbits[t >> 5] >> (t & 31)) & 1u;
+                gx_clear_below(a.startbits, c0, t);
+                gx_clear_below(a.gapbits, c0, t);
+            }
+        }
+        a.gx_state[ch] = valid ? 1u : 0u;
+        if (!valid) {
+            const uint32_t at = atomicAdd(a.gap_count, 1u);
+            if (at < a.gap_cap) reinterpret_cast<uint32_t*>(a.gap_list)[at] = (uint32_t)ch;
+            else raise_g(a, TD_E_SCRATCH, c0);
         }
     }
 }
 
-// one lane per skipped stretch: its slot (= pieces of its tile in front of it) becomes TOK_MISS | position | 0 ids
+// the rest of a document from its first chunk that failed the check, by one lane (rare)
+__global__ __launch_bounds__(64) void td_generic_redo(const EncodeArgs a) {
+    const RxTables T{a.rx_stage1, a.rx_stage2};
+    const RxProgram& P = *a.rx;
+    const uint32_t nbad = *a.gap_count < a.gap_cap ? *a.gap_count : a.gap_cap;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nbad; j += gridDim.x * blockDim.x) {
+        const int64_t ch = reinterpret_cast<const uint32_t*>(a.gap_list)[j];
+        if (ch > 0 && a.gx_state[ch - 1] == 0u) continue;  // (an earlier chunk of the same document failed too: its lane goes on to the end)
+        const int64_t c0 = ch * GX_CHUNK;
+        int64_t lo = 0, hi = a.n_docs;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.doc_offsets[mid] <= c0) lo = mid; else hi = mid;
+        }
+        const int64_t o0 = a.doc_offsets[lo], o1 = a.doc_offsets[lo + 1];
+        const int64_t t = a.gx_exit[ch - 1];
+        // bits of [c0, o1) anew; the word that holds o1 keeps what belongs to the next document
+        const int64_t wlast = o1 >> 5;
+        const uint32_t keep_s = (o1 & 31) ? a.startbits[wlast] & ~((1u << (o1 & 31)) - 1u) : 0u;
+        const uint32_t keep_g = (o1 & 31) ? a.gapbits[wlast] & ~((1u << (o1 & 31)) - 1u) : 0u;
+        GxWords W{a.startbits, a.gapbits, c0 >> 5, 0u, 0u};
+        if (t < o1) (void)gx_run(P, T, a.text, a.n, false, o0, o1, t, o1, W);
+        W.upto(wlast);
+        if (o1 & 31) { a.startbits[wlast] = W.s | keep_s; a.gapbits[wlast] = W.g | keep_g; }
+    }
+}
+
+// one lane per word of the gap bitmap: the slot of a skipped stretch (= pieces of its tile in front of it) becomes
+// TOK_MISS | position | 0 ids
 __global__ __launch_bounds__(256) void td_generic_gaps(const EncodeArgs a) {
-    const uint32_t ng = *a.gap_count < a.gap_cap ? *a.gap_count : a.gap_cap;
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += gridDim.x * blockDim.x) {
-        const int64_t p = a.gap_list[g];
-        const int64_t tile = p / K_TILE;
-        const int64_t w0 = (tile * K_TILE) >> 5, w1 = p >> 5;
-        uint32_t slot = 0;
-        for (int64_t w = w0; w < w1; ++w) slot += (uint32_t)__popc(a.startbits[w]);
-        slot += (uint32_t)__popc(a.startbits[w1] & ((1u << (p & 31)) - 1u));
-        uint32_t* sp = a.stage + (size_t)tile * K_STAGE + slot;
-        const uint32_t v = *sp;
-        uint32_t had = 1;  // ids the piece was given
-        if (v & TOK_LONGREF) had = a.long_list[v & 0x7FFFFFFFu].ntok;
-        else if (v & TOK_MISS) had = v & 127u;
-        *sp = TOK_MISS | ((uint32_t)(p - tile * K_TILE) << 7);
-        atomicAdd(&a.tile_extra[tile], 0u - had);  // (the scan adds counts and extras modulo 2^32)
-        atomicOr(&a.tile_count[tile], TILE_MISS_LISTED);
+    const int64_t nw = (a.n + 31) >> 5;
+    for (int64_t gw = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gw < nw; gw += (int64_t)gridDim.x * blockDim.x) {
+        for (uint32_t m = a.gapbits[gw]; m; m &= m - 1u) {
+            const int64_t p = gw * 32 + (__ffs(m) - 1);
+            if (p >= a.n) break;
+            const int64_t tile = p / K_TILE;
+            const int64_t w0 = (tile * K_TILE) >> 5, w1 = p >> 5;
+            uint32_t slot = 0;
+            for (int64_t w = w0; w < w1; ++w) slot += (uint32_t)__popc(a.startbits[w]);
+            slot += (uint32_t)__popc(a.startbits[w1] & ((1u << (p & 31)) - 1u));
+            uint32_t* sp = a.stage + (size_t)tile * K_STAGE + slot;
+            const uint32_t v = *sp;
+            uint32_t had = 1;  // ids the piece was given
+            if (v & TOK_LONGREF) had = a.long_list[v & 0x7FFFFFFFu].ntok;
+            else if (v & TOK_MISS) had = v & 127u;
+            *sp = TOK_MISS | ((uint32_t)(p - tile * K_TILE) << 7);
+            atomicAdd(&a.tile_extra[tile], 0u - had);  // (the scan adds counts and extras modulo 2^32)
+            atomicOr(&a.tile_count[tile], TILE_MISS_LISTED);
+        }
     }
 }
 
 hipError_t launch_generic_split(const EncodeArgs& a, hipStream_t stream) {
-    const size_t words = (size_t)((a.n + 31) / 32 + 8);
-    hipError_t e = hipMemsetAsync(a.startbits, 0, words * 4, stream);
-    if (e != hipSuccess) return e;
-    int64_t blocks = (a.n_docs + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    const int64_t n_chunks = (a.n + GX_CHUNK - 1) / GX_CHUNK;
+    int64_t blocks = (n_chunks + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(td_split_generic, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(td_generic_chunks, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(td_generic_commit, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(td_generic_redo, dim3(256), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_generic_gaps(const EncodeArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(td_generic_gaps, dim3(256), dim3(256), 0, stream, a);
+    const int64_t nw = (a.n + 31) >> 5;
+    int64_t blocks = (nw + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(td_generic_gaps, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -54,9 +54,12 @@ struct EncodeArgs {
     const RxProgram* rx;        // the compiled pattern
     const uint16_t* rx_stage1;  // general-category table (generated/unicode_gc.inc)
     const uint8_t* rx_stage2;
-    int64_t* gap_list;          // global byte positions of the stretches the pattern skips (they get no tokens)
+    int64_t* gap_list;          // (as uint32) the chunks that failed td_generic_commit's check
     uint32_t* gap_count;
     uint32_t gap_cap;
+    uint32_t* gapbits;          // [(n+31)/32+8] bit i set <=> a stretch of text the pattern skips starts at byte i (it gets no tokens)
+    int64_t* gx_exit;           // [n / 1024 + 1] per chunk: the first piece start at or behind the chunk end, as its own run found it
+    uint32_t* gx_state;         // [n / 1024 + 1] per chunk: 1 = its run agrees with the chunk in front of it
     uint32_t* deferred_list;    // fused tile loop (td_split_tiles<.., true>): the token tiles it left to td_probe_tiles
     uint32_t* deferred_count;   // entries on it
     int fused;                  // launch the fused tile loop (pre-tokenizer + lookup in one pass over the text)

@@ -151,8 +151,18 @@ TD_HD int rx_lit_at(const RxProgram& P, const RxLit l, bool caseless, const A& s
 // one alternative, anchored at `start`: end of its (non-empty) match, or -1
 template <class A>
 TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt alt, const A& s, int64_t start, int64_t n) {
-    int64_t beg[RX_MAX_SEQ], end[RX_MAX_SEQ];
-    uint32_t cnt[RX_MAX_SEQ];  // RX_CLASS: characters taken; RX_LITSET: literal chosen (b = skipped)
+    // (offsets from `start` in 32 bits: the backtracking state is what the matcher's registers go to on the device, and
+    // 64-bit positions doubled it; a single match is cut off 2 GiB behind its start)
+    if (n - start > 0x7FFFFFF0ll) n = start + 0x7FFFFFF0ll;
+    int32_t end_[RX_MAX_SEQ + 1];  // end_[i + 1] = where node i's match ends; end_[0] = 0: a node begins where the one in front of it ends
+    uint32_t cnt[RX_MAX_SEQ];      // RX_CLASS: characters taken; RX_LITSET: literal chosen (b = skipped)
+    end_[0] = 0;
+    struct Rel {
+        int32_t* v; int64_t base;
+        struct Ref { int32_t* p; int64_t base; TD_HD operator int64_t() const { return base + *p; } TD_HD Ref& operator=(int64_t x) { *p = (int32_t)(x - base); return *this; } };
+        TD_HD Ref operator[](int i) const { return Ref{v + i, base}; }
+    };
+    const Rel beg{end_, start}, end{end_ + 1, start};  // (beg[i] reads end[i - 1])
     const int nn = (int)alt.n_nodes;
     int i = 0;
     int64_t pos = start;
@@ -166,7 +176,6 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
             }
             const RxNode nd = P.nodes[alt.first_node + i];
             bool ok = true;
-            beg[i] = pos;
             if (nd.kind == RX_CLASS) {
                 uint32_t c = 0;
                 int64_t p = pos;
