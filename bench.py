@@ -238,6 +238,48 @@ def verify_against_oracle(x, offs, got_tok, got_off, pat, ranks, special, thread
         return "port-sample", ok, "" if ok else "mismatch inside the first 4 MiB"
 
 
+def verify_special_against_oracle(x, offs, got_tok, got_off, pat, ranks, special, threads: int):
+    """allowed_special = all: tiktoken's segmentation restated here (scanning forward, the longest special literal at a
+    position is cut out; the reference's own loop, tiktoken.cpp:130-154, is undefined behaviour), every segment encoded by the
+    compiled reference as a subject of its own, the special ids put in between.  -> (label, ok, detail)"""
+    import re
+    R = reference_tokenizer(pat, ranks, special)
+    lits = sorted((k.encode("utf-8") for k in special), key=lambda b: -len(b))
+    rx = re.compile(b"|".join(re.escape(b) for b in lits))
+    ids = {k.encode("utf-8"): v for k, v in special.items()}
+    buf = x.tobytes()
+    seg_offs, after, doc_first = [0], [], [0]  # segments as documents of the reference; the special id behind each (-1: none)
+    seg_src = []
+    for d in range(len(offs) - 1):
+        lo, hi = int(offs[d]), int(offs[d + 1])
+        p = lo
+        for m in rx.finditer(buf, lo, hi):
+            seg_src.append((p, m.start())); after.append(ids[m.group()]); p = m.end()
+        seg_src.append((p, hi)); after.append(-1)
+        doc_first.append(len(seg_src))
+    seg_text = np.concatenate([x[a:b] for a, b in seg_src]) if seg_src else np.zeros(0, np.uint8)
+    lens = np.asarray([b - a for a, b in seg_src], dtype=np.int64)
+    so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    if len(seg_text) == 0:
+        seg_text = np.zeros(1, np.uint8)
+    _, et, eo = R.encode_batch(seg_text, so, n_threads=max(1, threads), want_tokens=True)
+    # stitch
+    aft = np.asarray(after, dtype=np.int64)
+    extra = (aft >= 0).astype(np.int64)
+    seg_out = np.diff(eo) + extra                      # ids each segment contributes, its special included
+    out_off = np.concatenate([[0], np.cumsum(seg_out)])
+    exp = np.empty(int(out_off[-1]), dtype=np.int32)
+    # the segments' own ids
+    starts = out_off[:-1]
+    idx = np.repeat(starts - eo[:-1], np.diff(eo)) + np.arange(len(et))
+    exp[idx] = et
+    sp_pos = (out_off[1:] - 1)[aft >= 0]
+    exp[sp_pos] = aft[aft >= 0].astype(np.int32)
+    exp_doc = out_off[np.asarray(doc_first, dtype=np.int64)]
+    ok = bool(np.array_equal(exp_doc, got_off) and np.array_equal(exp, got_tok))
+    return "reference-full on every segment between special tokens (tiktoken segmentation restated in bench.py)", ok, "" if ok else _first_mismatch(offs, exp_doc, got_off, exp, got_tok)
+
+
 def _first_mismatch(offs, eo, go, et, gt) -> str:
     bad = np.nonzero(eo != go)[0]
     d = int(bad[0]) - 1 if len(bad) else -1
@@ -261,7 +303,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--corpus", default="english", choices=["english", "mixed", "code", "code_files"])
+    ap.add_argument("--corpus", default="english", choices=["english", "mixed", "code", "code_files", "chat"])
+    ap.add_argument("--allowed-special", default="none", choices=["none", "all"],
+                    help="all: every special token is searched for and cut out on the device (td_encode_device_with_special); "
+                         "meant for --corpus chat")
     ap.add_argument("--size-mb", type=int, default=1024, help="MiB of text (whole job for strong scaling, per GPU for weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--pattern", default="llama4", choices=["llama4", "tekken", "generic:autogen", "generic:words"],
@@ -364,9 +409,15 @@ def main():
         dist.broadcast(idt, src=0)
         comm = capi.RcclComm(bytes(idt.cpu().numpy().tobytes()), world, rank, dev.index)
 
+    allowed_ids = sorted(special.values()) if a.allowed_special == "all" else []
+
     def step():
-        tok.encode_device(d_text.data_ptr(), n, d_offs.data_ptr(), n_docs, d_tok.data_ptr(), cap, d_toff.data_ptr(),
-                          stream.cuda_stream)
+        if allowed_ids:
+            tok.encode_device_with_special(d_text.data_ptr(), n, d_offs.data_ptr(), n_docs, allowed_ids, d_tok.data_ptr(), cap, d_toff.data_ptr(),
+                                           stream.cuda_stream)
+        else:
+            tok.encode_device(d_text.data_ptr(), n, d_offs.data_ptr(), n_docs, d_tok.data_ptr(), cap, d_toff.data_ptr(),
+                              stream.cuda_stream)
         if comm is not None:  # the same exchange through the C ABI (td_comm_gather_counts), on the step's own stream
             comm.gather_counts(mine.data_ptr(), gathered.data_ptr(), stream.cuda_stream)
         elif use_dist:  # the path's only exchange: per-rank {tokens, documents} -> global bases
@@ -429,7 +480,10 @@ def main():
         got_off = d_toff[:n_docs + 1].cpu().numpy()
         got_tok = d_tok[:n_tok].cpu().numpy()
         threads = max(1, (os.cpu_count() or 1) // world)
-        label, ok, vdetail = verify_against_oracle(x, offs, got_tok, got_off, pat, ranks, special, threads)
+        if allowed_ids:
+            label, ok, vdetail = verify_special_against_oracle(x, offs, got_tok, got_off, pat, ranks, special, threads)
+        else:
+            label, ok, vdetail = verify_against_oracle(x, offs, got_tok, got_off, pat, ranks, special, threads)
         if use_dist:
             flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=gdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -494,7 +548,7 @@ def main():
                     "the reference's code_performance_benchmark file set (tests/golden/code_corpus.npz), tiled",
             "config": {"workload": f"Llama-4-Scout vocab{' + tekken split pattern (config 4 surrogate: tekken.json missing)' if a.pattern == 'tekken' else (' + generic split pattern ' + pat if a.pattern.startswith('generic') else '')}, "
                                    f"{job_bytes >> 20} MiB {'of the code_performance_benchmark file set' if a.corpus == 'code_files' else 'synthetic ' + a.corpus + ' text'}, {g_docs} documents, "
-                                   f"CoreBPE::encode semantics, input resident in HBM",
+                                   f"CoreBPE::encode semantics{' with allowed_special = all (searched for and cut out on the device)' if a.allowed_special == 'all' else ''}, input resident in HBM",
                        "bytes": job_bytes, "tokens": job_tok, "docs": g_docs,
                        "bytes_rank0": n, "tokens_rank0": n_tok, "docs_rank0": n_docs,
                        "parallelism": (f"dp{world}: contiguous byte-balanced document shards, "

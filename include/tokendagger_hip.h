@@ -150,6 +150,18 @@ int td_encode_batch_with_special_strs(td_tokenizer* t, const uint8_t* text, cons
 #define TD_INFO_FLAGGED_TILES 10 /* token tiles whose missed pieces went to td_merge_pieces, last call */
 int64_t td_info(const td_tokenizer* t, int what);
 
+/*
+ * CoreBPE::encode(text, allowed_special) (tiktoken.cpp:169-234) on DEVICE-RESIDENT text, asynchronous like td_encode_device: the
+ * allowed special tokens (by id) are searched for and cut out on the device — scanning forward, the longest allowed literal
+ * that starts at a position is replaced by its id, the text between two cuts is tokenized as a subject of its own
+ * (td_special.hip; the same results as td_encode_batch_with_special, whose search runs on host threads).  One allowed set is
+ * kept on the device per handle; a call with a different set first waits for the previous call's kernels.  Patterns of the
+ * scanner family only (generic patterns: TD_E_PATTERN).
+ */
+int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n_bytes, const void* d_doc_offsets, int64_t n_docs,
+                                  const int32_t* allowed_ids, int64_t n_allowed, void* d_out_tokens, int64_t out_capacity,
+                                  void* d_out_offsets, void* hip_stream);
+
 /* Options. */
 #define TD_OPT_LONG_POOL_BYTES 1 /* scratch for pieces longer than 64 bytes (default max(64 MiB, 2 x input)) */
 #define TD_OPT_PROFILE 2         /* 1: bracket the kernels of every td_encode_device call with HIP events on the

@@ -238,3 +238,41 @@ def code_files(n_bytes: int = 0):
     x = np.tile(unit, reps)
     offs = np.concatenate([uo[:-1] + r * len(unit) for r in range(reps)] + [[reps * len(unit)]]).astype(np.int64)
     return np.ascontiguousarray(x), offs
+
+
+def chat(n_bytes: int, seed: int = 0):
+    """Chat-formatted corpus: the English generator's paragraphs as turns of conversations in the Llama-4 chat template
+    (<|begin_of_text|><|header_start|>role<|header_end|>\n\n ... <|eot|>), one conversation per document.  Special tokens
+    are ~3 % of the bytes.  Some turns mention a special token's literal inside running text and a few literals are cut short
+    ("<|eot", "<|header_start|"), so the search has near misses to reject.  -> (uint8[n_bytes], int64 doc_offsets)"""
+    rng = np.random.default_rng(seed + 77)
+    text, offs = english(n_bytes, seed=seed)
+    paras = [text[offs[i]:offs[i + 1]].tobytes().rstrip(b"\n") for i in range(len(offs) - 1)]
+    out, docs, total, k = [], [0], 0, 0
+    roles = [b"system", b"user", b"assistant", b"ipython"]
+    near = [b"<|eot", b"<|header_start|", b"<|", b"<|end_of_text|", b"|>", b"<|python_start|>", b"<|image|>", b"<|fim_middle|>"]
+    while total < n_bytes and k < len(paras):
+        conv = [b"<|begin_of_text|>"]
+        for t in range(int(rng.integers(1, 7))):
+            if k >= len(paras):
+                break
+            body = paras[k]
+            k += 1
+            if rng.random() < 0.08:
+                cut = int(rng.integers(0, len(body) + 1))
+                body = body[:cut] + near[int(rng.integers(0, len(near)))] + body[cut:]
+            conv += [b"<|header_start|>", roles[min(t, 1) if t < 2 else int(rng.integers(1, 4))], b"<|header_end|>\n\n", body,
+                     b"<|eot|>" if rng.random() < 0.9 else b"<|eom|>"]
+        if rng.random() < 0.3:
+            conv.append(b"<|end_of_text|>")
+        doc = b"".join(conv)
+        out.append(doc)
+        total += len(doc)
+        docs.append(total)
+    buf = np.frombuffer(b"".join(out), dtype=np.uint8)
+    if len(buf) >= n_bytes:
+        buf = buf[:n_bytes].copy()
+        d = np.asarray(docs, dtype=np.int64)
+        d = d[d < n_bytes]
+        return buf, np.concatenate([d, [n_bytes]]).astype(np.int64)
+    return buf.copy(), np.asarray(docs, dtype=np.int64)

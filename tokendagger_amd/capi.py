@@ -37,7 +37,7 @@ EXPORTS = [
     "td_create_from_vocab", "td_token_bytes", "td_single_token", "td_decode_device", "td_decode_batch", "td_encode_batch_with_special",
     "td_encode_with_special_strs", "td_encode_batch_with_special_strs", "td_profile_read_ex", "td_profile_segment_name",
     "td_comm_unique_id", "td_comm_create", "td_comm_destroy", "td_comm_gather_counts", "td_comm_bases", "td_comm_gather_tokens",
-    "td_comm_last_error",
+    "td_comm_last_error", "td_encode_device_with_special",
 ]
 
 
@@ -84,6 +84,8 @@ def load_library():
     _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(str(lib_path), mode=ctypes.RTLD_GLOBAL)
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    lib.td_encode_device_with_special.restype = i32
+    lib.td_encode_device_with_special.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp]
     lib.td_comm_unique_id.restype = i32
     lib.td_comm_unique_id.argtypes = [vp]
     lib.td_comm_create.restype = i32
@@ -451,6 +453,14 @@ class HipTokenizer:
         """Asynchronous on `stream`; d_out_offsets[n_docs] receives the total token count."""
         self._check(self._lib.td_encode_device(self._h, d_text, n_bytes, d_doc_offsets, n_docs, mode, d_out_tokens,
                                                out_capacity, d_out_offsets, stream))
+
+    def encode_device_with_special(self, d_text: int, n_bytes: int, d_doc_offsets: int, n_docs: int, allowed_ids, d_out_tokens: int,
+                                   out_capacity: int, d_out_offsets: int, stream: int = 0):
+        """td_encode_device_with_special: allowed special tokens (ids) are searched for and cut out ON THE DEVICE."""
+        ids = np.ascontiguousarray(np.asarray(sorted(set(int(i) for i in allowed_ids)), dtype=np.int32))
+        self._check(self._lib.td_encode_device_with_special(self._h, ctypes.c_void_p(d_text), n_bytes, ctypes.c_void_p(d_doc_offsets), n_docs,
+                                                            ids.ctypes.data_as(ctypes.c_void_p), len(ids), ctypes.c_void_p(d_out_tokens),
+                                                            out_capacity, ctypes.c_void_p(d_out_offsets), ctypes.c_void_p(stream)))
 
     def device_status(self, stream: int = 0):
         pos = ctypes.c_int64(0)

@@ -165,6 +165,11 @@ struct td_tokenizer {
     EncodeArgs graph_key, last_key;
     hipStream_t graph_stream = nullptr, last_key_stream = nullptr;
     bool has_last_key = false;
+    // allowed special tokens on the device (td_encode_device_with_special): the sorted literal table of the last allowed set
+    std::vector<int32_t> sp_key;     // the allowed ids it was built for (sorted, unique)
+    DevBuf sp_bytes, sp_off, sp_len, sp_id, sp_parent, sp_first2, sp_hit, sp_acc, sp_cpos, sp_clit, sp_ccount;
+    uint32_t sp_n = 0, sp_maxlen = 0;
+    bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
     bool fused = true;  // pre-tokenizer and lookup in one pass over the text (TD_OPT_FUSED; TD_FUSED=0 in the environment turns it off)
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
     std::vector<Ev3> ev_pending, ev_free;
@@ -386,6 +391,22 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.use_fastpath = (mode == TD_MODE_ENCODE) || t->H.merge_closed;
     a.text_aligned = (((uintptr_t)d_text) & 15) == 0;
     a.stop_after = t->stop_after;
+    if (t->sp_active) {
+        a.sp.bytes = (const uint8_t*)t->sp_bytes.p;
+        a.sp.off = (const uint32_t*)t->sp_off.p;
+        a.sp.len = (const uint32_t*)t->sp_len.p;
+        a.sp.id = (const int32_t*)t->sp_id.p;
+        a.sp.parent = (const int32_t*)t->sp_parent.p;
+        a.sp.first2 = (const uint32_t*)t->sp_first2.p;
+        a.sp.hitbits = (uint32_t*)t->sp_hit.p;
+        a.sp.cand_pos = (int64_t*)t->sp_cpos.p;
+        a.sp.cand_lit = (int32_t*)t->sp_clit.p;
+        a.sp.cand_count = (uint32_t*)t->sp_ccount.p;
+        a.sp.cand_cap = (uint32_t)std::min<size_t>(t->sp_clit.cap / 4, 0x7FFFFFF0u);
+        a.sp.accbits = (uint32_t*)t->sp_acc.p;
+        a.sp.n = t->sp_n;
+        a.sp.maxlen = t->sp_maxlen;
+    }
     td_tokenizer::Ev3 ev{};
     if (t->profile) {
         if (!t->ev_free.empty()) { ev = t->ev_free.back(); t->ev_free.pop_back(); }
@@ -574,7 +595,7 @@ void td_destroy(td_tokenizer* t) {
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
         if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)
@@ -602,6 +623,101 @@ int td_encode_device(td_tokenizer* t, const void* d_text, int64_t n_bytes, const
     return locked(t, [&] {
         return encode_device_locked(t, d_text, n_bytes, d_doc_offsets, n_docs, mode, d_out_tokens, out_capacity,
                                     d_out_offsets, (hipStream_t)hip_stream);
+    });
+}
+
+// The allowed literals (every special string that carries one of the ids) as td_special.hip wants them: sorted bytewise, each
+// with the longest other literal that is a proper prefix of it, and the bitmap of their first two bytes.
+static int build_special_table(td_tokenizer* t, const int32_t* allowed_ids, int64_t n_allowed) {
+    std::vector<int32_t> key(allowed_ids, allowed_ids + n_allowed);
+    std::sort(key.begin(), key.end());
+    key.erase(std::unique(key.begin(), key.end()), key.end());
+    if (key == t->sp_key && t->sp_n) return TD_OK;
+    const HostTables& H = t->H;
+    std::vector<std::pair<std::string, int32_t>> lits;
+    for (int32_t id : key) {
+        bool found = false;
+        for (size_t k = 0; k < H.special_ids.size(); ++k)
+            if (H.special_ids[k] == id && !H.special_strs[k].empty()) { lits.emplace_back(H.special_strs[k], id); found = true; }
+        if (!found) { t->err = "Special token id " + std::to_string(id) + " not found in special encoder"; return TD_E_SPECIAL; }
+    }
+    std::sort(lits.begin(), lits.end(), [](const auto& x, const auto& y) { return x.first < y.first; });  // (bytewise: std::string compares as unsigned char)
+    lits.erase(std::unique(lits.begin(), lits.end(), [](const auto& x, const auto& y) { return x.first == y.first; }), lits.end());
+    const size_t n = lits.size();
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> off(n + 1, 0), lens(n + 1, 0), first2(2048, 0);
+    std::vector<int32_t> ids(n), parent(n, -1);
+    uint32_t maxlen = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const std::string& x = lits[i].first;
+        off[i] = (uint32_t)bytes.size();
+        lens[i] = (uint32_t)x.size();
+        bytes.insert(bytes.end(), x.begin(), x.end());
+        while (bytes.size() % 4) bytes.push_back(0);
+        if (x.size() > 48) { t->err = "special tokens longer than 48 bytes are not supported by the device search"; return TD_E_SPECIAL; }
+        ids[i] = lits[i].second;
+        maxlen = std::max<uint32_t>(maxlen, (uint32_t)x.size());
+        // longest proper prefix that is a literal: in sorted order a prefix stands in front of its extensions
+        for (size_t j = i; j-- > 0;) {
+            const std::string& y = lits[j].first;
+            if (y.size() < x.size() && x.compare(0, y.size(), y) == 0) { parent[i] = (int32_t)j; break; }
+            if (y.empty() || (uint8_t)y[0] != (uint8_t)x[0]) break;
+        }
+        const uint32_t b0 = (uint8_t)x[0];
+        if (x.size() == 1) for (uint32_t b1 = 0; b1 < 256; ++b1) first2[(b0 << 8 | b1) >> 5] |= 1u << ((b0 << 8 | b1) & 31);
+        else { const uint32_t kk = b0 << 8 | (uint8_t)x[1]; first2[kk >> 5] |= 1u << (kk & 31); }
+    }
+    if (bytes.empty()) bytes.push_back(0);
+    int rc;
+    if ((rc = ensure(t, t->sp_bytes, bytes.size() + 16))) return rc;
+    if ((rc = ensure(t, t->sp_off, (n + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->sp_len, (n + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->sp_id, std::max<size_t>(n, 1) * 4))) return rc;
+    if ((rc = ensure(t, t->sp_parent, std::max<size_t>(n, 1) * 4))) return rc;
+    if ((rc = ensure(t, t->sp_first2, 2048 * 4))) return rc;
+    HIP_TRY(t, hipMemcpy(t->sp_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    HIP_TRY(t, hipMemcpy(t->sp_off.p, off.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(t, hipMemcpy(t->sp_len.p, lens.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    if (n) HIP_TRY(t, hipMemcpy(t->sp_id.p, ids.data(), n * 4, hipMemcpyHostToDevice));
+    if (n) HIP_TRY(t, hipMemcpy(t->sp_parent.p, parent.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(t, hipMemcpy(t->sp_first2.p, first2.data(), 2048 * 4, hipMemcpyHostToDevice));
+    t->sp_key = key;
+    t->sp_n = (uint32_t)n;
+    t->sp_maxlen = maxlen;
+    return TD_OK;
+}
+
+int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n_bytes, const void* d_doc_offsets, int64_t n_docs,
+                                  const int32_t* allowed_ids, int64_t n_allowed, void* d_out_tokens, int64_t out_capacity,
+                                  void* d_out_offsets, void* hip_stream) {
+    if (!t || n_allowed < 0 || (n_allowed > 0 && !allowed_ids)) return TD_E_INVALID;
+    return locked(t, [&] {
+        if (n_allowed == 0 || n_bytes == 0)
+            return encode_device_locked(t, d_text, n_bytes, d_doc_offsets, n_docs, TD_MODE_ENCODE, d_out_tokens, out_capacity, d_out_offsets,
+                                        (hipStream_t)hip_stream);
+        if (t->H.pattern_kind == PATTERN_GENERIC) {
+            t->err = "td_encode_device_with_special: generic split patterns take their subjects from the document offsets; use td_encode_batch_with_special";
+            return (int)TD_E_PATTERN;
+        }
+        int rc;
+        // (the table of the previous call may still be read by its kernels: a different allowed set waits for them)
+        {
+            std::vector<int32_t> key(allowed_ids, allowed_ids + n_allowed);
+            std::sort(key.begin(), key.end());
+            key.erase(std::unique(key.begin(), key.end()), key.end());
+            if (key != t->sp_key && t->has_last) HIP_TRY(t, hipStreamSynchronize(t->last_stream));
+        }
+        if ((rc = build_special_table(t, allowed_ids, n_allowed))) return rc;
+        if ((rc = ensure(t, t->sp_hit, (size_t)((n_bytes + 31) / 32 + 8) * 4))) return rc;
+        if ((rc = ensure(t, t->sp_acc, (size_t)((n_bytes + 31) / 32 + 8) * 4))) return rc;
+        if ((rc = ensure(t, t->sp_cpos, (size_t)(n_bytes / 32 + 4096) * 8))) return rc;   // candidates: room for one per 32 bytes
+        if ((rc = ensure(t, t->sp_clit, (size_t)(n_bytes / 32 + 4096) * 4))) return rc;
+        if ((rc = ensure(t, t->sp_ccount, 64))) return rc;
+        t->sp_active = t->sp_n != 0;
+        rc = encode_device_locked(t, d_text, n_bytes, d_doc_offsets, n_docs, TD_MODE_ENCODE, d_out_tokens, out_capacity, d_out_offsets,
+                                  (hipStream_t)hip_stream);
+        t->sp_active = false;
+        return rc;
     });
 }
 

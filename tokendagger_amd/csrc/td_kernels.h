@@ -16,6 +16,23 @@ struct LongEntry {      // a piece longer than K_MAXSHORT bytes, merged by td_lo
     uint64_t pool_off;  // out: offset (in u32) of its tokens inside the pool
 };
 
+// The allowed special literals of a call, sorted bytewise (td_special.hip), and the two bitmaps of the cut search.
+struct SpecialTable {
+    const uint8_t* bytes;     // the literals, each dword-aligned and zero-padded to a multiple of 4 bytes
+    const uint32_t* off;      // [n] byte offset of literal i (a multiple of 4)
+    const uint32_t* len;      // [n] its length in bytes
+    const int32_t* id;        // [n]
+    const int32_t* parent;    // [n] the longest other literal that is a proper prefix of literal i, or -1
+    const uint32_t* first2;   // [2048] bit (b0 << 8 | b1): a literal starts with these two bytes
+    int64_t* cand_pos;        // [cand_cap] positions whose first two bytes start an allowed literal
+    int32_t* cand_lit;        // [cand_cap] the literal matched there, or -1
+    uint32_t* cand_count;
+    uint32_t cand_cap;
+    uint32_t* hitbits;        // [(n_text+31)/32] an allowed literal matches at this byte
+    uint32_t* accbits;        // ... and is cut out (not inside a literal cut out in front of it)
+    uint32_t n, maxlen;       // literals; bytes of the longest one.  n == 0: no cuts in this call
+};
+
 struct EncodeArgs {
     const Tables* Tp;           // the table descriptor lives in device memory (keeps the kernel argument block small
                                 // and lets out-of-line helpers take a pointer without spilling kernargs to scratch)
@@ -64,6 +81,7 @@ struct EncodeArgs {
     uint32_t* deferred_count;   // entries on it
     int fused;                  // launch the fused tile loop (pre-tokenizer + lookup in one pass over the text)
     int probe_deferred;         // td_probe_tiles: only the tiles on deferred_list (set by launch_encode)
+    SpecialTable sp;            // allowed special tokens to cut out of the text (sp.n == 0: none)
     uint32_t* flagged_list;     // the tiles td_probe_tiles flagged TILE_HAS_MISS, in the order its workgroups appended them
     uint32_t* flagged_count;    // entries on it
     int64_t* chunk_pref;        // [n_tiles/4096 + 2] token base of every 4096-tile chunk (exclusive scan of the chunk totals)
@@ -139,6 +157,9 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
 // generic split patterns (td_generic.hip), called by launch_encode in place of td_split_tiles / ahead of td_scan_tiles
 hipError_t launch_generic_split(const EncodeArgs& a, hipStream_t stream);
 hipError_t launch_generic_gaps(const EncodeArgs& a, hipStream_t stream);
+// allowed special tokens (td_special.hip): the cuts behind td_mark_docs, the ids in front of td_scan_tiles
+hipError_t launch_special_cuts(const EncodeArgs& a, hipStream_t stream);
+hipError_t launch_special_ids(const EncodeArgs& a, hipStream_t stream);
 // phases: 1 = lengths + offsets (td_decode_len, td_decode_chunks, document byte offsets), 2 = gather (td_decode_copy), 3 = both
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, int phases = 3);
 int encode_grid_blocks();  // persistent grid size of td_probe_tiles

@@ -2941,6 +2941,10 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(td_mark_docs, dim3(blocks), dim3(256), 0, stream, a.doc_offsets, nd, a.n, a.docbits, a.tile_first_doc);
     }
+    if (a.sp.n) {  // allowed special tokens: their two ends become ends of subject
+        const hipError_t se = launch_special_cuts(a, stream);
+        if (se != hipSuccess) return se;
+    }
     const int sblocks = a.n_stiles < split_grid_blocks() ? a.n_stiles : split_grid_blocks();
     const int pblocks = a.n_tiles < encode_grid_blocks() ? a.n_tiles : encode_grid_blocks();
     if (ev) (void)hipEventRecord(ev[1], stream);
@@ -3001,6 +3005,10 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         if (a.pat_flags & PV_GENERIC) {  // text the pattern skips gets no tokens
             const hipError_t ge = launch_generic_gaps(a, stream);
             if (ge != hipSuccess) return ge;
+        }
+        if (a.sp.n) {  // the bytes of a special token that was cut out get its id
+            const hipError_t se = launch_special_ids(a, stream);
+            if (se != hipSuccess) return se;
         }
         hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
         if (ev) (void)hipEventRecord(ev[5], stream);
