@@ -174,6 +174,8 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
 #define TD_OPT_GRAPH 7            /* 0: never replay a repeated td_encode_device call as a hipGraph (default 1: the second identical call in a
                                     row captures the step's launches, the following ones are one graph launch; TD_GRAPH=0 in the
                                     environment at td_create time also turns it off) */
+#define TD_OPT_DEVICE_SPECIALS 8  /* 0: td_encode_batch_with_special* always search for the allowed specials on host threads (default 1:
+                                    batches of a MiB and more search on the device, td_special.hip; same results) */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 16) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 

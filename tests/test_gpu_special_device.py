@@ -41,7 +41,12 @@ def _device(tok, text: bytes, offs, allowed_ids):
 
 def _check(tok, text: bytes, offs, allowed_ids, what):
     dt_, do_ = _device(tok, text, offs, allowed_ids)
+    tok.set_option(capi.TD_OPT_DEVICE_SPECIALS, 0)  # the host-side search
     ht, ho = tok.encode_batch_with_special(text, np.asarray(offs, dtype=np.int64), sorted(allowed_ids))
+    tok.set_option(capi.TD_OPT_DEVICE_SPECIALS, 1)
+    if len(text) >= 1 << 20:  # ... and the same entry point routed through the device search
+        rt, ro = tok.encode_batch_with_special(text, np.asarray(offs, dtype=np.int64), sorted(allowed_ids))
+        assert np.array_equal(ro, ho) and np.array_equal(rt, ht), f"{what}: td_encode_batch_with_special differs between its two routes"
     assert np.array_equal(do_, ho), f"{what}: document offsets differ between the device and the host search"
     bad = np.flatnonzero(dt_ != ht) if len(dt_) == len(ht) else [0]
     assert len(dt_) == len(ht) and len(bad) == 0, f"{what}: ids differ, first at {bad[:1]}"

@@ -27,6 +27,7 @@ TD_OPT_PIPE_THREADS = 4
 TD_OPT_SMALL_PATH = 5
 TD_OPT_FUSED = 6
 TD_OPT_GRAPH = 7
+TD_OPT_DEVICE_SPECIALS = 8
 
 EXPORTS = [
     "td_create", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",

@@ -169,6 +169,7 @@ struct td_tokenizer {
     std::vector<int32_t> sp_key;     // the allowed ids it was built for (sorted, unique)
     DevBuf sp_bytes, sp_off, sp_len, sp_id, sp_parent, sp_first2, sp_hit, sp_acc, sp_cpos, sp_clit, sp_ccount;
     uint32_t sp_n = 0, sp_maxlen = 0;
+    bool device_specials = true;     // host-buffer batches of a MiB and more search on the device (TD_OPT_DEVICE_SPECIALS)
     bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
     bool fused = true;  // pre-tokenizer and lookup in one pass over the text (TD_OPT_FUSED; TD_FUSED=0 in the environment turns it off)
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
@@ -1296,6 +1297,64 @@ int encode_special_locked(td_tokenizer* t, const uint8_t* text, const int64_t* d
     }
     SpecialIndex ix;
     if ((rc = build_special_index(t, allowed_bytes, allowed_offsets, allowed_ids, n_allowed, ix))) return rc;
+    // Batches of a MiB and more: the search runs on the device (td_special.hip; the same cuts, td_encode_device_with_special)
+    // when the allowed set can be named by ids (no other special string shares an allowed one's id) and the caller does not
+    // ask for the last segment (the single-string entry points do, for last_piece_token_len).
+    if (t->device_specials && !last_seg_lo && doc_offsets[n_docs] >= (1ll << 20) && t->H.pattern_kind != PATTERN_GENERIC && ix.count > 0) {
+        std::vector<int32_t> ids;
+        bool nameable = true;
+        for (const auto& e : ix.ents) {
+            ids.push_back(e.id);
+            size_t carriers = 0;
+            for (size_t k2 = 0; k2 < t->H.special_ids.size(); ++k2) carriers += t->H.special_ids[k2] == e.id && !t->H.special_strs[k2].empty();
+            size_t listed = 0;
+            for (const auto& e2 : ix.ents) listed += e2.id == e.id;
+            if (carriers != listed) { nameable = false; break; }
+            if (e.s->size() > 48) { nameable = false; break; }
+        }
+        if (nameable) {
+            const int64_t n = doc_offsets[n_docs];
+            if ((rc = ensure(t, t->h2d_text, (size_t)n + 64))) return rc;
+            if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;
+            if ((rc = ensure(t, t->d_offsets, (size_t)(n_docs + 1) * 8))) return rc;
+            const int64_t dev_cap = std::max<int64_t>(n, 1);
+            if ((rc = ensure(t, t->d_tokens, (size_t)dev_cap * 4))) return rc;
+            hipStream_t s = nullptr;
+            if ((rc = order_before(t, s))) return rc;
+            {
+                std::vector<int32_t> key(ids);
+                std::sort(key.begin(), key.end());
+                key.erase(std::unique(key.begin(), key.end()), key.end());
+                if (key != t->sp_key && t->has_last) HIP_TRY(t, hipStreamSynchronize(t->last_stream));
+            }
+            if ((rc = build_special_table(t, ids.data(), (int64_t)ids.size()))) return rc;
+            if ((rc = ensure(t, t->sp_hit, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
+            if ((rc = ensure(t, t->sp_acc, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
+            if ((rc = ensure(t, t->sp_cpos, (size_t)(n / 32 + 4096) * 8))) return rc;
+            if ((rc = ensure(t, t->sp_clit, (size_t)(n / 32 + 4096) * 4))) return rc;
+            if ((rc = ensure(t, t->sp_ccount, 64))) return rc;
+            HIP_TRY(t, hipMemcpyAsync(t->h2d_text.p, text, (size_t)n, hipMemcpyHostToDevice, s));
+            HIP_TRY(t, hipMemcpyAsync(t->h2d_offs.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+            t->sp_active = t->sp_n != 0;
+            rc = encode_device_locked(t, t->h2d_text.p, n, t->h2d_offs.p, n_docs, TD_MODE_ENCODE, t->d_tokens.p, dev_cap, t->d_offsets.p, s);
+            t->sp_active = false;
+            if (rc) return rc;
+            rc = device_status_locked(t, s, nullptr);
+            if (rc == TD_E_SCRATCH) rc = TD_OK + 1000;  // (more candidates than the device list holds: the host search below)
+            if (rc == TD_OK) {
+                HIP_TRY(t, hipMemcpy(out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+                const int64_t total = out_offsets[n_docs];
+                if (n_tokens) *n_tokens = total;
+                if (total > out_capacity) { t->err = "output capacity too small: " + std::to_string(total) + " tokens needed"; return TD_E_CAPACITY; }
+                if (total > 0) {
+                    if (!out_tokens) { t->err = "null out_tokens"; return TD_E_INVALID; }
+                    HIP_TRY(t, hipMemcpy(out_tokens, t->d_tokens.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+                }
+                return TD_OK;
+            }
+            if (rc != TD_OK + 1000) return rc;
+        }
+    }
     // 1. host: cut every document at the earliest occurrences of allowed special strings (tiktoken semantics; the
     //    reference's own loop, tiktoken.cpp:130-154,187-231, has iterator-invalidation UB).  Documents are independent:
     //    a few host threads take contiguous document ranges.
@@ -1526,6 +1585,10 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
 #endif
     if (what == TD_OPT_FUSED) {
         t->fused = value != 0;
+        return TD_OK;
+    }
+    if (what == TD_OPT_DEVICE_SPECIALS) {
+        t->device_specials = value != 0;
         return TD_OK;
     }
     if (what == TD_OPT_GRAPH) {
