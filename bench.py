@@ -314,6 +314,7 @@ def parse_args(argv=None):
                          "surrogate for BASELINE config 4 (tekken.json is absent from the reference checkout)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only for exercising the multi-rank path with several ranks on ONE GPU (RCCL refuses that)")
+    ap.add_argument("--single-document", action="store_true", help="the whole corpus as ONE document (parallelism inside a document)")
     ap.add_argument("--collective", default="torch", choices=["torch", "capi"],
                     help="who issues the step's all-gather of {tokens, documents}: torch.distributed (default) or the C ABI's "
                          "td_comm_gather_counts (RCCL opened by the tokenizer library itself; needs --dist-backend nccl)")
@@ -380,6 +381,8 @@ def main():
     total_bytes = (a.size_mb << 20) * (world if weak else 1)
     gx, goffs = build_corpus(a.corpus, total_bytes, seed=1000)  # identical on every rank
     total_bytes = len(gx)  # (the file-set corpus is a whole number of sets, not exactly --size-mb)
+    if a.single_document:
+        goffs = np.asarray([0, total_bytes], dtype=np.int64)
     g_docs = len(goffs) - 1
     d0, d1 = tdist.shard_documents(goffs, world, rank)
     b0, b1 = int(goffs[d0]), int(goffs[d1])

@@ -20,6 +20,11 @@ run mixed_tekken_1024 --corpus mixed --pattern tekken --size-mb 1024 --steps 20
 run code_256 --corpus code --size-mb 256 --steps 30 --no-cpu-baseline
 run code_files_256 --corpus code_files --size-mb 256 --steps 30 --no-cpu-baseline
 run code_files_1024 --corpus code_files --size-mb 1024 --steps 20 --no-cpu-baseline
+run chat_specials_256 --corpus chat --allowed-special all --size-mb 256 --steps 30 --no-cpu-baseline
+run chat_specials_1024 --corpus chat --allowed-special all --size-mb 1024 --steps 20 --no-cpu-baseline
+run generic_autogen_256 --pattern generic:autogen --size-mb 256 --steps 10 --warmup 2 --no-cpu-baseline
+run generic_autogen_64_single_document --pattern generic:autogen --size-mb 64 --single-document --steps 10 --warmup 2 --no-cpu-baseline
+run generic_autogen_64_many_documents --pattern generic:autogen --size-mb 64 --steps 10 --warmup 2 --no-cpu-baseline
 run 2rank_same_gpu_gloo_1024 --gpus 2 --same-gpu --dist-backend gloo --no-cpu-baseline --steps 30
 TD_BENCH_FORCE_DIST=1 run rccl_world1_torch_1024 --no-cpu-baseline --steps 50
 TD_BENCH_FORCE_DIST=1 run rccl_world1_capi_1024 --no-cpu-baseline --steps 50 --collective capi
