@@ -418,7 +418,10 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     // of a multi-GPU job) replays the step as ONE hipGraph launch instead of its dozen kernel launches: the second such call
     // captures the launches, the following ones replay them.  Anything else is launched kernel by kernel.  (The fixed cost
     // of a step — what a one-tile input takes — is what bends strong scaling at eight GPUs, not what a GiB on one GPU sees.)
-    if (t->graphs && !t->profile && !t->stop_after) {
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cap_status) != hipSuccess) { cap_status = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+    // (a caller that is capturing this stream into a graph of its own gets the plain launches captured there)
+    if (t->graphs && !t->profile && !t->stop_after && cap_status == hipStreamCaptureStatusNone) {
         const bool same_as_graph = t->graph_exec && t->graph_stream == stream && memcmp(&a, &t->graph_key, sizeof a) == 0;
         if (same_as_graph) {
             HIP_TRY(t, hipGraphLaunch(t->graph_exec, stream));
@@ -478,7 +481,8 @@ int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) 
                 t->err = "Invalid token for decoding at index " + std::to_string(c.err_pos);
                 break;
             case TD_E_SCRATCH:
-                t->err = "long-piece scratch exhausted near byte offset " + std::to_string(c.err_pos) + " (raise TD_OPT_LONG_POOL_BYTES)";
+                t->err = "device scratch exhausted near byte offset " + std::to_string(c.err_pos) +
+                         " (pieces above 64 bytes: raise TD_OPT_LONG_POOL_BYTES; allowed special tokens: more candidates than one per 32 bytes of the batch)";
                 break;
             default:
                 t->err = "device error " + std::to_string(c.err) + " at byte offset " + std::to_string(c.err_pos);
