@@ -1902,8 +1902,14 @@ constexpr int LP_TINY = 128;      // eight lanes per piece up to here
 constexpr int LP_LINKED = 255;    // sixteen lanes per piece up to here (links are bytes)
 constexpr uint32_t LP_END = 255;  // "no neighbour" in the link arrays
 template <int G>
-__device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Tables& T, uint32_t j, volatile uint32_t* id,
-                                                   volatile uint32_t* rk, volatile uint8_t* nx, volatile uint8_t* pv, int grp, int gl) {
+__device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Tables& T, uint32_t j, volatile uint32_t* vid,
+                                                   volatile uint32_t* vrk, volatile uint8_t* vnx, volatile uint8_t* vpv, int grp, int gl) {
+    // (plain pointers + a wavefront-scope fence at the end of every round: as volatile arrays every one of the sixteen reads of
+    // a lane's stripe was waited for on its own)
+    uint32_t* const id = const_cast<uint32_t*>(vid);
+    uint32_t* const rk = const_cast<uint32_t*>(vrk);
+    uint8_t* const nx = const_cast<uint8_t*>(vnx);
+    uint8_t* const pv = const_cast<uint8_t*>(vpv);
     const int64_t gs = a.long_list[j].gs;
     const uint32_t len = a.long_list[j].len;
     const uint8_t* p = a.text + gs;
@@ -1927,40 +1933,134 @@ __device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Ta
             nx[q] = (uint8_t)((q + 1 < len) ? q + 1 : LP_END);
             pv[q] = (uint8_t)(q ? q - 1 : LP_END);
         }
+        // A round is one dependent round trip to the pair table (about a microsecond), and a piece of a hundred bytes takes a
+        // hundred of them when every round applies ONE merge.  The sequential rule (lowest rank first, leftmost on ties;
+        // tiktoken.cpp:334-342) is kept while applying up to LP_K merges per round: the candidates are the LP_K lowest keys
+        // in order; all their new pairs are looked up together (two lookups each, a lane each); candidate c is applied only
+        // if it touches neither the parts nor the neighbours of the ones applied before it this round (so its lookups,
+        // made on the state in front of the round, still hold) and its key is lower than every key those created — then it
+        // is exactly what the sequential loop would merge next.  The first candidate that fails ends the round.
+#ifndef TD_LP_K
+#define TD_LP_K 2
+#endif
+        constexpr int LP_K = TD_LP_K;
+        wave_sync_lds();  // (the parts set up above are visible to the whole group)
+        static_assert(2 * LP_K <= G, "a lane per lookup");
+        constexpr uint32_t INF = 0xFFFFFFFFu;
+        auto gmin = [&](uint32_t v) {
+#pragma unroll
+            for (int d = G / 2; d >= 1; d >>= 1) {
+                const uint32_t o = __shfl_xor(v, d, G);
+                v = o < v ? o : v;
+            }
+            return v;
+        };
         for (;;) {
-            uint32_t best = 0xFFFFFFFFu;
+            // my stripe's two lowest keys (rank << 8 | position: ties go left, like the reference's strict '<' scan)
+            uint32_t b0 = INF, b1 = INF;
             for (uint32_t q = gl; q < len; q += G) {
                 const uint32_t r = rk[q];
                 if (r != (uint32_t)NO_RANK) {
-                    const uint32_t key = (r << 8) | q;  // ties go left, like the reference's strict '<' scan
-                    best = key < best ? key : best;
+                    const uint32_t key = (r << 8) | q;
+                    if (key < b0) { b1 = b0; b0 = key; } else if (key < b1) b1 = key;
                 }
             }
+            // the group's lowest keys in order, until a lane has given both of its own (its third is not known)
+            uint32_t ck[LP_K];
+            int nc = 0;
+            uint32_t used = 0;
 #pragma unroll
-            for (int d = G / 2; d >= 1; d >>= 1) {
-                const uint32_t o = __shfl_xor(best, d, G);
-                best = o < best ? o : best;
+            for (int c = 0; c < LP_K; ++c) {
+                ck[c] = INF;
+                if (nc == c) {
+                    const uint32_t cur = used == 0 ? b0 : used == 1 ? b1 : INF;
+                    const uint32_t g = gmin(cur);
+                    if (g != INF) {
+                        const bool mine = cur == g;
+                        if (mine) ++used;
+                        ck[c] = g;
+                        nc = c + 1;
+                        // (a lane that has given both of its keys may hold the next lowest one too: no further candidates)
+                        const uint32_t stop = gmin((mine && used == 2) ? 0u : 1u);
+                        if (stop == 0u && c + 1 < LP_K) { nc = -(c + 1); }
+                    }
+                }
             }
-            if (best == 0xFFFFFFFFu) break;
-            const uint32_t w = best & 255u, r = best >> 8;
-            const uint32_t nxt = nx[w];     // the part that is absorbed
-            const uint32_t nn = nx[nxt];    // the part after it
-            const uint32_t pw = pv[w];
-            const uint32_t id_nn = (nn != LP_END) ? id[nn] : 0u;
-            const uint32_t id_pw = (pw != LP_END) ? id[pw] : 0u;
-            --m;
-            if (gl == 0) {
-                id[w] = r;
-                rk[nxt] = (uint32_t)NO_RANK;
-                id[nxt] = TOK_NONE;
-                nx[w] = (uint8_t)nn;
-                if (nn != LP_END) pv[nn] = (uint8_t)w;
-                rk[w] = (nn != LP_END) ? (uint32_t)pair_lookup(T, r, id_nn) : (uint32_t)NO_RANK;
-            } else if (gl == 1 && pw != LP_END) {
-                rk[pw] = (uint32_t)pair_lookup(T, id_pw, r);
+            if (nc < 0) nc = -nc;
+            if (nc == 0) break;
+            // the candidates' parts and neighbours (state in front of the round; the same values in every lane of the group)
+            uint32_t cw[LP_K], cr[LP_K], cnx[LP_K], cnn[LP_K], cpw[LP_K], cidn[LP_K], cidp[LP_K];
+#pragma unroll
+            for (int c = 0; c < LP_K; ++c) {
+                cw[c] = ck[c] & 255u; cr[c] = ck[c] >> 8;
+                cnx[c] = LP_END; cnn[c] = LP_END; cpw[c] = LP_END; cidn[c] = 0; cidp[c] = 0;
+                if (c < nc) {
+                    cnx[c] = nx[cw[c]];
+                    cnn[c] = nx[cnx[c]];
+                    cpw[c] = pv[cw[c]];
+                    cidn[c] = cnn[c] != LP_END ? id[cnn[c]] : 0u;
+                    cidp[c] = cpw[c] != LP_END ? id[cpw[c]] : 0u;
+                }
             }
+            // the lookups: lane 2c the pair (merged part, part behind it), lane 2c + 1 the pair (part in front of it, merged part)
+            uint32_t mine_res = (uint32_t)NO_RANK;
+#pragma unroll
+            for (int c = 0; c < LP_K; ++c) {
+                if (c < nc && gl == 2 * c && cnn[c] != LP_END) mine_res = (uint32_t)pair_lookup(T, cr[c], cidn[c]);
+                if (c < nc && gl == 2 * c + 1 && cpw[c] != LP_END) mine_res = (uint32_t)pair_lookup(T, cidp[c], cr[c]);
+            }
+            uint32_t rw[LP_K], rp[LP_K];
+#pragma unroll
+            for (int c = 0; c < LP_K; ++c) {
+                rw[c] = __shfl(mine_res, 2 * c, G);
+                rp[c] = __shfl(mine_res, 2 * c + 1, G);
+            }
+            // which candidates are applied
+            uint32_t minnew = INF;
+            int napply = 0;
+#pragma unroll
+            for (int c = 0; c < LP_K; ++c) {
+                if (c < nc && napply == c) {
+                    bool ok = c == 0 || ck[c] < minnew;
+#pragma unroll
+                    for (int i = 0; i < LP_K; ++i) {
+                        if (i < c) {
+                            // my parts against the earlier one's parts and neighbours; my neighbours against its parts
+                            const uint32_t a0 = cw[i], a1 = cnx[i], n0 = cpw[i], n1 = cnn[i];
+                            const bool hit = cw[c] == a0 || cw[c] == a1 || cw[c] == n0 || cw[c] == n1 || cnx[c] == a0 || cnx[c] == a1 ||
+                                             cnx[c] == n0 || cnx[c] == n1 || (cpw[c] != LP_END && (cpw[c] == a0 || cpw[c] == a1)) ||
+                                             (cnn[c] != LP_END && (cnn[c] == a0 || cnn[c] == a1));
+                            ok = ok && !hit;
+                        }
+                    }
+                    if (ok) {
+                        napply = c + 1;
+                        const uint32_t kw = (cnn[c] != LP_END && rw[c] != (uint32_t)NO_RANK) ? ((rw[c] << 8) | cw[c]) : INF;
+                        const uint32_t kp = (cpw[c] != LP_END && rp[c] != (uint32_t)NO_RANK) ? ((rp[c] << 8) | cpw[c]) : INF;
+                        minnew = kw < minnew ? kw : minnew;
+                        minnew = kp < minnew ? kp : minnew;
+                    }
+                }
+            }
+            // apply: lane c does candidate c (they touch different entries)
+#pragma unroll
+            for (int c = 0; c < LP_K; ++c) {
+                if (c < napply && gl == c) {
+                    const uint32_t w = cw[c], nxt = cnx[c], nn = cnn[c], pw = cpw[c];
+                    id[w] = cr[c];
+                    rk[nxt] = (uint32_t)NO_RANK;
+                    id[nxt] = TOK_NONE;
+                    nx[w] = (uint8_t)nn;
+                    if (nn != LP_END) pv[nn] = (uint8_t)w;
+                    rk[w] = (nn != LP_END) ? rw[c] : (uint32_t)NO_RANK;
+                    if (pw != LP_END) rk[pw] = rp[c];
+                }
+            }
+            m -= (uint32_t)napply;
+            wave_sync_lds();
         }
     }
+    wave_sync_lds();
     unsigned long long off = 0;
     if (gl == 0) off = atomicAdd(a.pool_used, (unsigned long long)m);
     off = __shfl(off, 0, G);
