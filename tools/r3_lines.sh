@@ -1,9 +1,10 @@
 set -u
-# Round-3 bench lines of every BASELINE config (one gpurun call).  usage: tools/r3_lines.sh <tag>
+# Round-3 bench lines of every BASELINE config (one gpurun call).  usage: tools/r3_lines.sh <tag> [regex of line names to run]
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O
 cd $R
 nproc > $O/host.txt; grep -m1 "model name" /proc/cpuinfo >> $O/host.txt
-run() { name=$1; shift; timeout 400 python bench.py "$@" > $O/bench_$name.json 2> $O/bench_$name.err || echo "FAILED $name"; python - "$O/bench_$name.json" "$name" <<'PY'
+ONLY=${2:-.}
+run() { name=$1; shift; echo "$name" | grep -Eq "$ONLY" || return 0; timeout 400 python bench.py "$@" > $O/bench_$name.json 2> $O/bench_$name.err || echo "FAILED $name"; python - "$O/bench_$name.json" "$name" <<'PY'
 import json,sys
 try:
     j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=j["roofline"]
@@ -12,6 +13,7 @@ except Exception as e:
     print(sys.argv[2], "no line:", e)
 PY
 }
+run english_1024
 run english_256 --size-mb 256 --no-cpu-baseline
 run mixed_256 --corpus mixed --size-mb 256 --steps 30 --no-cpu-baseline
 run mixed_1024 --corpus mixed --size-mb 1024 --steps 20 --no-cpu-baseline
@@ -28,5 +30,6 @@ run generic_autogen_64_many_documents --pattern generic:autogen --size-mb 64 --s
 run 2rank_same_gpu_gloo_1024 --gpus 2 --same-gpu --dist-backend gloo --no-cpu-baseline --steps 30
 TD_BENCH_FORCE_DIST=1 run rccl_world1_torch_1024 --no-cpu-baseline --steps 50
 TD_BENCH_FORCE_DIST=1 run rccl_world1_capi_1024 --no-cpu-baseline --steps 50 --collective capi
+[ "$ONLY" = . ] || exit 0
 timeout 300 python tools/gpu_hostpath.py > $O/hostpath.txt 2>&1; tail -12 $O/hostpath.txt
 timeout 100 python tools/gpu_latency.py > $O/latency.txt 2>&1; cat $O/latency.txt | tail -3
