@@ -27,8 +27,12 @@ PATTERNS = {
     "hex": r"0x[0-9a-fA-F]{1,8}|\x41+|[\x{4e00}-\x{9fff}]+|[^\S\n]*\n|.", "opt": r"(?:ab|a)?c|[ab]+|\s*+x|.",
     # atomic optional groups: once a literal is chosen the matcher never comes back for the next one or the skip
     "atomic1": r"(?:a|ab)?+c|.", "atomic2": r"(?:ab|a)?+bc|.", "atomic3": r" ?(?:the|a|an)?+[a-z]+|\s+|.",
+    # lazy quantifiers: as few characters as possible first, one more per way back (PCRE2_NOTEMPTY makes a lone "x*?" take one)
+    "lazy1": r"[a-z]+?[0-9]|\s*?\S|.", "lazy2": r"\w{2,5}?\b|\w+?|\s??x|.", "lazy3": r"[ab]*?c|(?:ab|a)??b+|\p{L}*?\p{Lu}|\s+?", "lazy4": r"a??b|.{1,3}?[.!]|\d+?(?=\d)|.",
+    # look-behinds of one character class
+    "lookb1": r"(?<=[a-z])[0-9]+|(?<![0-9])[a-z]+|\s+|.", "lookb2": r"(?<!\S)\w+|(?<=\s)[^\w\s]+|\S|\s+(?<=\n)", "lookb3": r"\p{L}+(?<=s)|(?<=\p{Han})\p{Han}|(?<!.)#+|.",
 }
-REJECTED = [r"\012|.", r"[\d-z]", r"[\p{Han}-z]", r"\x{D800}", r"[\x{DFFF}]", r"(\w+)\s+\1", r"\S+?", r"\b+x", r"\Gabc", r"(?<=a)b", r"[[:alpha:]]+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:a|b)*"]
+REJECTED = [r"\012|.", r"[\d-z]", r"[\p{Han}-z]", r"\x{D800}", r"[\x{DFFF}]", r"(\w+)\s+\1", r"\b+x", r"\Gabc", r"(?<=ab)c", r"(?<=a)+b", r"(?<=a|b)c", r"[[:alpha:]]+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:a|b)*"]
 
 
 def _strings(n, seed):
@@ -103,7 +107,7 @@ def test_gpu_generic_patterns_equal_the_reference():
     import td_corpus
     from tokendagger_amd import capi
     _, mr, special = H.llama4()
-    for name in ("autogen", "words", "look", "letters_only", "opt", "atomic3"):
+    for name in ("autogen", "words", "look", "letters_only", "opt", "atomic3", "lazy2", "lookb2"):
         pat = PATTERNS[name]
         tok = capi.HipTokenizer(pat, mr, special, device=0)
         R = ref.RefTokenizer(pat, mr, special)
@@ -153,6 +157,10 @@ def test_gpu_left_context_assertions_refuse_special_cuts():
     with pytest.raises(tiktoken.TokenDaggerError):
         enc.encode(s, allowed_special="all")
     assert special["<|begin_of_text|>"] in plain.encode(s, allowed_special="all")
+    behind = tiktoken.Encoding(name="lb", pat_str=PATTERNS["lookb1"], mergeable_ranks=mr, special_tokens=special)  # (look-behinds too)
+    assert behind.encode("one two three") == behind.encode("one two three", allowed_special="all")
+    with pytest.raises(tiktoken.TokenDaggerError):
+        behind.encode(s, allowed_special="all")
 
 
 @pytest.mark.gpu
@@ -172,7 +180,7 @@ def test_gpu_generic_chunks_inside_large_documents():
     eng, mix, code = eng.tobytes(), mix.tobytes(), code.tobytes()
     snake = ("snake_case_name = naïve_café_%d; " * 40000 % tuple(range(40000))).encode()
     longrun = eng[:3000] + b"a" * 5000 + b" " * 3000 + b"_" * 2500 + eng[:3000] + "é".encode() * 2000 + eng[:5000]
-    for name in ("autogen", "words", "look", "cats", "lit", "wordb", "scripts"):
+    for name in ("autogen", "words", "look", "cats", "lit", "wordb", "scripts", "lazy1", "lookb1"):
         pat = PATTERNS[name]
         tok = capi.HipTokenizer(pat, mr, special, device=0)
         R = ref.RefTokenizer(pat, mr, special)

@@ -273,8 +273,8 @@ struct Reader {
         } else {
             return true;
         }
-        if (peek() == '+') { nd.possessive = 1; ++i; }
-        else if (peek() == '?') return fail("lazy quantifiers are not supported");
+        if (peek() == '+') { nd.possessive = RX_POSSESSIVE; ++i; }
+        else if (peek() == '?') { nd.possessive = RX_LAZY; ++i; }
         return true;
     }
 
@@ -349,8 +349,8 @@ struct Reader {
         }
         if (peek() == '?') {
             nd.min = 0; ++i;
-            if (peek() == '+') { nd.possessive = 1; ++i; }  // atomic: once a literal (or the skip) is chosen the matcher never comes back for another
-            else if (peek() == '?') return fail("lazy quantifiers are not supported");
+            if (peek() == '+') { nd.possessive = RX_POSSESSIVE; ++i; }  // atomic: once a literal (or the skip) is chosen the matcher never comes back for another
+            else if (peek() == '?') { nd.possessive = RX_LAZY; ++i; }   // lazy: the skip first
         } else if (peek() == '*' || peek() == '+' || peek() == '{') {
             return fail("repeated groups are not supported");
         }
@@ -446,13 +446,14 @@ struct Reader {
                 if (peek(1) != '?') return fail("capturing groups are not supported");
                 if (peek(2) == ':' ) { i += 3; if (!read_literal_group(false, first)) return false; continue; }
                 if (peek(2) == 'i' && peek(3) == ':') { i += 4; if (!read_literal_group(true, first)) return false; continue; }
-                if (peek(2) == '!' || peek(2) == '=') {
-                    const bool negative = peek(2) == '!';
-                    i += 3;
+                const bool behind = peek(2) == '<' && (peek(3) == '!' || peek(3) == '=');
+                if (peek(2) == '!' || peek(2) == '=' || behind) {
+                    const bool negative = peek(behind ? 3 : 2) == '!';
+                    i += behind ? 4 : 3;
                     RxNode nd{};
-                    nd.kind = negative ? RX_NLOOK : RX_PLOOK;
+                    nd.kind = behind ? (negative ? RX_NLOOKB : RX_PLOOKB) : (negative ? RX_NLOOK : RX_PLOOK);
                     if (!read_class_atom(nd.a)) return false;
-                    if (peek() != ')') return fail("a look-ahead may hold one character class only");
+                    if (peek() != ')') return fail("a look-ahead or look-behind may hold one character class only");
                     ++i;
                     if (!push_node(nd, first)) return false;
                     continue;

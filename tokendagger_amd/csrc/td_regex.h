@@ -12,12 +12,13 @@
 //     character classes   [...]  [^...]  \s \S \d \D \w \W \p{Xx} \P{Xx} (general categories, one- and two-letter; the scripts of
 //                         generated/unicode_scripts.inc: td_regex.cpp expands them into ranges; \p{Any})  .
 //                         literal and escaped characters, \r \n \t \f \v \xHH \x{H..}, ranges a-z
-//     quantifiers         ? * + {m} {m,} {m,n}   and their possessive forms ?+ *+ ++ {m,n}+
-//     groups of literals  (?:ab|c|[de])  (?i:'s|'t|ll)  optionally followed by ?   (case-insensitive: ASCII + U+017F / U+212A)
+//     quantifiers         ? * + {m} {m,} {m,n}   their possessive forms ?+ *+ ++ {m,n}+   and their lazy forms ?? *? +? {m,n}?
+//     groups of literals  (?:ab|c|[de])  (?i:'s|'t|ll)  optionally followed by ? ?+ ??   (case-insensitive: ASCII + U+017F / U+212A)
 //     look-ahead          (?!X)  (?=X)   with X one character class
+//     look-behind         (?<!X) (?<=X)  with X one character class (looks at what stands in FRONT of the subject, see ^ \b below)
 //     $ \Z                end of the subject (or in front of its final newline);  \z  the very end;  ^ \A  its start
 //     \b \B               word boundary (\w as PCRE2_UCP defines it) / not one
-//                         (^ \A \b \B look at what stands in FRONT of the subject: with them a call that cuts allowed special
+//                         (^ \A \b \B and look-behinds look at what stands in FRONT of the subject: with them a call that cuts allowed special
 //                         tokens out of the text is refused, TD_E_PATTERN — the reference would match the text behind a special
 //                         with the special as left context, tiktoken.cpp:86-93)
 //     a group followed by ?+ is atomic (the literal chosen, or the skip, is final); \0 followed by a digit (octal), a class
@@ -39,7 +40,9 @@ constexpr int RX_MAX_SEQ = 16;          // nodes of one alternative (the matcher
 constexpr uint32_t RX_INF = 0xFFFFu;    // no upper bound
 constexpr uint32_t RX_F_S = 1u, RX_F_W = 2u, RX_F_D = 4u;  // item flags: \s \w \d (bits 5..7 of the table byte >> 5)
 
-enum RxKind : uint8_t { RX_CLASS = 0, RX_LITSET = 1, RX_NLOOK = 2, RX_PLOOK = 3, RX_EOS = 4, RX_EOS_STRICT = 5, RX_BOS = 6, RX_WORDB = 7, RX_NWORDB = 8 };
+enum RxKind : uint8_t { RX_CLASS = 0, RX_LITSET = 1, RX_NLOOK = 2, RX_PLOOK = 3, RX_EOS = 4, RX_EOS_STRICT = 5, RX_BOS = 6, RX_WORDB = 7, RX_NWORDB = 8,
+                        RX_NLOOKB = 9, RX_PLOOKB = 10 };
+constexpr uint8_t RX_GREEDY = 0, RX_POSSESSIVE = 1, RX_LAZY = 2;  // RxNode::possessive
 
 struct RxItem {        // one member of a character class
     uint32_t gc_mask;  // general categories (bit = category id of generated/unicode_gc.inc)
@@ -57,7 +60,7 @@ struct RxClass {
 struct RxLit { uint16_t off, len; };
 struct RxNode {
     uint8_t kind;        // RxKind
-    uint8_t possessive;  // RX_CLASS: does not give characters back
+    uint8_t possessive;  // RX_GREEDY / RX_POSSESSIVE (does not give characters back; a group: atomic) / RX_LAZY (as few as possible first)
     uint8_t caseless;    // RX_LITSET
     uint8_t pad;
     uint16_t a, b;       // RX_CLASS / RX_*LOOK: a = class; RX_LITSET: a = first literal, b = number of literals
@@ -179,7 +182,8 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
             if (nd.kind == RX_CLASS) {
                 uint32_t c = 0;
                 int64_t p = pos;
-                while ((nd.max == RX_INF || c < nd.max) && p < n) {  // (RX_INF = no upper bound, not 65535: cnt[] is 32-bit)
+                const uint32_t take_max = nd.possessive == RX_LAZY ? nd.min : nd.max;  // (lazy: the minimum first, one more per way back)
+                while ((take_max == RX_INF || c < take_max) && p < n) {  // (RX_INF = no upper bound, not 65535: cnt[] is 32-bit)
                     uint32_t len;
                     const uint32_t cp = rx_char_at(s, p, n, len);
                     if (!rx_in_class(P, T, nd.a, cp)) break;
@@ -197,7 +201,8 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
                     len = rx_lit_at(P, P.lits[nd.a + k], nd.caseless != 0, s, pos, n);
                     if (len >= 0) break;
                 }
-                if (k < nd.b) { cnt[i] = k; pos += len; }
+                if (nd.min == 0 && nd.possessive == RX_LAZY) cnt[i] = nd.b;  // (lazy "(?:..)??": skipped first, the literals on the way back)
+                else if (k < nd.b) { cnt[i] = k; pos += len; }
                 else if (nd.min == 0) cnt[i] = nd.b;
                 else ok = false;
                 end[i] = pos;
@@ -220,6 +225,14 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
                 }
                 ok = (wl != wr) == (nd.kind == RX_WORDB);
                 end[i] = pos;
+            } else if (nd.kind == RX_NLOOKB || nd.kind == RX_PLOOKB) {  // look-behind on one character
+                bool in = false;
+                if (pos > 0) {
+                    uint32_t len;
+                    in = rx_in_class(P, T, nd.a, rx_char_at(s, rx_prev_char(s, 0, pos, n), n, len));
+                }
+                ok = (nd.kind == RX_PLOOKB) ? in : !in;
+                end[i] = pos;
             } else {  // look-ahead on one character
                 bool in = false;
                 if (pos < n) {
@@ -237,6 +250,17 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
         while (--i >= 0) {
             const RxNode nd = P.nodes[alt.first_node + i];
             if (nd.kind == RX_CLASS) {
+                if (nd.possessive == RX_LAZY) {  // one character more, if there is one and the bound allows it
+                    const int64_t p = end[i];
+                    if ((nd.max != RX_INF && cnt[i] >= nd.max) || p >= n) continue;
+                    uint32_t len;
+                    if (!rx_in_class(P, T, nd.a, rx_char_at(s, p, n, len))) continue;
+                    end[i] = p + len;
+                    ++cnt[i];
+                    pos = end[i];
+                    resumed = true;
+                    break;
+                }
                 if (nd.possessive || cnt[i] <= nd.min) continue;
                 end[i] = rx_prev_char(s, beg[i], end[i], n);
                 --cnt[i];
@@ -245,15 +269,16 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
                 break;
             }
             if (nd.kind == RX_LITSET) {
-                if (nd.possessive || cnt[i] >= nd.b) continue;  // (atomic group "(?:..)?+": no second choice; or already skipped)
-                uint32_t k = cnt[i] + 1;
+                const bool lazy = nd.possessive == RX_LAZY && nd.min == 0;
+                if (nd.possessive == RX_POSSESSIVE || (!lazy && cnt[i] >= nd.b)) continue;  // (atomic group "(?:..)?+": no second choice; or already skipped)
+                uint32_t k = (lazy && cnt[i] == nd.b) ? 0u : cnt[i] + 1;  // (lazy: the skip came first, now the literals in order)
                 int len = -1;
                 for (; k < nd.b; ++k) {
                     len = rx_lit_at(P, P.lits[nd.a + k], nd.caseless != 0, s, beg[i], n);
                     if (len >= 0) break;
                 }
                 if (k < nd.b) { cnt[i] = k; pos = beg[i] + len; end[i] = pos; resumed = true; break; }
-                if (nd.min == 0) { cnt[i] = nd.b; pos = beg[i]; end[i] = pos; resumed = true; break; }
+                if (nd.min == 0 && !lazy) { cnt[i] = nd.b; pos = beg[i]; end[i] = pos; resumed = true; break; }
                 continue;
             }
         }

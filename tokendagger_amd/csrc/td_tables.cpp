@@ -143,7 +143,7 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
         if (rx_compile(H.pattern, *P, why)) {
             H.pattern_kind = PATTERN_GENERIC;
             for (uint32_t k = 0; k < P->n_nodes; ++k)
-                if (P->nodes[k].kind == RX_BOS || P->nodes[k].kind == RX_WORDB || P->nodes[k].kind == RX_NWORDB) H.rx_left_context = true;
+                if (P->nodes[k].kind == RX_BOS || P->nodes[k].kind == RX_WORDB || P->nodes[k].kind == RX_NWORDB || P->nodes[k].kind == RX_NLOOKB || P->nodes[k].kind == RX_PLOOKB) H.rx_left_context = true;
         } else {
             H.rx_program.clear();
             err = "split pattern is not supported by the device pre-tokenizer: " + why +
