@@ -140,6 +140,7 @@ struct Ctl {  // small control block in device memory
     uint32_t gap_count;      // generic split patterns: stretches of text the pattern skipped
     uint32_t deferred_count; // fused tile loop: token tiles left to td_probe_tiles
     uint32_t giant_count;    // long pieces above 1 KiB
+    uint32_t tile_draw;      // fused tile loop: tiles handed out beyond every workgroup's first two
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 }  // namespace
@@ -352,6 +353,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     Ctl* ctl = (Ctl*)t->ctl.p;
     a.long_count = &ctl->long_count;
     a.giant_count = &ctl->giant_count;
+    a.tile_draw = &ctl->tile_draw;
     a.slow_count = &ctl->slow_count;
     a.pool = (uint32_t*)t->pool.p;
     a.pool_cap = t->pool.cap / 4;

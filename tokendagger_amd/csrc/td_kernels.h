@@ -58,6 +58,7 @@ struct EncodeArgs {
     uint32_t long_cap;
     uint32_t* long_count;
     uint32_t* giant_count;      // entries of long_list above 1 KiB (td_giant_pieces)
+    uint32_t* tile_draw;        // fused tile loop: counter the workgroups draw their tiles from (0 at launch)
     uint32_t* pool;             // long-piece scratch + token store
     uint64_t pool_cap;          // in u32
     unsigned long long* pool_used;
