@@ -296,10 +296,10 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->flagged_list, (size_t)(n_tiles + 64) * 4))) return rc;
     if ((rc = ensure(t, t->deferred_list, (size_t)(n_tiles + 64) * 4))) return rc;
     if (t->H.pattern_kind == PATTERN_GENERIC) {
-        if ((rc = ensure(t, t->gap_list, (size_t)(n / 1024 + 64) * 4))) return rc;   // chunks that failed the check
+        if ((rc = ensure(t, t->gap_list, (size_t)(n / gx_chunk_for(n) + 64) * 4))) return rc;   // chunks that failed the check
         if ((rc = ensure(t, t->gapbits, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
-        if ((rc = ensure(t, t->gx_exit, (size_t)(n / 1024 + 2) * 8))) return rc;
-        if ((rc = ensure(t, t->gx_state, (size_t)(n / 1024 + 2) * 4))) return rc;
+        if ((rc = ensure(t, t->gx_exit, (size_t)(n / gx_chunk_for(n) + 2) * 8))) return rc;
+        if ((rc = ensure(t, t->gx_state, (size_t)(n / gx_chunk_for(n) + 2) * 4))) return rc;
     }
     if ((rc = ensure(t, t->miss_list, (size_t)(n_tiles + 1) * K_MISS_LISTED_MAX * K_MISS_CLASSES * 8))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
@@ -369,6 +369,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.gap_list = (int64_t*)t->gap_list.p;
     a.gap_cap = (uint32_t)std::min<size_t>(t->gap_list.cap / 4, 0x7FFFFFF0u);
     a.gapbits = (uint32_t*)t->gapbits.p;
+    a.gx_chunk = gx_chunk_for(n);
     a.gx_exit = (int64_t*)t->gx_exit.p;
     a.gx_state = (uint32_t*)t->gx_state.p;
     a.gap_count = &ctl->gap_count;

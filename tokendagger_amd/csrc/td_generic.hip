@@ -61,7 +61,6 @@ __device__ __forceinline__ void raise_g(const EncodeArgs& a, int code, int64_t p
 // Matchers of tokenizer patterns resynchronise within a piece or two, so nearly every chunk passes; the documents of the
 // others are redone from their first failing chunk by one lane (td_generic_redo).  Documents that start inside a chunk
 // start with a true piece start and need no check.
-constexpr int GX_CHUNK = 1024;  // bytes per lane (a multiple of 32: a lane owns whole words of the bitmaps)
 
 struct GxWords {  // the lane's words of the START / gap bitmaps, written in increasing order
     uint32_t* sb;
@@ -114,6 +113,48 @@ __device__ __forceinline__ int64_t gx_run(const RxProgram& P, const RxTables& T,
     return o1;
 }
 
+// One chunk [c0, c1): the documents that have bytes in it, one after the other, from document `lo` (the one that holds c0) on;
+// returns the chunk's exit.  ONE loop for all of them: a lane that is done with a document goes on to the next one inside the
+// same loop, so the lanes of a wavefront need not be in the same document to share the matcher's call site.  (With a loop over
+// the documents around a loop over a document's pieces, the wavefront went through the k-th documents of its 64 chunks
+// together and every lane waited for the longest of them: a chunk took as long as its documents' longest stretches added up,
+// 2.3 times a chunk inside one document — 64 MiB of paragraphs ran at 9.7 GB/s, the same bytes as one document at 20.5.)
+__device__ __forceinline__ void gx_set_doc(GlobalDoc& s, const uint8_t* text, int64_t o0) { s.p = text + o0; }
+__device__ __forceinline__ void gx_set_doc(WindowDoc& s, const uint8_t*, int64_t o0) { s.o0 = o0; }
+template <class Doc>
+__device__ __forceinline__ int64_t gx_chunk(const EncodeArgs& a, const RxProgram& P, const RxTables& T, Doc& s, int64_t lo, int64_t c0, int64_t c1,
+                                            GxWords& W) {
+    int64_t d = lo - 1, o0 = 0, o1 = 0, pos = 0;  // (pos: offset in the text; pos >= o1: the next document's turn)
+    bool inside = false;
+    for (;;) {
+        if (pos >= o1) {
+            if (inside && o1 >= c1) return o1;  // the document ended at or behind the chunk end: nothing of it starts further on
+            ++d;
+            if (d >= a.n_docs) return c1;
+            const int64_t q0 = a.doc_offsets[d], q1 = a.doc_offsets[d + 1];
+            if (q0 >= c1) return c1;
+            if (q1 <= q0) continue;
+            o0 = q0; o1 = q1; inside = true;
+            gx_set_doc(s, a.text, o0);
+            pos = o0;
+            if (o0 < c0) {  // the chunk starts inside this document: speculate from its first character boundary
+                pos = c0;
+                for (int k = 0; k < 3 && pos < o1 && (a.text[pos] & 0xC0u) == 0x80u; ++k) ++pos;
+            }
+            continue;
+        }
+        if (pos >= c1) return pos;
+        int64_t ms, me;
+        rx_next_piece(P, T, s, pos - o0, o1 - o0, ms, me);
+        if (o0 + ms > pos) {  // skipped text: a piece of its own, without tokens
+            W.mark(pos, true);
+            if (o0 + ms >= c1) return o0 + ms;
+        }
+        W.mark(o0 + ms, false);
+        pos = o0 + me;
+    }
+}
+
 #ifndef TD_GX_WAVES
 #define TD_GX_WAVES 2
 #endif
@@ -125,7 +166,7 @@ __global__ __launch_bounds__(256, TD_GX_WAVES) void td_generic_chunks(const Enco
         reinterpret_cast<uint32_t*>(&sP)[w] = reinterpret_cast<const uint32_t*>(a.rx)[w];
     __syncthreads();
     const RxProgram& P = sP;
-    const int64_t n_chunks = (a.n + GX_CHUNK - 1) / GX_CHUNK;
+    const int64_t GX_CHUNK = a.gx_chunk, n_chunks = (a.n + GX_CHUNK - 1) / GX_CHUNK;
     for (int64_t ch = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ch < n_chunks; ch += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c0 = ch * GX_CHUNK, c1 = (c0 + GX_CHUNK < a.n) ? c0 + GX_CHUNK : a.n;
         // the document that holds c0: the last one with offset <= c0 (behind empty ones at the same offset)
@@ -135,20 +176,14 @@ __global__ __launch_bounds__(256, TD_GX_WAVES) void td_generic_chunks(const Enco
             if (a.doc_offsets[mid] <= c0) lo = mid; else hi = mid;
         }
         GxWords W{a.startbits, a.gapbits, c0 >> 5, 0u, 0u};
-        int64_t exit_at = -1;
-        for (int64_t d = lo; d < a.n_docs; ++d) {
-            const int64_t o0 = a.doc_offsets[d], o1 = a.doc_offsets[d + 1];
-            if (o0 >= c1) break;
-            if (o1 <= o0) continue;
-            int64_t from = o0;
-            if (o0 < c0) {  // the chunk starts inside this document: speculate from its first character boundary
-                from = c0;
-                for (int k = 0; k < 3 && from < o1 && (a.text[from] & 0xC0u) == 0x80u; ++k) ++from;
-            }
-            const int64_t e = gx_run(P, T, a.text, a.n, a.text_aligned != 0, o0, o1, from, c1, W);
-            if (e >= c1) { exit_at = e; break; }
+        int64_t exit_at;
+        if (a.text_aligned) {
+            WindowDoc s{a.text, 0, a.n, -1, 0u, 0u, 0u, 0u};
+            exit_at = gx_chunk(a, P, T, s, lo, c0, c1, W);
+        } else {  // (a text pointer that is not 16-byte aligned: plain byte loads)
+            GlobalDoc s{a.text};
+            exit_at = gx_chunk(a, P, T, s, lo, c0, c1, W);
         }
-        if (exit_at < 0) exit_at = c1;
         W.upto((c1 + 31) >> 5);
         if (c1 == a.n) {  // the words behind the text (td_probe_tiles reads a few of them)
             const int64_t wend = ((a.n + 31) >> 5) + 8;
@@ -164,7 +199,7 @@ __device__ __forceinline__ void gx_clear_below(uint32_t* bits, int64_t c0, int64
 }
 
 __global__ __launch_bounds__(256) void td_generic_commit(const EncodeArgs a) {
-    const int64_t n_chunks = (a.n + GX_CHUNK - 1) / GX_CHUNK;
+    const int64_t GX_CHUNK = a.gx_chunk, n_chunks = (a.n + GX_CHUNK - 1) / GX_CHUNK;
     for (int64_t ch = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ch < n_chunks; ch += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c0 = ch * GX_CHUNK, c1 = (c0 + GX_CHUNK < a.n) ? c0 + GX_CHUNK : a.n;
         bool valid = true;
@@ -203,7 +238,7 @@ __global__ __launch_bounds__(64) void td_generic_redo(const EncodeArgs a) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nbad; j += gridDim.x * blockDim.x) {
         const int64_t ch = reinterpret_cast<const uint32_t*>(a.gap_list)[j];
         if (ch > 0 && a.gx_state[ch - 1] == 0u) continue;  // (an earlier chunk of the same document failed too: its lane goes on to the end)
-        const int64_t c0 = ch * GX_CHUNK;
+        const int64_t c0 = ch * a.gx_chunk;
         int64_t lo = 0, hi = a.n_docs;
         while (hi - lo > 1) {
             const int64_t mid = (lo + hi) >> 1;
@@ -248,7 +283,7 @@ __global__ __launch_bounds__(256) void td_generic_gaps(const EncodeArgs a) {
 }
 
 hipError_t launch_generic_split(const EncodeArgs& a, hipStream_t stream) {
-    const int64_t n_chunks = (a.n + GX_CHUNK - 1) / GX_CHUNK;
+    const int64_t GX_CHUNK = a.gx_chunk, n_chunks = (a.n + GX_CHUNK - 1) / GX_CHUNK;
     int64_t blocks = (n_chunks + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;

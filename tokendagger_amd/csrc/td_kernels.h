@@ -33,6 +33,22 @@ struct SpecialTable {
     uint32_t n, maxlen;       // literals; bytes of the longest one.  n == 0: no cuts in this call
 };
 
+// Generic split patterns: text bytes per lane of td_generic_chunks.  A lane needs about 3 microseconds per byte (a
+// backtracking matcher, 64 lanes in 64 different states), so a chunk sets the floor of the kernel's duration: 1 KiB chunks
+// took 3 ms however small the text was (8 MiB: 2.6 GB/s; with 256-byte chunks 8.7).  Small enough for two chunks per lane
+// the GPU can hold (256 CUs x 8 waves x 64 lanes), not smaller than 64 bytes (a chunk's first piece or two are speculation
+// and matched twice), not larger than 1 KiB; a multiple of 32: a lane owns whole words of the bitmaps.
+inline int gx_chunk_for(int64_t n) {
+#ifdef TD_GX_CHUNK
+    (void)n;
+    return TD_GX_CHUNK;  // (A/B builds)
+#else
+    int c = 64;
+    while (c < 1024 && n / (2 * c) >= 262144) c *= 2;
+    return c;
+#endif
+}
+
 struct EncodeArgs {
     const Tables* Tp;           // the table descriptor lives in device memory (keeps the kernel argument block small
                                 // and lets out-of-line helpers take a pointer without spilling kernargs to scratch)
@@ -76,8 +92,9 @@ struct EncodeArgs {
     uint32_t* gap_count;
     uint32_t gap_cap;
     uint32_t* gapbits;          // [(n+31)/32+8] bit i set <=> a stretch of text the pattern skips starts at byte i (it gets no tokens)
-    int64_t* gx_exit;           // [n / 1024 + 1] per chunk: the first piece start at or behind the chunk end, as its own run found it
-    uint32_t* gx_state;         // [n / 1024 + 1] per chunk: 1 = its run agrees with the chunk in front of it
+    int32_t gx_chunk;           // bytes per chunk (gx_chunk_for(n))
+    int64_t* gx_exit;           // [n / gx_chunk + 1] per chunk: the first piece start at or behind the chunk end, as its own run found it
+    uint32_t* gx_state;         // [n / gx_chunk + 1] per chunk: 1 = its run agrees with the chunk in front of it
     uint32_t* deferred_list;    // fused tile loop (td_split_tiles<.., true>): the token tiles it left to td_probe_tiles
     uint32_t* deferred_count;   // entries on it
     int fused;                  // launch the fused tile loop (pre-tokenizer + lookup in one pass over the text)
