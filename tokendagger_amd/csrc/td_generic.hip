@@ -1,5 +1,5 @@
 // Generic split patterns on the device: what td_regex.cpp compiled is matched by the backtracking matcher of
-// td_regex.h, ONE LANE PER 1 KiB CHUNK of the text, speculatively inside a document and checked afterwards (below; round 2
+// td_regex.h, ONE LANE PER CHUNK of the text (64 B .. 1 KiB, gx_chunk_for), speculatively inside a document and checked afterwards (below; round 2
 // ran one lane per document: as fast as its longest document was long).  The kernels write the same START bitmap the
 // family's td_split_tiles writes, so td_probe_tiles and everything behind it run unchanged.
 //
@@ -52,7 +52,7 @@ __device__ __forceinline__ void raise_g(const EncodeArgs& a, int code, int64_t p
 
 // ---- inside a document: speculative chunks ---------------------------------------------------------------------------
 // The next piece from a position depends on the position and the subject only (rx_next_piece has no other state), so a
-// document can be matched in CHUNKS in parallel: every lane starts at the first character boundary of its 1 KiB chunk as if
+// document can be matched in CHUNKS in parallel: every lane starts at the first character boundary of its chunk as if
 // a piece started there, marks the piece starts it finds and notes where it left the chunk (its EXIT: the first piece start
 // at or behind the chunk end).  td_generic_commit then checks every chunk against its predecessor: the predecessor's exit
 // is this chunk's true ENTRY; if the chunk's own run marked a piece start exactly there, everything it found from there on
