@@ -519,6 +519,36 @@ bool rx_compile(const std::string& pattern, RxProgram& P, std::string& err) {
             if (rx_in_class_slow(P, T, c, cp)) m[cp >> 5] |= 1u << (cp & 31u);
         for (int k = 0; k < 4; ++k) P.classes[c].ascii[k] = m[k];
     }
+    // which alternatives can start with which ASCII character (a superset).  first(i) of an alternative's node i: a class
+    // gives its members (and what follows, if it may be empty), a group of literals their first bytes (both cases when
+    // caseless; and what follows, if it is optional), a zero-width assertion only ever restricts what follows, and the end
+    // of the alternative stands for "anything".
+    for (uint32_t c = 0; c < 128u; ++c) P.first_alts[c] = 0;
+    for (uint32_t a = 0; a < P.n_alts; ++a) {
+        uint32_t m[4] = {0, 0, 0, 0};
+        bool open = true;  // the nodes so far may all match empty
+        for (uint32_t k = 0; k < P.alts[a].n_nodes && open; ++k) {
+            const RxNode& nd = P.nodes[P.alts[a].first_node + k];
+            if (nd.kind == RX_CLASS) {
+                for (int q = 0; q < 4; ++q) m[q] |= P.classes[nd.a].ascii[q];
+                open = nd.min == 0;
+            } else if (nd.kind == RX_LITSET) {
+                for (uint32_t l = 0; l < nd.b; ++l) {
+                    const uint32_t ch = P.litbytes[P.lits[nd.a + l].off];
+                    if (ch >= 128u) continue;
+                    m[ch >> 5] |= 1u << (ch & 31u);
+                    if (nd.caseless) {
+                        const uint32_t lc = ch | 0x20u;
+                        if (lc >= 'a' && lc <= 'z') { m[(lc ^ 0x20u) >> 5] |= 1u << ((lc ^ 0x20u) & 31u); m[lc >> 5] |= 1u << (lc & 31u); }
+                    }
+                }
+                open = nd.min == 0;
+            }  // (assertions: zero-width, `open` stays)
+        }
+        if (open) m[0] = m[1] = m[2] = m[3] = 0xFFFFFFFFu;
+        for (uint32_t c = 0; c < 128u; ++c)
+            if ((m[c >> 5] >> (c & 31u)) & 1u) P.first_alts[c] |= 1u << a;
+    }
     return true;
 }
 

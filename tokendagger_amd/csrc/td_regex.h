@@ -75,7 +75,13 @@ struct RxProgram {
     RxItem items[RX_MAX_ITEMS];
     RxLit lits[RX_MAX_LITS];
     uint8_t litbytes[RX_MAX_LITBYTES];
+    // bit a of first_alts[c]: alternative a CAN match at a position whose first byte is the ASCII character c (a superset,
+    // filled in by rx_compile from the alternatives' leading nodes).  The matcher tries only those, in order: the others
+    // would fail at their first character.  On the device this is what keeps the lanes of a wavefront together: every lane
+    // goes through the alternatives loop once or twice with ITS alternative instead of all lanes through all of them.
+    uint32_t first_alts[128];
 };
+static_assert(RX_MAX_ALTS <= 32, "RxProgram::first_alts holds one bit per alternative");
 struct RxTables {  // generated/unicode_gc.inc (host arrays, or their copies in HBM)
     const uint16_t* stage1;
     const uint8_t* stage2;
@@ -291,8 +297,10 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
 // the pattern anchored at `start`: end of the match of the first alternative that matches, or -1
 template <class A>
 TD_HD int64_t rx_match_at(const RxProgram& P, const RxTables& T, const A& s, int64_t start, int64_t n) {
-    for (uint32_t a = 0; a < P.n_alts; ++a) {
-        const int64_t e = rx_match_alt(P, T, P.alts[a], s, start, n);
+    const uint32_t b = s.byte(start);  // (start < n)
+    uint32_t m = b < 128u ? P.first_alts[b] : (P.n_alts >= 32u ? 0xFFFFFFFFu : (1u << P.n_alts) - 1u);
+    for (; m; m &= m - 1u) {  // (ordered alternation: lowest alternative first)
+        const int64_t e = rx_match_alt(P, T, P.alts[td_ctz32(m)], s, start, n);
         if (e >= 0) return e;
     }
     return -1;
