@@ -27,23 +27,43 @@ struct WindowDoc {
     int64_t o0, n_text;
     mutable int64_t blk;
     mutable uint32_t w0, w1, w2, w3;
+    // ... and the 16 bytes BEHIND them requested as soon as a block is entered: the lanes of a wavefront cross their block
+    // boundaries at different times, so with a load at the crossing nearly every piece some lane made the whole wavefront
+    // wait a global-memory round trip (a lane needed 3 microseconds per byte; the matcher's arithmetic is a tenth of that).
+    mutable uint32_t x0, x1, x2, x3;
+    __device__ __forceinline__ void load_block(int64_t b, uint32_t& q0, uint32_t& q1, uint32_t& q2, uint32_t& q3) const {
+        if (16 * b + 16 <= n_text) {
+            const uint4 v = *reinterpret_cast<const uint4*>(text + 16 * b);
+            q0 = v.x; q1 = v.y; q2 = v.z; q3 = v.w;
+        } else {  // (the last, partial block of the text, or past it)
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16 && 16 * b + k < n_text; ++k) t[k >> 2] |= (uint32_t)text[16 * b + k] << (8 * (k & 3));
+            q0 = t[0]; q1 = t[1]; q2 = t[2]; q3 = t[3];
+        }
+    }
     __device__ __forceinline__ uint32_t byte(int64_t i) const {
         const int64_t g = o0 + i, b = g >> 4;
         if (b != blk) {
+            if (b == blk + 1) { w0 = x0; w1 = x1; w2 = x2; w3 = x3; }  // (requested when block b - 1 was entered)
+            else load_block(b, w0, w1, w2, w3);
             blk = b;
-            if (16 * b + 16 <= n_text) {
-                const uint4 v = *reinterpret_cast<const uint4*>(text + 16 * b);
-                w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
-            } else {  // (the last, partial block of the text)
-                uint32_t t[4] = {0, 0, 0, 0};
-                for (int k = 0; k < 16 && 16 * b + k < n_text; ++k) t[k >> 2] |= (uint32_t)text[16 * b + k] << (8 * (k & 3));
-                w0 = t[0]; w1 = t[1]; w2 = t[2]; w3 = t[3];
-            }
+            load_block(b + 1, x0, x1, x2, x3);  // (not waited for here: first looked at when the matcher gets there)
         }
         const uint32_t k = (uint32_t)g & 15u;
         const uint32_t lo = (k & 4u) ? w1 : w0, hi = (k & 4u) ? w3 : w2;
         return (((k & 8u) ? hi : lo) >> (8u * (k & 3u))) & 0xFFu;
     }
+};
+// the matcher's backtracking state of one lane in LDS: word k of lane t at [k * GX_THREADS + t] — every lane its own bank,
+// whatever nodes the lanes are at
+constexpr int GX_THREADS = 256;
+constexpr int GX_STATE_WORDS = 2 * RX_MAX_SEQ + 1;
+struct RxStateLds {
+    uint32_t* w;  // &s_state[threadIdx.x]
+    __device__ __forceinline__ int32_t get_e(int i) const { return (int32_t)w[i * GX_THREADS]; }
+    __device__ __forceinline__ void set_e(int i, int32_t v) { w[i * GX_THREADS] = (uint32_t)v; }
+    __device__ __forceinline__ uint32_t get_c(int i) const { return w[(RX_MAX_SEQ + 1 + i) * GX_THREADS]; }
+    __device__ __forceinline__ void set_c(int i, uint32_t v) { w[(RX_MAX_SEQ + 1 + i) * GX_THREADS] = v; }
 };
 __device__ __forceinline__ void raise_g(const EncodeArgs& a, int code, int64_t pos) {
     if (atomicCAS(a.err, 0, code) == 0) *a.err_pos = pos;
@@ -98,7 +118,7 @@ __device__ __forceinline__ int64_t gx_run(const RxProgram& P, const RxTables& T,
         }
         return o1;
     }
-    const WindowDoc s{text, o0, n_text, -1, 0u, 0u, 0u, 0u};
+    const WindowDoc s{text, o0, n_text, -2, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     while (pos < n) {
         if (o0 + pos >= lim) return o0 + pos;
         int64_t ms, me;
@@ -123,7 +143,7 @@ __device__ __forceinline__ void gx_set_doc(GlobalDoc& s, const uint8_t* text, in
 __device__ __forceinline__ void gx_set_doc(WindowDoc& s, const uint8_t*, int64_t o0) { s.o0 = o0; }
 template <class Doc>
 __device__ __forceinline__ int64_t gx_chunk(const EncodeArgs& a, const RxProgram& P, const RxTables& T, Doc& s, int64_t lo, int64_t c0, int64_t c1,
-                                            GxWords& W) {
+                                            GxWords& W, RxStateLds& st) {
     int64_t d = lo - 1, o0 = 0, o1 = 0, pos = 0;  // (pos: offset in the text; pos >= o1: the next document's turn)
     bool inside = false;
     for (;;) {
@@ -145,7 +165,7 @@ __device__ __forceinline__ int64_t gx_chunk(const EncodeArgs& a, const RxProgram
         }
         if (pos >= c1) return pos;
         int64_t ms, me;
-        rx_next_piece(P, T, s, pos - o0, o1 - o0, ms, me);
+        rx_next_piece(P, T, s, pos - o0, o1 - o0, ms, me, st);
         if (o0 + ms > pos) {  // skipped text: a piece of its own, without tokens
             W.mark(pos, true);
             if (o0 + ms >= c1) return o0 + ms;
@@ -158,9 +178,11 @@ __device__ __forceinline__ int64_t gx_chunk(const EncodeArgs& a, const RxProgram
 #ifndef TD_GX_WAVES
 #define TD_GX_WAVES 2
 #endif
-__global__ __launch_bounds__(256, TD_GX_WAVES) void td_generic_chunks(const EncodeArgs a) {
+__global__ __launch_bounds__(GX_THREADS, TD_GX_WAVES) void td_generic_chunks(const EncodeArgs a) {
     const RxTables T{a.rx_stage1, a.rx_stage2};
     __shared__ RxProgram sP;  // (the matcher reads a node, a class or a literal at every step: out of HBM each was a cache round trip)
+    __shared__ uint32_t s_state[GX_STATE_WORDS * GX_THREADS];
+    RxStateLds st{&s_state[threadIdx.x]};
     static_assert(sizeof(RxProgram) % 4 == 0, "copied as dwords");
     for (uint32_t w = threadIdx.x; w < sizeof(RxProgram) / 4; w += blockDim.x)
         reinterpret_cast<uint32_t*>(&sP)[w] = reinterpret_cast<const uint32_t*>(a.rx)[w];
@@ -178,11 +200,11 @@ __global__ __launch_bounds__(256, TD_GX_WAVES) void td_generic_chunks(const Enco
         GxWords W{a.startbits, a.gapbits, c0 >> 5, 0u, 0u};
         int64_t exit_at;
         if (a.text_aligned) {
-            WindowDoc s{a.text, 0, a.n, -1, 0u, 0u, 0u, 0u};
-            exit_at = gx_chunk(a, P, T, s, lo, c0, c1, W);
+            WindowDoc s{a.text, 0, a.n, -2, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            exit_at = gx_chunk(a, P, T, s, lo, c0, c1, W, st);
         } else {  // (a text pointer that is not 16-byte aligned: plain byte loads)
             GlobalDoc s{a.text};
-            exit_at = gx_chunk(a, P, T, s, lo, c0, c1, W);
+            exit_at = gx_chunk(a, P, T, s, lo, c0, c1, W, st);
         }
         W.upto((c1 + 31) >> 5);
         if (c1 == a.n) {  // the words behind the text (td_probe_tiles reads a few of them)
@@ -287,7 +309,7 @@ hipError_t launch_generic_split(const EncodeArgs& a, hipStream_t stream) {
     int64_t blocks = (n_chunks + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(td_generic_chunks, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(td_generic_chunks, dim3((unsigned)blocks), dim3(GX_THREADS), 0, stream, a);
     hipLaunchKernelGGL(td_generic_commit, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(td_generic_redo, dim3(256), dim3(64), 0, stream, a);
     return hipGetLastError();

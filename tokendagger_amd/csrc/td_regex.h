@@ -157,21 +157,39 @@ TD_HD int rx_lit_at(const RxProgram& P, const RxLit l, bool caseless, const A& s
     return (int)(q - p);
 }
 
+// The matcher's backtracking state: where every node of the alternative ends (relative to the match start, 32 bits) and
+// how many characters / which literal it took.  Indexed by the node the matcher is at — a run-time index: as arrays in
+// registers every access was a chain of 17 compares and selects on the device, so there the state lives in LDS
+// (td_generic.hip: RxStateLds, one bank per lane); on the host it is this struct.
+struct RxStateLocal {
+    int32_t e[RX_MAX_SEQ + 1];  // e[i + 1] = where node i's match ends; e[0] = 0: a node begins where the one in front of it ends
+    uint32_t c[RX_MAX_SEQ];     // RX_CLASS: characters taken; RX_LITSET: literal chosen (b = skipped)
+    TD_HD int32_t get_e(int i) const { return e[i]; }
+    TD_HD void set_e(int i, int32_t v) { e[i] = v; }
+    TD_HD uint32_t get_c(int i) const { return c[i]; }
+    TD_HD void set_c(int i, uint32_t v) { c[i] = v; }
+};
+
 // one alternative, anchored at `start`: end of its (non-empty) match, or -1
-template <class A>
-TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt alt, const A& s, int64_t start, int64_t n) {
+template <class A, class St>
+TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt alt, const A& s, int64_t start, int64_t n, St& st) {
     // (offsets from `start` in 32 bits: the backtracking state is what the matcher's registers go to on the device, and
     // 64-bit positions doubled it; a single match is cut off 2 GiB behind its start)
     if (n - start > 0x7FFFFFF0ll) n = start + 0x7FFFFFF0ll;
-    int32_t end_[RX_MAX_SEQ + 1];  // end_[i + 1] = where node i's match ends; end_[0] = 0: a node begins where the one in front of it ends
-    uint32_t cnt[RX_MAX_SEQ];      // RX_CLASS: characters taken; RX_LITSET: literal chosen (b = skipped)
-    end_[0] = 0;
-    struct Rel {
-        int32_t* v; int64_t base;
-        struct Ref { int32_t* p; int64_t base; TD_HD operator int64_t() const { return base + *p; } TD_HD Ref& operator=(int64_t x) { *p = (int32_t)(x - base); return *this; } };
-        TD_HD Ref operator[](int i) const { return Ref{v + i, base}; }
+    st.set_e(0, 0);
+    struct Cnt {
+        St& st;
+        struct Ref { St& st; int i; TD_HD operator uint32_t() const { return st.get_c(i); } TD_HD Ref& operator=(uint32_t x) { st.set_c(i, x); return *this; }
+                     TD_HD Ref& operator--() { st.set_c(i, st.get_c(i) - 1u); return *this; } TD_HD Ref& operator++() { st.set_c(i, st.get_c(i) + 1u); return *this; } };
+        TD_HD Ref operator[](int i) const { return Ref{st, i}; }
     };
-    const Rel beg{end_, start}, end{end_ + 1, start};  // (beg[i] reads end[i - 1])
+    struct Rel {
+        St& st; int off; int64_t base;
+        struct Ref { St& st; int i; int64_t base; TD_HD operator int64_t() const { return base + st.get_e(i); } TD_HD Ref& operator=(int64_t x) { st.set_e(i, (int32_t)(x - base)); return *this; } };
+        TD_HD Ref operator[](int i) const { return Ref{st, i + off, base}; }
+    };
+    const Cnt cnt{st};
+    const Rel beg{st, 0, start}, end{st, 1, start};  // (beg[i] reads end[i - 1])
     const int nn = (int)alt.n_nodes;
     int i = 0;
     int64_t pos = start;
@@ -295,12 +313,12 @@ TD_HD int64_t rx_match_alt(const RxProgram& P, const RxTables& T, const RxAlt al
 }
 
 // the pattern anchored at `start`: end of the match of the first alternative that matches, or -1
-template <class A>
-TD_HD int64_t rx_match_at(const RxProgram& P, const RxTables& T, const A& s, int64_t start, int64_t n) {
+template <class A, class St>
+TD_HD int64_t rx_match_at(const RxProgram& P, const RxTables& T, const A& s, int64_t start, int64_t n, St& st) {
     const uint32_t b = s.byte(start);  // (start < n)
     uint32_t m = b < 128u ? P.first_alts[b] : (P.n_alts >= 32u ? 0xFFFFFFFFu : (1u << P.n_alts) - 1u);
     for (; m; m &= m - 1u) {  // (ordered alternation: lowest alternative first)
-        const int64_t e = rx_match_alt(P, T, P.alts[td_ctz32(m)], s, start, n);
+        const int64_t e = rx_match_alt(P, T, P.alts[td_ctz32(m)], s, start, n, st);
         if (e >= 0) return e;
     }
     return -1;
@@ -308,10 +326,10 @@ TD_HD int64_t rx_match_at(const RxProgram& P, const RxTables& T, const A& s, int
 
 // The reference's loop body (tiktoken.cpp:86-122) from byte `pos` of the subject [0, n): the next piece is [ms, me).
 // Bytes [pos, ms) are skipped (no tokens).  When nothing matches any more, the rest [pos, n) is the last piece.
-template <class A>
-TD_HD void rx_next_piece(const RxProgram& P, const RxTables& T, const A& s, int64_t pos, int64_t n, int64_t& ms, int64_t& me) {
+template <class A, class St>
+TD_HD void rx_next_piece(const RxProgram& P, const RxTables& T, const A& s, int64_t pos, int64_t n, int64_t& ms, int64_t& me, St& st) {
     for (int64_t p = pos; p < n;) {
-        const int64_t e = rx_match_at(P, T, s, p, n);
+        const int64_t e = rx_match_at(P, T, s, p, n, st);
         if (e >= 0) { ms = p; me = e; return; }
         uint32_t len;
         (void)rx_char_at(s, p, n, len);
@@ -319,6 +337,12 @@ TD_HD void rx_next_piece(const RxProgram& P, const RxTables& T, const A& s, int6
     }
     ms = pos;
     me = n;
+}
+
+template <class A>
+TD_HD void rx_next_piece(const RxProgram& P, const RxTables& T, const A& s, int64_t pos, int64_t n, int64_t& ms, int64_t& me) {
+    RxStateLocal st;
+    rx_next_piece(P, T, s, pos, n, ms, me, st);
 }
 
 // ---- host side (td_regex.cpp) ----
