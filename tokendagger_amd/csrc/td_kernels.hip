@@ -438,7 +438,17 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     }
     __syncthreads();
 
-    constexpr int NPF = (K_WIN / 16 + K_THREADS - 1) / K_THREADS;  // 16-byte prefetch registers per lane for one window
+#ifndef TD_FUSED_NPRE
+#define TD_FUSED_NPRE 0
+#endif
+    constexpr int NPF = (K_WIN / 16 + K_THREADS - 1) / K_THREADS;  // 16-byte pieces per lane for one window
+    // ... of which the two-kernel form prefetches all into registers one tile ahead, and the FUSED loop NONE: its token
+    // phases have no room for them — the compiler parked them in scratch memory behind a wait (load, wait, scratch store at
+    // the prefetch; scratch load at the top of the next tile: 16 KiB of scratch traffic per 8 KiB tile, and the latency the
+    // prefetch was to hide waited for on the spot).  The tile's text is requested at the top of its iteration; five other
+    // workgroups on the CU cover the wait.  1024 MiB of English, same box: 2.15 ms with all three pieces prefetched, 2.07
+    // with one, 1.95 with none (-DTD_FUSED_NPRE=3 / 1 / 0).
+    constexpr int NPRE = FUSED ? TD_FUSED_NPRE : NPF;
     uint4 pf[NPF];
     const int64_t nwords = (a.n + 31) >> 5;
     // (uniform) the whole window lies inside the text and 16-byte loads are aligned: prefetched into registers; the others
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         if (!interior(w0)) return;
         const uint4* src16 = reinterpret_cast<const uint4*>(a.text + w0);
 #pragma unroll
-        for (int q = 0; q < NPF; ++q)
+        for (int q = 0; q < NPRE; ++q)
             if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = src16[q * K_THREADS + tid];
     };
 #pragma unroll
@@ -497,10 +507,14 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         const int tile_hi = K_HL + (int)((a.n - tile_g0 < KS_TILE) ? (a.n - tile_g0) : KS_TILE);
         static_assert(KS_CHUNK == 32, "a lane's stride is one 32-bit word of the masks");
 
-        // ---- phase 0: stage the text window and the document bits.  The text of this tile was requested one
-        //      iteration ago (registers pf[]), so its HBM latency is hidden behind the previous tile --------------
+        // ---- phase 0: stage the text window and the document bits (two-kernel form: the text was requested one iteration ago,
+        //      registers pf[]; FUSED: now, see NPRE) --------------
         uint32_t hib = 0;  // (any byte >= 0x80 in what this lane stages?)
         if (interior(wg0)) {
+            // (the pieces that are not prefetched — the window's tail, a few lanes — are requested now and staged last)
+#pragma unroll
+            for (int q = NPRE; q < NPF; ++q)
+                if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = reinterpret_cast<const uint4*>(a.text + wg0)[q * K_THREADS + tid];
 #pragma unroll
             for (int q = 0; q < NPF; ++q)
                 if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) {
@@ -521,8 +535,8 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             }
         }
         const uint32_t fd0 = pffd0, fd1 = pffd1;  // (FUSED) first documents of this tile's token tiles
-        // next tile of this workgroup.  (FUSED: requested behind the boundary phases instead — the token phases are long
-        // enough to hide the latency, and the prefetch registers are free while the register-hungry phases run)
+        // next tile of this workgroup.  (FUSED: its document bits are requested behind the boundary phases instead, its text
+        // when its turn comes)
         if (!FUSED && tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);
         for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
         if (tid == 0) { s_nh = 0; s_cur = 0; s_ncold = 0; s_last = -1; s_cross = -1; s_defer = 0; }
