@@ -30,9 +30,11 @@ PATTERNS = {
     # lazy quantifiers: as few characters as possible first, one more per way back (PCRE2_NOTEMPTY makes a lone "x*?" take one)
     "lazy1": r"[a-z]+?[0-9]|\s*?\S|.", "lazy2": r"\w{2,5}?\b|\w+?|\s??x|.", "lazy3": r"[ab]*?c|(?:ab|a)??b+|\p{L}*?\p{Lu}|\s+?", "lazy4": r"a??b|.{1,3}?[.!]|\d+?(?=\d)|.",
     # look-behinds of one character class
+    # repeated groups of single-character alternatives (= repeated classes)
+    "rep1": r"(?:a|b|[cd])+x?|(?:é|ü|0)*[.]|\s+|.", "rep2": r"(?i:s|k|t){2,4}|(?:-|_)++\w|(?:a|b)*?c|.",
     "lookb1": r"(?<=[a-z])[0-9]+|(?<![0-9])[a-z]+|\s+|.", "lookb2": r"(?<!\S)\w+|(?<=\s)[^\w\s]+|\S|\s+(?<=\n)", "lookb3": r"\p{L}+(?<=s)|(?<=\p{Han})\p{Han}|(?<!.)#+|.",
 }
-REJECTED = [r"\012|.", r"[\d-z]", r"[\p{Han}-z]", r"\x{D800}", r"[\x{DFFF}]", r"(\w+)\s+\1", r"\b+x", r"\Gabc", r"(?<=ab)c", r"(?<=a)+b", r"(?<=a|b)c", r"[[:alpha:]]+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:a|b)*"]
+REJECTED = [r"\012|.", r"[\d-z]", r"[\p{Han}-z]", r"\x{D800}", r"[\x{DFFF}]", r"(\w+)\s+\1", r"\b+x", r"\Gabc", r"(?<=ab)c", r"(?<=a)+b", r"(?<=a|b)c", r"[[:alpha:]]+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:ab|c)*", r"(?:a|)+"]
 
 
 def _strings(n, seed):

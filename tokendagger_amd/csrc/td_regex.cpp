@@ -330,6 +330,40 @@ struct Reader {
             for (auto& a : alts) utf8_append(a, cp);
         }
         for (auto& a : alts) done.push_back(a);
+        {   // a REPEATED group whose alternatives are single characters is a repeated class: (?:a|b|[cd])* == [abcd]*
+            const int q = peek();
+            if (q == '*' || q == '+' || (q == '{' && peek(1) >= '0' && peek(1) <= '9')) {
+                std::vector<uint32_t> cps;
+                for (auto& a : done) {
+                    if (a.empty()) return fail("empty alternative inside a group");
+                    uint32_t cp = (unsigned char)a[0];
+                    size_t need = cp < 0x80 ? 0 : cp < 0xE0 ? 1 : cp < 0xF0 ? 2 : 3;
+                    if (a.size() != need + 1) return fail("repeated groups are supported for alternatives of single characters only");
+                    if (need) cp &= 0xFFu >> (need + 2);
+                    for (size_t k = 1; k <= need; ++k) cp = (cp << 6) | ((unsigned char)a[k] & 0x3Fu);
+                    cps.push_back(cp);
+                    if (caseless) {
+                        if (cp >= 0x80) return fail("case-insensitive groups support ASCII literals only");
+                        const uint32_t lc = cp | 0x20u;
+                        if (lc >= 'a' && lc <= 'z') {
+                            cps.push_back(lc); cps.push_back(lc ^ 0x20u);
+                            if (lc == 's') cps.push_back(0x17Fu);   // (as the literal matcher: PCRE2_UCP folds these two onto s / k)
+                            if (lc == 'k') cps.push_back(0x212Au);
+                        }
+                    }
+                }
+                uint16_t first = 0, idx = 0;
+                for (size_t k = 0; k < cps.size(); ++k) {
+                    if (!new_item(range_item(cps[k], cps[k]), idx)) return false;
+                    if (k == 0) first = idx;
+                }
+                RxNode nd{};
+                nd.kind = RX_CLASS;
+                if (!new_class(first, (uint16_t)cps.size(), false, nd.a)) return false;
+                if (!read_quantifier(nd)) return false;
+                return push_node(nd, alt_first);
+            }
+        }
         RxNode nd{};
         nd.kind = RX_LITSET;
         nd.caseless = caseless ? 1 : 0;
@@ -351,8 +385,6 @@ struct Reader {
             nd.min = 0; ++i;
             if (peek() == '+') { nd.possessive = RX_POSSESSIVE; ++i; }  // atomic: once a literal (or the skip) is chosen the matcher never comes back for another
             else if (peek() == '?') { nd.possessive = RX_LAZY; ++i; }   // lazy: the skip first
-        } else if (peek() == '*' || peek() == '+' || peek() == '{') {
-            return fail("repeated groups are not supported");
         }
         return push_node(nd, alt_first);
     }

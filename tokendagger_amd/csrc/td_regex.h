@@ -13,7 +13,8 @@
 //                         generated/unicode_scripts.inc: td_regex.cpp expands them into ranges; \p{Any})  .
 //                         literal and escaped characters, \r \n \t \f \v \xHH \x{H..}, ranges a-z
 //     quantifiers         ? * + {m} {m,} {m,n}   their possessive forms ?+ *+ ++ {m,n}+   and their lazy forms ?? *? +? {m,n}?
-//     groups of literals  (?:ab|c|[de])  (?i:'s|'t|ll)  optionally followed by ? ?+ ??   (case-insensitive: ASCII + U+017F / U+212A)
+//     groups of literals  (?:ab|c|[de])  (?i:'s|'t|ll)  optionally followed by ? ?+ ??   (case-insensitive: ASCII + U+017F / U+212A);
+//                         with * + {m,n} (and their possessive / lazy forms) when every alternative is ONE character: a repeated class
 //     look-ahead          (?!X)  (?=X)   with X one character class
 //     look-behind         (?<!X) (?<=X)  with X one character class (looks at what stands in FRONT of the subject, see ^ \b below)
 //     $ \Z                end of the subject (or in front of its final newline);  \z  the very end;  ^ \A  its start
