@@ -56,6 +56,13 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
               const int32_t* ranks, int64_t n_special, const uint8_t* special_bytes,
               const int64_t* special_offsets, const int32_t* special_ids, int device, td_tokenizer** out);
 
+/* A second handle on the SAME tables: its own lock, workspace, control block and streams, but the device tables td_create
+ * uploaded (and their host copies) are shared, not copied — what a host thread per HIP stream needs to run encodes
+ * concurrently (the reference shares one CoreBPE between the threads of its pool, tokendagger/wrapper.py:212-235, each with
+ * its own match data, tiktoken.cpp:13-45).  Options set on `src` so far are inherited.  The tables are freed with the last
+ * handle that shares them; every handle is destroyed with td_destroy, in any order. */
+int td_clone(td_tokenizer* src, td_tokenizer** out);
+
 /* Replaces CoreBPE::~CoreBPE (tiktoken.hpp:69-73). */
 void td_destroy(td_tokenizer* t);
 
@@ -65,7 +72,7 @@ void td_destroy(td_tokenizer* t);
  * Threads and streams: a handle may be shared by host threads; calls serialise on one internal lock.  All calls of a
  * handle share ONE device workspace: work of a handle is ordered across streams by the library (a call on another
  * stream than the previous call's waits, on the device, for that call's kernels), so asynchronous calls on different
- * streams do not overlap each other — use one handle per stream for concurrency.  Every entry point leaves the
+ * streams do not overlap each other — use one handle per stream for concurrency (td_clone: without a second copy of the tables).  Every entry point leaves the
  * caller's current HIP device as it found it. */
 const char* td_last_error(const td_tokenizer* t);
 

@@ -30,7 +30,7 @@ TD_OPT_GRAPH = 7
 TD_OPT_DEVICE_SPECIALS = 8
 
 EXPORTS = [
-    "td_create", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",
+    "td_create", "td_clone", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",
     "td_device_status", "td_decode_bytes", "td_encode_with_special", "td_info", "td_set_option",
     "td_special_count", "td_special_get", "td_profile_read",
     "td_vocab_create", "td_vocab_destroy", "td_vocab_error", "td_vocab_load_tiktoken", "td_vocab_load_hf_special",
@@ -102,6 +102,8 @@ def load_library():
     lib.td_create.restype = i32
     lib.td_create.argtypes = [ctypes.c_char_p, i64, vp, vp, vp, i64, vp, vp, vp, i32, ctypes.POINTER(vp)]
     lib.td_destroy.argtypes = [vp]
+    lib.td_clone.restype = i32
+    lib.td_clone.argtypes = [vp, ctypes.POINTER(vp)]
     lib.td_last_error.restype = ctypes.c_char_p
     lib.td_last_error.argtypes = [vp]
     lib.td_encode_batch.restype = i32
@@ -294,6 +296,19 @@ class HipTokenizer:
         if rc != TD_OK:
             raise TokenDaggerHipError(rc, self._lib.td_last_error(None).decode("utf-8", "replace"))
         self._h = h
+
+    def clone(self) -> "HipTokenizer":
+        """td_clone: a second handle on the same device tables (own lock, workspace and streams) — one per host thread / HIP
+        stream for concurrent encodes.  Either handle may be closed first."""
+        other = type(self).__new__(type(self))
+        other._lib = self._lib
+        other._h = None
+        h = ctypes.c_void_p()
+        rc = self._lib.td_clone(self._h, ctypes.byref(h))
+        if rc != TD_OK:
+            raise TokenDaggerHipError(rc, self._lib.td_last_error(None).decode("utf-8", "replace"))
+        other._h = h
+        return other
 
     def close(self):
         if getattr(self, "_h", None):

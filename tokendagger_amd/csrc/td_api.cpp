@@ -145,12 +145,28 @@ struct Ctl {  // small control block in device memory
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 }  // namespace
 
-struct td_tokenizer {
+// What td_create builds and no call changes afterwards: the host tables and their copies in HBM (~30 MB for a 200 000-entry
+// vocabulary).  Shared by the handles td_clone makes from one another; freed with the last of them.
+struct SharedTables {
     HostTables H;
+    std::vector<void*> table_allocs;
+    int device = 0;
+    ~SharedTables() {
+        if (table_allocs.empty()) return;
+        DeviceGuard dg(device);
+        for (void* p : table_allocs) (void)hipFree(p);
+    }
+};
+
+struct td_tokenizer {
+    std::shared_ptr<SharedTables> shared;
+    HostTables& H;                           // = shared->H
     Tables dT;  // device pointers
     const Tables* dTp = nullptr;  // the same descriptor, in device memory
     int device = 0;
-    std::vector<void*> table_allocs;
+    std::vector<void*>& table_allocs;        // = shared->table_allocs (filled by td_create only)
+    explicit td_tokenizer(std::shared_ptr<SharedTables> s = std::make_shared<SharedTables>())
+        : shared(std::move(s)), H(shared->H), table_allocs(shared->table_allocs) {}
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
@@ -535,6 +551,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     }
     if (device >= ndev) { t->err = "device index out of range"; return fail(TD_E_INVALID); }
     t->device = device;
+    t->shared->device = device;
     DeviceGuard dg(device);  // uploads go to the handle's device; the caller's current device is restored on return
     {
         int cur = -1;
@@ -582,6 +599,32 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     return TD_OK;
 }
 
+int td_clone(td_tokenizer* src, td_tokenizer** out) {
+    if (!out) return TD_E_INVALID;
+    *out = nullptr;
+    if (!src) { g_create_err = "td_clone: bad argument"; return TD_E_INVALID; }
+    td_tokenizer* t = nullptr;
+    {
+        std::lock_guard<std::mutex> g(src->mu);  // (its options are read)
+        t = new td_tokenizer(src->shared);
+        t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
+        t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
+        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused;
+        t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
+        t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
+    }
+    DeviceGuard dg(t->device);
+    int rc = ensure(t, t->ctl, sizeof(Ctl));
+    if (rc == TD_OK && hipMemset(t->ctl.p, 0, sizeof(Ctl)) != hipSuccess) { t->err = "hipMemset failed"; rc = TD_E_HIP; }
+    if (rc != TD_OK) {
+        g_create_err = t->err;
+        td_destroy(t);
+        return rc;
+    }
+    *out = t;
+    return TD_OK;
+}
+
 void td_destroy(td_tokenizer* t) {
     if (!t) return;
     {
@@ -589,7 +632,6 @@ void td_destroy(td_tokenizer* t) {
         (void)hipDeviceSynchronize();
         bury(t);
         drop_graph(t);
-        for (void* p : t->table_allocs) (void)hipFree(p);
         for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
         for (auto& ev : t->ev_free) for (auto e : ev.e) (void)hipEventDestroy(e);
         if (t->last_done) (void)hipEventDestroy(t->last_done);
