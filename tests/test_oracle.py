@@ -135,3 +135,24 @@ def test_heap_form_of_the_merge_loop_is_the_same_function():
                 assert np.array_equal(O.encode(d), R.encode(d)), d[:40]
     finally:
         port.set_heap_threshold(4096)
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+@pytest.mark.parametrize("gen,size", [("english", 8 << 20), ("mixed", 4 << 20), ("code", 4 << 20), ("chat", 2 << 20)])
+def test_corpora_of_the_gpu_parity_tests_restatement_equals_reference(gen, size):
+    """tests/test_gpu_parity.py::test_corpora_vs_oracle compares the device with the RESTATEMENT on these very corpora (same
+    generators, sizes and seed); the restatement and the product read the same generated Unicode class tables, so here the
+    restatement is held to the compiled reference (PCRE2's own tables) on the same bytes: document by
+    document, and the whole corpus as one document."""
+    import td_corpus
+    x, offs = getattr(td_corpus, gen)(size, seed=7)
+    O = H.port_tokenizer()
+    R = H.ref_tokenizer()
+    pt, po = O.encode_batch(x.tobytes(), offs)
+    _, rt, ro = R.encode_batch(x, offs, n_threads=8, want_tokens=True)
+    assert np.array_equal(po, ro) and np.array_equal(pt, rt)
+    if gen == "english":
+        one = np.asarray([0, len(x)], dtype=np.int64)
+        pt, _ = O.encode_batch(x.tobytes(), one)
+        _, rt, _ = R.encode_batch(x, one, n_threads=1, want_tokens=True)
+        assert np.array_equal(pt, rt)
