@@ -32,9 +32,11 @@ PATTERNS = {
     # look-behinds of one character class
     # repeated groups of single-character alternatives (= repeated classes)
     "rep1": r"(?:a|b|[cd])+x?|(?:é|ü|0)*[.]|\s+|.", "rep2": r"(?i:s|k|t){2,4}|(?:-|_)++\w|(?:a|b)*?c|.",
+    # horizontal white space, "not a newline", POSIX classes (what PCRE2_UCP makes of them)
+    "horiz": r"\h+|[^\h\n]+|\N", "horiz2": r"\H{1,3}|\h", "posix1": r"[[:alpha:]]+|[[:digit:]]+|[[:space:]]+|[^[:alnum:][:space:]]+", "posix2": r"[[:upper:]][[:lower:]]*|[[:word:]]+|[[:cntrl:]]|[[:^alpha:]]",
     "lookb1": r"(?<=[a-z])[0-9]+|(?<![0-9])[a-z]+|\s+|.", "lookb2": r"(?<!\S)\w+|(?<=\s)[^\w\s]+|\S|\s+(?<=\n)", "lookb3": r"\p{L}+(?<=s)|(?<=\p{Han})\p{Han}|(?<!.)#+|.",
 }
-REJECTED = [r"\012|.", r"[\d-z]", r"[\p{Han}-z]", r"\x{D800}", r"[\x{DFFF}]", r"(\w+)\s+\1", r"\b+x", r"\Gabc", r"(?<=ab)c", r"(?<=a)+b", r"(?<=a|b)c", r"[[:alpha:]]+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:ab|c)*", r"(?:a|)+"]
+REJECTED = [r"\012|.", r"[\d-z]", r"[\p{Han}-z]", r"\x{D800}", r"[\x{DFFF}]", r"(\w+)\s+\1", r"\b+x", r"\Gabc", r"(?<=ab)c", r"(?<=a)+b", r"(?<=a|b)c", r"[[:punct:]]+", r"[[:graph:]]", r"\R", r"\v+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:ab|c)*", r"(?:a|)+"]
 
 
 def _strings(n, seed):
@@ -201,3 +203,19 @@ def test_gpu_generic_chunks_inside_large_documents():
             assert np.array_equal(toffs, eoffs), (name, what)
             assert np.array_equal(toks, etoks), (name, what)
         tok.close()
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_horizontal_space_and_posix_classes_on_their_boundary_characters():
+    """\\h is PCRE2's list of 19 characters, [[:alpha:]] ... what PCRE2_UCP turns them into: every listed character and its
+    neighbours, the C0 / C1 controls, letters, marks and digits of several scripts, against PCRE2."""
+    _, mr, special = H.llama4()
+    hs = [0x09, 0x20, 0xA0, 0x1680, 0x180E, 0x2000, 0x2005, 0x200A, 0x200B, 0x202F, 0x205F, 0x3000, 0x3001, 0x1FFF, 0x0A, 0x0B, 0x0C, 0x0D, 0x85, 0x2028, 0x2029]
+    chars = [chr(c) for c in hs] + [chr(c) for c in (0x00, 0x1F, 0x7F, 0x80, 0x9F, 0xAD)] + list("aZéßǅʰΩж中あ가٣३௧Ⅷ½_-'!§€〆́⃝")
+    rng = random.Random(9)
+    docs = ["".join(chars)] + ["".join(rng.choice(chars) for _ in range(rng.randrange(1, 40))) for _ in range(400)]
+    for name in ("horiz", "horiz2", "posix1", "posix2"):
+        R = ref.RefTokenizer(PATTERNS[name], mr, special)
+        for d in docs:
+            b = d.encode("utf-8")
+            assert [b[a:e] for a, e in H.rx_split(PATTERNS[name], b)] == R.split_pieces(b), (name, d)

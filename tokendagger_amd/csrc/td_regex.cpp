@@ -104,6 +104,21 @@ struct Reader {
         return true;
     }
     // behind "\\p" / "\\P": a general category (-> it) or a script (-> its ranges in `multi`, `multi_neg` when negated)
+    // general categories by name ("L", "Lu", "L&" ...) -> bit mask over the category ids; false: no such category
+    static bool gc_mask_of(const std::string& name, uint32_t& mask) {
+        mask = 0;
+        if (name.empty()) return false;
+        if (name.size() == 1 || name == "L&") {
+            const char c0 = name[0];
+            for (int g = 0; g < 30; ++g)
+                if (kGc[g][0] == c0 && (name.size() == 1 || g == 1 || g == 2 || g == 3)) mask |= 1u << g;
+            if (name == "L&") mask &= (1u << 1) | (1u << 2) | (1u << 3);
+        } else {
+            for (int g = 0; g < 30; ++g)
+                if (name == kGc[g]) mask |= 1u << g;
+        }
+        return mask != 0;
+    }
     bool read_property(bool upper_p, RxItem& it, std::vector<RxItem>* multi, bool* multi_neg) {
         std::string name;
         bool neg = upper_p;
@@ -117,15 +132,7 @@ struct Reader {
             name.push_back((char)s[i++]);
         }
         uint32_t mask = 0;
-        if (name.size() == 1 || name == "L&") {
-            const char c0 = name[0];
-            for (int g = 0; g < 30; ++g)
-                if (kGc[g][0] == c0 && (name.size() == 1 || g == 1 || g == 2 || g == 3)) mask |= 1u << g;
-            if (name == "L&") mask &= (1u << 1) | (1u << 2) | (1u << 3);
-        } else {
-            for (int g = 0; g < 30; ++g)
-                if (name == kGc[g]) mask |= 1u << g;
-        }
+        (void)gc_mask_of(name, mask);
         it = none_item();
         if (mask) {
             it.gc_mask = mask;
@@ -158,6 +165,15 @@ struct Reader {
             case 'D': it.flags = RX_F_D; it.negate = 1; return true;
             case 'p': return read_property(false, it, multi, multi_neg);
             case 'P': return read_property(true, it, multi, multi_neg);
+            case 'h': case 'H': case 'N': {  // horizontal white space (PCRE2's list) / anything but a newline, as ranges
+                if (!multi || !multi_neg) return fail(std::string("unsupported escape \\") + (char)c + " here");
+                static const uint32_t H_RANGES[][2] = {{0x09, 0x09}, {0x20, 0x20}, {0xA0, 0xA0}, {0x1680, 0x1680}, {0x180E, 0x180E}, {0x2000, 0x200A},
+                                                       {0x202F, 0x202F}, {0x205F, 0x205F}, {0x3000, 0x3000}};
+                if (c == 'N') { multi->push_back(range_item('\n', '\n')); *multi_neg = true; return true; }
+                for (auto& r : H_RANGES) multi->push_back(range_item(r[0], r[1]));
+                *multi_neg = c == 'H';
+                return true;
+            }
             default: break;
         }
         is_class = false;
@@ -174,7 +190,7 @@ struct Reader {
             case 'x': return read_hex(cp);
             default: break;
         }
-        if (c == 'v' || c == 'h' || c == 'H' || c == 'V' || c == 'R' || c == 'N' || c == 'X' || c == 'b' || c == 'B' || c == 'A' || c == 'Z' ||
+        if (c == 'v' || c == 'V' || c == 'R' || c == 'X' || c == 'b' || c == 'B' || c == 'A' || c == 'Z' ||
             c == 'z' || c == 'G' || c == 'K' || c == 'Q' || c == 'E' || c == 'k' || c == 'g' || c == 'c' || c == 'o' || c == 'u' || (c >= '1' && c <= '9'))
             return fail(std::string("unsupported escape \\") + (char)c);
         if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) return fail(std::string("unsupported escape \\") + (char)c);
@@ -196,7 +212,35 @@ struct Reader {
             int c = peek();
             if (c == ']' && !first_char) { ++i; break; }
             first_char = false;
-            if (c == '[' && peek(1) == ':') return fail("POSIX classes [:name:] are not supported");
+            if (c == '[' && peek(1) == ':') {  // POSIX class: what PCRE2_UCP makes of it (pcre2pattern: "[:alpha:] becomes \p{L}" ...)
+                const size_t e = s.find(":]", i + 2);
+                if (e == std::string::npos) return fail("unterminated POSIX class");
+                std::string name = s.substr(i + 2, e - (i + 2));
+                bool pneg = false;
+                if (!name.empty() && name[0] == '^') { pneg = true; name.erase(0, 1); }
+                RxItem pit = none_item();
+                auto gc = [&](std::initializer_list<const char*> cats) {
+                    uint32_t m = 0;
+                    for (const char* cname : cats) { uint32_t one = 0; if (gc_mask_of(cname, one)) m |= one; }
+                    return m;
+                };
+                if (name == "alpha") pit.gc_mask = gc({"L"});
+                else if (name == "lower") pit.gc_mask = gc({"Ll"});
+                else if (name == "upper") pit.gc_mask = gc({"Lu"});
+                else if (name == "digit") pit.flags = RX_F_D;
+                else if (name == "alnum") pit.gc_mask = gc({"L", "N"});
+                else if (name == "space") pit.flags = RX_F_S;
+                else if (name == "word") pit.flags = RX_F_W;
+                else if (name == "cntrl") pit.gc_mask = gc({"Cc"});
+                else return fail("POSIX class [:" + name + ":] is not supported");
+                if (pit.gc_mask == 0 && pit.flags == 0) return fail("POSIX class [:" + name + ":] is not supported");
+                pit.negate = pneg ? 1 : 0;
+                i = e + 2;
+                plain = false;
+                if (!new_item(pit, idx)) return false;
+                ++n;
+                continue;
+            }
             uint32_t lo;
             RxItem it;
             bool is_class = false;
