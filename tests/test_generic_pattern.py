@@ -33,10 +33,10 @@ PATTERNS = {
     # repeated groups of single-character alternatives (= repeated classes)
     "rep1": r"(?:a|b|[cd])+x?|(?:é|ü|0)*[.]|\s+|.", "rep2": r"(?i:s|k|t){2,4}|(?:-|_)++\w|(?:a|b)*?c|.",
     # horizontal white space, "not a newline", POSIX classes (what PCRE2_UCP makes of them)
-    "horiz": r"\h+|[^\h\n]+|\N", "horiz2": r"\H{1,3}|\h", "posix1": r"[[:alpha:]]+|[[:digit:]]+|[[:space:]]+|[^[:alnum:][:space:]]+", "posix2": r"[[:upper:]][[:lower:]]*|[[:word:]]+|[[:cntrl:]]|[[:^alpha:]]",
+    "horiz": r"\h+|[^\h\n]+|\N", "horiz2": r"\H{1,3}|\h", "vert": r"\v+|[^\v\h]+|\V", "posix1": r"[[:alpha:]]+|[[:digit:]]+|[[:space:]]+|[^[:alnum:][:space:]]+", "posix2": r"[[:upper:]][[:lower:]]*|[[:word:]]+|[[:cntrl:]]|[[:^alpha:]]",
     "lookb1": r"(?<=[a-z])[0-9]+|(?<![0-9])[a-z]+|\s+|.", "lookb2": r"(?<!\S)\w+|(?<=\s)[^\w\s]+|\S|\s+(?<=\n)", "lookb3": r"\p{L}+(?<=s)|(?<=\p{Han})\p{Han}|(?<!.)#+|.",
 }
-REJECTED = [r"\012|.", r"[\d-z]", r"[\p{Han}-z]", r"\x{D800}", r"[\x{DFFF}]", r"(\w+)\s+\1", r"\b+x", r"\Gabc", r"(?<=ab)c", r"(?<=a)+b", r"(?<=a|b)c", r"[[:punct:]]+", r"[[:graph:]]", r"\R", r"\v+", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:ab|c)*", r"(?:a|)+"]
+REJECTED = [r"\012|.", r"[\d-z]", r"[\p{Han}-z]", r"\x{D800}", r"[\x{DFFF}]", r"(\w+)\s+\1", r"\b+x", r"\Gabc", r"(?<=ab)c", r"(?<=a)+b", r"(?<=a|b)c", r"[[:punct:]]+", r"[[:graph:]]", r"\R", r"(a|b)+", r"\p{Klingon}+", r"[^\P{Han}]", r"(?i)abc", r"a|", r"(?:ab|c)*", r"(?:a|)+"]
 
 
 def _strings(n, seed):
@@ -214,7 +214,7 @@ def test_horizontal_space_and_posix_classes_on_their_boundary_characters():
     chars = [chr(c) for c in hs] + [chr(c) for c in (0x00, 0x1F, 0x7F, 0x80, 0x9F, 0xAD)] + list("aZéßǅʰΩж中あ가٣३௧Ⅷ½_-'!§€〆́⃝")
     rng = random.Random(9)
     docs = ["".join(chars)] + ["".join(rng.choice(chars) for _ in range(rng.randrange(1, 40))) for _ in range(400)]
-    for name in ("horiz", "horiz2", "posix1", "posix2"):
+    for name in ("horiz", "horiz2", "vert", "posix1", "posix2"):
         R = ref.RefTokenizer(PATTERNS[name], mr, special)
         for d in docs:
             b = d.encode("utf-8")

@@ -165,11 +165,16 @@ struct Reader {
             case 'D': it.flags = RX_F_D; it.negate = 1; return true;
             case 'p': return read_property(false, it, multi, multi_neg);
             case 'P': return read_property(true, it, multi, multi_neg);
-            case 'h': case 'H': case 'N': {  // horizontal white space (PCRE2's list) / anything but a newline, as ranges
+            case 'h': case 'H': case 'N': case 'v': case 'V': {  // horizontal / vertical white space (PCRE2's lists) / anything but a newline, as ranges
                 if (!multi || !multi_neg) return fail(std::string("unsupported escape \\") + (char)c + " here");
                 static const uint32_t H_RANGES[][2] = {{0x09, 0x09}, {0x20, 0x20}, {0xA0, 0xA0}, {0x1680, 0x1680}, {0x180E, 0x180E}, {0x2000, 0x200A},
                                                        {0x202F, 0x202F}, {0x205F, 0x205F}, {0x3000, 0x3000}};
                 if (c == 'N') { multi->push_back(range_item('\n', '\n')); *multi_neg = true; return true; }
+                if (c == 'v' || c == 'V') {
+                    multi->push_back(range_item(0x0A, 0x0D)); multi->push_back(range_item(0x85, 0x85)); multi->push_back(range_item(0x2028, 0x2029));
+                    *multi_neg = c == 'V';
+                    return true;
+                }
                 for (auto& r : H_RANGES) multi->push_back(range_item(r[0], r[1]));
                 *multi_neg = c == 'H';
                 return true;
@@ -190,7 +195,7 @@ struct Reader {
             case 'x': return read_hex(cp);
             default: break;
         }
-        if (c == 'v' || c == 'V' || c == 'R' || c == 'X' || c == 'b' || c == 'B' || c == 'A' || c == 'Z' ||
+        if (c == 'R' || c == 'X' || c == 'b' || c == 'B' || c == 'A' || c == 'Z' ||
             c == 'z' || c == 'G' || c == 'K' || c == 'Q' || c == 'E' || c == 'k' || c == 'g' || c == 'c' || c == 'o' || c == 'u' || (c >= '1' && c <= '9'))
             return fail(std::string("unsupported escape \\") + (char)c);
         if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) return fail(std::string("unsupported escape \\") + (char)c);
@@ -248,7 +253,6 @@ struct Reader {
             bool multi_neg = false;
             if (c == '\\') {
                 ++i;
-                if (peek() == 'v') return fail("unsupported escape \\v");
                 if (!read_escape(is_class, it, lo, &multi, &multi_neg)) return false;
             } else if (!read_codepoint_literal(lo)) {
                 return false;
@@ -445,7 +449,6 @@ struct Reader {
         uint32_t cp;
         if (c == '\\') {
             ++i;
-            if (peek() == 'v') return fail("unsupported escape \\v");
             bool is_class, multi_neg = false;
             RxItem it;
             std::vector<RxItem> multi;
@@ -546,8 +549,7 @@ struct Reader {
                 if (c == '\\') {
                     ++i;
                     RxItem it;
-                    if (peek() == 'v') return fail("unsupported escape \\v");
-                    std::vector<RxItem> multi;
+                        std::vector<RxItem> multi;
                     bool multi_neg = false;
                     ok = read_escape(is_class, it, cp, &multi, &multi_neg);
                 } else {

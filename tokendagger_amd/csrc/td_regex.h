@@ -9,7 +9,7 @@
 //
 // Supported syntax (td_regex.cpp rejects everything else with TD_E_PATTERN — there is no CPU regex fallback):
 //   top-level alternation  A1|A2|...  of sequences of
-//     character classes   [...]  [^...]  \s \S \d \D \w \W \h \H \N \p{Xx} \P{Xx} (general categories, one- and two-letter; the scripts of
+//     character classes   [...]  [^...]  \s \S \d \D \w \W \h \H \v \V \N \p{Xx} \P{Xx} (general categories, one- and two-letter; the scripts of
 //                         generated/unicode_scripts.inc: td_regex.cpp expands them into ranges; \p{Any})  .
 //                         POSIX classes inside brackets as PCRE2_UCP reads them: [:alpha:] [:lower:] [:upper:] [:digit:] [:alnum:]
 //                         [:space:] [:word:] [:cntrl:] and their negations [:^name:]
