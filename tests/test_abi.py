@@ -45,7 +45,7 @@ def test_no_cpu_fallback_without_gpu():
 def test_unsupported_pattern_rejected_before_touching_the_gpu():
     from tokendagger_amd import capi
     with pytest.raises(capi.TokenDaggerHipError) as e:
-        capi.HipTokenizer(cases.UNSUPPORTED_PATTERN, {b"a": 0}, {}, device=0)  # (back-reference, lazy quantifier: outside the generic subset)
+        capi.HipTokenizer(cases.UNSUPPORTED_PATTERN, {b"a": 0}, {}, device=0)  # (capturing group + back-reference: outside the generic subset)
     assert e.value.code == 2 and "not supported" in str(e.value)
 
 
