@@ -99,7 +99,8 @@ def all_strings() -> list[tuple[str, str]]:
     return [(f"{k}[{i}]", s) for k, v in ALL.items() for i, s in enumerate(v)]
 
 
-# outside the generic split-pattern subset (back-reference, lazy quantifier): construction must fail with TD_E_PATTERN
+# outside the generic split-pattern subset (a capturing group and a back-reference; the lazy quantifier behind it is
+# inside the subset since round 3): construction must fail with TD_E_PATTERN
 UNSUPPORTED_PATTERN = r"(\w+)\s+\1|\S+?"
 # patterns the generic compiler accepts: construction-time negative tests must not use these
 SUPPORTED_GENERIC_PATTERNS = [r"\w+|\s+", r"[a-z]+|\s+", r"\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+|\s+"]
