@@ -49,7 +49,8 @@ typedef struct td_tokenizer td_tokenizer;
  * Builds the device tables and uploads them to HIP device `device` (-1: current device).
  * pat_str (init_regex, tiktoken.cpp:47-68): the known tokenizer patterns (o200k / Llama-4, tekken, cl100k_base / Llama-3, Qwen2, GPT-2)
  * have kernels of their own; any other pattern within the backtracking subset listed in tokendagger_amd/csrc/td_regex.h is
- * compiled and matched one lane per document with PCRE2's semantics (text it skips gets no tokens, tiktoken.cpp:86-122);
+ * compiled and matched with PCRE2's semantics (text it skips gets no tokens, tiktoken.cpp:86-122), in parallel inside a
+ * document too (speculative chunks of 64 B .. 1 KiB, checked against their predecessors);
  * anything else is TD_E_PATTERN.  There is no CPU regex fallback.
  */
 int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, const int64_t* token_offsets,
