@@ -597,6 +597,38 @@ bool rx_compile(const std::string& pattern, RxProgram& P, std::string& err) {
             if (rx_in_class_slow(P, T, c, cp)) m[cp >> 5] |= 1u << (cp & 31u);
         for (int k = 0; k < 4; ++k) P.classes[c].ascii[k] = m[k];
     }
+    // PCRE2's auto-possessification, where it changes results.  PCRE2 makes a greedy quantifier possessive when the item
+    // behind it cannot start with a character the quantified item matches — harmless, except for one case it gets wrong
+    // (observed with the PCRE2 the reference links, 10.4x; probed in tests/test_generic_pattern.py): behind a quantified
+    // class it looks INTO a possessive optional group "(?:..)?+" and not past it, so "a+(?:q)?+a" never gives an 'a' back
+    // and does not match "aaa".  The reference is what PCRE2 does: a class with a greedy quantifier that can give back,
+    // directly in front of such a group none of whose literals starts with a member of the class, is possessive here too.
+    for (uint32_t a = 0; a < P.n_alts; ++a) {
+        for (uint32_t k = 0; k + 1 < P.alts[a].n_nodes; ++k) {
+            RxNode& nd = P.nodes[P.alts[a].first_node + k];
+            const RxNode& nx = P.nodes[P.alts[a].first_node + k + 1];
+            if (nd.kind != RX_CLASS || nd.possessive != RX_GREEDY || nd.min == nd.max) continue;
+            if (nx.kind != RX_LITSET || nx.possessive != RX_POSSESSIVE || nx.min != 0) continue;
+            bool touches = false;
+            for (uint32_t l = 0; l < nx.b && !touches; ++l) {
+                const RxLit lit = P.lits[nx.a + l];
+                const uint8_t* b = P.litbytes + lit.off;
+                uint32_t cp = b[0];
+                const uint32_t need = cp < 0x80 ? 0 : cp < 0xE0 ? 1 : cp < 0xF0 ? 2 : 3;
+                if (need) cp &= 0xFFu >> (need + 2);
+                for (uint32_t q = 1; q <= need && q < lit.len; ++q) cp = (cp << 6) | (b[q] & 0x3Fu);
+                touches = rx_in_class_slow(P, T, nd.a, cp);
+                if (!touches && nx.caseless && cp < 0x80) {
+                    const uint32_t lc = cp | 0x20u;
+                    if (lc >= 'a' && lc <= 'z') {
+                        touches = rx_in_class_slow(P, T, nd.a, lc) || rx_in_class_slow(P, T, nd.a, lc ^ 0x20u) ||
+                                  (lc == 's' && rx_in_class_slow(P, T, nd.a, 0x17Fu)) || (lc == 'k' && rx_in_class_slow(P, T, nd.a, 0x212Au));
+                    }
+                }
+            }
+            if (!touches) nd.possessive = RX_POSSESSIVE;
+        }
+    }
     // which alternatives can start with which ASCII character (a superset).  first(i) of an alternative's node i: a class
     // gives its members (and what follows, if it may be empty), a group of literals their first bytes (both cases when
     // caseless; and what follows, if it is optional), a zero-width assertion only ever restricts what follows, and the end

@@ -27,7 +27,8 @@
 //     a group followed by ?+ is atomic (the literal chosen, or the skip, is final); \0 followed by a digit (octal), a class
 //     escape as the start of a range ([\d-z]) and surrogates in \x{..} are rejected as PCRE2 rejects or reads them differently
 // Semantics are PCRE2's: ordered alternation, greedy quantifiers that give back one character at a time, possessive ones
-// that do not, a match may not be empty.  Invalid UTF-8 (which PCRE2_NO_UTF_CHECK leaves undefined in the reference) is
+// that do not, a match may not be empty — including the one place where PCRE2's auto-possessification is visible (a quantified
+// class directly in front of a possessive optional group, td_regex.cpp).  Invalid UTF-8 (which PCRE2_NO_UTF_CHECK leaves undefined in the reference) is
 // read as one character per byte that belongs to no category.
 #pragma once
 #include <stdint.h>
