@@ -250,9 +250,9 @@ def _random_pattern(rng):
 def test_random_patterns_equal_pcre2(seed):
     """Random alternations of quantified classes (greedy, possessive, lazy), literal groups (optional, atomic, lazy) and
     zero-width assertions, each on 130 strings.  This is what found PCRE2's auto-possessification reaching into "(?:..)?+"
-    (below) — and, with seed 7, a divergence that is the reference BUILD's own: PCRE2 10.39's JIT does not find "ab" in "-ab" with
-    (?:ab|a)x*b (it does in "ab"; the interpreter's semantics, and this implementation, match both) — which is why the seeds
-    are fixed."""
+    (below) — and, with other seeds, two divergences that are the reference BUILD's own: PCRE2 10.39's JIT does not find "ab" in
+    "-ab" with (?:ab|a)x*b, nor the two blanks of "K 9  A" with \\p{P}??\\p{Zs}+<blank>; PCRE2's interpreter (PCRE2_NO_JIT) and
+    this implementation do (oracle/pcre2_probe.c) — which is why the seeds are fixed."""
     _, mr, special = H.llama4()
     rng = random.Random(seed)
     al = " \t\n\r_aAbBxXyY019.,'-éÉ中ſK  "
