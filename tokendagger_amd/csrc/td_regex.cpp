@@ -207,7 +207,7 @@ struct Reader {
     // "[...]" (the '[' is consumed): the class; when `chars` is given and the class is a plain positive set of ASCII
     // characters, they are listed there too (for the expansion inside literal groups)
     bool read_bracket(uint16_t& cls, std::vector<uint32_t>* chars) {
-        bool neg = false, plain = true;
+        bool neg = false, plain = true, has_escape = false;
         if (peek() == '^') { neg = true; ++i; }
         const uint16_t first = (uint16_t)P.n_items;
         uint16_t n = 0, idx;
@@ -242,6 +242,7 @@ struct Reader {
                 pit.negate = pneg ? 1 : 0;
                 i = e + 2;
                 plain = false;
+                has_escape = true;
                 if (!new_item(pit, idx)) return false;
                 ++n;
                 continue;
@@ -259,6 +260,7 @@ struct Reader {
             }
             if (is_class) {
                 plain = false;
+                has_escape = true;
                 if (!multi.empty()) {  // a script: its ranges
                     if (multi_neg) return fail("a negated script property inside a character class is not supported");
                     for (const RxItem& m : multi) { if (!new_item(m, idx)) return false; ++n; }
@@ -294,7 +296,9 @@ struct Reader {
         }
         if (n == 0) return fail("empty character class");
         if (chars && (!plain || neg)) chars->clear();
-        return new_class(first, n, neg, cls);
+        if (!new_class(first, n, neg, cls)) return false;
+        P.classes[cls].pad[0] = has_escape ? 1 : 0;  // (compile-time note: \d \p{..} [:name:] ... inside, see rx_compile)
+        return true;
     }
 
     // quantifier behind a class atom
@@ -343,6 +347,7 @@ struct Reader {
     bool read_literal_group(bool caseless, uint32_t alt_first) {
         std::vector<std::string> alts(1);  // the alternatives in order; a bracket of plain ASCII characters multiplies the current one
         std::vector<std::string> done;
+        bool had_bracket = false;          // (compile-time note for rx_compile's auto-possessification pass)
         for (;;) {
             if (eof()) return fail("unterminated group");
             const int c = peek();
@@ -358,6 +363,7 @@ struct Reader {
                 if (!read_bracket(cls, &chars)) return false;
                 P.n_items = items0; P.n_classes = classes0;  // (only its characters are used)
                 if (chars.empty()) return fail("inside a group only classes of a few ASCII characters are supported");
+                if (chars.size() > 1) had_bracket = true;  // (PCRE2 compiles a bracket of ONE character to that character)
                 std::vector<std::string> next;
                 for (auto& a : alts)
                     for (uint32_t ch : chars) { next.push_back(a); utf8_append(next.back(), ch); }
@@ -409,11 +415,13 @@ struct Reader {
                 nd.kind = RX_CLASS;
                 if (!new_class(first, (uint16_t)cps.size(), false, nd.a)) return false;
                 if (!read_quantifier(nd)) return false;
+                nd.pad = 1;  // (compile-time note: a group in the pattern — PCRE2 never auto-possessifies it, see rx_compile)
                 return push_node(nd, alt_first);
             }
         }
         RxNode nd{};
         nd.kind = RX_LITSET;
+        nd.pad = had_bracket ? 1 : 0;
         nd.caseless = caseless ? 1 : 0;
         nd.a = (uint16_t)P.n_lits;
         nd.b = (uint16_t)done.size();
@@ -458,9 +466,13 @@ struct Reader {
                 uint16_t idx = 0;
                 for (const RxItem& m : multi)
                     if (!new_item(m, idx)) return false;
-                return new_class(first, (uint16_t)multi.size(), multi_neg, cls);
+                if (!new_class(first, (uint16_t)multi.size(), multi_neg, cls)) return false;
+                P.classes[cls].pad[0] = 1;
+                return true;
             }
-            return single_class(is_class ? it : range_item(cp, cp), cls);
+            if (!single_class(is_class ? it : range_item(cp, cp), cls)) return false;
+            P.classes[cls].pad[0] = is_class ? 1 : 0;
+            return true;
         }
         if (!read_codepoint_literal(cp)) return false;
         return single_class(range_item(cp, cp), cls);
@@ -602,13 +614,19 @@ bool rx_compile(const std::string& pattern, RxProgram& P, std::string& err) {
     // (observed with the PCRE2 the reference links, 10.4x; probed in tests/test_generic_pattern.py): behind a quantified
     // class it looks INTO a possessive optional group "(?:..)?+" and not past it, so "a+(?:q)?+a" never gives an 'a' back
     // and does not match "aaa".  The reference is what PCRE2 does: a class with a greedy quantifier that can give back,
-    // directly in front of such a group none of whose literals starts with a member of the class, is possessive here too.
+    // directly in front of such a group none of whose literals starts with a member of the class, is possessive here too
+    // (PCRE2's interpreter and its JIT agree on this, oracle/pcre2_probe.c; the decision was probed class kind by class kind
+    // and group kind by group kind, 868 combinations in tests/test_generic_pattern.py).  A class that stands for a repeated
+    // group of the pattern ((?:a|b)+) is left alone: PCRE2 does not auto-possessify groups.
     for (uint32_t a = 0; a < P.n_alts; ++a) {
         for (uint32_t k = 0; k + 1 < P.alts[a].n_nodes; ++k) {
             RxNode& nd = P.nodes[P.alts[a].first_node + k];
             const RxNode& nx = P.nodes[P.alts[a].first_node + k + 1];
-            if (nd.kind != RX_CLASS || nd.possessive != RX_GREEDY || nd.min == nd.max) continue;
+            if (nd.kind != RX_CLASS || nd.possessive != RX_GREEDY || nd.min == nd.max || nd.pad) continue;
             if (nx.kind != RX_LITSET || nx.possessive != RX_POSSESSIVE || nx.min != 0) continue;
+            // (a group with a bracket among its alternatives: PCRE2 compares only a class written without class escapes,
+            // properties and POSIX names with it — probed base by base, tests/test_generic_pattern.py)
+            if (nx.pad && P.classes[nd.a].pad[0]) continue;
             bool touches = false;
             for (uint32_t l = 0; l < nx.b && !touches; ++l) {
                 const RxLit lit = P.lits[nx.a + l];
