@@ -20,6 +20,9 @@ g++ -std=c++17 -O2 -fPIC -w -pthread -shared \
     "$ref/src/tiktoken/tiktoken.cpp" "$here/ref_driver.cpp" \
     "$pcre" -o "$out/libtdref.so"
 echo "built $out/libtdref.so"
+# PCRE2's interpreter behind the reference's split loop (oracle/pcre2_interp.c): the oracle of the random-pattern tests
+gcc -O1 -fPIC -shared -I"$here/shim" "$here/pcre2_interp.c" "$pcre" -o "$out/libpcre2interp.so"
+echo "built $out/libpcre2interp.so"
 # The reference's own Python extension (src/py_binding.cpp, unmodified, compiled where it lies) for the cpu_baseline leg that
 # follows the reference's benchmark METHOD (Tokenizer.encode_batch: Python threads over the pybind CoreBPE.encode,
 # tests/throughput_test.py:413-422).  extern/pybind11 is an empty submodule in the checkout: the installed pybind11 headers

@@ -22,6 +22,30 @@ def available() -> bool:
     return LIB_PATH.exists()
 
 
+INTERP_PATH = LIB_PATH.parent / "libpcre2interp.so"
+
+
+def interp_available() -> bool:
+    return INTERP_PATH.exists()
+
+
+_interp = None
+
+
+def interp_split(pattern: str, data: bytes) -> list[bytes]:
+    """The reference's split loop on PCRE2's INTERPRETER (oracle/pcre2_interp.c; the reference itself uses the JIT)."""
+    global _interp
+    if _interp is None:
+        _interp = ctypes.CDLL(str(INTERP_PATH))
+        _interp.interp_split.restype = ctypes.c_int64
+        _interp.interp_split.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+    out = np.zeros(2 * (len(data) + 2), dtype=np.int64)
+    k = _interp.interp_split(pattern.encode("utf-8"), data, len(data), out.ctypes.data, len(data) + 2)
+    if k < 0:
+        raise ValueError("PCRE2 does not compile the pattern")
+    return [data[out[2 * i]:out[2 * i + 1]] for i in range(k)]
+
+
 def _lib():
     lib = ctypes.CDLL(str(LIB_PATH))
     lib.tdref_last_error.restype = ctypes.c_char_p

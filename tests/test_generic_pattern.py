@@ -226,11 +226,12 @@ _BYTES_ONLY = {bytes([i]): i for i in range(256)}  # (split-only comparisons: th
 
 
 _FZ_ATOMS = [r"\s", r"\S", r"\d", r"\w", r"\W", r"\p{L}", r"\p{N}", r"\p{Lu}", r"\p{Ll}", r"[a-z]", r"[A-Z0-9_]", r"[^\s\p{L}\p{N}]", r"[^a-c\n]", r".", r"\h",
-             r"[[:alpha:]]", "a", "b", " ", r"\n", "x", "é", "中", r"\.", "-"]
+             r"[[:alpha:]]", "a", "b", " ", r"\n", "x", "é", "中", r"\.", "-", r"\v", r"\V", r"\H", r"\N", r"\p{Han}", r"[\p{Latin}0-9]", r"[[:upper:][:digit:]]",
+             r"[^[:space:]]", r"\P{L}", r"\x41", r"\x{e9}", r"[\x{4e00}-\x{9fff}]", r"\D", r"\p{P}", r"\p{Zs}"]
 _FZ_QUANT = ["", "", "", "?", "*", "+", "{1,3}", "{2}", "{0,2}", "?+", "*+", "++", "??", "*?", "+?", "{1,3}?", "{2,}+"]
-_FZ_GROUPS = [r"(?:ab|a)", r"(?i:the|an|a)", r"(?:x|y|[01])", r"(?:'s|'t)"]
-_FZ_GQ = ["", "?", "?+", "??"]
-_FZ_ZW = [r"(?=\s)", r"(?!\S)", r"(?=[0-9])", r"(?!a)", r"\b", r"\B", "^", "$", r"\z", r"(?<=a)", r"(?<!\s)", r"(?<=\p{L})"]
+_FZ_GROUPS = [r"(?:ab|a)", r"(?i:the|an|a)", r"(?:x|y|[01])", r"(?:'s|'t)", r"(?:a|b|[xy])", r"(?i:k|s)", r"(?:é|中)"]
+_FZ_GQ = ["", "?", "?+", "??", "+", "*", "{1,2}", "++", "*?"]
+_FZ_ZW = [r"\A", r"\Z", r"(?<![0-9])", r"(?=\p{L})", r"(?=\s)", r"(?!\S)", r"(?=[0-9])", r"(?!a)", r"\b", r"\B", "^", "$", r"\z", r"(?<=a)", r"(?<!\s)", r"(?<=\p{L})"]
 
 
 def _random_pattern(rng):
@@ -248,15 +249,15 @@ def _random_pattern(rng):
     return "|".join(alt() for _ in range(rng.randrange(1, 5)))
 
 
-@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.skipif(not ref.interp_available(), reason="PCRE2 interpreter oracle (oracle/_ref/libpcre2interp.so) not built")
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_random_patterns_equal_pcre2(seed):
     """Random alternations of quantified classes (greedy, possessive, lazy), literal groups (optional, atomic, lazy) and
     zero-width assertions, each on 130 strings.  This is what found PCRE2's auto-possessification reaching into "(?:..)?+"
-    (below) — and, with other seeds, two divergences that are the reference BUILD's own: PCRE2 10.39's JIT does not find "ab" in
-    "-ab" with (?:ab|a)x*b, nor the two blanks of "K 9  A" with \\p{P}??\\p{Zs}+<blank>; PCRE2's interpreter (PCRE2_NO_JIT) and
-    this implementation do (oracle/pcre2_probe.c) — which is why the seeds are fixed."""
-    mr, special = _BYTES_ONLY, {}
+    (below).  The oracle is PCRE2's INTERPRETER behind the reference's split loop (oracle/pcre2_interp.c), not the compiled
+    reference: the reference JIT-compiles its pattern, and the JIT of the PCRE2 linked here (10.39) has bugs of its own on
+    such patterns — it does not find "ab" in "-ab" with (?:ab|a)x*b, nor the two blanks of "K 9  A" with
+    \\p{P}??\\p{Zs}+<blank>; the interpreter and this implementation do (oracle/pcre2_probe.c)."""
     rng = random.Random(seed)
     al = " \t\n\r_aAbBxXyY019.,'-éÉ中ſK  "
     strings = ["".join(rng.choice(al) for _ in range(rng.randrange(0, 40))) for _ in range(120)]
@@ -267,10 +268,9 @@ def test_random_patterns_equal_pcre2(seed):
             H.rx_split(pat, b"abc")
         except ValueError:
             continue  # (outside the subset: rejected, never approximated)
-        R = ref.RefTokenizer(pat, mr, special)
         for s in strings:
             b = s.encode("utf-8")
-            assert [b[a:e] for a, e in H.rx_split(pat, b)] == R.split_pieces(b), (pat, s)
+            assert [b[a:e] for a, e in H.rx_split(pat, b)] == ref.interp_split(pat, b), (pat, s)
 
 
 @pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
