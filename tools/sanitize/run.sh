@@ -12,3 +12,9 @@ g++ $F $S/tab_asan.cpp $C/td_tables.cpp $C/td_regex.cpp -o /tmp/td_tab_asan
 python $S/vocab_files.py $seed 4000 /tmp/td_vocab_asan
 python $S/patterns.py $seed 20000 /tmp/td_rx_asan
 /tmp/td_tab_asan $seed 300
+# The code the DEVICE shares with the host (td_common.h: scanners, exact-key probes, merge rounds; td_regex.h: the matcher) runs
+# in the CPU twin; under the sanitizers (round 3: the twin tests, the generic-pattern tests and 30 000 fuzz documents, no report):
+#   g++ -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined tests/twin/td_twin.cpp $C/td_tables.cpp $C/td_regex.cpp \
+#       -o tests/twin/_build/libtdtwin.so
+#   LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python tools/fuzz_twin_vs_reference.py llama4 1 200
+#   (then delete tests/twin/_build/libtdtwin.so: tests/helpers.py rebuilds the plain one)
