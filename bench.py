@@ -375,6 +375,9 @@ def main():
     elif a.pattern == "generic:words":
         pat = r"\w+|[^\w\s]+|\s+"
     tok = capi.HipTokenizer(pat, ranks, special, device=dev.index)
+    # a repeated step as ONE hipGraph launch (opt-in since round 4: captured on a private stream of the handle during the
+    # warm-up); TD_BENCH_GRAPH=0 times plain launches
+    tok.set_option(capi.TD_OPT_GRAPH, 0 if os.environ.get("TD_BENCH_GRAPH") == "0" else 1)
 
     # ---- the corpus and this rank's share of it -------------------------------------------------------------
     weak = a.scaling == "weak" and world > 1

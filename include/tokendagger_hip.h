@@ -74,7 +74,13 @@ void td_destroy(td_tokenizer* t);
  * handle share ONE device workspace: work of a handle is ordered across streams by the library (a call on another
  * stream than the previous call's waits, on the device, for that call's kernels), so asynchronous calls on different
  * streams do not overlap each other — use one handle per stream for concurrency (td_clone: without a second copy of the tables).  Every entry point leaves the
- * caller's current HIP device as it found it. */
+ * caller's current HIP device as it found it.
+ *
+ * The legacy (null) stream: the library never uses it on its own — copies it waits for, table uploads and the host-buffer
+ * entry points run on a private non-blocking stream of the handle, results come back through pinned memory — so it neither
+ * synchronises with the application's blocking streams nor breaks a stream capture another thread has open.  Kernels are
+ * launched on the null stream only where the CALLER passes hip_stream == NULL to a *_device entry point.  (Workspace growth
+ * calls hipMalloc / hipFree: td_reserve up front if the application captures in global mode.) */
 const char* td_last_error(const td_tokenizer* t);
 
 /*
@@ -179,9 +185,11 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
 #define TD_OPT_SMALL_PATH 5       /* 0: never take the one-launch path for inputs of at most 4 KiB (default 1: on) */
 #define TD_OPT_FUSED 6            /* 0: pre-tokenizer and lookup as two kernels, two passes over the text (default 1: one fused pass;
                                     TD_FUSED=0 in the environment at td_create time also turns it off).  Same results either way. */
-#define TD_OPT_GRAPH 7            /* 0: never replay a repeated td_encode_device call as a hipGraph (default 1: the second identical call in a
-                                    row captures the step's launches, the following ones are one graph launch; TD_GRAPH=0 in the
-                                    environment at td_create time also turns it off) */
+#define TD_OPT_GRAPH 7            /* 1: replay a repeated td_encode_device call as a hipGraph (default 0: off; TD_GRAPH=1 in the environment
+                                    at td_create time also turns it on): the second identical call in a row captures the step's launches on
+                                    a PRIVATE non-blocking stream of the handle (the caller's stream is never put into capture), the
+                                    following ones are one hipGraphLaunch on the caller's stream.  A capture that fails is ended and the
+                                    step is launched kernel by kernel; same results either way. */
 #define TD_OPT_DEVICE_SPECIALS 8  /* 0: td_encode_batch_with_special* always search for the allowed specials on host threads (default 1:
                                     batches of a MiB and more search on the device, td_special.hip; same results) */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 16) */

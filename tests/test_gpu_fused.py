@@ -207,4 +207,4 @@ def test_repeated_device_calls_replay_a_graph_with_the_same_results(tok):
             if R is not None:
                 _, et, eo = R.encode_batch(text, offs, n_threads=os.cpu_count() or 1, want_tokens=True)
                 assert np.array_equal(outs[-1][1], eo) and np.array_equal(outs[-1][0], et)
-    tok.set_option(capi.TD_OPT_GRAPH, 1)
+    tok.set_option(capi.TD_OPT_GRAPH, 0)  # (the default)

@@ -176,8 +176,16 @@ struct td_tokenizer {
     int64_t pool_bytes_opt = 0;
     bool profile = false;
     int stop_after = 0;
-    // the last step as a hipGraph (encode_device_locked)
-    bool graphs = true;
+    // The library never touches the legacy (null) stream on its own: a legacy-stream operation is illegal while ANY thread of
+    // the process captures a blocking stream, and synchronises with every blocking stream of every other thread.  Copies the
+    // host waits for, table uploads and the host-buffer entry points run on `s_own` (non-blocking, private to the handle);
+    // small results come back through `h_ctl` (pinned).
+    hipStream_t s_own = nullptr;
+    hipStream_t s_cap = nullptr;       // hipGraph capture only (non-blocking: the CALLER's stream is never put into capture)
+    void* h_ctl = nullptr;             // pinned, 256 B: the control block / an 8-byte total on their way to the host
+    // the last step as a hipGraph (encode_device_locked): opt-in (TD_OPT_GRAPH, TD_GRAPH=1)
+    bool graphs = false;
+    int graph_failures = 0;
     hipGraphExec_t graph_exec = nullptr;
     EncodeArgs graph_key, last_key;
     hipStream_t graph_stream = nullptr, last_key_stream = nullptr;
@@ -253,6 +261,30 @@ void bury(td_tokenizer* t) {  // caller has synchronised every stream this handl
     t->graveyard.clear();
 }
 
+int own_streams(td_tokenizer* t) {
+    if (!t->s_own) HIP_TRY(t, hipStreamCreateWithFlags(&t->s_own, hipStreamNonBlocking));
+    if (!t->h_ctl) HIP_TRY(t, hipHostMalloc(&t->h_ctl, 256, hipHostMallocDefault));
+    return TD_OK;
+}
+// A copy (or fill) the host waits for: on the call's stream, then that stream is synchronised.  Never the legacy stream.
+int copy_wait(td_tokenizer* t, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    if (bytes == 0) return TD_OK;
+    HIP_TRY(t, hipMemcpyAsync(dst, src, bytes, kind, s));
+    HIP_TRY(t, hipStreamSynchronize(s));
+    return TD_OK;
+}
+int zero_wait(td_tokenizer* t, void* dst, size_t bytes, hipStream_t s) {
+    HIP_TRY(t, hipMemsetAsync(dst, 0, bytes, s));
+    HIP_TRY(t, hipStreamSynchronize(s));
+    return TD_OK;
+}
+// Everything this handle has in flight is done when this returns (its own streams + the last call's event: the caller's
+// stream itself may be gone by now, the event is ours).
+void drain(td_tokenizer* t) {
+    if (t->has_last && t->last_done) (void)hipEventSynchronize(t->last_done);
+    for (hipStream_t st : {t->s_own, t->s_h2d, t->s_k, t->s_d2h}) if (st) (void)hipStreamSynchronize(st);
+}
+
 // Runs f() with the handle locked and its device current; a failure's message is published to this thread's slot.
 template <class F>
 int locked(td_tokenizer* t, F&& f) {
@@ -290,8 +322,9 @@ int upload(td_tokenizer* t, const V* src, size_t count, const V** dst) {
     void* p = nullptr;
     const size_t bytes = std::max<size_t>(count * sizeof(V), 16);
     HIP_TRY(t, hipMalloc(&p, bytes + 16));
-    HIP_TRY(t, hipMemcpy(p, src, count * sizeof(V), hipMemcpyHostToDevice));
     t->table_allocs.push_back(p);
+    int rc = copy_wait(t, p, src, count * sizeof(V), hipMemcpyHostToDevice, t->s_own);
+    if (rc) return rc;
     *dst = (const V*)p;
     return TD_OK;
 }
@@ -434,9 +467,12 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
         t->ev_pending.push_back(ev);
     }
     // A call that repeats the previous one exactly (same buffers, sizes, stream: a loop over a resident batch, one rank's step
-    // of a multi-GPU job) replays the step as ONE hipGraph launch instead of its dozen kernel launches: the second such call
-    // captures the launches, the following ones replay them.  Anything else is launched kernel by kernel.  (The fixed cost
-    // of a step — what a one-tile input takes — is what bends strong scaling at eight GPUs, not what a GiB on one GPU sees.)
+    // of a multi-GPU job) can replay the step as ONE hipGraph launch instead of its dozen kernel launches (opt-in: TD_OPT_GRAPH):
+    // the second such call captures the launches, the following ones replay them.  The capture runs on a PRIVATE non-blocking
+    // stream in thread-local mode — nothing executes during a capture, so it needs no ordering with the caller's stream — and
+    // the caller's stream only ever sees hipGraphLaunch: no stream of the application is in capture because of this library,
+    // other threads' legacy-stream work (torch's default stream) stays legal, and a failed capture costs nothing but itself:
+    // it is ended, the error is cleared and the step is launched kernel by kernel.
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing(stream, &cap_status) != hipSuccess) { cap_status = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
     // (a caller that is capturing this stream into a graph of its own gets the plain launches captured there)
@@ -450,45 +486,53 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
         if (repeats) {
             drop_graph(t);
             hipGraph_t g = nullptr;
-            hipError_t ce = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+            hipError_t ce = t->s_cap ? hipSuccess : hipStreamCreateWithFlags(&t->s_cap, hipStreamNonBlocking);
+            if (ce == hipSuccess) ce = hipStreamBeginCapture(t->s_cap, hipStreamCaptureModeThreadLocal);
             if (ce == hipSuccess) {
-                const hipError_t le = launch_encode(a, stream, nullptr);
-                ce = hipStreamEndCapture(stream, &g);
+                const hipError_t le = launch_encode(a, t->s_cap, nullptr);
+                ce = hipStreamEndCapture(t->s_cap, &g);  // (always: also ends a capture that was invalidated)
                 if (le != hipSuccess) ce = le;
             }
             if (ce == hipSuccess && g && hipGraphInstantiate(&t->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
                 (void)hipGraphDestroy(g);
                 t->graph_key = a;
                 t->graph_stream = stream;
+                t->graph_failures = 0;
                 HIP_TRY(t, hipGraphLaunch(t->graph_exec, stream));
                 return order_after(t, stream);
             }
             if (g) (void)hipGraphDestroy(g);
             t->graph_exec = nullptr;
-            t->graphs = false;  // capture is not available here: plain launches from now on
             (void)hipGetLastError();
+            // not this time: plain launches below; two more identical calls try again, three failures in a row give up
+            if (++t->graph_failures >= 3) t->graphs = false;
+            t->has_last_key = false;
+        } else {
+            t->last_key = a;
+            t->last_key_stream = stream;
+            t->has_last_key = true;
         }
-        t->last_key = a;
-        t->last_key_stream = stream;
-        t->has_last_key = true;
     }
     HIP_TRY(t, launch_encode(a, stream, t->profile ? ev.e : nullptr));
     return order_after(t, stream);
 }
 
 int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) {
+    if (!t->ctl.p) { HIP_TRY(t, hipStreamSynchronize(stream)); return TD_OK; }
+    int rc0 = own_streams(t);
+    if (rc0) return rc0;
+    static_assert(sizeof(Ctl) <= 256, "h_ctl");
+    HIP_TRY(t, hipMemcpyAsync(t->h_ctl, t->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, stream));  // (behind the call's kernels)
     HIP_TRY(t, hipStreamSynchronize(stream));
     if (!t->has_last || t->last_stream == stream) bury(t);  // nothing of this handle is in flight any more
-    if (!t->ctl.p) return TD_OK;
-    Ctl c;
-    HIP_TRY(t, hipMemcpy(&c, t->ctl.p, sizeof c, hipMemcpyDeviceToHost));
+    const Ctl c = *(const Ctl*)t->h_ctl;
     t->last_long = c.long_count;
     t->last_far = c.slow_count;
     t->last_deferred = c.deferred_count;
     t->last_flagged = c.flagged_count;
     if (err_pos) *err_pos = c.err_pos;
     if (c.err != 0) {
-        HIP_TRY(t, hipMemset(t->ctl.p, 0, sizeof(Ctl)));
+        if ((rc0 = zero_wait(t, t->ctl.p, sizeof(Ctl), stream))) return rc0;
         switch (c.err) {
             case TD_E_UNKNOWN_BYTE:
                 t->err = "No value found for piece at byte offset " + std::to_string(c.err_pos) + ": byte sequence is not in the vocabulary";
@@ -557,6 +601,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || cur != device) { t->err = "hipSetDevice failed"; return fail(TD_E_HIP); }
     }
+    if ((rc = own_streams(t))) return fail(rc);
     const HostTables& H = t->H;
     const Tables hv = H.view();
     Tables d;
@@ -594,7 +639,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     t->dT = d;
     if ((rc = upload(t, &t->dT, 1, &t->dTp))) return fail(rc);
     if ((rc = ensure(t, t->ctl, sizeof(Ctl)))) return fail(rc);
-    if (hipMemset(t->ctl.p, 0, sizeof(Ctl)) != hipSuccess) { t->err = "hipMemset failed"; return fail(TD_E_HIP); }
+    if ((rc = zero_wait(t, t->ctl.p, sizeof(Ctl), t->s_own))) return fail(rc);
     *out = t;
     return TD_OK;
 }
@@ -614,8 +659,9 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }
     DeviceGuard dg(t->device);
-    int rc = ensure(t, t->ctl, sizeof(Ctl));
-    if (rc == TD_OK && hipMemset(t->ctl.p, 0, sizeof(Ctl)) != hipSuccess) { t->err = "hipMemset failed"; rc = TD_E_HIP; }
+    int rc = own_streams(t);
+    if (rc == TD_OK) rc = ensure(t, t->ctl, sizeof(Ctl));
+    if (rc == TD_OK) rc = zero_wait(t, t->ctl.p, sizeof(Ctl), t->s_own);
     if (rc != TD_OK) {
         g_create_err = t->err;
         td_destroy(t);
@@ -629,7 +675,7 @@ void td_destroy(td_tokenizer* t) {
     if (!t) return;
     {
         DeviceGuard dg(t->device);  // reached from finalisers at arbitrary points: the caller's device must survive
-        (void)hipDeviceSynchronize();
+        drain(t);  // (not hipDeviceSynchronize: other handles' and the application's streams are none of this handle's business)
         bury(t);
         drop_graph(t);
         for (auto& ev : t->ev_pending) for (auto e : ev.e) (void)hipEventDestroy(e);
@@ -640,7 +686,8 @@ void td_destroy(td_tokenizer* t) {
             for (DevBuf* b : {&sl.d_text, &sl.d_offs, &sl.d_tok, &sl.d_toff}) if (b->p) (void)hipFree(b->p);
             for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_off, sl.ev_tok}) if (e) (void)hipEventDestroy(e);
         }
-        for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h}) if (st) (void)hipStreamDestroy(st);
+        for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h, t->s_own, t->s_cap}) if (st) (void)hipStreamDestroy(st);
+        if (t->h_ctl) (void)hipHostFree(t->h_ctl);
         if (t->small_in) (void)hipHostFree(t->small_in);
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
         if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
@@ -725,12 +772,15 @@ static int build_special_table(td_tokenizer* t, const int32_t* allowed_ids, int6
     if ((rc = ensure(t, t->sp_id, std::max<size_t>(n, 1) * 4))) return rc;
     if ((rc = ensure(t, t->sp_parent, std::max<size_t>(n, 1) * 4))) return rc;
     if ((rc = ensure(t, t->sp_first2, 2048 * 4))) return rc;
-    HIP_TRY(t, hipMemcpy(t->sp_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
-    HIP_TRY(t, hipMemcpy(t->sp_off.p, off.data(), (n + 1) * 4, hipMemcpyHostToDevice));
-    HIP_TRY(t, hipMemcpy(t->sp_len.p, lens.data(), (n + 1) * 4, hipMemcpyHostToDevice));
-    if (n) HIP_TRY(t, hipMemcpy(t->sp_id.p, ids.data(), n * 4, hipMemcpyHostToDevice));
-    if (n) HIP_TRY(t, hipMemcpy(t->sp_parent.p, parent.data(), n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(t, hipMemcpy(t->sp_first2.p, first2.data(), 2048 * 4, hipMemcpyHostToDevice));
+    if ((rc = own_streams(t))) return rc;
+    // (the callers have waited for the kernels that read the previous table; the call that uses this one is ordered behind
+    // these copies by the host: each is waited for)
+    if ((rc = copy_wait(t, t->sp_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice, t->s_own))) return rc;
+    if ((rc = copy_wait(t, t->sp_off.p, off.data(), (n + 1) * 4, hipMemcpyHostToDevice, t->s_own))) return rc;
+    if ((rc = copy_wait(t, t->sp_len.p, lens.data(), (n + 1) * 4, hipMemcpyHostToDevice, t->s_own))) return rc;
+    if ((rc = copy_wait(t, t->sp_id.p, ids.data(), n * 4, hipMemcpyHostToDevice, t->s_own))) return rc;
+    if ((rc = copy_wait(t, t->sp_parent.p, parent.data(), n * 4, hipMemcpyHostToDevice, t->s_own))) return rc;
+    if ((rc = copy_wait(t, t->sp_first2.p, first2.data(), 2048 * 4, hipMemcpyHostToDevice, t->s_own))) return rc;
     t->sp_key = key;
     t->sp_n = (uint32_t)n;
     t->sp_maxlen = maxlen;
@@ -755,7 +805,7 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
             std::vector<int32_t> key(allowed_ids, allowed_ids + n_allowed);
             std::sort(key.begin(), key.end());
             key.erase(std::unique(key.begin(), key.end()), key.end());
-            if (key != t->sp_key && t->has_last) HIP_TRY(t, hipStreamSynchronize(t->last_stream));
+            if (key != t->sp_key && t->has_last) HIP_TRY(t, hipEventSynchronize(t->last_done));
         }
         if ((rc = build_special_table(t, allowed_ids, n_allowed))) return rc;
         if ((rc = ensure(t, t->sp_hit, (size_t)((n_bytes + 31) / 32 + 8) * 4))) return rc;
@@ -935,7 +985,7 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
     if (n_tokens) *n_tokens = tok_base;
     HIP_TRY(t, hipStreamSynchronize(t->s_k));
     if (first_err != TD_OK) {
-        HIP_TRY(t, hipMemset(t->ctl.p, 0, sizeof(Ctl)));
+        if ((rc = zero_wait(t, t->ctl.p, sizeof(Ctl), t->s_k))) return rc;
         return first_err;
     }
     if (capacity_miss) {
@@ -960,7 +1010,8 @@ int encode_batch_small(td_tokenizer* t, const uint8_t* text, const int64_t* doc_
         memset(t->small_out, 0, SMALL_OUT_BYTES);
     }
     int rc;
-    hipStream_t s = nullptr;
+    if ((rc = own_streams(t))) return rc;
+    hipStream_t s = t->s_own;
     if ((rc = order_before(t, s))) return rc;
     const size_t offs_bytes = (((size_t)(n_docs + 1) * 8) + 15) & ~(size_t)15;
     uint8_t* in = (uint8_t*)t->small_in;
@@ -1025,7 +1076,8 @@ int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc
     // worst case one token per byte; typical text needs a quarter of that
     const int64_t dev_cap = std::max<int64_t>(n, 1);
     if ((rc = ensure(t, t->d_tokens, (size_t)dev_cap * 4))) return rc;
-    hipStream_t s = nullptr;
+    if ((rc = own_streams(t))) return rc;
+    hipStream_t s = t->s_own;
     if ((rc = order_before(t, s))) return rc;
     if (n > 0) HIP_TRY(t, hipMemcpyAsync(t->h2d_text.p, text, (size_t)n, hipMemcpyHostToDevice, s));
     HIP_TRY(t, hipMemcpyAsync(t->h2d_offs.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
@@ -1033,7 +1085,7 @@ int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc
     if (rc) return rc;
     rc = device_status_locked(t, s, nullptr);
     if (rc) return rc;
-    HIP_TRY(t, hipMemcpy(out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    if ((rc = copy_wait(t, out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, s))) return rc;
     const int64_t total = out_offsets[n_docs];
     if (n_tokens) *n_tokens = total;
     if (total > out_capacity) {
@@ -1042,7 +1094,7 @@ int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc
     }
     if (total > 0) {
         if (!out_tokens) { t->err = "null out_tokens"; return TD_E_INVALID; }
-        HIP_TRY(t, hipMemcpy(out_tokens, t->d_tokens.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        if ((rc = copy_wait(t, out_tokens, t->d_tokens.p, (size_t)total * 4, hipMemcpyDeviceToHost, s))) return rc;
     }
     return TD_OK;
 }
@@ -1106,7 +1158,8 @@ static int decode_bytes_small(td_tokenizer* t, const int32_t* tokens, int64_t n_
         memset(t->small_dec_out, 0, 64 + SMALL_DEC_MAX_BYTES);
     }
     int rc;
-    hipStream_t s = nullptr;
+    if ((rc = own_streams(t))) return rc;
+    hipStream_t s = t->s_own;
     if ((rc = order_before(t, s))) return rc;
     memcpy(t->small_dec_in, tokens, (size_t)n_tokens * 4);
     SmallDecArgs a;
@@ -1155,31 +1208,33 @@ int td_decode_bytes(td_tokenizer* t, const int32_t* tokens, int64_t n_tokens, ui
             if (rc != -1) return rc;
         }
         if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4 + 16))) return rc;
-        if ((rc = order_before(t, nullptr))) return rc;
-        HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
+        if ((rc = own_streams(t))) return rc;
+        hipStream_t s = t->s_own;
+        if ((rc = order_before(t, s))) return rc;
+        if ((rc = copy_wait(t, t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice, s))) return rc;
         // lengths and offsets first: the byte total sizes the device buffer of the gather
         DecodeArgs a;
-        if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, nullptr, a))) return rc;
-        HIP_TRY(t, launch_decode(a, nullptr, 1));
-        if ((rc = order_after(t, nullptr))) return rc;
+        if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, s, a))) return rc;
+        HIP_TRY(t, launch_decode(a, s, 1));
+        if ((rc = order_after(t, s))) return rc;
         int64_t err_pos = 0;
-        rc = device_status_locked(t, nullptr, &err_pos);
+        rc = device_status_locked(t, s, &err_pos);
         if (rc == TD_E_BAD_TOKEN && err_pos >= 0 && err_pos < n_tokens)
             t->err = "Invalid token for decoding: " + std::to_string(tokens[err_pos]);  // reference: tiktoken.cpp:249
         if (rc) return rc;
-        int64_t total = 0;
-        HIP_TRY(t, hipMemcpy(&total, a.chunk_pref + (n_tokens + 4095) / 4096, 8, hipMemcpyDeviceToHost));
+        if ((rc = copy_wait(t, t->h_ctl, a.chunk_pref + (n_tokens + 4095) / 4096, 8, hipMemcpyDeviceToHost, s))) return rc;
+        const int64_t total = *(const int64_t*)t->h_ctl;
         if (n_bytes) *n_bytes = total;
         if (total > out_capacity) { t->err = "decode capacity too small"; return (int)TD_E_CAPACITY; }
         if (total > 0 && !out) { t->err = "null out"; return (int)TD_E_INVALID; }
         if ((rc = ensure(t, t->dec_out, (size_t)total + 16))) return rc;
         a.out = (uint8_t*)t->dec_out.p;
         a.out_cap = total;
-        HIP_TRY(t, launch_decode(a, nullptr, 2));
-        if ((rc = order_after(t, nullptr))) return rc;
-        rc = device_status_locked(t, nullptr, nullptr);
+        HIP_TRY(t, launch_decode(a, s, 2));
+        if ((rc = order_after(t, s))) return rc;
+        rc = device_status_locked(t, s, nullptr);
         if (rc) return rc;
-        if (total > 0) HIP_TRY(t, hipMemcpy(out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost));
+        if ((rc = copy_wait(t, out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost, s))) return rc;
         return (int)TD_OK;
     });
 }
@@ -1199,34 +1254,36 @@ int td_decode_batch(td_tokenizer* t, const int32_t* tokens, const int64_t* tok_o
         if ((rc = ensure(t, t->dec_tokens, (size_t)n_tokens * 4 + 16))) return rc;
         if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;
         if ((rc = ensure(t, t->d_offsets, (size_t)(n_docs + 1) * 8))) return rc;
-        if ((rc = order_before(t, nullptr))) return rc;
-        HIP_TRY(t, hipMemcpy(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice));
-        HIP_TRY(t, hipMemcpy(t->h2d_offs.p, tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+        if ((rc = own_streams(t))) return rc;
+        hipStream_t s = t->s_own;
+        if ((rc = order_before(t, s))) return rc;
+        HIP_TRY(t, hipMemcpyAsync(t->dec_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice, s));
+        if ((rc = copy_wait(t, t->h2d_offs.p, tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s))) return rc;
         DecodeArgs a;
-        if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, nullptr, a))) return rc;
+        if ((rc = decode_args(t, t->dec_tokens.p, n_tokens, nullptr, INT64_MAX, nullptr, s, a))) return rc;
         a.doc_tok_offsets = (const int64_t*)t->h2d_offs.p;
         a.n_docs = n_docs;
         a.doc_byte_offsets = (int64_t*)t->d_offsets.p;
-        HIP_TRY(t, launch_decode(a, nullptr, 1));
-        if ((rc = order_after(t, nullptr))) return rc;
+        HIP_TRY(t, launch_decode(a, s, 1));
+        if ((rc = order_after(t, s))) return rc;
         int64_t err_pos = 0;
-        rc = device_status_locked(t, nullptr, &err_pos);
+        rc = device_status_locked(t, s, &err_pos);
         if (rc == TD_E_BAD_TOKEN && err_pos >= 0 && err_pos < n_tokens) t->err = "Invalid token for decoding: " + std::to_string(tokens[err_pos]);
         if (rc) return rc;
-        HIP_TRY(t, hipMemcpy(out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+        if ((rc = copy_wait(t, out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, s))) return rc;
         const int64_t total = out_offsets[n_docs];
         if (n_bytes) *n_bytes = total;
         if (total > out_capacity) { t->err = "decode capacity too small"; return (int)TD_E_CAPACITY; }
         if ((rc = ensure(t, t->dec_out, (size_t)total + 16))) return rc;
         a.out = (uint8_t*)t->dec_out.p;
         a.out_cap = total;
-        HIP_TRY(t, launch_decode(a, nullptr, 2));
-        if ((rc = order_after(t, nullptr))) return rc;
-        rc = device_status_locked(t, nullptr, nullptr);
+        HIP_TRY(t, launch_decode(a, s, 2));
+        if ((rc = order_after(t, s))) return rc;
+        rc = device_status_locked(t, s, nullptr);
         if (rc) return rc;
         if (total > 0) {
             if (!out) { t->err = "null out"; return (int)TD_E_INVALID; }
-            HIP_TRY(t, hipMemcpy(out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost));
+            if ((rc = copy_wait(t, out, t->dec_out.p, (size_t)total, hipMemcpyDeviceToHost, s))) return rc;
         }
         return (int)TD_OK;
     });
@@ -1368,13 +1425,14 @@ int encode_special_locked(td_tokenizer* t, const uint8_t* text, const int64_t* d
             if ((rc = ensure(t, t->d_offsets, (size_t)(n_docs + 1) * 8))) return rc;
             const int64_t dev_cap = std::max<int64_t>(n, 1);
             if ((rc = ensure(t, t->d_tokens, (size_t)dev_cap * 4))) return rc;
-            hipStream_t s = nullptr;
+            if ((rc = own_streams(t))) return rc;
+            hipStream_t s = t->s_own;
             if ((rc = order_before(t, s))) return rc;
             {
                 std::vector<int32_t> key(ids);
                 std::sort(key.begin(), key.end());
                 key.erase(std::unique(key.begin(), key.end()), key.end());
-                if (key != t->sp_key && t->has_last) HIP_TRY(t, hipStreamSynchronize(t->last_stream));
+                if (key != t->sp_key && t->has_last) HIP_TRY(t, hipEventSynchronize(t->last_done));
             }
             if ((rc = build_special_table(t, ids.data(), (int64_t)ids.size()))) return rc;
             if ((rc = ensure(t, t->sp_hit, (size_t)((n + 31) / 32 + 8) * 4))) return rc;
@@ -1391,13 +1449,13 @@ int encode_special_locked(td_tokenizer* t, const uint8_t* text, const int64_t* d
             rc = device_status_locked(t, s, nullptr);
             if (rc == TD_E_SCRATCH) rc = TD_OK + 1000;  // (more candidates than the device list holds: the host search below)
             if (rc == TD_OK) {
-                HIP_TRY(t, hipMemcpy(out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+                if ((rc = copy_wait(t, out_offsets, t->d_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, s))) return rc;
                 const int64_t total = out_offsets[n_docs];
                 if (n_tokens) *n_tokens = total;
                 if (total > out_capacity) { t->err = "output capacity too small: " + std::to_string(total) + " tokens needed"; return TD_E_CAPACITY; }
                 if (total > 0) {
                     if (!out_tokens) { t->err = "null out_tokens"; return TD_E_INVALID; }
-                    HIP_TRY(t, hipMemcpy(out_tokens, t->d_tokens.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+                    if ((rc = copy_wait(t, out_tokens, t->d_tokens.p, (size_t)total * 4, hipMemcpyDeviceToHost, s))) return rc;
                 }
                 return TD_OK;
             }
