@@ -170,7 +170,9 @@ int64_t td_info(const td_tokenizer* t, int what);
  * that starts at a position is replaced by its id, the text between two cuts is tokenized as a subject of its own
  * (td_special.hip; the same results as td_encode_batch_with_special, whose search runs on host threads).  One allowed set is
  * kept on the device per handle; a call with a different set first waits for the previous call's kernels.  Patterns of the
- * scanner family only (generic patterns: TD_E_PATTERN).
+ * scanner family only (generic patterns: TD_E_PATTERN).  Limit of the device search: an allowed literal of more than 48 bytes
+ * fails with TD_E_INVALID and a message that says so (TD_E_SPECIAL stays "no such special token"); the host-buffer entry
+ * points (td_encode_batch_with_special*) have no such limit — they search on host threads then.
  */
 int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n_bytes, const void* d_doc_offsets, int64_t n_docs,
                                   const int32_t* allowed_ids, int64_t n_allowed, void* d_out_tokens, int64_t out_capacity,
@@ -267,7 +269,9 @@ int td_create_from_vocab(const td_vocab* v, int device, td_tokenizer** out);
  *                          total) into d_table[2 * world] on every rank; asynchronous on `stream`
  *   td_comm_bases          host: exclusive prefix sums of a gathered table -> this rank's token / document base and the totals
  *   td_comm_gather_tokens  grouped ncclSend / ncclRecv: every rank's ids (table[2 r] of them) end up contiguous, in rank order,
- *                          in d_root_tokens on `root`; `table` is the gathered table on the HOST; asynchronous on `stream`
+ *                          in d_root_tokens on `root`; `table` is the gathered table on the HOST; asynchronous on `stream`.
+ *                          A root buffer that is too small fails on the ROOT only (TD_E_CAPACITY), after the root has taken
+ *                          the other ranks' ids into a scratch buffer: no rank is left with a pending send.
  */
 #define TD_COMM_ID_BYTES 128
 typedef struct td_comm td_comm;

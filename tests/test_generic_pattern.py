@@ -205,6 +205,45 @@ def test_gpu_generic_chunks_inside_large_documents():
         tok.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_gpu_generic_chunks_that_never_resynchronise():
+    """Counted repeats do not resynchronise: in a long run of digits under {1,3} where a chunk's speculative run groups them
+    depends on where it started, so most chunks of the run fail the check, and a chunk BEHIND a failed one may pass it
+    against that one's speculative (wrong) exit (3-byte fullwidth digits from offset 0 with 64-byte chunks —
+    chunk 1 fails, chunks 2 and 3 "validate" against the wrong grouping, chunk 4 fails again with a wrong entry).  One lane per
+    document puts it right from the first failed chunk on (td_generic_redo); runs in the middle of ordinary text exercise its
+    jump over the chunks that are back in step."""
+    import td_corpus
+    from tokendagger_amd import capi
+    _, mr, special = H.llama4()
+    eng, _ = td_corpus.english(1 << 20, seed=18)
+    eng = eng.tobytes()
+    fw = "１２３４５６７８９０".encode()          # 3 bytes each
+    ar = "٠١٢٣٤٥٦٧٨٩".encode()                   # 2 bytes each
+    docs = [fw * 400,                               # the ADVICE case: from offset 0, nothing but digits
+            b"7" * 5000,
+            eng[:5000] + b"1234567890" * 700 + eng[5000:9000] + fw * 333 + b" x " + ar * 500 + eng[9000:20000],
+            b"ab" + fw * 50 + b"12" + fw * 77 + b"3" + ar * 99 + b"." ,
+            eng[20000:300000] + b"0" * 1025 + eng[300000:600000] + fw * 1000 + eng[600000:],
+            (b"9" * 70 + b" ") * 300]
+    for pat in (r"\p{N}{1,3}|\P{N}+", r"\d{1,3}|\D+", r" ?\p{N}{2,4}|[^\p{N}]+|\p{N}", r"\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+|\s+"):
+        tok = capi.HipTokenizer(pat, mr, special, device=0)
+        R = ref.RefTokenizer(pat, mr, special)
+        for cut in (None, 1, 37):
+            dd = docs if cut is None else [d[cut:] for d in docs]   # (other alignments against the chunk grid)
+            text = b"".join(dd)
+            offs = np.concatenate([[0], np.cumsum([len(d) for d in dd])]).astype(np.int64)
+            for view, o in (("documents", offs), ("one document", np.asarray([0, len(text)], dtype=np.int64))):
+                if view == "one document" and cut:  # (a cut may fall inside a character: as ONE document that is the same text again)
+                    continue
+                toks, toffs = tok.encode_batch(text, o)
+                _, etoks, eoffs = R.encode_batch(np.frombuffer(text, dtype=np.uint8), o, n_threads=8, want_tokens=True)
+                assert np.array_equal(toffs, eoffs), (pat, cut, view)
+                assert np.array_equal(toks, etoks), (pat, cut, view)
+        tok.close()
+
+
 @pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
 def test_horizontal_space_and_posix_classes_on_their_boundary_characters():
     """\\h is PCRE2's list of 19 characters, [[:alpha:]] ... what PCRE2_UCP turns them into: every listed character and its

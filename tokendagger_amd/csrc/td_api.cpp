@@ -525,7 +525,8 @@ int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) 
     HIP_TRY(t, hipMemcpyAsync(t->h_ctl, t->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, stream));  // (behind the call's kernels)
     HIP_TRY(t, hipStreamSynchronize(stream));
     if (!t->has_last || t->last_stream == stream) bury(t);  // nothing of this handle is in flight any more
-    const Ctl c = *(const Ctl*)t->h_ctl;
+    Ctl c = *(const Ctl*)t->h_ctl;
+    if (c.err == TD_E_BAD_TOKEN) c.err_pos = 0x7FFFFFFFFFFFFFFFll - c.err_pos;  // (td_decode_len keeps the LOWEST invalid index as a maximum)
     t->last_long = c.long_count;
     t->last_far = c.slow_count;
     t->last_deferred = c.deferred_count;
@@ -751,7 +752,11 @@ static int build_special_table(td_tokenizer* t, const int32_t* allowed_ids, int6
         lens[i] = (uint32_t)x.size();
         bytes.insert(bytes.end(), x.begin(), x.end());
         while (bytes.size() % 4) bytes.push_back(0);
-        if (x.size() > 48) { t->err = "special tokens longer than 48 bytes are not supported by the device search"; return TD_E_SPECIAL; }
+        if (x.size() > 48) {
+            t->err = "td_encode_device_with_special: the allowed special token '" + x + "' is " + std::to_string(x.size()) +
+                     " bytes long; the device search takes literals of at most 48 bytes (td_encode_batch_with_special searches on the host)";
+            return TD_E_INVALID;
+        }
         ids[i] = lits[i].second;
         maxlen = std::max<uint32_t>(maxlen, (uint32_t)x.size());
         // longest proper prefix that is a literal: in sorted order a prefix stands in front of its extensions

@@ -155,21 +155,43 @@ int td_comm_gather_tokens(td_comm* c, const int32_t* d_tokens, const int64_t* ta
     if (mine > 0 && !d_tokens) return fail(TD_E_INVALID, "td_comm_gather_tokens: null token buffer");
     int64_t total = 0;
     for (int r = 0; r < c->world; ++r) total += table[2 * r];
-    if (c->rank == root && (total > root_capacity || (total > 0 && !d_root_tokens)))
-        return fail(TD_E_CAPACITY, "td_comm_gather_tokens: root buffer too small: " + std::to_string(total) + " ids");
+    // A root buffer that is too small must not leave the other ranks' sends without a receive (they cannot see root_capacity,
+    // ADVICE r3): the root still takes part — it receives into a scratch buffer of the right size, and reports TD_E_CAPACITY
+    // once the exchange is complete on its stream.  Every other rank's call succeeds.
     hipStream_t s = (hipStream_t)stream;
+    int32_t* dst = d_root_tokens;
+    void* scratch = nullptr;
+    const bool short_root = c->rank == root && (total > root_capacity || (total > 0 && !d_root_tokens));
+    if (short_root) {
+        if (hipMalloc(&scratch, (size_t)total * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TD_E_HIP, "td_comm_gather_tokens: root buffer too small (" + std::to_string(total) +
+                                      " ids) and no memory for a scratch buffer to complete the exchange: the other ranks' sends are pending");
+        }
+        dst = (int32_t*)scratch;
+    }
+    auto done = [&](int rc) {
+        if (scratch) {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(scratch);
+        }
+        return rc;
+    };
     ncclResult_t r = R->GroupStart();
-    if (r != ncclSuccess) return nccl_fail(R, "ncclGroupStart", r);
+    if (r != ncclSuccess) return done(nccl_fail(R, "ncclGroupStart", r));
+    hipError_t he = hipSuccess;
     if (c->rank == root) {
         int64_t base = 0;
         for (int p = 0; p < c->world; ++p) {
             const int64_t cnt = table[2 * p];
             if (p == root) {
-                if (cnt > 0 && d_root_tokens + base != d_tokens)
-                    (void)hipMemcpyAsync(d_root_tokens + base, d_tokens, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s);
+                if (cnt > 0 && !short_root && dst + base != d_tokens) {
+                    const hipError_t e1 = hipMemcpyAsync(dst + base, d_tokens, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s);
+                    if (he == hipSuccess) he = e1;
+                }
             } else if (cnt > 0) {
-                r = R->Recv(d_root_tokens + base, (size_t)cnt, ncclInt32, p, c->comm, s);
-                if (r != ncclSuccess) { (void)R->GroupEnd(); return nccl_fail(R, "ncclRecv", r); }
+                r = R->Recv(dst + base, (size_t)cnt, ncclInt32, p, c->comm, s);
+                if (r != ncclSuccess) { (void)R->GroupEnd(); return done(nccl_fail(R, "ncclRecv", r)); }
             }
             base += cnt;
         }
@@ -178,7 +200,9 @@ int td_comm_gather_tokens(td_comm* c, const int32_t* d_tokens, const int64_t* ta
         if (r != ncclSuccess) { (void)R->GroupEnd(); return nccl_fail(R, "ncclSend", r); }
     }
     r = R->GroupEnd();
-    if (r != ncclSuccess) return nccl_fail(R, "ncclGroupEnd", r);
+    if (r != ncclSuccess) return done(nccl_fail(R, "ncclGroupEnd", r));
+    if (he != hipSuccess) return done(fail(TD_E_HIP, std::string("td_comm_gather_tokens: hipMemcpyAsync: ") + hipGetErrorString(he)));
+    if (short_root) return done(fail(TD_E_CAPACITY, "td_comm_gather_tokens: root buffer too small: " + std::to_string(total) + " ids"));
     return TD_OK;
 }
 

@@ -252,30 +252,60 @@ __global__ __launch_bounds__(256) void td_generic_commit(const EncodeArgs a) {
     }
 }
 
-// the rest of a document from its first chunk that failed the check, by one lane (rare)
+// A document with chunks that failed the check is put right by ONE lane — the lane of its FIRST failed chunk (a
+// later failed chunk's predecessor may have been "validated" against a failed chunk's speculative exit, so its entry is not
+// known to be true and two lanes of one document would write the same words).  The lane goes chunk by chunk: a chunk is
+// matched anew from its true entry; if it leaves the chunk where the chunk's first run had left it and the chunk behind was
+// validated against that exit, everything up to the document's next failed chunk is what a sequential run finds (induction
+// as in td_generic_commit) and the lane jumps there; otherwise the chunk behind is matched anew as well.  gx_exit is only read
+// here (a chunk that holds a document boundary carries the NEXT document's exit).
 __global__ __launch_bounds__(64) void td_generic_redo(const EncodeArgs a) {
     const RxTables T{a.rx_stage1, a.rx_stage2};
     const RxProgram& P = *a.rx;
     const uint32_t nbad = *a.gap_count < a.gap_cap ? *a.gap_count : a.gap_cap;
+    const int64_t GX_CHUNK = a.gx_chunk;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nbad; j += gridDim.x * blockDim.x) {
         const int64_t ch = reinterpret_cast<const uint32_t*>(a.gap_list)[j];
-        if (ch > 0 && a.gx_state[ch - 1] == 0u) continue;  // (an earlier chunk of the same document failed too: its lane goes on to the end)
-        const int64_t c0 = ch * a.gx_chunk;
+        const int64_t c0 = ch * GX_CHUNK;
         int64_t lo = 0, hi = a.n_docs;
         while (hi - lo > 1) {
             const int64_t mid = (lo + hi) >> 1;
             if (a.doc_offsets[mid] <= c0) lo = mid; else hi = mid;
         }
         const int64_t o0 = a.doc_offsets[lo], o1 = a.doc_offsets[lo + 1];
-        const int64_t t = a.gx_exit[ch - 1];
-        // bits of [c0, o1) anew; the word that holds o1 keeps what belongs to the next document
-        const int64_t wlast = o1 >> 5;
-        const uint32_t keep_s = (o1 & 31) ? a.startbits[wlast] & ~((1u << (o1 & 31)) - 1u) : 0u;
-        const uint32_t keep_g = (o1 & 31) ? a.gapbits[wlast] & ~((1u << (o1 & 31)) - 1u) : 0u;
-        GxWords W{a.startbits, a.gapbits, c0 >> 5, 0u, 0u};
-        if (t < o1) (void)gx_run(P, T, a.text, a.n, false, o0, o1, t, o1, W);
-        W.upto(wlast);
-        if (o1 & 31) { a.startbits[wlast] = W.s | keep_s; a.gapbits[wlast] = W.g | keep_g; }
+        bool first = true;  // no chunk that starts inside this document in front of this one has failed
+        for (int64_t k = ch - 1; k * GX_CHUNK > o0; --k)
+            if (a.gx_state[k] == 0u) { first = false; break; }
+        if (!first) continue;
+        int64_t m = ch, t = a.gx_exit[ch - 1];  // chunk being matched anew, its true entry (a failed chunk starts inside a document: ch > 0)
+        while (t < o1) {
+            const int64_t m0 = m * GX_CHUNK, m1 = m0 + GX_CHUNK;
+            const int64_t lim = m1 < o1 ? m1 : o1;
+            int64_t e = t;  // (t >= lim: the chunk lies inside one piece and has no bits)
+            GxWords W{a.startbits, a.gapbits, m0 >> 5, 0u, 0u};
+            if (t < lim) e = gx_run(P, T, a.text, a.n, false, o0, o1, t, lim, W);
+            if (lim == m1) {
+                W.upto(m1 >> 5);
+            } else {  // the document ends inside this chunk: the word that holds o1 keeps what belongs to the next document
+                const int64_t wlast = o1 >> 5;
+                const uint32_t keep_s = (o1 & 31) ? a.startbits[wlast] & ~((1u << (o1 & 31)) - 1u) : 0u;
+                const uint32_t keep_g = (o1 & 31) ? a.gapbits[wlast] & ~((1u << (o1 & 31)) - 1u) : 0u;
+                W.upto(wlast);
+                if (o1 & 31) { a.startbits[wlast] = W.s | keep_s; a.gapbits[wlast] = W.g | keep_g; }
+                break;
+            }
+            if (m1 >= o1) break;
+            if (a.gx_state[m + 1] != 0u && a.gx_exit[m] == e) {  // back in step with the first runs: on to the next failed chunk of the document
+                int64_t k = m + 2;
+                while (k * GX_CHUNK < o1 && a.gx_state[k] != 0u) ++k;
+                if (k * GX_CHUNK >= o1) break;
+                m = k;
+                t = a.gx_exit[k - 1];
+            } else {
+                ++m;
+                t = e;
+            }
+        }
     }
 }
 

@@ -2958,7 +2958,7 @@ __global__ __launch_bounds__(K_THREADS) void td_small_decode(const SmallDecArgs 
     const Tables T = uniform_tables(a.Tp);
     const int tid = threadIdx.x;
     constexpr int PER = SMALL_DEC_MAX_TOKENS / K_THREADS;  // ids per lane (consecutive: the scan is over lanes)
-    if (tid == 0) { s_err = 0; s_errpos = 0; }
+    if (tid == 0) { s_err = 0; s_errpos = 0xFFFFFFFFu; }
     __syncthreads();
     int32_t ids[PER];
     uint32_t so[PER], ln[PER];
@@ -2977,7 +2977,10 @@ __global__ __launch_bounds__(K_THREADS) void td_small_decode(const SmallDecArgs 
                 so[k] = T.tok_off[ids[k]];
                 ln[k] = T.tok_off[ids[k] + 1] - so[k];
             }
-            if (ln[k] == 0 && atomicCAS(&s_err, 0u, (uint32_t)TD_E_BAD_TOKEN) == 0u) s_errpos = (uint32_t)i;  // (no token is empty)
+            if (ln[k] == 0) {  // (no token is empty)  The reference throws on the FIRST invalid id (tiktoken.cpp:249): the lowest index
+                s_err = (uint32_t)TD_E_BAD_TOKEN;
+                atomicMin(&s_errpos, (uint32_t)i);
+            }
         }
         mine += ln[k];
     }
@@ -3187,7 +3190,13 @@ __global__ __launch_bounds__(1024) void td_decode_len(const DecodeArgs a) {
         const int32_t id = ids[k];
         uint32_t len = 0;
         if (id >= 0 && id <= T.max_id) len = T.tok_off[id + 1] - T.tok_off[id];
-        if (len == 0 && atomicCAS(a.err, 0, TD_E_BAD_TOKEN) == 0) *a.err_pos = i;  // (no token is empty)
+        if (len == 0) {  // (no token is empty)  The reference throws on the FIRST invalid id (tiktoken.cpp:249): the lowest index wins,
+            // kept as the MAXIMUM of (INT64_MAX - index) so that the zeroed control block needs no other initial value; the
+            // host turns it back (device_status_locked).  Only while the error on record is this one.
+            const int was = atomicCAS(a.err, 0, TD_E_BAD_TOKEN);
+            if (was == 0 || was == TD_E_BAD_TOKEN)
+                atomicMax(reinterpret_cast<unsigned long long*>(a.err_pos), (unsigned long long)(0x7FFFFFFFFFFFFFFFll - i));
+        }
         v[k] = len;
     }
     const unsigned long long mine = (unsigned long long)v[0] + v[1] + v[2] + v[3];
