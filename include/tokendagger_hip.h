@@ -162,6 +162,8 @@ int td_encode_batch_with_special_strs(td_tokenizer* t, const uint8_t* text, cons
 #define TD_INFO_FAR_PIECES 8     /* pieces whose end the pre-tokenizer's window could not see (td_split_far_pieces), last call */
 #define TD_INFO_DEFERRED_TILES 9 /* token tiles (4 KiB) the fused tile loop left to td_probe_tiles, last call (as of the last td_device_status) */
 #define TD_INFO_FLAGGED_TILES 10 /* token tiles whose missed pieces went to td_merge_pieces, last call */
+#define TD_INFO_LB_TIMEOUTS 12   /* ... and tiles it staged because their output base was not known in time (bounded look-back), last call */
+#define TD_INFO_DIRECT_TILES 11  /* pre-tokenizer tiles (8 KiB) whose ids the fused tile loop wrote straight to the output (TD_OPT_DIRECT), last call */
 int64_t td_info(const td_tokenizer* t, int what);
 
 /*
@@ -194,6 +196,11 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
                                     step is launched kernel by kernel; same results either way. */
 #define TD_OPT_DEVICE_SPECIALS 8  /* 0: td_encode_batch_with_special* always search for the allowed specials on host threads (default 1:
                                     batches of a MiB and more search on the device, td_special.hip; same results) */
+#define TD_OPT_DIRECT 9            /* 0: every tile's ids are staged and packed by td_pack_tokens (rounds 1-3).  Default 1: the fused tile loop
+                                    writes a tile's ids straight to the output when the tile's base is known in time (decoupled look-back
+                                    over per-tile id counts; tiles that are not — and everything behind a tile whose count cannot be settled
+                                    inside the loop — are staged as before).  Same results either way; TD_DIRECT=0 in the environment at
+                                    td_create time also turns it off. */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 16) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 

@@ -221,22 +221,27 @@ def test_gpu_generic_chunks_that_never_resynchronise():
     eng = eng.tobytes()
     fw = "１２３４５６７８９０".encode()          # 3 bytes each
     ar = "٠١٢٣٤٥٦٧٨٩".encode()                   # 2 bytes each
-    docs = [fw * 400,                               # the ADVICE case: from offset 0, nothing but digits
-            b"7" * 5000,
-            eng[:5000] + b"1234567890" * 700 + eng[5000:9000] + fw * 333 + b" x " + ar * 500 + eng[9000:20000],
-            b"ab" + fw * 50 + b"12" + fw * 77 + b"3" + ar * 99 + b"." ,
-            eng[20000:300000] + b"0" * 1025 + eng[300000:600000] + fw * 1000 + eng[600000:],
-            (b"9" * 70 + b" ") * 300]
-    for pat in (r"\p{N}{1,3}|\P{N}+", r"\d{1,3}|\D+", r" ?\p{N}{2,4}|[^\p{N}]+|\p{N}", r"\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+|\s+"):
+    # (every document a few KB: the first three patterns take "everything that is no digit" as ONE piece, and the reference's
+    # merge loop is quadratic in the piece length)
+    small = [fw * 400,                              # the ADVICE case: from offset 0, nothing but digits
+             b"7" * 5000,
+             eng[:1500] + b"1234567890" * 700 + eng[5000:6200] + fw * 333 + b" x " + ar * 500 + eng[9000:9900],
+             b"ab" + fw * 50 + b"12" + fw * 77 + b"3" + ar * 99 + b".",
+             eng[20000:21000] + b"0" * 1025 + eng[300000:301700] + fw * 1000 + eng[600000:600800],
+             (b"9" * 70 + b" ") * 300]
+    big = small + [eng[20000:300000] + b"0" * 1025 + eng[300000:600000] + fw * 1000 + eng[600000:]]
+    for pat, docs in ((r"\p{N}{1,3}|\P{N}+", small), (r"\d{1,3}|\D+", small), (r" ?\p{N}{2,4}|[^\p{N}]+|\p{N}", small),
+                      (r"\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+|\s+", big)):
         tok = capi.HipTokenizer(pat, mr, special, device=0)
         R = ref.RefTokenizer(pat, mr, special)
         for cut in (None, 1, 37):
             dd = docs if cut is None else [d[cut:] for d in docs]   # (other alignments against the chunk grid)
             text = b"".join(dd)
             offs = np.concatenate([[0], np.cumsum([len(d) for d in dd])]).astype(np.int64)
-            for view, o in (("documents", offs), ("one document", np.asarray([0, len(text)], dtype=np.int64))):
-                if view == "one document" and cut:  # (a cut may fall inside a character: as ONE document that is the same text again)
-                    continue
+            views = [("documents", offs)]
+            if cut is None and docs is small:  # (a cut may fall inside a character: as ONE document that is the same text again)
+                views.append(("one document", np.asarray([0, len(text)], dtype=np.int64)))
+            for view, o in views:
                 toks, toffs = tok.encode_batch(text, o)
                 _, etoks, eoffs = R.encode_batch(np.frombuffer(text, dtype=np.uint8), o, n_threads=8, want_tokens=True)
                 assert np.array_equal(toffs, eoffs), (pat, cut, view)

@@ -41,12 +41,19 @@ def tok():
 
 
 def _both(tok, text: bytes, offs):
+    """-> (fused loop with direct placement, TD_OPT_DIRECT = 1), (two-kernel form); the fused loop with every tile staged (the
+    default) is run in between and must agree with the first."""
     offs = np.asarray(offs, dtype=np.int64)
     tok.set_option(TD_OPT_FUSED, 1)
+    tok.set_option(capi.TD_OPT_DIRECT, 1)
     ft, fo = tok.encode_batch(text, offs)
+    tok.set_option(capi.TD_OPT_DIRECT, 0)
+    st, so = tok.encode_batch(text, offs)
     tok.set_option(TD_OPT_FUSED, 0)
     ut, uo = tok.encode_batch(text, offs)
     tok.set_option(TD_OPT_FUSED, 1)
+    assert np.array_equal(fo, so), "document offsets differ between direct placement and the staged form of the fused loop"
+    assert np.array_equal(ft, st), "ids differ between direct placement and the staged form of the fused loop"
     return (ft, fo), (ut, uo)
 
 
@@ -208,3 +215,40 @@ def test_repeated_device_calls_replay_a_graph_with_the_same_results(tok):
                 _, et, eo = R.encode_batch(text, offs, n_threads=os.cpu_count() or 1, want_tokens=True)
                 assert np.array_equal(outs[-1][1], eo) and np.array_equal(outs[-1][0], et)
     tok.set_option(capi.TD_OPT_GRAPH, 0)  # (the default)
+
+
+def test_direct_placement_takes_the_tiles_it_can_and_stages_the_rest(tok):
+    """Round 4, opt-in (TD_OPT_DIRECT = 1; measured slower than the staged form on this chip): the fused
+    loop writes a tile's ids straight to the output when the tile's base is known in time (decoupled look-back).  Plain
+    English: nearly every tile; English with a rare word per tile: still (the few missed pieces are merged inside the loop);
+    a piece above 64 bytes or a tile full of missed pieces breaks the chain: the tiles in front of it are placed directly,
+    the ones behind it are staged — same ids either way (every _check compares the two)."""
+    x, o = td_corpus.english(64 << 20, seed=91)
+    _check(tok, x.tobytes(), o, "english 64 MiB")
+    n8 = (len(x) + 8191) // 8192
+    assert tok.info(capi.TD_INFO_DIRECT_TILES) == 0  # (_both ends on the staged forms: the counter is the last call's)
+    tok.set_option(capi.TD_OPT_DIRECT, 1)
+    tok.encode_batch(x.tobytes(), o)
+    # (a workgroup's last tiles are placed without the delay that lets their predecessors publish: of the five or six
+    # tiles a workgroup has here some are staged; 1024 MiB: 98 % direct)
+    assert tok.info(capi.TD_INFO_DIRECT_TILES) >= n8 // 4, (tok.info(capi.TD_INFO_DIRECT_TILES), n8)
+    rare = _rare_words(6 << 20, 92, 3000)
+    _check(tok, rare, [0, len(rare)], "rare words, one document")
+    tok.set_option(capi.TD_OPT_DIRECT, 1)
+    tok.encode_batch(rare, np.asarray([0, len(rare)], dtype=np.int64))
+    assert tok.info(capi.TD_INFO_DIRECT_TILES) > 0
+    # the chain breaks in the middle: a run of 200 bytes (a piece above 64 bytes) at 3 MiB
+    b = bytearray(x[:6 << 20].tobytes())
+    b[3 << 20:(3 << 20) + 200] = b"=" * 200
+    oo = o[o < (6 << 20)]
+    oo = np.concatenate([oo, [6 << 20]]) if oo[-1] != (6 << 20) else oo
+    _check(tok, bytes(b), oo, "chain broken at 3 MiB")
+    tok.set_option(capi.TD_OPT_DIRECT, 1)
+    tok.encode_batch(bytes(b), oo)
+    d = tok.info(capi.TD_INFO_DIRECT_TILES)
+    assert 0 < d <= (3 << 20) // 8192 + 1, d
+    # capacity: nothing is written past the end of a too small output, the needed size comes back
+    with pytest.raises(capi.TokenDaggerHipError) as e:
+        tok.encode_batch(x[:1 << 20].tobytes(), o[o <= (1 << 20)], capacity=1000)
+    assert e.value.code == capi.TD_E_CAPACITY
+    tok.set_option(capi.TD_OPT_DIRECT, 0)  # (the default)

@@ -28,6 +28,9 @@ TD_OPT_SMALL_PATH = 5
 TD_OPT_FUSED = 6
 TD_OPT_GRAPH = 7
 TD_OPT_DEVICE_SPECIALS = 8
+TD_OPT_DIRECT = 9
+TD_INFO_DIRECT_TILES = 11
+TD_INFO_LB_TIMEOUTS = 12
 
 EXPORTS = [
     "td_create", "td_clone", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",

@@ -141,6 +141,8 @@ struct Ctl {  // small control block in device memory
     uint32_t deferred_count; // fused tile loop: token tiles left to td_probe_tiles
     uint32_t giant_count;    // long pieces above 1 KiB
     uint32_t tile_draw;      // fused tile loop: tiles handed out beyond every workgroup's first two
+    uint32_t direct_tiles;   // (statistics) pre-tokenizer tiles whose ids the fused loop wrote straight to the output
+    uint32_t lb_timeouts;    // ... and tiles it staged because their base was not known in time (behind direct_tiles)
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 }  // namespace
@@ -170,7 +172,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, gapbits, gx_exit, gx_state, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf tile_state, slab, docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, gapbits, gx_exit, gx_state, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -196,10 +198,11 @@ struct td_tokenizer {
     uint32_t sp_n = 0, sp_maxlen = 0;
     bool device_specials = true;     // host-buffer batches of a MiB and more search on the device (TD_OPT_DEVICE_SPECIALS)
     bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
+    bool direct = false; // the fused loop places a tile's ids itself when their output base is known in time (TD_OPT_DIRECT; TD_DIRECT=0 turns it off)
     bool fused = true;  // pre-tokenizer and lookup in one pass over the text (TD_OPT_FUSED; TD_FUSED=0 in the environment turns it off)
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
     std::vector<Ev3> ev_pending, ev_free;
-    int64_t last_long = 0, last_far = 0, last_deferred = 0, last_flagged = 0;
+    int64_t last_long = 0, last_far = 0, last_deferred = 0, last_flagged = 0, last_direct = 0, last_timeouts = 0;
     const RxProgram* d_rx = nullptr;      // generic split pattern: the compiled program and its tables in HBM
     const uint16_t* d_rx_s1 = nullptr;
     const uint8_t* d_rx_s2 = nullptr;
@@ -338,6 +341,8 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
     if ((rc = ensure(t, t->slow_list, (size_t)(n_tiles * 8 + 64) * 8))) return rc;
     if ((rc = ensure(t, t->tile_flag, (size_t)(n_tiles + 2) * 4))) return rc;   // (per pre-tokenizer tile: fewer than n_tiles)
     if ((rc = ensure(t, t->tile_carry, (size_t)(n_tiles + 2) * 8))) return rc;
+    if ((rc = ensure(t, t->tile_state, (size_t)(n_tiles + 2) * 8))) return rc;   // (per pre-tokenizer tile too)
+    if (t->direct && t->H.pattern_kind != PATTERN_GENERIC && (rc = ensure(t, t->slab, (size_t)direct_grid_blocks() * SLAB_RING * SLAB_WORDS * 4))) return rc;
     if ((rc = ensure(t, t->stage, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;
     if ((rc = ensure(t, t->stage2, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;  // ids of merged pieces
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
@@ -426,6 +431,10 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.deferred_list = (uint32_t*)t->deferred_list.p;
     a.deferred_count = &ctl->deferred_count;
     a.fused = t->fused ? 1 : 0;
+    a.direct = (t->direct && t->fused && !t->sp_active && t->H.pattern_kind != PATTERN_GENERIC && d_out && !t->stop_after) ? 1 : 0;
+    a.tile_state = (unsigned long long*)t->tile_state.p;
+    a.slab = (uint32_t*)t->slab.p;
+    a.direct_tiles = &ctl->direct_tiles;
     a.probe_deferred = 0;
     a.miss_cap = (uint32_t)((n_tiles + 1) * K_MISS_LISTED_MAX);
     a.chunk_pref = (int64_t*)t->chunk_pref.p;
@@ -531,6 +540,8 @@ int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) 
     t->last_far = c.slow_count;
     t->last_deferred = c.deferred_count;
     t->last_flagged = c.flagged_count;
+    t->last_direct = c.direct_tiles;
+    t->last_timeouts = c.lb_timeouts;
     if (err_pos) *err_pos = c.err_pos;
     if (c.err != 0) {
         if ((rc0 = zero_wait(t, t->ctl.p, sizeof(Ctl), stream))) return rc0;
@@ -572,6 +583,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     td_tokenizer* t = new td_tokenizer;
     if (const char* e = getenv("TD_FUSED")) t->fused = atoi(e) != 0;
     if (const char* e = getenv("TD_GRAPH")) t->graphs = atoi(e) != 0;
+    if (const char* e = getenv("TD_DIRECT")) t->direct = atoi(e) != 0;
     std::string err;
     int rc = build_tables(pat_str, n_vocab, token_bytes, token_offsets, ranks, n_special, special_bytes, special_offsets,
                           special_ids, t->H, err);
@@ -655,7 +667,7 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t = new td_tokenizer(src->shared);
         t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
         t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
-        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused;
+        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct;
         t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }
@@ -693,7 +705,7 @@ void td_destroy(td_tokenizer* t) {
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
         if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->tile_state, &t->slab, &t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)
@@ -1678,6 +1690,8 @@ int64_t td_info(const td_tokenizer* t, int what) {
         case TD_INFO_FAR_PIECES: return t->last_far;
         case TD_INFO_DEFERRED_TILES: return t->last_deferred;
         case TD_INFO_FLAGGED_TILES: return t->last_flagged;
+        case TD_INFO_DIRECT_TILES: return t->last_direct;
+        case TD_INFO_LB_TIMEOUTS: return t->last_timeouts;
     }
     return -1;
 }
@@ -1697,6 +1711,10 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
 #endif
     if (what == TD_OPT_FUSED) {
         t->fused = value != 0;
+        return TD_OK;
+    }
+    if (what == TD_OPT_DIRECT) {
+        t->direct = value != 0;
         return TD_OK;
     }
     if (what == TD_OPT_DEVICE_SPECIALS) {

@@ -67,6 +67,7 @@ constexpr uint32_t TOK_MISS = 0x40000000u;    // | tile position << 7 | length: 
 // tile_count[]: slots of the tile (bits 0..12) | 16-byte units of its missed pieces (bits 13..25, written by td_probe_tiles,
 // cleared by td_merge_*) | flags
 constexpr uint32_t TILE_HAS_LONG = 0x80000000u, TILE_HAS_MISS = 0x40000000u, TILE_COUNT_MASK = 0x1FFFu;
+constexpr uint32_t TILE_DIRECT = 0x10000000u;       // the fused tile loop wrote the tile's ids and document offsets itself: td_pack_tokens skips it
 constexpr uint32_t TILE_MISS_LISTED = 0x20000000u;  // the tile's (few) missed pieces are on the global miss list: td_merge_pieces need not scan its slots
 constexpr int K_MISS_LISTED_MAX = 6;                // more missed pieces than this in a tile: TILE_HAS_MISS instead
 constexpr int K_MISS_CLASSES = 5;                   // one list per length class (<= 8, 16, 32, 48, 64 bytes): a row of a list is one batch

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) void td_generic_redo(const EncodeArgs a) {
             if (a.gx_state[k] == 0u) { first = false; break; }
         if (!first) continue;
         int64_t m = ch, t = a.gx_exit[ch - 1];  // chunk being matched anew, its true entry (a failed chunk starts inside a document: ch > 0)
-        while (t < o1) {
+        for (;;) {  // (chunk m starts inside the document: m0 < o1.  A chunk behind the last piece start, t >= o1, is cleared)
             const int64_t m0 = m * GX_CHUNK, m1 = m0 + GX_CHUNK;
             const int64_t lim = m1 < o1 ? m1 : o1;
             int64_t e = t;  // (t >= lim: the chunk lies inside one piece and has no bits)

@@ -115,7 +115,24 @@ struct EncodeArgs {
     int use_fastpath;           // whole-piece lookup before the merge loop (CoreBPE::encode) or not
     int text_aligned;           // text pointer is 16-byte aligned
     int stop_after;             // ablation (only in -DTD_ABLATE builds): leave the tile loop after phase N (0 = run everything)
+    // direct placement (round 4, td_split_tiles<.., true>): the fused loop writes a tile's ids straight to out_tokens when the
+    // output base of the tile is known in time (decoupled look-back over the per-tile id counts)
+    int direct;                 // try it (family patterns, fused loop, no special cuts)
+    unsigned long long* tile_state;  // [n_stiles + 1] per pre-tokenizer tile: status << 62 | value (TS_* below); zeroed by td_prepare
+    uint32_t* slab;             // [fused grid][SLAB_RING][SLAB_WORDS] a workgroup's slots of the tile whose placement is pending (stays in the L2)
+    uint32_t* direct_tiles;     // (statistics) pre-tokenizer tiles placed directly
 };
+// per-tile state of the look-back
+constexpr unsigned long long TS_NONE = 0ull, TS_AGG = 1ull, TS_PREFIX = 2ull, TS_BROKEN = 3ull, TS_VALUE_MASK = (1ull << 62) - 1ull;
+constexpr int SLAB_MAX_MISSES = 2 * 6;        // (2 * K_MISS_LISTED_MAX: both token tiles of a pre-tokenizer tile)
+constexpr int SLAB_META = 5136;               // behind the slots (FZ_NPC + 8 of them at most): per merged piece its slot | ids << 16, then its
+                                              // token tile (0 / 1) << 12 | position in that tile
+constexpr int SLAB_MIDS = SLAB_META + 2 * SLAB_MAX_MISSES;  // ... and the ids of the merged pieces, 64 each (a multiple of 4)
+constexpr int SLAB_WORDS = SLAB_MIDS + SLAB_MAX_MISSES * 64;
+#ifndef TD_SLAB_RING
+#define TD_SLAB_RING 3
+#endif
+constexpr int SLAB_RING = TD_SLAB_RING;       // slabs per workgroup: a tile is placed SLAB_RING - 1/2 iterations after its slots were written
 
 struct DecodeArgs {
     const Tables* Tp;
@@ -181,6 +198,8 @@ hipError_t launch_special_ids(const EncodeArgs& a, hipStream_t stream);
 // phases: 1 = lengths + offsets (td_decode_len, td_decode_chunks, document byte offsets), 2 = gather (td_decode_copy), 3 = both
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, int phases = 3);
 int encode_grid_blocks();  // persistent grid size of td_probe_tiles
+int fused_grid_blocks();   // persistent grid size of the fused tile loop
+int direct_grid_blocks();  // ... with direct placement (SLAB_RING slabs per workgroup)
 int merge_grid_blocks();   // persistent grid size of td_merge_pieces
 
 }  // namespace td

@@ -179,6 +179,7 @@ __global__ void td_prepare(const EncodeArgs a) {
     for (int64_t i = gid; i <= a.n_stiles; i += gsz) {
         a.tile_flag[i] = 0;
         a.tile_carry[i] = -1;
+        a.tile_state[i] = TS_NONE;
     }
     if (gid < a.ctl_reset_words) a.ctl_reset[gid] = 0;
 }
@@ -247,6 +248,23 @@ __device__ __noinline__ uint32_t stage_window_edge(uint8_t* s_txt, const uint8_t
         hib |= w[0] | w[1] | w[2] | w[3];
     }
     return hib;
+}
+
+// Streaming accesses (the text, the ids on their way out, the START bits): marked non-temporal so that they do not push the
+// lines that ARE used again — the exact-key table's hot lines and the fused loop's slabs — out of the 4 MB of L2 an XCD has
+// (the slabs are rewritten every other tile, and between two uses of a slab line about as much text and output as the L2
+// holds streams through it).  -DTD_NO_NT: plain accesses (A/B).
+#ifndef TD_NO_NT
+#define TD_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define TD_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define TD_NT_LOAD(p) (*(p))
+#define TD_NT_STORE(v, p) (*(p) = (v))
+#endif
+typedef uint32_t td_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load16(const uint4* p) {  // (the builtin takes scalars and vector types, not HIP's uint4 struct)
+    const td_u32x4 v = TD_NT_LOAD(reinterpret_cast<const td_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // LDS traffic between the lanes of ONE wavefront: program order is execution order, the fence keeps the compiler from
@@ -323,6 +341,140 @@ __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const 
     return TOK_MISS | ((uint32_t)i << 7) | len;  // (the caller notes it: note_miss)
 }
 
+// ---- (used by td_merge_pieces and, for the few missed pieces of a tile it places itself, by the fused tile loop) ----
+// 17 text bytes at global offset g as five dwords (byte k = bits 8(k&3).. of w[k>>2]); zero past the end of the text
+__device__ __forceinline__ void load_piece_window(const uint8_t* text, int64_t n_text, int64_t g, uint32_t (&w)[5]) {
+    const uintptr_t addr = (uintptr_t)(text + g);
+    const int64_t g4 = g - (int64_t)(addr & 3);  // text offset of the aligned dword that holds byte g
+    if (g4 >= 0 && g4 + 24 <= n_text) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(text + g4);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
+        const uint32_t sh = (uint32_t)(addr & 3) * 8;
+        w[0] = __funnelshift_r(d0, d1, sh); w[1] = __funnelshift_r(d1, d2, sh); w[2] = __funnelshift_r(d2, d3, sh);
+        w[3] = __funnelshift_r(d3, d4, sh); w[4] = __funnelshift_r(d4, d5, sh);
+    } else {
+        for (int k = 0; k < 5; ++k) w[k] = 0;
+        for (int k = 0; k < 17; ++k)
+            if (g + k >= 0 && g + k < n_text) w[k >> 2] |= (uint32_t)text[g + k] << (8 * (k & 3));
+    }
+}
+
+// parts + keys of the piece text[g, g + st.len) into the lane's units: the piece's bytes 16 at a time in registers (+ the
+// byte behind them), so that the sixteen byte-pair ranks of a unit are independent loads that go out back to back
+__device__ __forceinline__ void mg_init_piece(const uint8_t* text, int64_t n_text, const Tables& T, const int32_t* s_byteid, uint32_t* keys, uint32_t* ids,
+                                              const MergeState& st, int64_t g) {
+    for (uint32_t c = 0; c * 16u < st.len; ++c) {
+        uint32_t w[5];
+        load_piece_window(text, n_text, g + 16 * c, w);
+        // all sixteen byte-pair ranks first (loads only: with the LDS stores of mg_put in between, every load waited for
+        // the one before it), then the slots
+        int32_t rk[16];
+        typedef const int32_t __attribute__((address_space(1)))* gbp_t;  // (global loads, not flat ones)
+        gbp_t const bp = (gbp_t)(uintptr_t)T.byte_pair;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const uint32_t bn = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu;
+            rk[j] = bp[(b << 8) | bn];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t jj = 16u * c + j;
+            if (jj < st.len) {
+                const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                const uint32_t sl = mg_slot(st.t, jj);
+                ids[sl] = (uint32_t)s_byteid[b];
+                keys[sl] = (jj + 1 < st.len && rk[j] != NO_RANK) ? (((uint32_t)rk[j] << 6) | jj) : MG_DEAD;  // (= mg_put)
+            }
+        }
+    }
+    mg_pad(keys, st);
+}
+
+// ---- parts of the fused loop's direct placement: what a tile with missed pieces needs.  (Tried out of line — they are rare on
+// plain text, and with them inlined the loop is 56 KB of code — but the calls cost 79 spilled VGPRs on the hot path: 2.7 -> 3.2 ms.) ----
+// One lane per missed piece of the tile (first wavefront, all 64 lanes call): merge it (keys / ids in LDS), ids + slot + position
+// to the slab; returns the piece's id count (0: this lane has none).
+__device__ __forceinline__ uint32_t fz_merge_piece(const Tables* Tp, const uint8_t* text, int64_t n_text, uint32_t* keys, uint32_t* slab, uint32_t rec,
+                                                uint32_t hh, uint32_t n0, long long tile_g0, int* err, long long* err_pos) {
+    const Tables T = uniform_tables(Tp);
+    const int lane = threadIdx.x & 63;
+    uint32_t* const ids = keys + SLAB_MAX_MISSES * 4 * MG_UNIT;
+    MergeState st;
+    st.len = rec & 127u;
+    st.alive = st.len >= 64u ? ~0ull : ((1ull << st.len) - 1ull);
+    const uint32_t units = (st.len + 15u) >> 4;
+    st.t = wave_incl_scan(units, lane) - units;
+    const uint32_t pos = (rec >> 7) & 0xFFFu;
+    const int64_t gpos = tile_g0 + (int64_t)hh * K_TILE + pos;
+    if (st.len) mg_init_piece(text, n_text, T, T.byte_id, keys, ids, st, gpos);
+    for (;;) {
+        const bool more = mg_round_t<uint64_t>(T, keys, ids, st);
+        if (!__any(more)) break;
+    }
+    uint32_t nt = 0;
+    if (st.len) {
+        uint32_t* const mo = slab + SLAB_MIDS + lane * 64;
+        for (uint64_t al = st.alive; al; al &= al - 1ull) {
+            const uint32_t jb = (uint32_t)td_ctz64(al);
+            const uint32_t id = ids[mg_slot(st.t, jb)];
+            if ((int32_t)id >= T.pseudo_base && atomicCAS(err, 0, TD_E_UNKNOWN_BYTE) == 0) *err_pos = gpos + jb;
+            mo[nt++] = id;
+        }
+        slab[SLAB_META + lane] = ((rec >> 19) + (hh ? n0 : 0u)) | (nt << 16);
+        slab[SLAB_META + SLAB_MAX_MISSES + lane] = (hh << 12) | pos;
+    }
+    return nt;
+}
+// extra ids of the merged pieces in front of slot k; *mine = the merged piece that IS slot k (or -1)
+__device__ __forceinline__ uint32_t fz_shift_of(const uint32_t* meta, uint32_t pnm, uint32_t k, int* mine) {
+    uint32_t sh = 0;
+    int m = -1;
+    for (uint32_t q = 0; q < pnm; ++q) {
+        const uint32_t e = meta[q], ms = e & 0xFFFFu;
+        if (ms < k) sh += (e >> 16) - 1u;
+        if (ms == k) m = (int)q;
+    }
+    *mine = m;
+    return sh;
+}
+// a tile with merged pieces, placed directly: slot k -> dst[k + the extra ids in front of it]
+__device__ __forceinline__ void fz_place_with_misses(const uint32_t* slab, int32_t* dst, uint32_t pnp, uint32_t pnm) {
+    const uint32_t* const meta = slab + SLAB_META;
+    const uint32_t* const mids = slab + SLAB_MIDS;
+    for (uint32_t k = threadIdx.x; k < pnp; k += K_THREADS) {
+        const uint32_t v = slab[k];
+        int mine = -1;
+        const uint32_t o = k + fz_shift_of(meta, pnm, k, &mine);
+        if ((v & 0xC0000000u) == TOK_MISS && mine >= 0) {
+            const uint32_t nq = meta[mine] >> 16;
+            for (uint32_t q = 0; q < nq; ++q) dst[o + q] = (int32_t)mids[mine * 64 + q];
+        } else {
+            dst[o] = (int32_t)v;
+        }
+    }
+}
+// ... staged: the layout td_pack_tokens reads (a merged piece: TOK_MISS | position << 7 | ids, its ids at its own bytes' slots of merge_out)
+__device__ __forceinline__ void fz_stage_with_misses(const uint32_t* slab, uint32_t* st0, uint32_t* mo0, uint32_t pnp, uint32_t pn0, uint32_t pnm) {
+    const uint32_t* const meta = slab + SLAB_META;
+    const uint32_t* const mids = slab + SLAB_MIDS;
+    for (uint32_t k = threadIdx.x; k < pnp; k += K_THREADS) {
+        uint32_t v = slab[k];
+        if ((v & 0xC0000000u) == TOK_MISS) {
+            for (uint32_t q = 0; q < pnm; ++q) {
+                const uint32_t e = meta[q];
+                if ((e & 0xFFFFu) == k) {
+                    const uint32_t mp = meta[SLAB_MAX_MISSES + q], hq = mp >> 12, pos = mp & 0xFFFu, nq = e >> 16;
+                    uint32_t* const mo = mo0 + (size_t)hq * K_STAGE + pos;
+                    for (uint32_t r = 0; r < nq; ++r) mo[r] = mids[q * 64 + r];
+                    v = TOK_MISS | (pos << 7) | nq;
+                }
+            }
+        }
+        if (k < pn0) st0[k] = v; else st0[K_STAGE + (k - pn0)] = v;
+    }
+}
+
 // ------------------------------------------------------------------ td_split_tiles ----------
 // Pre-tokenizer: the regex split of the reference (CoreBPE::split_text, tiktoken.cpp:70-128) as a
 // data-parallel boundary detector.  Output: one bit per text byte in HBM (a.startbits), set where a
@@ -368,13 +520,33 @@ constexpr int FZ_R_COLDK = ((FZ_NPC + 8) * 2 + 15) & ~15;     // u16[FZ_CCAP] pi
 constexpr int FZ_R_PB = FZ_R_COLDK + FZ_CCAP * 2;             // u16[K_THREADS] pieces before each lane's 32 bytes
 constexpr int FZ_R_SM = FZ_R_PB + K_THREADS * 2;              // u32[K_THREADS] START bits of each lane's 32 bytes
 constexpr int FZ_R_TOK_END = FZ_R_SM + K_THREADS * 4;
+static_assert(SLAB_MIDS >= FZ_NPC + 8, "a slab holds the slots of the fullest tile the fused loop takes");
 constexpr int FZ_R_BYTES = ((FZ_R_SPLIT_END > FZ_R_TOK_END ? FZ_R_SPLIT_END : FZ_R_TOK_END) + 15) & ~15;
+// s_pd[ring slot]: a tile whose placement is pending (written by the token phases of iteration i, read by the placement in
+// the middle of iteration i + SLAB_RING: the slot's turn comes round again just before it is overwritten)
+constexpr int PD_KIND = 0;      // 0 nothing pending, 1 its id count is settled (look back, then place or stage), 2 verbatim copy to the staging region
+constexpr int PD_TILE = 1, PD_NP = 2, PD_N0 = 3, PD_COUNT = 4, PD_NMISS = 5, PD_FDD = 6, PD_EXT0 = 7;
+constexpr int PD_WORDS = 8;     // (what the merged pieces of the tile need is in the slab: SLAB_META)
+static_assert(SLAB_MAX_MISSES == 2 * K_MISS_LISTED_MAX, "slab layout");
+#ifndef TD_LB_MAX_POLLS
+#define TD_LB_MAX_POLLS 2       // look-back: rounds that found a predecessor without a count yet before the tile is staged instead
+#endif
+#ifndef TD_LB_DRAIN_POLLS
+#define TD_LB_DRAIN_POLLS 64    // ... when the workgroup has no tile left to work on meanwhile
+#endif
+#ifndef TD_LB_MAX_ROUNDS
+#define TD_LB_MAX_ROUNDS 4      // ... and rounds of 256 predecessors that all had a count but none a prefix
+#endif
 #ifndef TD_FUSED_MIN_WAVES
 #define TD_FUSED_MIN_WAVES 6  // (256 MiB: English 0.66 ms at 5 and at 6, 0.71 at 4; source code 0.98 / 0.96 / 1.09; mixed-script 1.63 / 1.56 / 1.87)
 #endif
 
-template <uint32_t PV, bool FUSED>
+// DIRECT (only with FUSED): the loop also places the ids of the tiles whose output base it learns in time (TD_OPT_DIRECT,
+// see "placement" below).  An instantiation of its own: the code it adds (20 KB) and the registers it takes cost the loop
+// 5-7 % even on the tiles that do not use it.
+template <uint32_t PV, bool FUSED, bool DIRECT>
 __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
+    static_assert(FUSED || !DIRECT, "direct placement is part of the fused tile loop");
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
     __shared__ __attribute__((aligned(16))) uint8_t s_R[FZ_R_BYTES];  // class masks | heads | cold list; FUSED: then piece list | slots
     uint64_t* const s_mask = reinterpret_cast<uint64_t*>(s_R);       // [(K_MWORDS + 1) * MK_COUNT] class masks, word-major
@@ -392,7 +564,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
 
     const int tid = threadIdx.x;
 #ifdef TD_FUSED_TIMING
-    unsigned long long tt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_readcyclecounter(), t_total0 = t_last, n_tiles_done = 0;
+    unsigned long long tt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_readcyclecounter(), t_total0 = t_last, n_tiles_done = 0;
 #define FZ_TICK(i) { const unsigned long long t_now = __builtin_readcyclecounter(); tt[i] += t_now - t_last; t_last = t_now; }
 #else
 #define FZ_TICK(i)
@@ -407,10 +579,16 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     __shared__ uint32_t s_wave[8];
     __shared__ uint32_t s_hflags[2], s_nrec[2], s_ncoldp;          // per token tile of the pair: TILE_HAS_LONG; missed pieces
     __shared__ uint32_t s_rec[2][K_MISS_LISTED_MAX];               // the first few: slot << 19 | tile position << 7 | length
-    __shared__ unsigned long long s_pend[64];                      // miss-list entries of the last tiles, not appended yet
+    __shared__ unsigned long long s_pend[48];                      // miss-list entries of the last tiles, not appended yet
     __shared__ uint32_t s_npend;
     __shared__ uint32_t s_flagl[32];                               // flagged token tiles of this workgroup, not appended yet
     __shared__ uint32_t s_nflagl;
+    // direct placement (see place_prev below): the tile whose ids wait in this workgroup's slab
+    __shared__ uint32_t s_pd[DIRECT ? SLAB_RING : 1][PD_WORDS];  // (not referenced without DIRECT: no LDS then)
+    __shared__ uint32_t s_stat[2];                                 // tiles placed directly / staged because their base was not known in time
+    __shared__ unsigned long long s_lbv[4];                        // look-back: what a wavefront's 64 predecessors end in
+    __shared__ uint32_t s_lbs[4][3];
+    __shared__ uint32_t s_brk;                                     // this workgroup has seen the chain of counts broken (sticky)
     // first wavefront: the np entries waiting in s_pend go to their class's global list; ONE atomic per class (td_probe_tiles)
     auto append_pending = [&](uint32_t npd) {
         const int ln = tid & 63;
@@ -434,7 +612,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             const int len = tid >> 2, w = tid & 3, nb = len - 4 * w;  // bytes of dword w that belong to a len-byte key
             s_kmask[tid] = w == 3 || nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
         }
-        if (tid == 0) { s_nflagl = 0; s_npend = 0; }
+        if (tid == 0) { s_nflagl = 0; s_npend = 0; s_brk = 0; }
+        if (DIRECT && tid < SLAB_RING * PD_WORDS) (&s_pd[0][0])[tid] = 0;
+        if (tid < 2) s_stat[tid] = 0;
     }
     __syncthreads();
 
@@ -475,11 +655,21 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         const uint4* src16 = reinterpret_cast<const uint4*>(a.text + w0);
 #pragma unroll
         for (int q = 0; q < NPRE; ++q)
-            if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = src16[q * K_THREADS + tid];
+            if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = nt_load16(src16 + q * K_THREADS + tid);
     };
 #pragma unroll
     for (int q = 0; q < NPF; ++q) pf[q] = make_uint4(0, 0, 0, 0);
-    if ((int)blockIdx.x < a.n_stiles) load_window((int64_t)blockIdx.x * KS_TILE - K_HL);
+    // The first tile: dealt by blockIdx in the two-kernel form and with TD_DRAW_TWO_AHEAD; DRAWN like every other one otherwise —
+    // a workgroup that has not started yet (the grid is sized to what the occupancy query says is resident; when fewer are,
+    // the rest start when the first ones are done) then holds no tile the look-back of the others would wait for
+    int first_tile = (int)blockIdx.x;
+    if constexpr (DIRECT) {
+        if (tid == 0) s_next[0] = (int)atomicAdd(a.tile_draw, 1u);
+        __syncthreads();
+        first_tile = __builtin_amdgcn_readfirstlane(s_next[0]);
+        __syncthreads();
+    }
+    if (first_tile < a.n_stiles) load_window((int64_t)first_tile * KS_TILE - K_HL);
     const int tid_outer = tid;
     // FUSED: the workgroups DRAW their tiles.  The grid is persistent (as many workgroups as fit the chip) and the SIMDs
     // issue from their oldest wavefront first, so the workgroups that came to a CU first run faster than the ones that
@@ -494,8 +684,18 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     constexpr bool DRAW = false;
 #endif
     int next_tile = 0, par = 0;
-    if (DRAW && tid == 0) s_next[0] = (int)(blockIdx.x + gridDim.x);  // (read behind several barriers)
-    for (int tile = blockIdx.x; tile < a.n_stiles; tile = DRAW ? next_tile : tile + (int)gridDim.x) {
+    int ring = 0;  // (uniform) the ring slot of this iteration: iteration number mod SLAB_RING
+    if (DRAW && !DIRECT && tid == 0) s_next[0] = (int)(blockIdx.x + gridDim.x);  // (read behind several barriers)
+    // (FUSED with direct placement: the loop runs one more time than the workgroup has tiles — the iteration without a tile
+    // places the last tile's ids, place_prev below)
+    for (int tile = first_tile;; tile = DRAW ? next_tile : tile + (int)gridDim.x) {
+        const bool have = tile < a.n_stiles;  // (uniform)
+        if (!have) {  // (s_pd: written in front of the barrier that ends an iteration)
+            bool pending = false;
+            if constexpr (DIRECT)
+                for (int r = 0; r < SLAB_RING; ++r) pending = pending || s_pd[r][PD_KIND] != 0u;
+            if (!pending) break;
+        }
         // The lane index is made opaque once per tile: everything derived from it is then recomputed inside the iteration (a
         // few integer operations) instead of being hoisted out of the tile loop — the compiler hoisted dozens of such per-lane
         // values, ran out of registers and parked them in scratch memory, reloading them in the hot loops.
@@ -506,6 +706,48 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         const int64_t wg0 = tile_g0 - K_HL;  // global offset of window index 0 (multiple of 64)
         const int tile_hi = K_HL + (int)((a.n - tile_g0 < KS_TILE) ? (a.n - tile_g0) : KS_TILE);
         static_assert(KS_CHUNK == 32, "a lane's stride is one 32-bit word of the masks");
+        const uint32_t fd0 = pffd0, fd1 = pffd1;  // (FUSED) first documents of this tile's token tiles
+        // ---- placement of an EARLIER tile of this workgroup, part 1 (direct placement, round 4) ----
+        // Rounds 1-3 wrote every id twice: a slot per piece into the staging region, then td_pack_tokens moved the slots to
+        // their place once a device-wide scan had the bases (0.59 of 2.65 ms and 40 % of the fabric traffic of a step).  Here
+        // the token phases leave a tile's slots in a slab of this workgroup (SLAB_RING of them, used in turn), settle the tile's id
+        // count inside the loop (its few missed pieces are merged by the first wavefront) and publish it; SLAB_RING - 1
+        // iterations later — the workgroups that have the tiles in front have had that long to publish theirs — the
+        // workgroup looks back over the published counts for the tile's base (decoupled look-back: per tile a status word,
+        // "count" or "inclusive prefix") and moves the slots from the slab to where they belong, document offsets included.
+        // The loads this takes (the slots, the first documents, the first 256 status words) are requested HERE, in front of
+        // the text of the tile whose turn it is: one wait covers them all.  The wait for a predecessor is BOUNDED: a tile
+        // whose base is not known after TD_LB_MAX_POLLS more rounds is copied to the staging region instead and placed by
+        // td_pack_tokens (its count stays published: the chain goes on), and a tile whose count cannot be settled here
+        // (pieces above 64 bytes, more missed pieces than the lists take, what the window cannot decide) breaks the chain
+        // for good: it and everything behind it are staged as in round 3.
+        // (What this does NOT save is fabric traffic: the L2 of this chip does not keep written lines — the slots come back
+        // from the memory side, Infinity Cache at best — see DESIGN.md.)
+        typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16 bytes at a dword-aligned address
+        const uint32_t pkind = DIRECT ? s_pd[ring][PD_KIND] : 0u;  // (uniform)
+        int B = 0;
+        uint32_t pnp = 0, pn0 = 0, pcount = 0, pnm = 0, pext0 = 0, pdsl = 0;
+        uint4 xs[3];
+        int64_t pdm = 0, pdpos = 0;
+        unsigned long long stw = 0;
+        const uint32_t* const pslab = a.slab + ((size_t)blockIdx.x * SLAB_RING + ring) * SLAB_WORDS;
+        if (DIRECT && pkind) {
+            B = (int)s_pd[ring][PD_TILE];
+            pnp = s_pd[ring][PD_NP]; pn0 = s_pd[ring][PD_N0]; pcount = s_pd[ring][PD_COUNT]; pnm = s_pd[ring][PD_NMISS]; pext0 = s_pd[ring][PD_EXT0];
+            const uint32_t nv4 = (pnp + 3u) >> 2;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                xs[q] = make_uint4(0, 0, 0, 0);
+                if ((uint32_t)tid + 256u * q < nv4) xs[q] = reinterpret_cast<const uint4*>(pslab)[tid + 256 * q];
+            }
+            const uint32_t pfdd = s_pd[ring][PD_FDD];
+            pdm = (int64_t)pfdd + tid;
+            pdpos = a.n;
+            if (pkind == 1u && pfdd != 0xFFFFFFFFu && pdm < a.n_docs) { pdpos = a.doc_offsets[pdm]; pdsl = a.doc_slot[pdm]; }
+            const int idx0 = B - 1 - tid;  // my predecessor (tile -1: an inclusive prefix of 0)
+            stw = (pkind == 1u && idx0 >= 0) ? __hip_atomic_load(&a.tile_state[idx0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (TS_PREFIX << 62);
+        }
+        if (have) {
 
         // ---- phase 0: stage the text window and the document bits (two-kernel form: the text was requested one iteration ago,
         //      registers pf[]; FUSED: now, see NPRE) --------------
@@ -514,7 +756,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             // (the pieces that are not prefetched — the window's tail, a few lanes — are requested now and staged last)
 #pragma unroll
             for (int q = NPRE; q < NPF; ++q)
-                if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = reinterpret_cast<const uint4*>(a.text + wg0)[q * K_THREADS + tid];
+                if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = nt_load16(reinterpret_cast<const uint4*>(a.text + wg0) + q * K_THREADS + tid);
 #pragma unroll
             for (int q = 0; q < NPF; ++q)
                 if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) {
@@ -534,14 +776,163 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 s_doc[w] = dw;
             }
         }
-        const uint32_t fd0 = pffd0, fd1 = pffd1;  // (FUSED) first documents of this tile's token tiles
+        // DIRECT: the NEXT tile of this workgroup is drawn now and read behind the boundary phases (round 3 drew two tiles ahead: a
+        // tile then ran one and a half iterations after its number was handed out, and since the workgroups of a CU do not
+        // run at one speed, tiles next to each other were up to 15 us apart — what the look-back of the direct placement waits for)
+        if (DRAW && DIRECT && tid == 0) s_next[0] = (int)atomicAdd(a.tile_draw, 1u);
         // next tile of this workgroup.  (FUSED: its document bits are requested behind the boundary phases instead, its text
         // when its turn comes)
         if (!FUSED && tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);
         for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
         if (tid == 0) { s_nh = 0; s_cur = 0; s_ncold = 0; s_last = -1; s_cross = -1; s_defer = 0; }
         if (__ballot((hib & 0x80808080u) != 0) && lane == 0) s_nonascii = 1;  // (reset behind phase 1; __syncthreads_or costs extra barriers)
+        }  // (have)
+        // ---- placement, part 2: the first round of the look-back goes through the barrier that ends the staging ----
+        auto lb_post = [&](unsigned long long w) {  // what a wavefront's 64 predecessors end in -> LDS
+            const uint32_t status = (uint32_t)(w >> 62);
+            const uint64_t na = __ballot(status != (uint32_t)TS_AGG);
+            const int first = na ? (int)td_ctz64(na) : 64;
+            const uint32_t mysum = wave_incl_scan(lane < first ? (uint32_t)w : 0u, lane);  // (a count is below 2^16)
+            if (lane == 63) { s_lbs[tid >> 6][0] = (uint32_t)first; s_lbs[tid >> 6][1] = mysum; }
+            if (lane == first) { s_lbs[tid >> 6][2] = status; s_lbv[tid >> 6] = w & TS_VALUE_MASK; }
+        };
+        if (DIRECT && pkind == 1u) lb_post(stw);
         __syncthreads();
+        if (DIRECT && pkind) {
+            const uint32_t* const slab = pslab;
+            const uint32_t* const meta = slab + SLAB_META;
+            const int64_t pg0 = (int64_t)B * KS_TILE, pg1 = (pg0 + KS_TILE < a.n) ? pg0 + KS_TILE : a.n;
+            long long base = -1;  // >= 0: the tile's base; -1: the chain is broken in front of it; -2: not known in time
+            if (pkind == 1u) {
+                long long acc = 0;
+                int j = B - 1, polls = 0, rounds = 0;
+                for (;;) {
+                    uint32_t tstatus = (uint32_t)TS_AGG;  // what the chain of counts ends in (TS_AGG: not inside these 256)
+                    unsigned long long tval = 0;
+                    int tdist = 0;
+#pragma unroll
+                    for (int w = 0; w < K_THREADS / 64; ++w) {
+                        if (tstatus == (uint32_t)TS_AGG) {
+                            acc += s_lbs[w][1];
+                            const int f = (int)s_lbs[w][0];
+                            if (f < 64) { tstatus = s_lbs[w][2]; tval = s_lbv[w]; tdist = w * 64 + f; }
+                        }
+                    }
+                    if (tstatus == (uint32_t)TS_PREFIX) { base = acc + (long long)tval; break; }
+                    if (tstatus == (uint32_t)TS_BROKEN) { base = -1; break; }
+                    if (tstatus == (uint32_t)TS_NONE) {
+                        // (an iteration without a tile — the workgroup's last placements — has nothing else to do: it waits longer)
+                        if (++polls > (have ? TD_LB_MAX_POLLS : TD_LB_DRAIN_POLLS)) { base = -2; break; }
+                        j -= tdist;  // (the counts in front of it are in acc)
+                        __builtin_amdgcn_s_sleep(8);
+                    } else {
+                        if (++rounds >= TD_LB_MAX_ROUNDS) { base = -2; break; }  // (a chain of counts this long: the tiles in front are not being placed)
+                        j -= K_THREADS;
+                    }
+                    __syncthreads();  // (everybody has read s_lbs)
+                    const int idx = j - tid;
+                    lb_post(idx >= 0 ? __hip_atomic_load(&a.tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (TS_PREFIX << 62));
+                    __syncthreads();
+                }
+            }
+            FZ_TICK(8)
+            const int tB4 = B * (KS_TILE / K_TILE);
+            const bool ptwo = tB4 + 1 < a.n_tiles;
+            uint32_t* const st0 = a.stage + (size_t)tB4 * K_STAGE;
+            auto shift_of = [&](uint32_t k, int& mine) { return fz_shift_of(meta, pnm, k, &mine); };
+            if (pkind == 1u && base >= 0) {
+                // -- direct: slot k of the tile -> out_tokens[base + k + the extra ids of the merged pieces in front of it]
+                int32_t* const dst = a.out_tokens + base;
+                const bool fits = base + (long long)pcount <= (long long)a.out_cap;  // (else: td_scan_tiles raises TD_E_CAPACITY; nothing is written)
+                if (fits && pnm == 0u) {  // every slot an id: 16-byte stores (at dword-aligned addresses)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const uint32_t v = (uint32_t)tid + 256u * q;
+                        if (4u * v + 4u <= pnp) {
+                            u32x4a4 o;
+                            o.x = xs[q].x; o.y = xs[q].y; o.z = xs[q].z; o.w = xs[q].w;
+                            TD_NT_STORE(o, reinterpret_cast<u32x4a4*>(dst + 4u * v));
+                        } else if (4u * v < pnp) {  // the tile's last, partial piece
+                            dst[4u * v] = (int32_t)xs[q].x;
+                            if (4u * v + 1u < pnp) dst[4u * v + 1u] = (int32_t)xs[q].y;
+                            if (4u * v + 2u < pnp) dst[4u * v + 2u] = (int32_t)xs[q].z;
+                        }
+                    }
+                    for (uint32_t k = 3072u + tid; k < pnp; k += K_THREADS) dst[k] = (int32_t)slab[k];  // (a tile of more than 3072 pieces)
+                } else if (fits) {
+                    fz_place_with_misses(slab, dst, pnp, pnm);
+                }
+                {   // the documents that start in the tile (their slots: written by the token phases, a.doc_slot)
+                    if (pdpos < pg1) {
+                        const uint32_t k = pdsl + (pdpos >= pg0 + K_TILE ? pn0 : 0u);
+                        int mine = -1;
+                        TD_NT_STORE((int64_t)(base + (long long)(k + (pnm ? shift_of(k, mine) : 0u))), &a.out_offsets[pdm]);
+                    }
+                    if (__all(pdpos < pg1) && tid >= K_THREADS - 64) {  // more than 256 documents start in the tile: the last wavefront takes the rest
+                        for (int64_t d = pdm + 64; d < a.n_docs; d += 64) {
+                            const int64_t pd = a.doc_offsets[d];
+                            if (pd >= pg1) break;
+                            const uint32_t k = a.doc_slot[d] + (pd >= pg0 + K_TILE ? pn0 : 0u);
+                            int mine = -1;
+                            a.out_offsets[d] = base + (long long)(k + (pnm ? shift_of(k, mine) : 0u));
+                        }
+                    }
+                }
+                if (tid == 0) {
+                    a.tile_count[tB4] = pn0 | TILE_DIRECT;
+                    a.tile_extra[tB4] = pext0;
+                    if (ptwo) {
+                        a.tile_count[tB4 + 1] = (pnp - pn0) | TILE_DIRECT;
+                        a.tile_extra[tB4 + 1] = pcount - pnp - pext0;
+                    }
+                    __hip_atomic_store(&a.tile_state[B], (TS_PREFIX << 62) | (unsigned long long)(base + (long long)pcount), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    s_stat[0] += 1u;
+                }
+            } else {
+                // -- staged: the slots go to the tile's staging regions in the layout td_pack_tokens reads (a merged piece:
+                //    TOK_MISS | position << 7 | ids, its ids at its own bytes' slots of merge_out)
+                if (pnm == 0u || pkind != 1u) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const uint32_t k0 = 4u * ((uint32_t)tid + 256u * q);
+                        const uint32_t xv[4] = {xs[q].x, xs[q].y, xs[q].z, xs[q].w};
+#pragma unroll
+                        for (uint32_t e = 0; e < 4; ++e) {
+                            const uint32_t k = k0 + e;
+                            if (k < pnp) { if (k < pn0) st0[k] = xv[e]; else st0[K_STAGE + (k - pn0)] = xv[e]; }
+                        }
+                    }
+                    for (uint32_t k = 3072u + tid; k < pnp; k += K_THREADS) { const uint32_t v = slab[k]; if (k < pn0) st0[k] = v; else st0[K_STAGE + (k - pn0)] = v; }
+                } else {
+                    fz_stage_with_misses(slab, st0, a.merge_out + (size_t)tB4 * K_STAGE, pnp, pn0, pnm);
+                }
+                if (pkind == 1u && tid == 0) {
+                    uint32_t m0 = 0, m1 = 0;
+                    for (uint32_t q = 0; q < pnm; ++q) { if (meta[SLAB_MAX_MISSES + q] >> 12) m1 = 1; else m0 = 1; }
+                    a.tile_count[tB4] = pn0 | (m0 ? TILE_MISS_LISTED : 0u);
+                    a.tile_extra[tB4] = pext0;
+                    if (ptwo) {
+                        a.tile_count[tB4 + 1] = (pnp - pn0) | (m1 ? TILE_MISS_LISTED : 0u);
+                        a.tile_extra[tB4 + 1] = pcount - pnp - pext0;
+                    }
+                    if (base == -1) {  // the chain is broken in front of this tile: the tiles behind it need not look further
+                        __hip_atomic_store(&a.tile_state[B], TS_BROKEN << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_brk = 1u;
+                    } else {
+                        s_stat[1] += 1u;  // (statistics: not known in time)
+                    }
+                }
+            }
+            if (tid == 0) s_pd[ring][PD_KIND] = 0;  // (read again at the top of the next iteration: barriers in between)
+            FZ_TICK(11)
+        }
+        if (!have) {  // (an iteration without a tile: it placed one pending tile; the others' turns follow)
+            __syncthreads();
+            ring = __builtin_amdgcn_readfirstlane(ring + 1 == SLAB_RING ? 0 : ring + 1);
+            continue;
+        }
+        {
         FZ_TICK(0)
         const bool tile_ascii = !s_nonascii;
 
@@ -873,19 +1264,24 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             if (g < a.n) {
                 uint32_t v = s_start[K_HL / 32 + tid];
                 if (g + 32 > a.n) v &= (1u << (int)(a.n - g)) - 1u;
-                a.startbits[(tile_g0 >> 5) + tid] = v;
+                TD_NT_STORE(v, &a.startbits[(tile_g0 >> 5) + tid]);
             }
         }
         if constexpr (DRAW) {
             // (thread 0 waits for its draw right here and stores it for the iteration after the next one; keeping it in a
             // register until the next tile's text is waited for was no faster and cost spills)
-            next_tile = __builtin_amdgcn_readfirstlane(s_next[par]);  // (written one iteration ago; uniform: a scalar register)
-            if (tid == 0) s_next[par ^ 1] = (int)(2u * gridDim.x + atomicAdd(a.tile_draw, 1u));
-            par = __builtin_amdgcn_readfirstlane(par ^ 1);
+            if constexpr (!DIRECT) {
+                next_tile = __builtin_amdgcn_readfirstlane(s_next[par]);  // (written one iteration ago; uniform: a scalar register)
+                if (tid == 0) s_next[par ^ 1] = (int)(2u * gridDim.x + atomicAdd(a.tile_draw, 1u));
+                par = __builtin_amdgcn_readfirstlane(par ^ 1);
+            } else {
+                next_tile = __builtin_amdgcn_readfirstlane(s_next[0]);  // (drawn at the top of this iteration; uniform: a scalar register)
+            }
             if (next_tile < a.n_stiles) load_window((int64_t)next_tile * KS_TILE - K_HL);
         } else if (FUSED && tile + (int)gridDim.x < a.n_stiles) {
             load_window(wg0 + (int64_t)gridDim.x * KS_TILE);
         }
+        }  // (the boundary phases)
         if constexpr (FUSED) {
             // ================= token phases: the tile's pieces -> slots of the staging regions (see the note above) =========
             constexpr int NT4 = KS_TILE / K_TILE;  // token tiles per pre-tokenizer tile
@@ -912,11 +1308,19 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             const uint32_t w0s = s_wave[0], w1s = s_wave[1], w2s = s_wave[2], w3s = s_wave[3];
             const uint32_t np = w0s + w1s + w2s + w3s, n0 = w0s + w1s;  // pieces of the tile / of its first token tile (lanes 0..127)
             const uint32_t pbase = (wv > 0 ? w0s : 0u) + (wv > 1 ? w1s : 0u) + (wv > 2 ? w2s : 0u) + incl - cnt;
+            // direct placement: this tile's slots go to the workgroup's slab (place_prev above takes them from there half an
+            // iteration later) unless the chain of counts is known to be broken already
+            const bool cand = DIRECT && !s_brk;  // (uniform; s_brk: written in front of the barriers of the boundary phases)
+            auto break_chain = [&]() {  // (thread 0) this tile's id count is not settled inside the loop
+                __hip_atomic_store(&a.tile_state[tile], TS_BROKEN << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_brk = 1u;  // (this workgroup's later tiles take the staged path from the start; the others find out when they look back)
+            };
             if (tile_deferred || np > (uint32_t)FZ_NPC) {  // (uniform) td_probe_tiles takes these token tiles, behind the far kernels
                 if (tid == 0) {
                     const uint32_t at = atomicAdd(a.deferred_count, two ? 2u : 1u);
                     a.deferred_list[at] = (uint32_t)tile4;
                     if (two) a.deferred_list[at + 1] = (uint32_t)tile4 + 1u;
+                    if (DIRECT) break_chain();
                 }
             } else {
                 {
@@ -931,6 +1335,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 s_sm[tid] = smask0;
                 if (tid == 0) s_plist[np] = (uint16_t)cross;  // end of the tile's last piece: where the boundary scan crossed the tile end
                 const uint64_t fdd = fd0 != 0xFFFFFFFFu ? fd0 : fd1;
+                // (parked now: what is kept in a register to the end of the tile is spilled, and a reload from scratch memory behind the
+                // slot stores waits for every one of them)
+                if (cand && tid == 0) { s_pd[ring][PD_FDD] = (uint32_t)fdd; s_pd[ring][PD_TILE] = (uint32_t)tile; s_pd[ring][PD_NP] = np; s_pd[ring][PD_N0] = n0; }
                 const int64_t dmine = (int64_t)fdd + tid;
                 const int64_t dpos = (fdd != 0xFFFFFFFFu && dmine < a.n_docs) ? a.doc_offsets[dmine] : a.n;  // (used in the last phase)
                 __syncthreads();
@@ -939,8 +1346,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 //      (three dwords cut out of LDS with funnel shifts, masked by length; ONE 16-byte load of the first slot of
                 //      the exact-key table each), then the compares and the slot stores.  An empty slot is a miss; a slot held
                 //      by another key and longer pieces are put aside (probe_piece_cold behind the loop). ----
-                uint32_t* const dst0 = a.stage + (size_t)tile4 * K_STAGE;
-                uint32_t* const dst1 = dst0 + K_STAGE - n0;  // (slot k >= n0 is slot k - n0 of the second token tile)
+                uint32_t* const slab = a.slab + ((size_t)blockIdx.x * SLAB_RING + ring) * SLAB_WORDS;
+                uint32_t* const dst0 = cand ? slab : a.stage + (size_t)tile4 * K_STAGE;
+                uint32_t* const dst1 = cand ? slab : dst0 + K_STAGE - n0;  // (slot k >= n0 is slot k - n0 of the second token tile)
                 auto note_miss = [&](uint32_t k, uint32_t res) {  // res: TOK_MISS | position in ITS token tile << 7 | length
                     const uint32_t h = k >= n0 ? 1u : 0u;
                     const uint32_t mi = atomicAdd(&s_nrec[h], 1u);
@@ -1009,13 +1417,65 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 }
                 __syncthreads();
                 FZ_TICK(6)
+                // (uniform) the tile's id count can be settled right here: every piece is a token or one of a few missed pieces
+                const bool resolved = cand && !cold_overflow && !(s_hflags[0] | s_hflags[1]) && s_nrec[0] <= (uint32_t)K_MISS_LISTED_MAX &&
+                                      s_nrec[1] <= (uint32_t)K_MISS_LISTED_MAX;
                 if (cold_overflow) {  // more pieces for the long route than the list holds: td_probe_tiles does the tile over
                     if (tid == 0) {
                         const uint32_t at = atomicAdd(a.deferred_count, two ? 2u : 1u);
                         a.deferred_list[at] = (uint32_t)tile4;
                         if (two) a.deferred_list[at + 1] = (uint32_t)tile4 + 1u;
+                        if (DIRECT) break_chain();
                     }
+                } else if (resolved) {
+                    FZ_TICK(12)
+                    // ---- the few missed pieces of the tile are merged here, one lane each (the first wavefront; the others go on
+                    //      to the documents): ids to the slab behind the slots, count and extras to s_pv ----
+                    if (tid < 64) {
+                        const uint32_t nr0 = s_nrec[0], nr1 = s_nrec[1], nm = nr0 + nr1;
+                        uint32_t ext0 = 0, ext1 = 0;
+                        if (nm) {  // (rare on plain text: out of line)
+                            static_assert(2 * SLAB_MAX_MISSES * 4 * MG_UNIT * 4 <= FZ_R_COLDK, "keys + ids of the merged pieces fit the (dead) piece list");
+                            uint32_t rec = 0, hh = 0;
+                            if ((uint32_t)lane < nm) {
+                                hh = (uint32_t)lane >= nr0 ? 1u : 0u;
+                                rec = s_rec[hh][(uint32_t)lane - (hh ? nr0 : 0u)];
+                            }
+                            const uint32_t nt = fz_merge_piece(a.Tp, a.text, a.n, reinterpret_cast<uint32_t*>(s_R), slab, rec, hh, n0, tile_g0, a.err, a.err_pos);
+                            const uint32_t e0 = wave_incl_scan((nt && !hh) ? nt - 1u : 0u, lane), e1 = wave_incl_scan((nt && hh) ? nt - 1u : 0u, lane);
+                            ext0 = (uint32_t)__builtin_amdgcn_readlane((int)e0, 63);
+                            ext1 = (uint32_t)__builtin_amdgcn_readlane((int)e1, 63);
+                        }
+                        FZ_TICK(13)
+                        if (tid == 0) {
+                            const uint32_t count = s_pd[ring][PD_NP] + ext0 + ext1;
+                            s_pd[ring][PD_KIND] = 1u; s_pd[ring][PD_COUNT] = count; s_pd[ring][PD_NMISS] = nm; s_pd[ring][PD_EXT0] = ext0;
+                            __hip_atomic_store(&a.tile_state[s_pd[ring][PD_TILE]], (TS_AGG << 62) | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    FZ_TICK(7)
+                    {   // the slot of every document that starts in this tile (as below)
+                        const int64_t tile_end_g = wg0 + tile_hi;
+                        auto slot_of = [&](int64_t p) {
+                            const int lp = (int)(p - tile_g0);
+                            const uint32_t k = (uint32_t)s_pb[lp >> 5] + __popc(s_sm[lp >> 5] & ((1u << (lp & 31)) - 1u));
+                            return k >= n0 ? k - n0 : k;
+                        };
+                        if (dpos < tile_end_g) {
+                            a.doc_slot[dmine] = slot_of(dpos);
+                            for (int64_t d = dmine + K_THREADS; d < a.n_docs; d += K_THREADS) {
+                                const int64_t p = a.doc_offsets[d];
+                                if (p >= tile_end_g) break;
+                                a.doc_slot[d] = slot_of(p);
+                            }
+                        }
+                    }
+                    FZ_TICK(9)
                 } else {
+                if (DIRECT && tid == 0) {  // a tile whose count is settled by the kernels behind this one: the chain ends here
+                    break_chain();
+                    if (cand) { s_pd[ring][PD_KIND] = 2u; s_pd[ring][PD_NMISS] = 0; }
+                }
                 // ---- per token tile: slot count + flags; its missed pieces to the global lists (few) or the tile flagged (many) ----
                 if (tid < 64) {  // (first wavefront: program order between its lanes' LDS accesses; td_probe_tiles has the notes)
 #pragma unroll
@@ -1025,7 +1485,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                         if (listed && (uint32_t)tid < nr) s_pend[np0 + tid] = ((unsigned long long)((uint32_t)tile4 + h) << 32) | s_rec[h][tid];
                         const uint32_t np1 = listed ? np0 + nr : np0;
                         wave_sync_lds();
-                        if (np1 > 64u - (uint32_t)K_MISS_LISTED_MAX) {
+                        if (np1 > 48u - (uint32_t)K_MISS_LISTED_MAX) {  // (s_pend holds 48)
                             append_pending(np1);
                             wave_sync_lds();
                             if (tid == 0) s_npend = 0;
@@ -1079,6 +1539,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             }
         }
         __syncthreads();
+        ring = __builtin_amdgcn_readfirstlane(ring + 1 == SLAB_RING ? 0 : ring + 1);
         FZ_TICK(10)
 #ifdef TD_FUSED_TIMING
         ++n_tiles_done;
@@ -1086,11 +1547,13 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     }
 #ifdef TD_FUSED_TIMING
     if (FUSED && tid == 0 && (blockIdx.x % 211) == 0)
-        printf("fused wg %d: %llu tiles, total %llu cycles | stage %llu masks %llu rules %llu heads %llu | list %llu probe %llu cold %llu merge %llu write %llu docs %llu tail %llu\n",
+        printf("fused wg %d: %llu tiles, total %llu cycles | stage %llu masks %llu rules %llu heads %llu | list %llu probe %llu cold %llu bookkeeping %llu lookback %llu docs %llu tail %llu place %llu | t12 %llu t13 %llu\n",
                (int)blockIdx.x, n_tiles_done, (unsigned long long)(__builtin_readcyclecounter() - t_total0), tt[0], tt[1], tt[2], tt[3], tt[4], tt[5], tt[6], tt[7],
-               tt[8], tt[9], tt[10]);
+               tt[8], tt[9], tt[10], tt[11], tt[12], tt[13]);
 #endif
     if constexpr (FUSED) {
+        if (DIRECT && tid == 0 && s_stat[0]) atomicAdd(a.direct_tiles, s_stat[0]);
+        if (DIRECT && tid == 0 && s_stat[1]) atomicAdd(a.direct_tiles + 1, s_stat[1]);
         if (tid < 64) append_pending(s_npend);  // (what is still waiting in LDS)
         if (tid == 0 && s_nflagl) {
             const uint32_t nf = s_nflagl, at = atomicAdd(a.flagged_count, nf);
@@ -1542,55 +2005,6 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
 // version that worked tile by tile — a workgroup per tile, the tile's ~80 missed pieces in five class batches one after
 // the other — ran 163 rounds per tile at 2 % lane utilisation and was slower than round 1; batches have to be FULL, so they
 // are filled across tiles.)
-// 17 text bytes at global offset g as five dwords (byte k = bits 8(k&3).. of w[k>>2]); zero past the end of the text
-__device__ __forceinline__ void load_piece_window(const EncodeArgs& a, int64_t g, uint32_t (&w)[5]) {
-    const uintptr_t addr = (uintptr_t)(a.text + g);
-    const int64_t g4 = g - (int64_t)(addr & 3);  // text offset of the aligned dword that holds byte g
-    if (g4 >= 0 && g4 + 24 <= a.n) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(a.text + g4);
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
-        const uint32_t sh = (uint32_t)(addr & 3) * 8;
-        w[0] = __funnelshift_r(d0, d1, sh); w[1] = __funnelshift_r(d1, d2, sh); w[2] = __funnelshift_r(d2, d3, sh);
-        w[3] = __funnelshift_r(d3, d4, sh); w[4] = __funnelshift_r(d4, d5, sh);
-    } else {
-        for (int k = 0; k < 5; ++k) w[k] = 0;
-        for (int k = 0; k < 17; ++k)
-            if (g + k >= 0 && g + k < a.n) w[k >> 2] |= (uint32_t)a.text[g + k] << (8 * (k & 3));
-    }
-}
-
-// parts + keys of the piece text[g, g + st.len) into the lane's units: the piece's bytes 16 at a time in registers (+ the
-// byte behind them), so that the sixteen byte-pair ranks of a unit are independent loads that go out back to back
-__device__ __forceinline__ void mg_init_piece(const EncodeArgs& a, const Tables& T, const int32_t* s_byteid, uint32_t* keys, uint32_t* ids,
-                                              const MergeState& st, int64_t g) {
-    for (uint32_t c = 0; c * 16u < st.len; ++c) {
-        uint32_t w[5];
-        load_piece_window(a, g + 16 * c, w);
-        // all sixteen byte-pair ranks first (loads only: with the LDS stores of mg_put in between, every load waited for
-        // the one before it), then the slots
-        int32_t rk[16];
-        typedef const int32_t __attribute__((address_space(1)))* gbp_t;  // (global loads, not flat ones)
-        gbp_t const bp = (gbp_t)(uintptr_t)T.byte_pair;
-#pragma unroll
-        for (uint32_t j = 0; j < 16; ++j) {
-            const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            const uint32_t bn = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu;
-            rk[j] = bp[(b << 8) | bn];
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 16; ++j) {
-            const uint32_t jj = 16u * c + j;
-            if (jj < st.len) {
-                const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                const uint32_t sl = mg_slot(st.t, jj);
-                ids[sl] = (uint32_t)s_byteid[b];
-                keys[sl] = (jj + 1 < st.len && rk[j] != NO_RANK) ? (((uint32_t)rk[j] << 6) | jj) : MG_DEAD;  // (= mg_put)
-            }
-        }
-    }
-    mg_pad(keys, st);
-}
-
 // ------------------------------------------------------------------ td_merge_pieces ---------
 // Every wavefront works alone (no workgroup barrier): it walks its share of the tiles flagged TILE_HAS_MISS, collects their
 // TOK_MISS slots into five LDS queues by length class (<= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units), and whenever a
@@ -1661,7 +2075,7 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
         const uint32_t tile = (uint32_t)(rec >> 32), pos = ((uint32_t)rec >> 7) & 0xFFFu;
         const int64_t gpos = (int64_t)tile * K_TILE + pos;
         TD_TICK(t_dummy)
-        if (st.len) mg_init_piece(a, T, s_byteid, keys, ids, st, gpos);
+        if (st.len) mg_init_piece(a.text, a.n, T, s_byteid, keys, ids, st, gpos);
         TD_TICK(t_init)
         for (;;) {  // (pieces of at most 32 bytes: the part mask is one register)
             if (TD_STOP(41)) break;
@@ -2490,7 +2904,7 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
     uint32_t tcA = 0, dfA = 0, tcB = 0, dfB = 0, tcC = 0, dfC = 0;          // A = this tile, B = the next one, C = the one after
     int64_t baseA = 0, baseB = 0, baseC = 0;
 #define PK_FETCH(t, X) { tc##X = a.tile_count[t]; base##X = a.tile_base[t] + a.chunk_pref[(t) / K_SCAN_CHUNK]; df##X = a.tile_first_doc[t]; }
-#define PK_FAST(X) (!(tc##X & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_MISS_LISTED)) && (tc##X & TILE_COUNT_MASK) <= 1024u && \
+#define PK_FAST(X) (!(tc##X & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_MISS_LISTED | TILE_DIRECT)) && (tc##X & TILE_COUNT_MASK) <= 1024u && \
                     base##X + (int64_t)(tc##X & TILE_COUNT_MASK) <= a.out_cap)
     uint4 cx0 = make_uint4(0, 0, 0, 0), cx1 = cx0, cx2 = cx0, cx3 = cx0, nx0 = cx0, nx1 = cx0, nx2 = cx0, nx3 = cx0;
     uint32_t ch0 = 0, ctl = 0, cdsl = 0, nh0 = 0, ntl = 0, ndsl = 0;
@@ -2530,6 +2944,13 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         tcA = tcB; baseA = baseB; dfA = dfB; tcB = tcC; baseB = baseC; dfB = dfC;
         fast_cur = fast_next;
         cx0 = nx0; cx1 = nx1; cx2 = nx2; cx3 = nx3; ch0 = nh0; ctl = ntl; cdsl = ndsl; cdpos = ndpos;
+        if (tc & TILE_DIRECT) {  // the fused tile loop wrote this tile's ids and document offsets itself
+            if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
+                const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
+                for (int64_t d = d_end + lane; d <= a.n_docs; d += 64) a.out_offsets[d] = total;
+            }
+            continue;
+        }
         if (fast_this && !TD_STOP(61)) {
             const uint32_t g_c = tc & TILE_COUNT_MASK;
             int32_t* dst = a.out_tokens + base;
@@ -3052,14 +3473,21 @@ static int long_grid_blocks() {  // (work is dealt round-robin to the wavefronts
     return g_blocks_long;
 }
 static int g_blocks_fused = 0;
-static int fused_grid_blocks() {
-    if (!g_blocks_fused) g_blocks_fused = resident_blocks((const void*)td_split_tiles<0u, true>, 3);
+int fused_grid_blocks() {
+    if (!g_blocks_fused) g_blocks_fused = resident_blocks((const void*)td_split_tiles<0u, true, false>, 3);
     const char* e = getenv("TD_FUSED_BLOCKS_PER_CU");
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_fused;
 }
+static int g_blocks_direct = 0;
+int direct_grid_blocks() {  // the fused loop with direct placement (an instantiation of its own: other registers, more LDS)
+    if (!g_blocks_direct) g_blocks_direct = resident_blocks((const void*)td_split_tiles<0u, true, true>, 3);
+    const char* e = getenv("TD_FUSED_BLOCKS_PER_CU");
+    if (e && atoi(e) > 0) return 256 * atoi(e);
+    return g_blocks_direct;
+}
 static int split_grid_blocks() {
-    if (!g_blocks_split) g_blocks_split = resident_blocks((const void*)td_split_tiles<0u, false>, 3);
+    if (!g_blocks_split) g_blocks_split = resident_blocks((const void*)td_split_tiles<0u, false, false>, 3);
     const char* e = getenv("TD_SPLIT_BLOCKS_PER_CU");
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_split;
@@ -3102,9 +3530,11 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         if (a.stop_after) fused = false;  // (the phase numbers are the unfused kernels')
 #endif
         const int fblocks = a.n_stiles < fused_grid_blocks() ? a.n_stiles : fused_grid_blocks();
+        const int dblocks = a.direct ? (a.n_stiles < direct_grid_blocks() ? a.n_stiles : direct_grid_blocks()) : 0;
 #define TD_LAUNCH_SPLIT(PVX)                                                                                          \
-    if (fused) hipLaunchKernelGGL((td_split_tiles<(PVX), true>), dim3(fblocks), dim3(K_THREADS), 0, stream, a);       \
-    else hipLaunchKernelGGL((td_split_tiles<(PVX), false>), dim3(sblocks), dim3(K_THREADS), 0, stream, a)
+    if (fused && a.direct) hipLaunchKernelGGL((td_split_tiles<(PVX), true, true>), dim3(dblocks), dim3(K_THREADS), 0, stream, a); \
+    else if (fused) hipLaunchKernelGGL((td_split_tiles<(PVX), true, false>), dim3(fblocks), dim3(K_THREADS), 0, stream, a);      \
+    else hipLaunchKernelGGL((td_split_tiles<(PVX), false, false>), dim3(sblocks), dim3(K_THREADS), 0, stream, a)
         switch (a.pat_flags) {
             case PV_GPT2: TD_LAUNCH_SPLIT(PV_GPT2); break;
             case 0u: TD_LAUNCH_SPLIT(0u); break;
