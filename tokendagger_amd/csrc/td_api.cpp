@@ -917,6 +917,7 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
         d = e;
     }
     const int nchunks = (int)cd.size() - 1;
+    t->last_direct = t->last_timeouts = 0;
     struct Pending { int64_t d0, d1, b0, nbytes, ntok; };
     std::vector<Pending> pend((size_t)nchunks);
     int64_t tok_base = 0;
@@ -955,6 +956,8 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
         const int64_t nd = P.d1 - P.d0;
         const int64_t* to = (const int64_t*)sl.h_offs;
         P.ntok = to[nd];
+        t->last_direct += sl.h_ctl->direct_tiles;  // (td_info: sums over the call's chunks)
+        t->last_timeouts += sl.h_ctl->lb_timeouts;
         if (sl.h_ctl->err != 0 && first_err == TD_OK) {
             first_err = sl.h_ctl->err;
             const long long pos = sl.h_ctl->err_pos + (first_err == TD_E_UNKNOWN_BYTE || first_err == TD_E_SCRATCH ? P.b0 : 0);
