@@ -1093,13 +1093,19 @@ TD_HD bool mg_round_t(const Tables& T, uint32_t* keys, uint32_t* ids, MergeState
     const uint32_t base = st.t << 4, sx = ((st.t >> 2) & 3u) << 2;  // slot of part j = base + (j ^ sx)
     uint32_t m = MG_DEAD;
     for (uint32_t c = 0; c < units; ++c) {
+        // the unit's sixteen keys: four 16-byte LDS reads issued back to back, THEN the minimum (the compiler, left alone, reused
+        // one register quadruple and waited for every read before the next: four LDS round trips in a row per unit and round)
+        U4 k0 = *reinterpret_cast<const U4*>(keys + base + ((16u * c + 0u) ^ sx));
+        U4 k1 = *reinterpret_cast<const U4*>(keys + base + ((16u * c + 4u) ^ sx));
+        U4 k2 = *reinterpret_cast<const U4*>(keys + base + ((16u * c + 8u) ^ sx));
+        U4 k3 = *reinterpret_cast<const U4*>(keys + base + ((16u * c + 12u) ^ sx));
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
+        asm volatile("" : "+v"(k0.x), "+v"(k1.x), "+v"(k2.x), "+v"(k3.x));
 #endif
-        for (uint32_t q = 0; q < 4; ++q) {
-            const U4 k = *reinterpret_cast<const U4*>(keys + base + ((16u * c + 4u * q) ^ sx));
-            m = td_min3(td_min3(k.x, k.y, k.z), k.w, m);
-        }
+        m = td_min3(td_min3(k0.x, k0.y, k0.z), k0.w, m);
+        m = td_min3(td_min3(k1.x, k1.y, k1.z), k1.w, m);
+        m = td_min3(td_min3(k2.x, k2.y, k2.z), k2.w, m);
+        m = td_min3(td_min3(k3.x, k3.y, k3.z), k3.w, m);
     }
     if (m == MG_DEAD) return false;
     const uint32_t w = m & 63u, r = m >> 6;
