@@ -2601,7 +2601,6 @@ __global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
 // Cost: (distinct ranks that occur) x (len / 1024) sweep steps — far from quadratic for the repetitive inputs that produce
 // such pieces, still slow for a megabyte of random letters.
 constexpr int GP_THREADS = 1024;
-constexpr uint32_t GP_SEL = 0x80000000u;  // rank word: the pair that starts here merges in this round
 template <bool IS_MAX>
 __device__ __forceinline__ int gp_wave_scan(int x) {  // inclusive add- or max-scan across the wavefront (DPP)
     constexpr int ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118, ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143;
@@ -2649,10 +2648,34 @@ __device__ __forceinline__ uint32_t gp_block_min(uint32_t x, uint32_t* s_m) {  /
     return m;
 }
 
+// Round 4: BANDS of ranks instead of one rank per round.  A round's candidates are the pairs that rank strictly below their
+// left neighbour pair and not above their right one (in a run of equal ranks that starts so: every second one) — no two of
+// them overlap.  The ones below a bound B merge together; B is lowered until (1) every pair below B that is left over is
+// overlapped by a merging one (so the sequential loop, tiktoken.cpp:322-343, has nothing below B to merge but the selected
+// pairs) and (2) every pair the merges create — and every transient pair the sequential order would see between two merges
+// one part apart — ranks at or above B (so nothing new can come in between).  Then the selected merges do not interact
+// and the result is the sequential one whatever their order.  A bound that ends up at the lowest rank present falls back to
+// the plain sequential step (leftmost pair of the lowest rank).  Checked against the heap form of the reference's loop on
+// the CPU first (1 600 random pieces over the Llama-4 vocabulary and over toy vocabularies whose ranks are NOT in merge order):
+// a megabyte of random letters takes ~45 rounds instead of one per distinct rank (tens of thousands).
+constexpr uint32_t GP_INF = 0x00FFFFFFu;   // rank word: low 24 bits = rank of the pair that starts here (GP_INF: none)
+constexpr uint32_t GP_BASE = 0x40000000u;  //            the pair is a candidate of this round
+constexpr int GP_E = 4;                    // parts per thread and step
+// (the scope of the loads of what other lanes wrote: workgroup — a piece is one workgroup's, and a CU's waves share its L1;
+// agent scope sends every one of these loads to the memory side of the fabric: 554 -> ? ms for a megabyte of random letters)
+#ifndef GP_LD_SCOPE
+#define GP_LD_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+__device__ __forceinline__ uint32_t gp_ld(const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, GP_LD_SCOPE); }  // (written by other lanes of this workgroup)
+__device__ __forceinline__ uint32_t gp_rank(const Tables& T, uint32_t l, uint32_t r) {
+    const int32_t v = pair_lookup(T, l, r);
+    return v == NO_RANK ? GP_INF : (uint32_t)v;
+}
+
 __global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a) {
     __shared__ int s_w[GP_THREADS / 64];
     __shared__ uint32_t s_m[GP_THREADS / 64];
-    __shared__ uint32_t s_viol;
+    __shared__ unsigned long long s_off;
     const Tables T = uniform_tables(a.Tp);
     const int tid = threadIdx.x;
     static_assert(K_GIANT_MIN == LP_MEDIUM, "what td_long_pieces leaves");
@@ -2665,124 +2688,180 @@ __global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a
         if (len <= (uint32_t)LP_MEDIUM) continue;  // (uniform: td_long_pieces')
         const int64_t gs = a.long_list[j].gs;
         const uint8_t* p = a.text + gs;
-        unsigned long long off = 0;
-        if (tid == 0) off = atomicAdd(a.pool_used, 4ull * len);
-        {   // (broadcast through LDS: 64-bit)
-            __shared__ unsigned long long s_off;
-            if (tid == 0) s_off = off;
-            __syncthreads();
-            off = s_off;
-            __syncthreads();
-        }
+        if (tid == 0) s_off = atomicAdd(a.pool_used, 4ull * len);
+        __syncthreads();
+        const unsigned long long off = s_off;
+        __syncthreads();
         if (off + 4ull * len > a.pool_cap) {
             if (tid == 0) raise(a, TD_E_SCRATCH, gs);
             continue;
         }
-        uint32_t* id_cur = a.pool + off;       // two generations of (ids, pair ranks): the round reads one, writes the other
+        uint32_t* id_cur = a.pool + off;       // two generations of (ids, rank words): a round reads one, writes the other
         uint32_t* rk_cur = id_cur + len;
         uint32_t* id_nxt = rk_cur + len;
-        uint32_t* rk_nxt = id_nxt + len;
+        uint32_t* rk_nxt = id_nxt + len;       // (during a round: the ranks of the pairs the merges create, where the compaction takes them from)
         // generation 0: one part per byte, rank of every byte pair
-        uint32_t m = len, lmin = (uint32_t)NO_RANK;
+        uint32_t m = len, lmin = GP_INF;
         for (uint32_t i = tid; i < len; i += GP_THREADS) {
             const uint32_t b = p[i];
-            const uint32_t r = (i + 1 < len) ? (uint32_t)T.byte_pair[(b << 8) | p[i + 1]] : (uint32_t)NO_RANK;
+            const int32_t r0 = (i + 1 < len) ? T.byte_pair[(b << 8) | p[i + 1]] : NO_RANK;
+            const uint32_t r = r0 == NO_RANK ? GP_INF : (uint32_t)r0;
             id_cur[i] = (uint32_t)T.byte_id[b];
             rk_cur[i] = r;
             lmin = r < lmin ? r : lmin;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         uint32_t g = gp_block_min(lmin, s_m);
-        bool single = false;  // redo of a round that failed the order check: only the leftmost pair of rank g merges
-        while (g != (uint32_t)NO_RANK) {
-            // ---- which pairs merge: rank g and an even distance from the start of their run of g-pairs ----
-            int carry = -1;  // last position so far whose pair is not of rank g
-            uint32_t first_sel = 0xFFFFFFFFu;
-            for (uint32_t i0 = 0; i0 < m; i0 += GP_THREADS) {
-                const uint32_t i = i0 + tid;
-                const uint32_t r = i < m ? __hip_atomic_load(rk_cur + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~GP_SEL : (uint32_t)NO_RANK;
-                const bool isg = r == g;
+        while (g != GP_INF) {
+            // ---- sweep 1: the round's candidates.  rank word i gets GP_BASE when pair i ranks below its left neighbour pair's
+            //      run start ... (see above): r_i <= r_{i+1}, the run of equal ranks it lies in starts at rs with r_rs < r_{rs-1},
+            //      and i - rs is even ----
+            int carry = -1;  // last position so far where the rank differs from the one in front of it (run start)
+            for (uint32_t i0 = 0; i0 < m; i0 += GP_THREADS * GP_E) {
+                const uint32_t i = i0 + (uint32_t)tid * GP_E;
+                uint32_t r[GP_E + 2];  // r[0] = rank at i - 1 ... r[GP_E + 1] = rank at i + GP_E
+#pragma unroll
+                for (int e = 0; e < GP_E + 2; ++e) {
+                    const uint32_t q = i + (uint32_t)e - 1u;
+                    r[e] = (q < m) ? (gp_ld(rk_cur + q) & GP_INF) : GP_INF;  // (q = i - 1 wraps for i = 0: >= m)
+                }
+                int last = -1;  // my last run start
+#pragma unroll
+                for (int e = 0; e < GP_E; ++e)
+                    if (i + (uint32_t)e < m && (i + (uint32_t)e == 0u || r[e + 1] != r[e])) last = (int)(i + (uint32_t)e);
                 int tot;
-                int lastnon = gp_block_scan<true>(isg ? (int)0x80000000 : (int)i, s_w, tot);
-                lastnon = lastnon > carry ? lastnon : carry;
-                const bool sel = isg && !(((int)i - lastnon - 1) & 1);
-                if (i < m) rk_cur[i] = sel ? (r | GP_SEL) : r;
-                if (sel && i < first_sel) first_sel = i;
-                carry = tot > carry ? tot : carry;
-            }
-            if (single) {  // keep the leftmost selection only
-                first_sel = gp_block_min(first_sel, s_m);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __syncthreads();
-                for (uint32_t i = tid; i < m; i += GP_THREADS)
-                    if (i != first_sel) rk_cur[i] = __hip_atomic_load(rk_cur + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~GP_SEL;
-            }
-            if (tid == 0) s_viol = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            // ---- next generation: surviving parts compacted, changed pairs looked up, the order assumption checked ----
-            uint32_t out_base = 0;
-            lmin = (uint32_t)NO_RANK;
-            auto ld = [](const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };  // (written by other lanes: past the L1)
-            for (uint32_t i0 = 0; i0 < m; i0 += GP_THREADS) {
-                const uint32_t i = i0 + tid;
-                bool surv = false;
-                uint32_t A = 0, nr = (uint32_t)NO_RANK;
-                if (i < m) {
-                    const uint32_t r0 = ld(rk_cur + i);
-                    const bool selm1 = i > 0 && (ld(rk_cur + i - 1) & GP_SEL);
-                    surv = !selm1;
-                    if (surv) {
-                        const bool sel0 = (r0 & GP_SEL) != 0;
-                        const bool sel1 = i + 1 < m && (ld(rk_cur + i + 1) & GP_SEL);
-                        const bool sel2 = i + 2 < m && (ld(rk_cur + i + 2) & GP_SEL);
-                        A = sel0 ? g : ld(id_cur + i);
-                        const uint32_t n1 = sel0 ? i + 2 : i + 1;  // the part that follows mine in the next generation
-                        if (n1 < m) {
-                            const bool seln1 = sel0 ? sel2 : sel1;
-                            const uint32_t B = seln1 ? g : ld(id_cur + n1);
-                            if (!sel0 && !sel1) nr = r0 & ~GP_SEL;  // neither part changed
-                            else {
-                                nr = (uint32_t)pair_lookup(T, A, B);
-                                if (nr < g) s_viol = 1;             // a new pair below g: the sequential order would differ
-                            }
-                            if (sel0 && sel2) {  // between my merge and the next one of the run the sequential loop sees (g, id[i+2])
-                                const uint32_t tr = (uint32_t)pair_lookup(T, g, ld(id_cur + i + 2));
-                                if (tr < g) s_viol = 1;
-                            }
+                const int incl = gp_block_scan<true>(last, s_w, tot);  // (max-scan: identity 0x80000000 < -1)
+                int before = __shfl_up(incl, 1);                       // run start in front of my first part: the thread before me ...
+                if ((tid & 63) == 0) before = -1;
+                {   // ... (across wavefronts: the scan's own prefix) — recomputed from the totals
+                    int pre = carry;
+                    for (int w = 0; w < (tid >> 6); ++w) pre = s_w[w] > pre ? s_w[w] : pre;
+                    before = before > pre ? before : pre;
+                }
+                int rs = before;
+#pragma unroll
+                for (int e = 0; e < GP_E; ++e) {
+                    const uint32_t q = i + (uint32_t)e;
+                    if (q < m) {
+                        if (q == 0u || r[e + 1] != r[e]) rs = (int)q;
+                        const uint32_t rq = r[e + 1];
+                        bool base = rq != GP_INF && rq <= r[e + 2] && !(((int)q - rs) & 1);
+                        if (base) {  // the run's start ranks strictly below the pair in front of it
+                            const uint32_t rl = rs > 0 ? (gp_ld(rk_cur + rs - 1) & GP_INF) : GP_INF;
+                            base = rq < rl;
                         }
+                        rk_cur[q] = rq | (base ? GP_BASE : 0u);
                     }
                 }
-                int tot;
-                const int incl = gp_block_scan<false>(surv ? 1 : 0, s_w, tot);
-                if (surv) {
-                    const uint32_t o = out_base + (uint32_t)incl - 1u;
-                    id_nxt[o] = A;
-                    rk_nxt[o] = nr;
-                    lmin = nr < lmin ? nr : lmin;
-                }
-                out_base += (uint32_t)tot;
+                carry = tot > carry ? tot : carry;
+                __syncthreads();  // (s_w is read above after the scan's last barrier)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            const uint32_t gn = gp_block_min(lmin, s_m);  // (barriers: s_viol is final)
-            if (s_viol && !single) {  // redo this round sequentially: drop the selection marks, keep generation `cur`
-                __syncthreads();
-                for (uint32_t i = tid; i < m; i += GP_THREADS) rk_cur[i] = ld(rk_cur + i) & ~GP_SEL;
+            __syncthreads();
+            // ---- sweeps 2: the bound.  sel_i = GP_BASE and rank < B; lowered until the two conditions hold ----
+            uint32_t B = GP_INF;       // merge the candidates that rank below B
+            uint32_t first_sel = 0;    // B == 0: the plain sequential step — only this pair merges
+            for (;;) {
+                auto sel_of = [&](uint32_t q, uint32_t w) { return B ? ((w & GP_BASE) && (w & GP_INF) < B) : (q == first_sel); };
+                uint32_t vmin = GP_INF, smax = 0;  // lowest rank that has to stay above the merged ones; highest merged rank
+                for (uint32_t q = tid; q < m; q += GP_THREADS) {
+                    const uint32_t w0 = gp_ld(rk_cur + q), r0 = w0 & GP_INF;
+                    const uint32_t wm1 = q >= 1 ? gp_ld(rk_cur + q - 1) : GP_INF, wp1 = q + 1 < m ? gp_ld(rk_cur + q + 1) : GP_INF;
+                    const bool s0 = sel_of(q, w0), sm1 = q >= 1 && sel_of(q - 1, wm1), sp1 = q + 1 < m && sel_of(q + 1, wp1);
+                    if (!s0) {
+                        if (!sm1 && !sp1 && r0 < vmin) vmin = r0;  // a pair that is left over and not overlapped by a merging one
+                        continue;
+                    }
+                    smax = r0 > smax ? r0 : smax;
+                    const uint32_t wp2 = q + 2 < m ? gp_ld(rk_cur + q + 2) : GP_INF, wm2 = q >= 2 ? gp_ld(rk_cur + q - 2) : GP_INF;
+                    const bool sp2 = q + 2 < m && sel_of(q + 2, wp2), sm2 = q >= 2 && sel_of(q - 2, wm2);
+                    if (q + 2 < m) {  // the pair my merged part makes with what follows it
+                        const uint32_t idn = gp_ld(id_cur + q + 2);
+                        const uint32_t nr = gp_rank(T, r0, sp2 ? (wp2 & GP_INF) : idn);
+                        rk_nxt[q] = nr;
+                        vmin = nr < vmin ? nr : vmin;
+                        if (sp2) {  // two merges one part apart: the pair the sequential order sees in between
+                            const uint32_t tr = r0 <= (wp2 & GP_INF) ? gp_rank(T, r0, idn) : gp_rank(T, gp_ld(id_cur + q + 1), wp2 & GP_INF);
+                            vmin = tr < vmin ? tr : vmin;
+                        }
+                    } else {
+                        rk_nxt[q] = GP_INF;
+                    }
+                    if (q >= 1 && !sm2) {  // ... and with the (unchanged) part in front of it
+                        const uint32_t nl = gp_rank(T, gp_ld(id_cur + q - 1), r0);
+                        rk_nxt[q - 1] = nl;
+                        vmin = nl < vmin ? nl : vmin;
+                    }
+                }
+                vmin = gp_block_min(vmin, s_m);
+                smax = ~gp_block_min(~smax, s_m);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __syncthreads();
-                single = true;
-                continue;
+                if (B == 0u || smax < vmin) break;       // (the sequential step needs no check)
+                B = vmin;
+                if (B <= g) {  // nothing but the lowest rank is left below the bound: its leftmost pair alone
+                    B = 0u;
+                    uint32_t f = 0xFFFFFFFFu;
+                    for (uint32_t q = tid; q < m; q += GP_THREADS)
+                        if ((gp_ld(rk_cur + q) & GP_INF) == g && q < f) f = q;
+                    first_sel = gp_block_min(f, s_m);
+                }
             }
-            single = false;
-            m = out_base;
-            g = gn;
-            uint32_t* t0 = id_cur; id_cur = id_nxt; id_nxt = t0;
-            uint32_t* t1 = rk_cur; rk_cur = rk_nxt; rk_nxt = t1;
-            __syncthreads();
+            // ---- sweep 3: next generation — surviving parts compacted, the new ranks taken from rk_nxt ----
+            {
+                auto sel_of = [&](uint32_t q, uint32_t w) { return B ? ((w & GP_BASE) && (w & GP_INF) < B) : (q == first_sel); };
+                uint32_t out_base = 0;
+                lmin = GP_INF;
+                for (uint32_t i0 = 0; i0 < m; i0 += GP_THREADS * GP_E) {
+                    const uint32_t i = i0 + (uint32_t)tid * GP_E;
+                    uint32_t A[GP_E], nr[GP_E];
+                    bool surv[GP_E];
+                    uint32_t cnt = 0;
+                    uint32_t wprev = i >= 1 && i - 1 < m ? gp_ld(rk_cur + i - 1) : GP_INF;
+                    bool sprev = i >= 1 && i - 1 < m && sel_of(i - 1, wprev);
+#pragma unroll
+                    for (int e = 0; e < GP_E; ++e) {
+                        const uint32_t q = i + (uint32_t)e;
+                        surv[e] = false; A[e] = 0; nr[e] = GP_INF;
+                        if (q < m) {
+                            const uint32_t w0 = gp_ld(rk_cur + q);
+                            const bool s0 = sel_of(q, w0);
+                            surv[e] = !sprev;
+                            if (surv[e]) {
+                                const bool sn = q + 1 < m && sel_of(q + 1, gp_ld(rk_cur + q + 1));
+                                A[e] = s0 ? (w0 & GP_INF) : gp_ld(id_cur + q);
+                                nr[e] = (s0 || sn) ? gp_ld(rk_nxt + q) : (w0 & GP_INF);  // (a merged part's pairs: looked up by the sweeps above)
+                                if (s0 && q + 2 >= m) nr[e] = GP_INF;
+                                if (!s0 && q + 1 >= m) nr[e] = GP_INF;
+                                ++cnt;
+                            }
+                            sprev = s0;
+                        }
+                    }
+                    int tot;
+                    const int incl = gp_block_scan<false>((int)cnt, s_w, tot);
+                    uint32_t o = out_base + (uint32_t)incl - cnt;
+#pragma unroll
+                    for (int e = 0; e < GP_E; ++e)
+                        if (surv[e]) {
+                            id_nxt[o] = A[e];
+                            rk_nxt[o] = nr[e];
+                            lmin = nr[e] < lmin ? nr[e] : lmin;
+                            ++o;
+                        }
+                    out_base += (uint32_t)tot;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                g = gp_block_min(lmin, s_m);
+                m = out_base;
+                uint32_t* t0 = id_cur; id_cur = id_nxt; id_nxt = t0;
+                uint32_t* t1 = rk_cur; rk_cur = rk_nxt; rk_nxt = t1;
+                __syncthreads();
+            }
         }
         // the ids of the piece: generation `cur`
         for (uint32_t i = tid; i < m; i += GP_THREADS) {
-            const uint32_t v = __hip_atomic_load(id_cur + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t v = gp_ld(id_cur + i);
             if ((int32_t)v >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gs);
         }
         if (tid == 0) {
