@@ -1,0 +1,23 @@
+set -u
+# Closing run of a round on the final sources (ONE gpurun call): the full GPU suite FIRST (what the driver runs, same flags),
+# then the default bench line (what the driver records), then the profiles the numbers in DESIGN.md come from.
+# usage: tools/final_round.sh <tag>      -> gpurun_out/<tag>/ ; publish with python tools/publish_round.py <tag> <round>
+R=$GRAFT_REPO_ROOT; tag=$1; O=$R/gpurun_out/$tag; mkdir -p $O
+cd $R
+nproc > $O/host.txt; grep -m1 "model name" /proc/cpuinfo >> $O/host.txt
+timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_default.time; tail -3 $O/bench_default.time
+python - "$O/bench_default.json" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = j["roofline"]
+print(f'headline {j["value"]:.1f} GB/s  {j["ms_per_step"]:.4f} ms  dominant {r["kernel"]} {r["kernel_ms_avg"]} ms frac {r["frac"]}  whole-step frac {r["whole_step"]["frac"]}  fixed {r.get("fixed_overhead_us")} us  verified {j["config"]["verified_vs_oracle"]}')
+print('cpu_baseline', j.get("cpu_baseline", {}).get("value"), 'python', (j.get("drop_in_python") or {}).get("threads_8"), 'x', (j.get("drop_in_python") or {}).get("vs_reference_encode_batch"))
+for k, v in (j.get("configs") or {}).items():
+    print(f'  {k:<34} {v.get("value")} GB/s  {v.get("ms_per_step")} ms  {v.get("verified_vs_oracle", v.get("error"))}  ({v.get("wall_s")} s)')
+PY
+bash tools/measure_workload.sh $tag english 1024 > $O/measure_english.log 2>&1; tail -14 $O/measure_english.log
+bash tools/prof_workload.sh $tag mixed 256 > $O/prof_mixed.log 2>&1; tail -6 $O/prof_mixed.log
+bash tools/prof_workload.sh $tag code_files 256 > $O/prof_code_files.log 2>&1; tail -6 $O/prof_code_files.log
+cp $R/profiles/hbm_traffic.json $O/hbm_traffic.json
+timeout 200 python tools/gpu_pybatch.py 256 > $O/pybatch.txt 2>&1; grep -v amdgpu $O/pybatch.txt
+find $O -name "*.db" -size +20M -delete

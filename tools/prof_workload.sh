@@ -1,5 +1,5 @@
 set -u
-# usage: tools/r3_prof.sh <tag> <corpus> <MiB> [bench args]: rocprofv3 kernel stats of the bench command -> gpurun_out/<tag>/stats_<corpus>_<MiB>.txt (+ the raw .db)
+# usage: tools/prof_workload.sh <tag> <corpus> <MiB> [bench args]: rocprofv3 kernel stats of the bench command -> gpurun_out/<tag>/stats_<corpus>_<MiB>.txt (+ the raw .db)
 R=$GRAFT_REPO_ROOT; tag=$1; c=$2; mb=$3; shift 3; O=$R/gpurun_out/$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --corpus $c --size-mb $mb --no-cpu-baseline --no-verify --steps 10 --warmup 3 $*"

@@ -1,5 +1,5 @@
-"""Copy the summaries of a tools/r3_final.sh run (gpurun_out/<tag>/) into profiles/: kernel stats, HBM traffic, hbm_traffic.json.
-usage: python tools/r3_publish.py <tag>"""
+"""Copy the summaries of a tools/final_round.sh run (gpurun_out/<tag>/) into profiles/ under the round's names.
+usage: python tools/publish_round.py <tag> <round number>"""
 import json
 import shutil
 import sys
@@ -7,13 +7,15 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 src = ROOT / "gpurun_out" / sys.argv[1]
+rn = int(sys.argv[2])
 prof = ROOT / "profiles"
-shutil.copy(src / "stats_english_1024.txt", prof / "r3_01_kernel_stats_english_1024.txt")
-with open(prof / "r3_02_kernel_stats_other_corpora.txt", "w") as f:
-    for name in ("stats_mixed_256.txt", "stats_code_files_256.txt", "stats_chat_256.txt"):
-        f.write((src / name).read_text().rstrip("\n") + "\n\n")
+shutil.copy(src / "stats_english_1024.txt", prof / f"r{rn}_01_kernel_stats_english_1024.txt")
+with open(prof / f"r{rn}_02_kernel_stats_other_corpora.txt", "w") as f:
+    for name in ("stats_mixed_256.txt", "stats_code_files_256.txt"):
+        if (src / name).exists():
+            f.write((src / name).read_text().rstrip("\n") + "\n\n")
 t = json.loads((src / "hbm_traffic.json").read_text())
-lines = ["# HBM traffic per launch, rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the bench command (tools/r3_measure.sh)",
+lines = ["# fabric traffic of the L2s per launch, rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the bench command (tools/measure_workload.sh)",
          "# bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (counter unit KiB; factor 2: the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md), averaged over the launches",
          f"# kernel sources {t['kernel_source_sha']} ({t['source']})", ""]
 ALG = {"english_llama4_1024": 1970829960}  # text + 4 x ids + 8 x (documents + 1)
@@ -26,6 +28,11 @@ for key in sorted(k for k, v in t.items() if isinstance(v, dict)):
     for k, v in sorted(t[key]["per_kernel"].items(), key=lambda kv: -kv[1]):
         lines.append(f"  {k:<32} {v / 1e6:8.1f} MB")
     lines.append("")
-(prof / "r3_03_hbm_traffic.txt").write_text("\n".join(lines))
+(prof / f"r{rn}_03_hbm_traffic.txt").write_text("\n".join(lines))
 shutil.copy(src / "hbm_traffic.json", prof / "hbm_traffic.json")
+bdir = prof / f"r{rn}_bench"
+bdir.mkdir(exist_ok=True)
+for name in ("bench_default.json", "bench_default.time", "pybatch.txt", "host.txt", "pytest_gpu.log"):
+    if (src / name).exists():
+        shutil.copy(src / name, bdir / name)
 print("published", src, "->", prof)

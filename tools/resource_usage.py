@@ -1,4 +1,4 @@
-"""hipcc -Rpass-analysis=kernel-resource-usage of the device sources -> profiles/r3_resource_usage.txt
+"""hipcc -Rpass-analysis=kernel-resource-usage of the device sources -> profiles/r4_resource_usage.txt
 (VGPRs, spilled VGPRs, scratch bytes per lane, waves/SIMD, LDS bytes per workgroup of every kernel)."""
 import re
 import subprocess
@@ -9,7 +9,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import bench
 
-out = [f"# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage on the round-3 sources (kernel source sha {bench.kernel_source_sha()})",
+out = [f"# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage on the round-4 sources (kernel source sha {bench.kernel_source_sha()})",
        "# kernel | VGPRs | spilled VGPRs | scratch B/lane | waves/SIMD | LDS B/workgroup"]
 for src in ("td_kernels.hip", "td_generic.hip", "td_special.hip"):
     p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT / 'include'}", "-c",
@@ -27,5 +27,5 @@ for src in ("td_kernels.hip", "td_generic.hip", "td_special.hip"):
         if k.startswith("LDS"):
             name = cur["name"].replace("td::", "").replace("(td::EncodeArgs)", "")
             out.append(f"{name} | {cur['VGPRs']} | {cur['VGPRs Spill']} | {cur['ScratchSize [bytes/lane]']} | {cur['Occupancy [waves/SIMD]']} | {v}")
-(ROOT / "profiles" / "r3_resource_usage.txt").write_text("\n".join(out) + "\n")
+(ROOT / "profiles" / "r4_resource_usage.txt").write_text("\n".join(out) + "\n")
 print("\n".join(out))
