@@ -9,6 +9,14 @@ import sys
 import numpy as np
 import pytest
 
+# (the extension module is linked against libtokendagger_hip.so, whose HIP runtime has to be the one torch bundles when torch is
+# in the process: capi.load_library() sees to that BEFORE the module is loaded — pytest imports this file while collecting the
+# GPU suite too, and a system HIP runtime bound here left torch without a GPU in round 4's first closing run)
+capi = pytest.importorskip("tokendagger_amd.capi")
+try:
+    capi.load_library()
+except ImportError as e:  # not built
+    pytest.skip(str(e), allow_module_level=True)
 core = pytest.importorskip("tokendagger_amd._tokendagger_core")
 
 

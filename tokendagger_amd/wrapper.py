@@ -15,7 +15,10 @@ from typing import AbstractSet, Collection, Literal, Sequence
 
 import numpy as np
 
-from . import _tokendagger_core as _core
+from . import capi as _capi
+
+_capi.load_library()  # (first: it makes the HIP runtime of this process the one torch bundles, when torch is installed)
+from . import _tokendagger_core as _core  # noqa: E402
 
 MODE_ENCODE, MODE_ORDINARY = 0, 1
 
