@@ -198,6 +198,7 @@ struct td_tokenizer {
     uint32_t sp_n = 0, sp_maxlen = 0;
     bool device_specials = true;     // host-buffer batches of a MiB and more search on the device (TD_OPT_DEVICE_SPECIALS)
     bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
+    bool pack_split = false;  // (TD_PACK_SPLIT=1 at td_create time: A/B)
     bool direct = false; // the fused loop places a tile's ids itself when their output base is known in time (TD_OPT_DIRECT; TD_DIRECT=0 turns it off)
     bool fused = true;  // pre-tokenizer and lookup in one pass over the text (TD_OPT_FUSED; TD_FUSED=0 in the environment turns it off)
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
@@ -431,6 +432,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.deferred_list = (uint32_t*)t->deferred_list.p;
     a.deferred_count = &ctl->deferred_count;
     a.fused = t->fused ? 1 : 0;
+    a.pack_split = t->pack_split ? 1 : 0;
     a.direct = (t->direct && t->fused && !t->sp_active && t->H.pattern_kind != PATTERN_GENERIC && d_out && !t->stop_after) ? 1 : 0;
     a.tile_state = (unsigned long long*)t->tile_state.p;
     a.slab = (uint32_t*)t->slab.p;
@@ -584,6 +586,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if (const char* e = getenv("TD_FUSED")) t->fused = atoi(e) != 0;
     if (const char* e = getenv("TD_GRAPH")) t->graphs = atoi(e) != 0;
     if (const char* e = getenv("TD_DIRECT")) t->direct = atoi(e) != 0;
+    if (const char* e = getenv("TD_PACK_SPLIT")) t->pack_split = atoi(e) != 0;
     std::string err;
     int rc = build_tables(pat_str, n_vocab, token_bytes, token_offsets, ranks, n_special, special_bytes, special_offsets,
                           special_ids, t->H, err);
@@ -667,7 +670,7 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t = new td_tokenizer(src->shared);
         t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
         t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
-        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct;
+        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split;
         t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }

@@ -117,6 +117,7 @@ struct EncodeArgs {
     int stop_after;             // ablation (only in -DTD_ABLATE builds): leave the tile loop after phase N (0 = run everything)
     // direct placement (round 4, td_split_tiles<.., true>): the fused loop writes a tile's ids straight to out_tokens when the
     // output base of the tile is known in time (decoupled look-back over the per-tile id counts)
+    int pack_split;             // td_pack_tokens as a pair: the plain tiles at 8 wavefronts per SIMD, then the others (TD_PACK_SPLIT)
     int direct;                 // try it (family patterns, fused loop, no special cuts)
     unsigned long long* tile_state;  // [n_stiles + 1] per pre-tokenizer tile: status << 62 | value (TS_* below); zeroed by td_prepare
     uint32_t* slab;             // [fused grid][SLAB_RING][SLAB_WORDS] a workgroup's slots of the tile whose placement is pending (stays in the L2)

@@ -639,6 +639,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     // global-memory round trip at the top of every tile and another one in front of the document slots: 13 % + 5 % of the
     // fused loop.)
     uint32_t pfd0 = 0, pfd1 = 0, pffd0 = 0xFFFFFFFFu, pffd1 = 0xFFFFFFFFu;
+    uint32_t pft = 0;  // (FUSED) one byte of every 64-byte line of the next window: pulls the text into the L2, see load_window
     static_assert(K_WIN / 32 <= 2 * K_THREADS, "two prefetched document words per lane cover the window");
     auto load_window = [&](int64_t w0) {
         {
@@ -652,6 +653,13 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             }
         }
         if (!interior(w0)) return;
+#ifdef TD_TEXT_L2_PREFETCH
+        // (Measured in round 4 and NOT in, -DTD_TEXT_L2_PREFETCH: the next window's text cannot be prefetched into registers, NPRE
+        // above, and waiting for it at the top of its iteration is 14 % of the loop — so ONE byte per 64-byte line and lane, a
+        // single register across the token phases that nobody looks at, pulls the window into this XCD's L2.  1.951 -> 2.007 ms
+        // per GiB of English, 0.766 -> 0.791 ms per 256 MiB of code: the one register is 1 -> 5 spilled VGPRs at the cap.)
+        if (FUSED && NPRE == 0 && tid < (K_WIN + 63) / 64) pft = *reinterpret_cast<const volatile uint8_t*>(a.text + w0 + 64 * tid);
+#endif
         const uint4* src16 = reinterpret_cast<const uint4*>(a.text + w0);
 #pragma unroll
         for (int q = 0; q < NPRE; ++q)
@@ -748,6 +756,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             stw = (pkind == 1u && idx0 >= 0) ? __hip_atomic_load(&a.tile_state[idx0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (TS_PREFIX << 62);
         }
         if (have) {
+        if (FUSED) asm volatile("" :: "v"(pft));  // (see load_window: the prefetch byte's register is free from here on)
 
         // ---- phase 0: stage the text window and the document bits (two-kernel form: the text was requested one iteration ago,
         //      registers pf[]; FUSED: now, see NPRE) --------------
@@ -2957,8 +2966,11 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
 // and six dependent global loads in a row; plain English has a marker in every third tile.)
 constexpr int PK_G = 8;       // rows of 64 slots per group of the marker path
 constexpr int PK_ECAP = 256;  // merged pieces the expansion list holds
-__global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
-    __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];  // dst offset << 32 | tile position << 7 | ids
+// PLAIN_ONLY: only the pipelined path of the plain tiles (every slot an id, at most 1024 of them); SKIP_PLAIN: everything else.
+// Launched as a pair (a.pack_split): the first has none of the marker path's registers — 8 wavefronts per SIMD instead of 4 —
+// the second finds next to nothing to do on plain text.  <false, false>: one kernel for all tiles (rounds 2-3).
+template <bool PLAIN_ONLY, bool SKIP_PLAIN>
+__device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long long (*s_elist)[PK_ECAP]) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef TD_PACK_TIMING
     unsigned long long t_meta = 0, t_rows = 0, t_scan = 0, t_plain = 0, t_list = 0, t_flush = 0, t_docs = 0, t_plainpath = 0, n_mt = 0, n_pt = 0, n_fl = 0;
@@ -3008,11 +3020,11 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
     if (tile_first < a.n_tiles) PK_FETCH(tile_first, A)
     if (tile_first + nwaves < a.n_tiles) PK_FETCH(tile_first + nwaves, B)
     bool fast_cur = tile_first < a.n_tiles && PK_FAST(A);
-    if (fast_cur) PK_LOAD(tile_first, A, c)
+    if (fast_cur && !SKIP_PLAIN) PK_LOAD(tile_first, A, c)
     for (int tile = tile_first; tile < a.n_tiles; tile += nwaves) {
         if (tile + 2 * nwaves < a.n_tiles) PK_FETCH(tile + 2 * nwaves, C)
         const bool fast_next = tile + nwaves < a.n_tiles && PK_FAST(B);
-        if (fast_next) PK_LOAD(tile + nwaves, B, n)  // (in front of this tile's stores)
+        if (fast_next && !SKIP_PLAIN) PK_LOAD(tile + nwaves, B, n)  // (in front of this tile's stores)
         const uint32_t tc = tcA;
         const int64_t base = baseA;
         const int64_t dfirst = (int64_t)dfA;
@@ -3023,6 +3035,8 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         tcA = tcB; baseA = baseB; dfA = dfB; tcB = tcC; baseB = baseC; dfB = dfC;
         fast_cur = fast_next;
         cx0 = nx0; cx1 = nx1; cx2 = nx2; cx3 = nx3; ch0 = nh0; ctl = ntl; cdsl = ndsl; cdpos = ndpos;
+        if (SKIP_PLAIN && fast_this) continue;       // (the other kernel of the pair; the closing offsets with it when this is the last tile)
+        if (PLAIN_ONLY && !fast_this) continue;
         if (tc & TILE_DIRECT) {  // the fused tile loop wrote this tile's ids and document offsets itself
             if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
                 const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
@@ -3058,6 +3072,7 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
             }
             continue;
         }
+        if constexpr (PLAIN_ONLY) continue;
         const uint32_t cnt = tc & TILE_COUNT_MASK;
         const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
         const int64_t g_lo = (int64_t)tile * K_TILE;
@@ -3243,6 +3258,17 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
         printf("pack wave b%d: total %llu meta %llu plainpath %llu (%llu tiles) | marker tiles %llu: rows %llu scan %llu plain %llu list %llu flush %llu docs %llu\n", (int)blockIdx.x,
                (unsigned long long)(__builtin_readcyclecounter() - t_total0), t_meta, t_plainpath, n_pt, n_mt, t_rows, t_scan, t_plain, t_list, t_flush, t_docs);
 #endif
+}
+__global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
+    __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];  // dst offset << 32 | tile position << 7 | ids
+    pack_body<false, false>(a, s_elist);
+}
+__global__ __launch_bounds__(K_THREADS, 8) void td_pack_plain(const EncodeArgs a) {
+    pack_body<true, false>(a, nullptr);
+}
+__global__ __launch_bounds__(K_THREADS) void td_pack_rest(const EncodeArgs a) {
+    __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];
+    pack_body<false, true>(a, s_elist);
 }
 
 // ------------------------------------------------------------------ td_small_encode ---------
@@ -3663,7 +3689,12 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         }
         hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
         if (ev) (void)hipEventRecord(ev[5], stream);
-        hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
+        if (a.pack_split) {
+            hipLaunchKernelGGL(td_pack_plain, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
+            hipLaunchKernelGGL(td_pack_rest, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
+        } else {
+            hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
+        }
     } else if (ev) {
         (void)hipEventRecord(ev[5], stream);
     }
