@@ -148,23 +148,47 @@ def test_gpu_python_surface_with_the_reference_tests_pattern():
 
 
 @pytest.mark.gpu
-def test_gpu_left_context_assertions_refuse_special_cuts():
-    """the reference matches a segment behind a special token with the text in front as left context
-    (tiktoken.cpp:86-93); segments are subjects of their own here, so a pattern with ^ \\A \\b \\B refuses the cut instead of
-    approximating it.  Without a cut (no allowed special in the text) the pattern works as ever."""
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_gpu_left_context_behind_special_cuts_equals_the_reference():
+    """The reference matches a segment behind a special token with the text in front of it as left context (pcre2_match on
+    text[0, end) from start_offset, tiktoken.cpp:86-93): \\A and ^ cannot match there, \\b and a one-character look-behind see the
+    special's last character.  Round 3 refused such cuts; round 4 sends every segment down with that character in front of it,
+    marked as context (EncodeArgs::gx_prefix).  Against CoreBPE::encode(text, {one special}) of the compiled reference (with
+    ONE allowed special its segmentation loop is deterministic, tests/test_special_reference.py), batch and single-string forms.
+    The patterns here match every character: where a segment's tail matches nothing, the reference's split_text pushes
+    text.substr(start_offset) — the rest of the WHOLE text, special token and all, tiktoken.cpp:99 ignores end_offset — as one
+    piece and then goes on behind the special token, so that text is tokenized twice; that is not reproduced (the tail piece
+    ends where the segment ends)."""
     import tokendagger as tiktoken
+    from tokendagger_amd import capi
     _, mr, special = H.llama4()
-    enc = tiktoken.Encoding(name="wb", pat_str=PATTERNS["wordb"], mergeable_ranks=mr, special_tokens=special)
-    plain = tiktoken.Encoding(name="w", pat_str=PATTERNS["words"], mergeable_ranks=mr, special_tokens=special)
-    s = "one two<|begin_of_text|>three"
-    assert enc.encode("one two three") == enc.encode("one two three", allowed_special="all")  # (nothing to cut)
-    with pytest.raises(tiktoken.TokenDaggerError):
-        enc.encode(s, allowed_special="all")
-    assert special["<|begin_of_text|>"] in plain.encode(s, allowed_special="all")
-    behind = tiktoken.Encoding(name="lb", pat_str=PATTERNS["lookb1"], mergeable_ranks=mr, special_tokens=special)  # (look-behinds too)
-    assert behind.encode("one two three") == behind.encode("one two three", allowed_special="all")
-    with pytest.raises(tiktoken.TokenDaggerError):
-        behind.encode(s, allowed_special="all")
+    rng = random.Random(21)
+    names = ["<|begin_of_text|>", "<|eot|>", "<|header_start|>"]
+    frags = ["one", " two", "three", "x", " ", "\n", "#", "##", "9", " 42", "naïve", "中文", "_", "-", "a1", "", "s", " s"]
+    total = {"wordb": PATTERNS["wordb"] + r"|\s+", "anchors": PATTERNS["anchors"], "lookb1": PATTERNS["lookb1"], "lookb2": PATTERNS["lookb2"] + r"|\s",
+             "lookb3": PATTERNS["lookb3"] + r"|\n", "bnd2": PATTERNS["bnd2"] + r"|\s", "words": PATTERNS["words"]}
+    for pname, pat in total.items():
+        tok = capi.HipTokenizer(pat, mr, special, device=0)
+        R = ref.RefTokenizer(pat, mr, special)
+        enc = tiktoken.Encoding(name=pname, pat_str=pat, mergeable_ranks=mr, special_tokens=special)
+        for name in names:
+            docs = []
+            for _ in range(120):
+                parts = []
+                for _ in range(rng.randrange(0, 8)):
+                    parts.append(rng.choice(frags))
+                    if rng.random() < 0.5:
+                        parts.append(rng.choice(names))  # (the allowed one, or another special's literal: ordinary text then)
+                docs.append("".join(parts).encode("utf-8"))
+            docs += [name.encode(), (name * 2 + "a").encode(), ("a" + name).encode(), (name + "a b" + name + " c").encode(), b"", ("é" + name + "é").encode()]
+            blob, offs = H.pack_docs(docs)
+            toks, toffs = tok.encode_batch_with_special_strs(blob, offs, [name])
+            for i, d in enumerate(docs):
+                want = R.encode_special(d, [name]).tolist()
+                assert toks[toffs[i]:toffs[i + 1]].tolist() == want, (pname, name, d)
+            for d in docs[:25]:  # the single-string form of the Python surface (CoreBPE.encode(text, allowed_special))
+                assert enc.encode(d.decode("utf-8"), allowed_special={name}) == R.encode_special(d, [name]).tolist(), (pname, name, d)
+        tok.close()
 
 
 @pytest.mark.gpu

@@ -199,6 +199,11 @@ struct td_tokenizer {
     bool device_specials = true;     // host-buffer batches of a MiB and more search on the device (TD_OPT_DEVICE_SPECIALS)
     bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
     bool pack_split = false;  // (TD_PACK_SPLIT=1 at td_create time: A/B)
+    // generic patterns with left-context assertions behind special cuts: per document of the NEXT host batch, the bytes at its
+    // start that are context only (set around encode_batch_locked by encode_special_locked)
+    const uint8_t* gx_prefix_host = nullptr;
+    DevBuf gx_prefix;
+    const uint8_t* gx_prefix_dev = nullptr;
     bool direct = false; // the fused loop places a tile's ids itself when their output base is known in time (TD_OPT_DIRECT; TD_DIRECT=0 turns it off)
     bool fused = true;  // pre-tokenizer and lookup in one pass over the text (TD_OPT_FUSED; TD_FUSED=0 in the environment turns it off)
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
@@ -428,6 +433,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.gx_exit = (int64_t*)t->gx_exit.p;
     a.gx_state = (uint32_t*)t->gx_state.p;
     a.gap_count = &ctl->gap_count;
+    a.gx_prefix = t->gx_prefix_dev;
     a.flagged_list = (uint32_t*)t->flagged_list.p;
     a.deferred_list = (uint32_t*)t->deferred_list.p;
     a.deferred_count = &ctl->deferred_count;
@@ -708,7 +714,7 @@ void td_destroy(td_tokenizer* t) {
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
         if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->tile_state, &t->slab, &t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->gx_prefix, &t->tile_state, &t->slab, &t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)
@@ -1087,11 +1093,12 @@ int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc
     int rc;
     if ((rc = check_offsets(t, "doc_offsets", doc_offsets, n_docs, text))) return rc;
     const int64_t n = doc_offsets[n_docs];
+    const bool with_prefix = t->gx_prefix_host != nullptr;  // (generic pattern: the plain path below, whatever the size)
     if (n > 0 && n <= SMALL_MAX_BYTES && n_docs <= SMALL_MAX_DOCS && t->small_enabled && t->H.pattern_kind != PATTERN_GENERIC) {  // (the one-launch kernel knows the family's scanners only)
         rc = encode_batch_small(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
         if (rc != -1) return rc;  // (-1: a piece above 64 bytes; the general path below handles it)
     }
-    if (n >= 2 * t->pipe_chunk_bytes && out_tokens)
+    if (n >= 2 * t->pipe_chunk_bytes && out_tokens && !with_prefix)
         return encode_batch_pipelined(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
     if ((rc = ensure(t, t->h2d_text, (size_t)n + 64))) return rc;
     if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;
@@ -1104,7 +1111,13 @@ int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc
     if ((rc = order_before(t, s))) return rc;
     if (n > 0) HIP_TRY(t, hipMemcpyAsync(t->h2d_text.p, text, (size_t)n, hipMemcpyHostToDevice, s));
     HIP_TRY(t, hipMemcpyAsync(t->h2d_offs.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    if (with_prefix) {
+        if ((rc = ensure(t, t->gx_prefix, (size_t)n_docs + 16))) return rc;
+        HIP_TRY(t, hipMemcpyAsync(t->gx_prefix.p, t->gx_prefix_host, (size_t)n_docs, hipMemcpyHostToDevice, s));
+        t->gx_prefix_dev = (const uint8_t*)t->gx_prefix.p;
+    }
     rc = encode_device_locked(t, t->h2d_text.p, n, t->h2d_offs.p, n_docs, mode, t->d_tokens.p, dev_cap, t->d_offsets.p, s);
+    t->gx_prefix_dev = nullptr;
     if (rc) return rc;
     rc = device_status_locked(t, s, nullptr);
     if (rc) return rc;
@@ -1535,26 +1548,38 @@ int encode_special_locked(td_tokenizer* t, const uint8_t* text, const int64_t* d
         if (n_tokens) *n_tokens = ntok;
         return rc;
     }
-    if (t->H.rx_left_context) {
-        // The reference matches every segment with the text in front of it as left context (pcre2_match on text[0, end) from
-        // start_offset, tiktoken.cpp:86-93): behind a special token \\A and ^ cannot match and \\b sees the special's last
-        // character.  The segments go to the device as subjects of their own, so for a pattern with these assertions the
-        // cut would be a silent approximation: refused instead.
-        t->err = "the split pattern uses ^, \\A, \\b or \\B: cutting allowed special tokens out of the text is not supported with it";
-        return TD_E_PATTERN;
-    }
-    std::vector<uint8_t> seg_text;
+    // The reference matches every segment with the text in front of it as left context (pcre2_match on text[0, end) from
+    // start_offset, tiktoken.cpp:86-93): behind a special token \\A and ^ cannot match, \\b and a one-character look-behind see the
+    // special's last character.  For a pattern with such assertions (rx_left_context) every segment that stands behind a
+    // special token is sent down WITH that character in front of it, marked as context (gx_prefix): the matcher starts behind
+    // it, sees it, and its bytes get no tokens.  (Round 3 refused the cut.)
+    const bool ctx = t->H.rx_left_context && t->H.pattern_kind == PATTERN_GENERIC;
+    std::vector<uint8_t> seg_text, prefix;
     std::vector<int64_t> seg_offs((size_t)nseg + 1, 0);
     {
+        if (ctx) prefix.assign((size_t)nseg, 0);
         int64_t tot = 0;
-        for (int64_t sg = 0; sg < nseg; ++sg) { tot += ends[(size_t)sg] - starts[(size_t)sg]; seg_offs[(size_t)sg + 1] = tot; }
+        for (int64_t d = 0; d < n_docs; ++d)
+            for (int64_t k = doc_seg[(size_t)d]; k < doc_seg[(size_t)d + 1]; ++k) {
+                const int64_t lo = starts[(size_t)k], hi = ends[(size_t)k];
+                if (ctx && k > doc_seg[(size_t)d] && hi > lo) {  // behind a special token of the same document
+                    int64_t c = 1;
+                    while (c < 4 && lo - c > doc_offsets[d] && (text[lo - c] & 0xC0u) == 0x80u) ++c;
+                    prefix[(size_t)k] = (uint8_t)c;
+                }
+                tot += hi - lo + (ctx ? prefix[(size_t)k] : 0);
+                seg_offs[(size_t)k + 1] = tot;
+            }
         seg_text.resize((size_t)std::max<int64_t>(tot, 1));
-        for (int64_t sg = 0; sg < nseg; ++sg)
-            if (ends[(size_t)sg] > starts[(size_t)sg])
-                memcpy(seg_text.data() + seg_offs[(size_t)sg], text + starts[(size_t)sg], (size_t)(ends[(size_t)sg] - starts[(size_t)sg]));
+        for (int64_t k = 0; k < nseg; ++k) {
+            const int64_t pre = ctx ? prefix[(size_t)k] : 0, lo = starts[(size_t)k] - pre, hi = ends[(size_t)k];
+            if (hi > lo) memcpy(seg_text.data() + seg_offs[(size_t)k], text + lo, (size_t)(hi - lo));
+        }
     }
     std::vector<int32_t> toks((size_t)std::max<int64_t>(seg_offs[(size_t)nseg], 1));
+    if (ctx) t->gx_prefix_host = prefix.data();
     rc = encode_batch_locked(t, seg_text.data(), seg_offs.data(), nseg, TD_MODE_ENCODE, toks.data(), (int64_t)toks.size(), toffs.data(), &ntok);
+    t->gx_prefix_host = nullptr;
     if (rc) return rc;
     // 3. stitch: offsets first (they do not need the capacity), then the ids
     const int64_t need = ntok + n_special;
@@ -1596,14 +1621,20 @@ int32_t last_piece_token_len_host(td_tokenizer* t, const uint8_t* text, int64_t 
     const Tables hv = t->H.view();
     if (t->H.pattern_kind == PATTERN_GENERIC) {
         // the compiled pattern over the whole segment (no provable restart points): its last piece
-        struct SegAcc { const uint8_t* p; uint32_t byte(int64_t i) const { return p[i]; } } S{text + s_lo};
+        // (a segment behind a special token is matched with the special's last character in front of it, like the batch path)
+        int64_t pre = 0;
+        if (t->H.rx_left_context && s_lo > 0) {
+            pre = 1;
+            while (pre < 4 && s_lo - pre > 0 && (text[s_lo - pre] & 0xC0u) == 0x80u) ++pre;
+        }
+        struct SegAcc { const uint8_t* p; uint32_t byte(int64_t i) const { return p[i]; } } S{text + s_lo - pre};
         const RxProgram& P = *reinterpret_cast<const RxProgram*>(t->H.rx_program.data());
         const RxTables RT = rx_host_tables();
-        const int64_t n = s_hi - s_lo;
-        int64_t ms = 0, me = 0;
-        for (int64_t pos = 0; pos < n; pos = me) rx_next_piece(P, RT, S, pos, n, ms, me);
+        const int64_t n = s_hi - s_lo + pre;
+        int64_t ms = pre, me = pre;
+        for (int64_t pos = pre; pos < n; pos = me) rx_next_piece(P, RT, S, pos, n, ms, me);
         const uint32_t len = (uint32_t)(me - ms);
-        const uint8_t* pb = text + s_lo + ms;
+        const uint8_t* pb = text + s_lo - pre + ms;
         std::vector<int32_t> tmp;
         const int32_t whole = (len == 1) ? t->H.byte_id[pb[0]] : piece_lookup(hv, piece_key_host(pb, len), len, [pb](uint32_t i) { return (uint32_t)pb[i]; });
         if (whole != NO_RANK) return 1;

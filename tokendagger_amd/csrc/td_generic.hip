@@ -161,6 +161,13 @@ __device__ __forceinline__ int64_t gx_chunk(const EncodeArgs& a, const RxProgram
                 pos = c0;
                 for (int k = 0; k < 3 && pos < o1 && (a.text[pos] & 0xC0u) == 0x80u; ++k) ++pos;
             }
+            if (a.gx_prefix) {  // left context only (the end of the special token this segment stands behind): matched from behind it
+                const int64_t pre = a.gx_prefix[d];
+                if (pre) {
+                    if (o0 >= c0) W.mark(o0, true);  // (its bytes: a stretch without tokens, like text the pattern skips)
+                    if (pos < o0 + pre) pos = o0 + pre;
+                }
+            }
             continue;
         }
         if (pos >= c1) return pos;

@@ -95,6 +95,8 @@ struct EncodeArgs {
     int32_t gx_chunk;           // bytes per chunk (gx_chunk_for(n))
     int64_t* gx_exit;           // [n / gx_chunk + 1] per chunk: the first piece start at or behind the chunk end, as its own run found it
     uint32_t* gx_state;         // [n / gx_chunk + 1] per chunk: 1 = its run agrees with the chunk in front of it
+    const uint8_t* gx_prefix;   // [n_docs] or null: the first gx_prefix[d] bytes of document d are LEFT CONTEXT only (the last character of
+                                // the special token a segment stands behind, tiktoken.cpp:86-93): matched from behind them, no tokens
     uint32_t* deferred_list;    // fused tile loop (td_split_tiles<.., true>): the token tiles it left to td_probe_tiles
     uint32_t* deferred_count;   // entries on it
     int fused;                  // launch the fused tile loop (pre-tokenizer + lookup in one pass over the text)
