@@ -297,3 +297,47 @@ def test_calls_leave_the_current_device_alone():
     [t.join() for t in th]
     assert len(errs) == 4 and all("Invalid token for decoding: 100000000" in e for e in errs)
     tok.close()
+
+
+def test_encode_batch_lists_from_several_threads(enc):
+    """`encode_batch(list[str]) -> list[list[int]]` builds its result with shared int objects, reference counts added per distinct
+    id and the lists' item arrays filled by threads with the GIL released (csrc/py_binding.cpp: IntCache; the reference fans
+    single calls out to a thread pool, tokendagger/wrapper.py:212-235).  Several Python threads on ONE Encoding at once: the same
+    lists as one after the other, ordinary mutable lists of ints, and the shared ints' reference counts back to where they
+    were when the lists are gone."""
+    import gc
+    import sys
+    import threading
+    import td_corpus
+    texts = []
+    for seed in range(4):
+        x, offs = td_corpus.english(3 << 20, seed=40 + seed)
+        s = x.tobytes().decode("ascii")
+        texts.append([s[offs[i]:offs[i + 1]] for i in range(0, len(offs) - 1)] + ["", "x", "naïve 中文 <|eot|>"])
+    want = [enc.encode_batch(t) for t in texts]
+    for w, t in zip(want, texts):
+        assert type(w) is list and len(w) == len(t) and type(w[0]) is list and type(w[0][0]) is int
+        assert w[1] == enc.encode(t[1]) and w[-1] == enc.encode(t[-1]) and w[-3] == []
+    probe = want[0][0][0]
+    before = sys.getrefcount(probe)
+    got = [None] * 4
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                got[k] = enc.encode_batch(texts[k])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert got == want
+    got[0][0].append(7)  # (ordinary lists)
+    del got
+    gc.collect()
+    assert sys.getrefcount(probe) == before

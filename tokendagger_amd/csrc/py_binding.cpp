@@ -106,14 +106,36 @@ public:
         for (PyObject* o : objs_) Py_XDECREF(o);
         objs_.clear();
     }
-    void ensure(int64_t max_id) {  // (GIL held)
-        if ((int64_t)objs_.size() > max_id) return;
-        const size_t old = objs_.size();
-        objs_.resize((size_t)max_id + 1, nullptr);
-        for (size_t i = old; i < objs_.size(); ++i) {
-            objs_[i] = PyLong_FromLong((long)i);
-            if (!objs_[i]) throw py::error_already_set();
+    // Made ONCE (GIL held), for every id the tokenizer can produce, and never resized: threads of other encode_batch calls on
+    // the same tokenizer read the table with the GIL released.
+    void ensure(int64_t max_id) {
+        if (!objs_.empty()) return;
+        std::vector<PyObject*> v((size_t)std::max<int64_t>(max_id, 0) + 1, nullptr);
+        for (size_t i = 0; i < v.size(); ++i) {
+            v[i] = PyLong_FromLong((long)i);
+            if (!v[i]) {
+                for (size_t k = 0; k < i; ++k) Py_DECREF(v[k]);
+                throw py::error_already_set();
+            }
         }
+        objs_.swap(v);
+    }
+    bool covers(int64_t id) const { return id < (int64_t)objs_.size(); }
+    // ids the table does not hold (never from a tokenizer's own encode): plain lists, one fresh int per id
+    static py::list plain_lists(const int32_t* ids, const int64_t* offs, int64_t n_docs) {
+        py::list outer((size_t)n_docs);
+        for (int64_t d = 0; d < n_docs; ++d) {
+            const Py_ssize_t len = (Py_ssize_t)(offs[d + 1] - offs[d]);
+            PyObject* l = PyList_New(len);
+            if (!l) throw py::error_already_set();
+            for (Py_ssize_t i = 0; i < len; ++i) {
+                PyObject* o = PyLong_FromLong((long)ids[offs[d] + i]);
+                if (!o) { Py_DECREF(l); throw py::error_already_set(); }
+                PyList_SET_ITEM(l, i, o);
+            }
+            PyList_SET_ITEM(outer.ptr(), (Py_ssize_t)d, l);
+        }
+        return outer;
     }
     // ids[0..n) cut at offs[0..n_docs] -> list[list[int]] (GIL held on entry and on return)
     py::list lists(const int32_t* ids, const int64_t* offs, int64_t n_docs) {
@@ -124,7 +146,8 @@ public:
                 if (ids[i] < 0) throw std::runtime_error("negative token id");
                 mx = std::max(mx, ids[i]);
             }
-            ensure(mx);
+            ensure(std::max<int64_t>(mx, max_id_hint));
+            if (!covers(mx)) return plain_lists(ids, offs, n_docs);
             py::list outer((size_t)n_docs);
             for (int64_t d = 0; d < n_docs; ++d) {
                 const Py_ssize_t len = (Py_ssize_t)(offs[d + 1] - offs[d]);
@@ -153,7 +176,8 @@ public:
             for (int k = 0; k < threads; ++k) { max_seen = std::max(max_seen, tmax[(size_t)k]); min_seen = std::min(min_seen, tmin[(size_t)k]); }
         }
         if (min_seen < 0) throw std::runtime_error("negative token id");
-        ensure(max_seen);
+        ensure(std::max<int64_t>(max_seen, max_id_hint));
+        if (!covers(max_seen)) return plain_lists(ids, offs, n_docs);
         {
             py::gil_scoped_release rel;
             parallel_ranges((size_t)n, threads, [&](size_t lo, size_t hi, int k) {
@@ -192,6 +216,7 @@ public:
         }
         return outer;
     }
+    int64_t max_id_hint = 0;  // the highest id the tokenizer can produce (regular and special tokens)
 private:
     std::vector<PyObject*> objs_;
 };
@@ -244,6 +269,7 @@ public:
         }
         if (rc != TD_OK) throw TiktokenError(td_last_error(nullptr));
         for (const auto& it : special) special_ids_[it.token_string] = it.rank;
+        set_id_hint();
     }
     // Vocabulary files read by the C++ loaders (td_vocab_*): no Python-side VocabItem objects at all.  Empty paths
     // are skipped; `pattern` overrides the pattern a tekken file carries.
@@ -281,6 +307,12 @@ public:
         }
         td_vocab_destroy(v);
         if (rc != TD_OK) throw TiktokenError(err);
+        set_id_hint();
+    }
+    void set_id_hint() {
+        int64_t m = td_info(h_, TD_INFO_MAX_ID);
+        for (const auto& kv : special_ids_) m = std::max<int64_t>(m, kv.second);
+        ints_.max_id_hint = std::max<int64_t>(m, 0);
     }
     std::string pattern() const { return pattern_; }
     std::map<std::string, int32_t> special_map() const { return special_ids_; }
