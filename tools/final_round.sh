@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT; tag=$1; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
 nproc > $O/host.txt; grep -m1 "model name" /proc/cpuinfo >> $O/host.txt
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 ( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_default.time; tail -3 $O/bench_default.time
 python - "$O/bench_default.json" <<'PY'
 import json, sys
@@ -15,6 +16,8 @@ print('cpu_baseline', j.get("cpu_baseline", {}).get("value"), 'python', (j.get("
 for k, v in (j.get("configs") or {}).items():
     print(f'  {k:<34} {v.get("value")} GB/s  {v.get("ms_per_step")} ms  {v.get("verified_vs_oracle", v.get("error"))}  ({v.get("wall_s")} s)')
 PY
+timeout 400 python bench.py --gpus 2 --same-gpu --dist-backend gloo --no-cpu-baseline --steps 30 > $O/bench_2rank_same_gpu_gloo.json 2> $O/bench_2rank.err; python -c "
+import json,sys; j=json.loads(open('$O/bench_2rank_same_gpu_gloo.json').read().strip().splitlines()[-1]); print('2 ranks on one GPU (gloo):', j['value'], 'GB/s', j['config']['verified_vs_oracle'], j['config']['parallelism'][:60])" 2>&1 | tail -1
 bash tools/measure_workload.sh $tag english 1024 > $O/measure_english.log 2>&1; tail -14 $O/measure_english.log
 bash tools/prof_workload.sh $tag mixed 256 > $O/prof_mixed.log 2>&1; tail -6 $O/prof_mixed.log
 bash tools/prof_workload.sh $tag code_files 256 > $O/prof_code_files.log 2>&1; tail -6 $O/prof_code_files.log

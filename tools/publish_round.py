@@ -32,7 +32,7 @@ for key in sorted(k for k, v in t.items() if isinstance(v, dict)):
 shutil.copy(src / "hbm_traffic.json", prof / "hbm_traffic.json")
 bdir = prof / f"r{rn}_bench"
 bdir.mkdir(exist_ok=True)
-for name in ("bench_default.json", "bench_default.time", "pybatch.txt", "host.txt", "pytest_gpu.log"):
+for name in ("bench_default.json", "bench_default.time", "bench_2rank_same_gpu_gloo.json", "pybatch.txt", "host.txt", "pytest_gpu.log", "smoke.log"):
     if (src / name).exists():
         shutil.copy(src / name, bdir / name)
 print("published", src, "->", prof)
