@@ -127,6 +127,38 @@ def test_heavy_halves_go_to_the_merge_kernel(tok, golden):
     _check(tok, golden["text"].tobytes(), golden["offsets"], "golden documents")
 
 
+def test_miss_lists_that_are_full_leave_their_tiles_to_the_scan_behind_the_rows(tok):
+    """td_collect_misses puts the missed pieces of the flagged tiles on lists sized for a few times the density of real text; a
+    class of a tile that finds no room is merged by the scan at the end of td_merge_pieces.  TD_COLL_SHRINK (read by td_create)
+    makes the lists 1/k of their size: with k = 40 a part of the tiles overflow, with k = 10^6 nearly all of them (a list then
+    holds 65 records), and the ids must not change."""
+    pat, mr, special = H.llama4()
+    x, o = td_corpus.mixed(3 << 20, seed=11)
+    rng = random.Random(5)
+    emoji = "".join(rng.choice("😀🎉👨‍💻🇩🇪✨🔥 aé中") for _ in range(30000)).encode()
+    want = tok.encode_batch(x.tobytes(), o)
+    want_e = tok.encode_batch(emoji, np.asarray([0, len(emoji)], dtype=np.int64))
+    if ref.available():
+        _, et, eo = H.ref_tokenizer().encode_batch(x, np.asarray(o, dtype=np.int64), n_threads=os.cpu_count() or 1, want_tokens=True)
+        assert np.array_equal(want[0], et) and np.array_equal(want[1], eo)
+    for k in (40, 1000000):
+        os.environ["TD_COLL_SHRINK"] = str(k)
+        try:
+            t2 = capi.HipTokenizer(pat, mr, special, device=0)
+        finally:
+            del os.environ["TD_COLL_SHRINK"]
+        try:
+            t2.set_option(capi.TD_OPT_SMALL_PATH, 0)
+            for fused in (1, 0):
+                t2.set_option(TD_OPT_FUSED, fused)
+                got = t2.encode_batch(x.tobytes(), o)
+                assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), f"lists 1/{k}, fused={fused}: mixed-script text"
+                got = t2.encode_batch(emoji, np.asarray([0, len(emoji)], dtype=np.int64))
+                assert np.array_equal(got[1], want_e[1]) and np.array_equal(got[0], want_e[0]), f"lists 1/{k}, fused={fused}: emoji"
+        finally:
+            t2.close()
+
+
 def test_long_pieces_and_deferred_tiles(tok):
     rng = random.Random(3)
     filler, _ = td_corpus.english(1 << 18, seed=2)

@@ -143,6 +143,7 @@ struct Ctl {  // small control block in device memory
     uint32_t tile_draw;      // fused tile loop: tiles handed out beyond every workgroup's first two
     uint32_t direct_tiles;   // (statistics) pre-tokenizer tiles whose ids the fused loop wrote straight to the output
     uint32_t lb_timeouts;    // ... and tiles it staged because their base was not known in time (behind direct_tiles)
+    uint32_t ovf_count;      // td_collect_misses: tiles with a length class that found its lists full
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 }  // namespace
@@ -172,7 +173,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf tile_state, slab, docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, gapbits, gx_exit, gx_state, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf coll_ctr, tile_state, slab, docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, gapbits, gx_exit, gx_state, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -199,6 +200,7 @@ struct td_tokenizer {
     bool device_specials = true;     // host-buffer batches of a MiB and more search on the device (TD_OPT_DEVICE_SPECIALS)
     bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
     bool pack_split = false;  // (TD_PACK_SPLIT=1 at td_create time: A/B)
+    int coll_shrink = 1;      // (TD_COLL_SHRINK=<k> at td_create time, tests: td_collect_misses' lists 1/k of their size)
     // generic patterns with left-context assertions behind special cuts: per document of the NEXT host batch, the bytes at its
     // start that are context only (set around encode_batch_locked by encode_special_locked)
     const uint8_t* gx_prefix_host = nullptr;
@@ -339,7 +341,36 @@ int upload(td_tokenizer* t, const V* src, size_t count, const V** dst) {
 }
 
 
-int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
+// The miss lists in one buffer: the tile loops' five (room for K_MISS_LISTED_MAX per tile each), then td_collect_misses'
+// K_MISS_CLASSES x COLL_SUBS.  A class gets room for the most records n bytes can hold up to 64 Ki, beyond that for a fixed share
+// of n: a miss of <= 8 bytes every 8 bytes of text, 9..16 every 18, 17..32 every 34, longer ones whatever fits (2.1 bytes of list
+// per byte of text; mixed-script text has a miss every 51 bytes over all classes).  What finds no room is merged by the slow scan
+// at the end of td_merge_pieces.  dense (encode_ordinary with a vocabulary whose tokens the merge loop does not all reproduce: no
+// whole-piece lookup, EVERY piece of two bytes or more is merged): the worst case, 5.8 bytes per byte of text.  TD_COLL_SHRINK=<k>
+// (tests): 1/k of that.
+struct CollLayout {
+    unsigned long long base[K_MISS_CLASSES];
+    uint32_t cap[K_MISS_CLASSES];
+    unsigned long long total;
+};
+static CollLayout coll_layout(const td_tokenizer* t, int64_t n, int64_t n_tiles, bool dense) {
+    static const int minlen[K_MISS_CLASSES] = {2, 9, 17, 33, 49}, share[K_MISS_CLASSES] = {8, 18, 34, 33, 49};
+    CollLayout L;
+    unsigned long long at = (unsigned long long)(n_tiles + 1) * K_MISS_LISTED_MAX * K_MISS_CLASSES;
+    for (int c = 0; c < K_MISS_CLASSES; ++c) {
+        const int64_t worst = n / minlen[c] + 1;
+        int64_t cls = dense ? worst : std::min<int64_t>(worst, std::max<int64_t>(n / share[c] + 1, 65536));
+        if (t->coll_shrink > 1) cls = cls / t->coll_shrink + 1;
+        const int64_t per_list = std::min<int64_t>((cls + COLL_SUBS - 1) / COLL_SUBS + 64, 0x7FFFFFF0ll);
+        L.base[c] = at;
+        L.cap[c] = (uint32_t)per_list;
+        at += (unsigned long long)per_list * COLL_SUBS;
+    }
+    L.total = at;
+    return L;
+}
+
+int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs, bool dense = false) {
     const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
     int rc;
     if ((rc = ensure(t, t->docbits, (size_t)((n + 31) / 32 + 2) * 4))) return rc;
@@ -361,7 +392,11 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs) {
         if ((rc = ensure(t, t->gx_exit, (size_t)(n / gx_chunk_for(n) + 2) * 8))) return rc;
         if ((rc = ensure(t, t->gx_state, (size_t)(n / gx_chunk_for(n) + 2) * 4))) return rc;
     }
-    if ((rc = ensure(t, t->miss_list, (size_t)(n_tiles + 1) * K_MISS_LISTED_MAX * K_MISS_CLASSES * 8))) return rc;
+    {
+        CollLayout L = coll_layout(t, n, n_tiles, dense);
+        if ((rc = ensure(t, t->miss_list, (size_t)L.total * 8))) return rc;
+        if ((rc = ensure(t, t->coll_ctr, (size_t)K_MISS_CLASSES * COLL_SUBS * COLL_STRIDE * 4))) return rc;
+    }
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
     if ((rc = ensure(t, t->doc_slot, (size_t)(n_docs + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_first_doc, (size_t)(n_tiles + 1) * 4))) return rc;
@@ -385,7 +420,8 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
         HIP_TRY(t, hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * 8, stream));
         return order_after(t, stream);
     }
-    if ((rc = reserve_ws(t, n, n_docs))) return rc;
+    const bool dense = mode != TD_MODE_ENCODE && !t->H.merge_closed;
+    if ((rc = reserve_ws(t, n, n_docs, dense))) return rc;
     const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
     if (n_tiles > 0x7FFFFFF0ll) { t->err = "input too large"; return TD_E_INVALID; }
     EncodeArgs a;
@@ -422,6 +458,12 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.merge_next = &ctl->merge_next;
     a.miss_list = (unsigned long long*)t->miss_list.p;
     a.miss_count = ctl->miss_count;
+    {
+        const CollLayout L = coll_layout(t, n, n_tiles, dense);
+        for (int c = 0; c < K_MISS_CLASSES; ++c) { a.coll_base[c] = L.base[c]; a.coll_cap[c] = L.cap[c]; }
+        a.coll_count = (uint32_t*)t->coll_ctr.p;
+        a.ovf_count = &ctl->ovf_count;
+    }
     a.flagged_count = &ctl->flagged_count;
     a.rx = t->d_rx;
     a.rx_stage1 = t->d_rx_s1;
@@ -593,6 +635,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if (const char* e = getenv("TD_GRAPH")) t->graphs = atoi(e) != 0;
     if (const char* e = getenv("TD_DIRECT")) t->direct = atoi(e) != 0;
     if (const char* e = getenv("TD_PACK_SPLIT")) t->pack_split = atoi(e) != 0;
+    if (const char* e = getenv("TD_COLL_SHRINK")) t->coll_shrink = std::max(1, atoi(e));
     std::string err;
     int rc = build_tables(pat_str, n_vocab, token_bytes, token_offsets, ranks, n_special, special_bytes, special_offsets,
                           special_ids, t->H, err);
@@ -676,7 +719,7 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t = new td_tokenizer(src->shared);
         t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
         t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
-        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split;
+        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->coll_shrink = src->coll_shrink;
         t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }
@@ -714,7 +757,7 @@ void td_destroy(td_tokenizer* t) {
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
         if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->gx_prefix, &t->tile_state, &t->slab, &t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->coll_ctr, &t->gx_prefix, &t->tile_state, &t->slab, &t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)

@@ -64,12 +64,15 @@ constexpr uint32_t TOK_NONE = 0xFFFFFFFFu;    // empty slot in the byte-indexed 
 constexpr uint32_t TOK_LONGREF = 0x80000000u; // | index into the long-piece list
 constexpr uint32_t TOK_MISS = 0x40000000u;    // | tile position << 7 | length: a piece of 2..64 bytes that is not a token; td_merge_tiles
                                               // replaces the slot by the ids its byte-pair merge produces
-// tile_count[]: slots of the tile (bits 0..12) | 16-byte units of its missed pieces (bits 13..25, written by td_probe_tiles,
-// cleared by td_merge_*) | flags
+constexpr uint32_t TOK_MERGED = 0x20000000u;  // in a TOK_MISS slot: the piece is merged, the low 7 bits count its ids (position << 7 stays)
+// tile_count[]: slots of the tile (bits 0..12) | length classes that found no room on td_collect_misses' lists (bits 13..17) | flags
 constexpr uint32_t TILE_HAS_LONG = 0x80000000u, TILE_HAS_MISS = 0x40000000u, TILE_COUNT_MASK = 0x1FFFu;
 constexpr uint32_t TILE_DIRECT = 0x10000000u;       // the fused tile loop wrote the tile's ids and document offsets itself: td_pack_tokens skips it
 constexpr uint32_t TILE_MISS_LISTED = 0x20000000u;  // the tile's (few) missed pieces are on the global miss list: td_merge_pieces need not scan its slots
 constexpr int K_MISS_LISTED_MAX = 6;                // more missed pieces than this in a tile: TILE_HAS_MISS instead
+constexpr int COLL_SUBS = 11;                       // td_collect_misses: lists per length class (a wavefront appends to list gw % COLL_SUBS: same-address
+constexpr int COLL_STRIDE = 32;                     //   atomics are served one after the other), their counters COLL_STRIDE words apart
+constexpr uint32_t TILE_OVF_SHIFT = 13;             // tile_count bits 13..17: length classes of the tile whose records found no room on a list
 constexpr int K_MISS_CLASSES = 5;                   // one list per length class (<= 8, 16, 32, 48, 64 bytes): a row of a list is one batch
 constexpr int ID_BITS = 21;                   // ids / ranks must be < 2^21 (pair slots pack 2 ids + rank in 64 bit)
 constexpr uint64_t PAIR_EMPTY = ~0ull;

@@ -84,6 +84,13 @@ struct EncodeArgs {
                                     // one list per length class, miss_cap entries apart
     uint32_t* miss_count;       // [K_MISS_CLASSES] entries on them
     uint32_t miss_cap;          // (room for K_MISS_LISTED_MAX per tile on every list)
+    // ... and of the flagged tiles (many missed pieces): td_collect_misses puts them on COLL_SUBS more lists per length class, in the
+    // same buffer behind the five above (list (c, s) starts coll_base[c] + s * coll_cap[c] records into miss_list), so that
+    // td_merge_pieces only ever takes full rows from lists.  coll_count[(c * COLL_SUBS + s) * COLL_STRIDE] = entries on list (c, s).
+    uint32_t* coll_count;
+    uint32_t coll_cap[K_MISS_CLASSES];
+    unsigned long long coll_base[K_MISS_CLASSES];
+    uint32_t* ovf_count;        // tiles with a class whose records found no room (tile_count bits TILE_OVF_SHIFT..: td_merge_pieces scans those)
     // generic split patterns (PV_GENERIC; td_generic.hip)
     const RxProgram* rx;        // the compiled pattern
     const uint16_t* rx_stage1;  // general-category table (generated/unicode_gc.inc)

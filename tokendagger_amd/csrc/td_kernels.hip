@@ -182,6 +182,7 @@ __global__ void td_prepare(const EncodeArgs a) {
         a.tile_state[i] = TS_NONE;
     }
     if (gid < a.ctl_reset_words) a.ctl_reset[gid] = 0;
+    if (gid < K_MISS_CLASSES * COLL_SUBS) a.coll_count[gid * COLL_STRIDE] = 0;
 }
 
 // ------------------------------------------------------------------ shared helpers ----------
@@ -467,7 +468,7 @@ __device__ __forceinline__ void fz_stage_with_misses(const uint32_t* slab, uint3
                     const uint32_t mp = meta[SLAB_MAX_MISSES + q], hq = mp >> 12, pos = mp & 0xFFFu, nq = e >> 16;
                     uint32_t* const mo = mo0 + (size_t)hq * K_STAGE + pos;
                     for (uint32_t r = 0; r < nq; ++r) mo[r] = mids[q * 64 + r];
-                    v = TOK_MISS | (pos << 7) | nq;
+                    v = TOK_MISS | TOK_MERGED | (pos << 7) | nq;
                 }
             }
         }
@@ -2014,76 +2015,148 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
 // version that worked tile by tile — a workgroup per tile, the tile's ~80 missed pieces in five class batches one after
 // the other — ran 163 rounds per tile at 2 % lane utilisation and was slower than round 1; batches have to be FULL, so they
 // are filled across tiles.)
+// ------------------------------------------------------------------ td_collect_misses ---------
+// The missed pieces of the FLAGGED tiles (more than K_MISS_LISTED_MAX of them in the tile: mixed-script text and code have ~80 per
+// tile) go onto lists by length class too, so that td_merge_pieces takes nothing but full rows.  (Rounds 2-4: td_merge_pieces scanned
+// the flagged tiles itself and queued their pieces in LDS until a class had a full batch — 28 % of its time on mixed-script text,
+// 36 % on the code file set, at the three wavefronts per SIMD its key arrays + queues allowed.)  A WAVEFRONT per tile: pass 1
+// counts the tile's misses per class, ONE atomic per class reserves their places (on list gw % COLL_SUBS of the class: the
+// counters of one class are COLL_SUBS different cache lines), pass 2 writes the records — no LDS, full occupancy.  A class that
+// finds no room (lists are sized for a few times the density of real text, not for the worst case of a miss every two bytes)
+// is noted in the tile's count word; td_merge_pieces scans those tiles for those classes after the rows.
+__global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (K_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (K_THREADS / 64);
+    const int n_flagged = (int)*a.flagged_count;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t sub = (uint32_t)gw % (uint32_t)COLL_SUBS;
+    for (int f = gw; f < n_flagged; f += nw) {
+        const uint32_t tile = a.flagged_list[f];
+        const uint32_t tc = a.tile_count[tile];
+        const uint32_t cnt = tc & TILE_COUNT_MASK;
+        const uint32_t* slots = a.stage + (size_t)tile * K_STAGE;
+        const uint32_t rows = (cnt + 63u) >> 6;
+        // pass 1: misses per class (a lane counts its own, 8 bits a class: at most 65 rows)
+        uint64_t mine = 0;
+        for (uint32_t row = 0; row < rows; row += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t k = (row + r) * 64u + lane;
+                v[r] = k < cnt ? slots[k] : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if ((v[r] & 0xC0000000u) == TOK_MISS) mine += 1ull << (8u * mq_class(v[r] & 127u));
+        }
+        uint32_t n[K_MISS_CLASSES];
+#pragma unroll
+        for (int c = 0; c < K_MISS_CLASSES; ++c)
+            n[c] = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)(mine >> (8 * c)) & 0xFFu, lane), 63);
+        // one atomic per class (lane c)
+        uint32_t myn = 0, mycap = 0;
+#pragma unroll
+        for (int c = 0; c < K_MISS_CLASSES; ++c)
+            if (lane == c) { myn = n[c]; mycap = a.coll_cap[c]; }
+        uint32_t at = 0;
+        if (myn) at = atomicAdd(&a.coll_count[((uint32_t)lane * COLL_SUBS + sub) * COLL_STRIDE], myn);
+        const bool full = myn && (at > mycap || myn > mycap - at);
+        const uint32_t ovf = (uint32_t)__ballot(full) & ((1u << K_MISS_CLASSES) - 1u);
+        uint32_t atc[K_MISS_CLASSES];
+        unsigned long long* dstc[K_MISS_CLASSES];
+#pragma unroll
+        for (int c = 0; c < K_MISS_CLASSES; ++c) {
+            atc[c] = (uint32_t)__builtin_amdgcn_readlane((int)at, c);
+            dstc[c] = a.miss_list + a.coll_base[c] + (size_t)sub * a.coll_cap[c];
+        }
+        if (ovf) {
+            // the places this tile took before the end of a full list hold no records: empty ones (length 0: the lane that gets one idles)
+#pragma unroll
+            for (int c = 0; c < K_MISS_CLASSES; ++c)
+                if ((ovf >> c) & 1u)
+                    for (uint32_t k = atc[c] + lane; k < a.coll_cap[c] && k < atc[c] + n[c]; k += 64u) dstc[c][k] = 0ull;
+            if (lane == 0) {
+                a.tile_count[tile] = tc | (ovf << TILE_OVF_SHIFT);
+                atomicAdd(a.ovf_count, 1u);
+            }
+        }
+        // pass 2: the records (the tile's slots come from the L2 this time)
+        for (uint32_t row = 0; row < rows; row += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t k = (row + r) * 64u + lane;
+                v[r] = k < cnt ? slots[k] : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bool miss = (v[r] & 0xC0000000u) == TOK_MISS;
+                if (!__ballot(miss)) continue;
+                const uint32_t cls = mq_class(v[r] & 127u);
+                const unsigned long long rec =
+                    ((unsigned long long)tile << 32) | ((((row + r) * 64u + lane) & 0x1FFFu) << 19) | (v[r] & 0x7FFFFu);
+#pragma unroll
+                for (int c = 0; c < K_MISS_CLASSES; ++c) {
+                    const uint64_t b = __ballot(miss && cls == (uint32_t)c);
+                    if (b) {
+                        if (miss && cls == (uint32_t)c && !((ovf >> c) & 1u)) dstc[c][atc[c] + (uint32_t)__popcll((unsigned long long)(b & lt))] = rec;
+                        atc[c] += (uint32_t)__popcll((unsigned long long)b);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ td_merge_pieces ---------
-// Every wavefront works alone (no workgroup barrier): it walks its share of the tiles flagged TILE_HAS_MISS, collects their
-// TOK_MISS slots into five LDS queues by length class (<= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units), and whenever a
-// queue holds a full batch (64 / units pieces, whatever tiles they come from) merges it: one piece per owner lane, the
-// rounds of a batch run until its longest chain is done — pieces of one class need about the same number of rounds.
+// Every wavefront works alone (no workgroup barrier).  Its work comes as ROWS of the miss lists — K_MISS_CLASSES lists the tile
+// loops fill (tiles with a few missed pieces) and K_MISS_CLASSES x COLL_SUBS lists td_collect_misses fills (the flagged tiles) —
+// a row = one full batch of one length class (64 / units pieces; <= 8, 16, 32, 48, 64 bytes = 1, 1, 2, 3, 4 units), dealt
+// round-robin over all wavefronts of the grid.  One piece per owner lane, the rounds of a batch run until its longest chain is
+// done — pieces of one class need about the same number of rounds.
 // A merged piece's ids go to its own bytes' slots of the result buffer (a.merge_out[tile * K_STAGE + tile position + i]:
 // pieces do not overlap and a piece has at most as many ids as bytes), its slot becomes TOK_MISS | position << 7 | ids and
 // the tile's extra ids are added to tile_extra; td_pack_tokens expands the markers.
-constexpr int MQ_CLASSES = 5;
-constexpr int MQ_CAP = 128;  // largest queue: a full batch + one row of slots (classes of 2+ units: batches of 32 / 21 / 16 -> 96)
-__device__ __forceinline__ uint32_t mq_base(uint32_t c) { return c < 2u ? c * 128u : 256u + (c - 2u) * 96u; }  // a wavefront's queues, end to end
-__device__ __forceinline__ uint32_t mq_size(uint32_t c) { return c < 2u ? 128u : 96u; }
-constexpr int MQ_WORDS = 2 * 128 + 3 * 96;  // (sized so that THREE workgroups fit a CU: with 128 entries for every class two did)
+// Behind the rows, only when td_collect_misses found a list full (*ovf_count): the tiles it marked are scanned for the classes it
+// marked, 16 pieces of 4 units at a time — slow, and only there so that no input is refused.
+constexpr int MG_LISTS = K_MISS_CLASSES * (1 + COLL_SUBS);
+static_assert(MG_LISTS <= 64, "a lane per list");
 
 #ifndef TD_MERGE_MIN_WAVES
-#define TD_MERGE_MIN_WAVES 3
+#define TD_MERGE_MIN_WAVES 4
 #endif
 __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces(const EncodeArgs a) {
     constexpr int NW = K_THREADS / 64;
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[NW][64 * MG_UNIT];
     __shared__ __attribute__((aligned(16))) uint32_t s_ids[NW][64 * MG_UNIT];
-    __shared__ unsigned long long s_q[NW][MQ_WORDS];  // tile << 32 | slot index << 19 | tile position << 7 | length
     __shared__ int32_t s_byteid[256];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    auto q_at = [&](uint32_t c, uint32_t i) -> unsigned long long& { return s_q[wv][mq_base(c) + i % mq_size(c)]; };
     const Tables T = uniform_tables(a.Tp);
     for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
     __syncthreads();
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t* const keys = s_keys[wv];
     uint32_t* const ids = s_ids[wv];
-    // queue heads and fill counts, one byte per class (wave-uniform; read with a run-time class so that the batch code
-    // exists once: unrolled over the classes and inlined at both call sites the kernel was 20 000 instructions, twice the
-    // instruction cache)
-    uint64_t qheads = 0, qcnts = 0;
-    static_assert(MQ_CAP + 64 <= 255 && MQ_CLASSES <= 8, "one byte per class");
-    auto qhead_of = [&](int c) { return (uint32_t)(qheads >> (8 * c)) & 0xFFu; };
-    auto qcnt_of = [&](int c) { return (uint32_t)(qcnts >> (8 * c)) & 0xFFu; };
-    auto qset = [](uint64_t& word, int c, uint32_t v) { word = (word & ~(0xFFull << (8 * c))) | ((uint64_t)v << (8 * c)); };
 
-    // one batch of class c: the first min(count, 64 / units) pieces of its queue
 #ifdef TD_MERGE_TIMING
     unsigned long long t_init = 0, t_rounds = 0, t_out = 0, t_total0 = __builtin_readcyclecounter(), n_batches = 0, n_rounds = 0;
 #define TD_TICK(var) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_now = __builtin_readcyclecounter(); var += t_now - t_last; t_last = t_now; }
 #else
 #define TD_TICK(var)
 #endif
-    auto run_batch = [&](int c) {
+    // one batch: lane's piece = rec (0: none), its units start at unit `t0`; wide: part masks of 64 bits (pieces above 32 bytes)
+    auto run_batch = [&](const unsigned long long rec, const uint32_t t0, const bool wide) {
 #ifdef TD_MERGE_TIMING
-        unsigned long long t_last = __builtin_readcyclecounter(), t_dummy = 0;
+        unsigned long long t_last = __builtin_readcyclecounter();
         ++n_batches;
 #endif
-        const uint32_t u = mq_units((uint32_t)c);
-        const uint32_t qc = qcnt_of(c), qh = qhead_of(c);
-        const uint32_t np = qc < 64u / u ? qc : 64u / u;
-        const uint32_t i = (uint32_t)lane / u;
         MergeState st;
-        st.alive = 0; st.t = (uint32_t)lane; st.len = 0;
-        unsigned long long rec = 0;
-        if ((uint32_t)lane == i * u && i < np) {
-            rec = q_at((uint32_t)c, qh + i);
-            st.len = (uint32_t)rec & 127u;
-            st.alive = st.len >= 64u ? ~0ull : ((1ull << st.len) - 1ull);
-        }
-        qset(qheads, c, (qh + np) % mq_size((uint32_t)c));
-        qset(qcnts, c, qc - np);
+        st.t = t0;
+        st.len = (uint32_t)rec & 127u;
+        st.alive = st.len >= 64u ? ~0ull : ((1ull << st.len) - 1ull);
         const uint32_t tile = (uint32_t)(rec >> 32), pos = ((uint32_t)rec >> 7) & 0xFFFu;
         const int64_t gpos = (int64_t)tile * K_TILE + pos;
-        TD_TICK(t_dummy)
         if (st.len) mg_init_piece(a.text, a.n, T, s_byteid, keys, ids, st, gpos);
         TD_TICK(t_init)
         for (;;) {  // (pieces of at most 32 bytes: the part mask is one register)
@@ -2091,15 +2164,14 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
 #ifdef TD_MERGE_TIMING
             ++n_rounds;
 #endif
-            const bool more = c <= 2 ? mg_round_t<uint32_t>(T, keys, ids, st) : mg_round_t<uint64_t>(T, keys, ids, st);  // (c is uniform)
+            const bool more = wide ? mg_round_t<uint64_t>(T, keys, ids, st) : mg_round_t<uint32_t>(T, keys, ids, st);  // (uniform)
             if (!__any(more)) break;
         }
         TD_TICK(t_rounds)
-        // A merged piece's ids go to its own bytes' slots of the tile's region of merge_out (pieces do not overlap and a
-        // piece has at most as many ids as bytes); the tile's extra ids are added with ONE atomic per tile of the batch (a
-        // batch's pieces come from one or two tiles, and 64 atomics on one address are served one after the other).
-        // (Filling the region densely instead needs the atomic's answer before the ids can be written: +0.2 ms on
-        // mixed-script text, and td_pack_tokens was no faster for it.)
+        // A merged piece's ids go to its own bytes' slots of the tile's region of merge_out; the tile's extra ids are added with
+        // ONE atomic per tile of the batch (a batch's pieces come from a few tiles, and 64 atomics on one address are served
+        // one after the other).  (Filling the region densely instead needs the atomic's answer before the ids can be
+        // written: +0.2 ms on mixed-script text, and td_pack_tokens was no faster for it.)
         uint32_t extra = 0;
         if (st.len) {
             uint32_t* out = a.merge_out + (size_t)tile * K_STAGE + pos;
@@ -2110,7 +2182,7 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
                 if ((int32_t)id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gpos + j);
                 out[nt++] = id;
             }
-            a.stage[(size_t)tile * K_STAGE + (((uint32_t)rec >> 19) & 0x1FFFu)] = TOK_MISS | (pos << 7) | nt;
+            a.stage[(size_t)tile * K_STAGE + (((uint32_t)rec >> 19) & 0x1FFFu)] = TOK_MISS | TOK_MERGED | (pos << 7) | nt;
             extra = nt > 1 ? nt - 1 : 0;
         }
         for (uint64_t pend = __ballot(extra != 0); pend;) {
@@ -2125,128 +2197,81 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
         TD_TICK(t_out)
     };
 
-    // Wavefronts DRAW their tiles, two at a time, from the list of flagged tiles td_probe_tiles made.  History: dealt
-    // round-robin, a corpus whose heavy stretches repeat with a period (a file set read again and again) sent them all to the
-    // same wavefronts (2.8 ms with 3 workgroups per CU, 2.3 with 2, 3.0 with 1: the stride decided); drawn as runs of
-    // consecutive tiles that grew while the tiles were light (same-address atomics are served one after the other, tens of
-    // nanoseconds each, so light tiles must not be drawn one by one), whole heavy stretches went to single wavefronts
-    // (2.7 ms instead of 1.2 on the reference's code file set).  With the list, light tiles are not drawn at all.
-    // The draw one past the last is a virtual tile: no rows, it drains the partial batches through the same single call
-    // site of run_batch.
-    const int run = 2;
-    const int n_flagged = (int)*a.flagged_count;
-    int fpos = 0, run_end = 0, run_first = 0;  // position on the flagged list
-    uint32_t run_counts = 0, run_tiles = 0;
-    // first the global miss lists (the few missed pieces of sparsely hit tiles, one list per length class): a "row" is one
-    // batch's worth of records of one class, dealt round-robin; then the flagged tiles.  list_row >= 0: the next draw is a row.
-    uint32_t n_listed[MQ_CLASSES], rows_before[MQ_CLASSES + 1];
-    static_assert(MQ_CLASSES == K_MISS_CLASSES, "one miss list per queue class");
-    rows_before[0] = 0;
+    // the lists, one per lane: 0..4 the tile loops' (class = lane), then td_collect_misses' (class-major)
+    uint32_t l_cls = 0, l_cnt = 0;
+    unsigned long long l_base = 0;
+    if (lane < K_MISS_CLASSES) {
+        l_cls = (uint32_t)lane;
+        const uint32_t c0 = a.miss_count[lane];
+        l_cnt = c0 < a.miss_cap ? c0 : a.miss_cap;
+        l_base = (unsigned long long)lane * a.miss_cap;
+    } else if (lane < MG_LISTS) {
+        const uint32_t q = (uint32_t)lane - K_MISS_CLASSES;
+        l_cls = q / COLL_SUBS;
+        uint32_t cap = 0;
+        unsigned long long base = 0;
 #pragma unroll
-    for (int c = 0; c < MQ_CLASSES; ++c) {
-        n_listed[c] = a.miss_count[c] < a.miss_cap ? a.miss_count[c] : a.miss_cap;
-        const uint32_t per = 64u / mq_units((uint32_t)c);
-        rows_before[c + 1] = rows_before[c] + (n_listed[c] + per - 1u) / per;
+        for (int c = 0; c < K_MISS_CLASSES; ++c)
+            if (l_cls == (uint32_t)c) { cap = a.coll_cap[c]; base = a.coll_base[c]; }
+        const uint32_t c0 = a.coll_count[q * COLL_STRIDE];
+        l_cnt = c0 < cap ? c0 : cap;
+        l_base = base + (unsigned long long)(q % COLL_SUBS) * cap;
     }
-    const int list_rows = (int)rows_before[MQ_CLASSES];
-    const int nwaves_all = gridDim.x * NW;
-    int list_row = blockIdx.x * NW + wv;
+    const uint32_t l_per = 64u / mq_units(l_cls);
+    const uint32_t l_rows = (l_cnt + l_per - 1u) / l_per;
+    const uint32_t l_incl = wave_incl_scan(l_rows, lane), l_excl = l_incl - l_rows;
+    const uint32_t total_rows = (uint32_t)__builtin_amdgcn_readlane((int)l_incl, 63);
+    const uint32_t gw = (uint32_t)blockIdx.x * NW + (uint32_t)wv, nwaves_all = gridDim.x * NW;
+
+    // One call site of run_batch (the batch code is large: the kernel must stay inside the instruction cache): first the rows, then —
+    // normally never — the overflow scan.
+    const uint32_t n_ovf = *a.ovf_count;
+    const int n_flagged = n_ovf ? (int)*a.flagged_count : 0;
+    uint32_t row = gw;
+    int of = (int)gw - (int)nwaves_all;  // overflow scan: position on the flagged list, the tile's state
+    uint32_t o_tile = 0, o_mask = 0, o_cnt = 0, o_row = 0, o_v = 0;
+    uint64_t o_pend = 0;
     for (;;) {
-        if (list_row >= 0 && list_row < list_rows) {
-            int c = 0;
-#pragma unroll
-            for (int q = 1; q < MQ_CLASSES; ++q)
-                if ((uint32_t)list_row >= rows_before[q]) c = q;
-            uint32_t nl = 0, rb = 0;
-#pragma unroll
-            for (int q = 0; q < MQ_CLASSES; ++q)
-                if (q == c) { nl = n_listed[q]; rb = rows_before[q]; }
-            const uint32_t per = 64u / mq_units((uint32_t)c);
-            const uint32_t li = ((uint32_t)list_row - rb) * per + lane;
-            const bool have = (uint32_t)lane < per && li < nl;
-            const uint64_t b = __ballot(have);
-            const uint32_t qc = qcnt_of(c);
-            if (have) q_at((uint32_t)c, qhead_of(c) + qc + (uint32_t)lane) = a.miss_list[(size_t)c * a.miss_cap + li];
-            qset(qcnts, c, qc + (uint32_t)__popcll((unsigned long long)b));
-            wave_sync();
-            list_row += nwaves_all;
-            fpos = 0; run_end = 0;      // (not a tile: falls through to the batch loop below with no rows)
-        } else if (list_row >= 0) {
-            list_row = -1;              // lists done: tiles from here on
-            if (n_flagged == 0) { fpos = 0; run_end = 1; }  // (no tile to scan: straight to the drain)
-            continue;
-        }
-        const bool from_list = list_row >= 0;
-        if (!from_list && fpos >= run_end) {
-            uint32_t t0 = 0;
-            if (lane == 0) t0 = atomicAdd(a.merge_next, (uint32_t)run);
-            fpos = (int)uni32(t0);
-            run_end = fpos + run;
-            run_first = fpos;
-            run_tiles = (lane < run && fpos + lane < n_flagged) ? a.flagged_list[fpos + lane] : 0u;
-            run_counts = (lane < run && fpos + lane < n_flagged) ? a.tile_count[run_tiles] : 0u;
-        }
-        const bool drain = !from_list && fpos >= n_flagged;
-        uint32_t cnt = 0;
-        int tile = 0;
-        if (!drain && !from_list) {
-            tile = (int)(uint32_t)__builtin_amdgcn_readlane((int)run_tiles, fpos - run_first);
-            cnt = (uint32_t)__builtin_amdgcn_readlane((int)run_counts, fpos - run_first) & TILE_COUNT_MASK;
-        }
-        const uint32_t* slots = a.stage + (size_t)((drain || from_list) ? 0 : tile) * K_STAGE;
-        const uint32_t rows = (drain || from_list) ? 1u : (cnt + 63u) >> 6;
-        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rowbits = 0;
-#pragma unroll 1
-        for (uint32_t row = 0; row < rows; ++row) {
-            if (!drain && !from_list) {
-                if ((row & 7u) == 0) {  // the tile's slots, eight rows of 64 at a time (eight independent loads in flight)
-                    uint32_t mm = 0;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const uint32_t k = (row + r) * 64u + lane;
-                        v[r] = k < cnt ? slots[k] : 0u;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) mm |= ((v[r] & 0xC0000000u) == TOK_MISS ? 1u : 0u) << r;
-                    rowbits = 0;  // (uniform) rows of the group that hold a missed piece
-                    if (__ballot(mm != 0)) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) rowbits |= (__ballot((mm >> r) & 1u) ? 1u : 0u) << r;
-                    }
-                }
-                const uint32_t rr = row & 7u;
-                if (!((rowbits >> rr) & 1u)) {
-                    if (!(rowbits >> rr)) row |= 7u;  // nothing in the rest of the group either
+        unsigned long long rec = 0;
+        uint32_t t0 = (uint32_t)lane;
+        bool wide = false;
+        if (row < total_rows) {
+            const int L = (int)td_ctz64(__ballot(l_rows != 0u && row >= l_excl && row < l_incl));
+            const uint32_t c = (uint32_t)__shfl((int)l_cls, L), r_in = row - (uint32_t)__shfl((int)l_excl, L), cntL = (uint32_t)__shfl((int)l_cnt, L);
+            const unsigned long long base = ((unsigned long long)(uint32_t)__shfl((int)(l_base >> 32), L) << 32) | (uint32_t)__shfl((int)(uint32_t)l_base, L);
+            const uint32_t u = mq_units(c), per = 64u / u;
+            const uint32_t i = (uint32_t)lane / u, idx = r_in * per + i;
+            if ((uint32_t)lane == i * u && i < per && idx < cntL) rec = a.miss_list[base + idx];
+            wide = c > 2u;
+            row += nwaves_all;
+        } else if (n_ovf) {
+            if (!o_pend) {  // the next row of slots with a piece of a marked class
+                ++o_row;
+                if (o_row * 64u >= o_cnt) {
+                    of += (int)nwaves_all;
+                    if (of >= n_flagged) break;
+                    o_tile = a.flagged_list[of];
+                    const uint32_t tc = a.tile_count[o_tile];
+                    o_mask = (tc >> TILE_OVF_SHIFT) & ((1u << K_MISS_CLASSES) - 1u);
+                    o_cnt = o_mask ? (tc & TILE_COUNT_MASK) : 0u;
+                    o_row = 0xFFFFFFFFu;
                     continue;
                 }
-                const uint32_t vr = rr < 4 ? (rr < 2 ? (rr == 0 ? v[0] : v[1]) : (rr == 2 ? v[2] : v[3]))
-                                           : (rr < 6 ? (rr == 4 ? v[4] : v[5]) : (rr == 6 ? v[6] : v[7]));
-                const bool miss = (vr & 0xC0000000u) == TOK_MISS;
-                const uint32_t cls = mq_class(vr & 127u);
-                const unsigned long long rec = ((unsigned long long)(uint32_t)tile << 32) | (((row * 64u + lane) & 0x1FFFu) << 19) | (vr & 0x7FFFFu);
-#pragma unroll
-                for (int c = 0; c < MQ_CLASSES; ++c) {
-                    const uint64_t b = __ballot(miss && cls == (uint32_t)c);
-                    if (b) {
-                        const uint32_t qc = qcnt_of(c);
-                        if (miss && cls == (uint32_t)c)
-                            q_at((uint32_t)c, qhead_of(c) + qc + (uint32_t)__popcll((unsigned long long)(b & lt))) = rec;
-                        qset(qcnts, c, qc + (uint32_t)__popcll((unsigned long long)b));
-                    }
-                }
-                wave_sync();
+                const uint32_t k = o_row * 64u + (uint32_t)lane;
+                o_v = k < o_cnt ? a.stage[(size_t)o_tile * K_STAGE + k] : 0u;
+                o_pend = __ballot((o_v & (0xC0000000u | TOK_MERGED)) == TOK_MISS && ((o_mask >> mq_class(o_v & 127u)) & 1u));  // (not merged by a row meanwhile)
+                continue;
             }
-            for (;;) {  // full batches (when draining: whatever is left), the classes in turn
-                int c = -1;
-#pragma unroll
-                for (int q = MQ_CLASSES - 1; q >= 0; --q)
-                    if (drain ? qcnt_of(q) != 0u : qcnt_of(q) >= 64u / mq_units((uint32_t)q)) c = q;
-                if (c < 0) break;
-                run_batch(c);
-            }
+            const uint32_t rank = (uint32_t)__popcll((unsigned long long)(o_pend & lt));
+            const bool sel = ((o_pend >> lane) & 1ull) && rank < 16u;
+            if (sel) rec = ((unsigned long long)o_tile << 32) | (((o_row * 64u + (uint32_t)lane) & 0x1FFFu) << 19) | (o_v & 0x7FFFFu);
+            t0 = rank * 4u;
+            wide = true;
+            o_pend &= ~__ballot(sel);
+        } else {
+            break;
         }
-        if (drain) break;
-        if (!from_list) ++fpos;
+        run_batch(rec, t0, wide);
     }
 #ifdef TD_MERGE_TIMING
     if (lane == 0 && (blockIdx.x % 97) == 0 && wv == 0)
@@ -3566,7 +3591,7 @@ int encode_grid_blocks() {
     return g_blocks_encode;
 }
 int merge_grid_blocks() {
-    if (!g_blocks_merge) g_blocks_merge = resident_blocks((const void*)td_merge_pieces, 3);
+    if (!g_blocks_merge) g_blocks_merge = resident_blocks((const void*)td_merge_pieces, 4);
     const char* e = getenv("TD_MERGE_BLOCKS_PER_CU");
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_merge;
@@ -3673,6 +3698,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     if (tokens && merges) {
         const int wtiles = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
         const int mblocks = wtiles < merge_grid_blocks() ? wtiles : merge_grid_blocks();
+        hipLaunchKernelGGL(td_collect_misses, dim3(wtiles < 256 * 8 ? wtiles : 256 * 8), dim3(K_THREADS), 0, stream, a);
         hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(K_THREADS), 0, stream, a);
     }
     if (ev) (void)hipEventRecord(ev[4], stream);
