@@ -688,6 +688,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     }
     if ((rc = upload(t, H.byte_id.data(), H.byte_id.size(), &d.byte_id))) return fail(rc);
     if ((rc = upload(t, H.byte_pair.data(), H.byte_pair.size(), &d.byte_pair))) return fail(rc);
+    if ((rc = upload(t, H.byte_pair_id.data(), H.byte_pair_id.size(), &d.byte_pair_id))) return fail(rc);
     if ((rc = upload(t, H.piece_slots.data(), H.piece_slots.size(), &d.piece_slots))) return fail(rc);
     if ((rc = upload(t, H.piece12_slots.data(), H.piece12_slots.size(), &d.piece12_slots))) return fail(rc);
     if ((rc = upload(t, H.pair_slots.data(), H.pair_slots.size(), &d.pair_slots))) return fail(rc);

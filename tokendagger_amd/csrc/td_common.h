@@ -76,6 +76,11 @@ constexpr uint32_t TILE_OVF_SHIFT = 13;             // tile_count bits 13..17: l
 constexpr int K_MISS_CLASSES = 5;                   // one list per length class (<= 8, 16, 32, 48, 64 bytes): a row of a list is one batch
 constexpr int ID_BITS = 21;                   // ids / ranks must be < 2^21 (pair slots pack 2 ids + rank in 64 bit)
 constexpr uint64_t PAIR_EMPTY = ~0ull;
+constexpr uint64_t PAIR_KEY_MASK = (1ull << (2 * ID_BITS)) - 1;  // (left id << ID_BITS | right id) of a slot >> ID_BITS
+// bit 63 of a pair slot, set: NO pair whose first seat (hash_pair) is this slot sits in its second one (hash_pair2) — a probe of
+// the first seat that does not find its pair there is final, and nine in ten are: the merge rounds are bound by the number of
+// probes the vector L1 takes, not by their latency.  Clear: look at the second seat too.
+constexpr uint64_t PAIR_FINAL = 1ull << 63;
 
 struct PieceSlot {  // 16 B; len == 0 marks an empty slot
     uint64_t key;   // len <= 8: the bytes, little-endian, zero padded; len > 8: hash_bytes()
@@ -96,6 +101,7 @@ struct Tables {
     const uint8_t* ucls2;         // [nblocks*256]
     const int32_t* byte_id;       // [256]    id of the 1-byte token, or pseudo id (>= pseudo_base) if absent
     const int32_t* byte_pair;     // [65536]  rank of the 2-byte token (b0<<8|b1) or NO_RANK
+    const uint64_t* byte_pair_id; // [65536]  the same | id of the 1-byte token b0 << 32: what the lane-per-piece merge needs to set a part up, in ONE load
     const PieceSlot* piece_slots; // open addressing, linear probing
     const uint64_t* pair_slots;   // cuckoo table: (left<<42 | right<<21 | rank), PAIR_EMPTY if empty
     const Piece12Slot* piece12_slots;  // open addressing, linear probing, inserted in rank order (tokens of 1..12 bytes; they are also in piece_slots)
@@ -182,10 +188,12 @@ TD_HD int32_t pair_match(uint64_t e1, uint64_t e2, uint32_t left, uint32_t right
     // (selects, no early return: with one, the compiler sinks the second slot's load behind the first compare and a
     // lookup becomes two dependent round trips)
     const uint64_t key = ((uint64_t)left << ID_BITS) | right;
-    const bool m1 = (e1 >> ID_BITS) == key, m2 = (e2 >> ID_BITS) == key;
+    const bool m1 = ((e1 >> ID_BITS) & PAIR_KEY_MASK) == key, m2 = ((e2 >> ID_BITS) & PAIR_KEY_MASK) == key;
     const uint32_t v = (uint32_t)(m1 ? e1 : e2) & ((1u << ID_BITS) - 1);
-    return (m1 || m2) ? (int32_t)v : NO_RANK;  // (an empty slot is all ones and matches no key: ids are < 2^21)
+    return (m1 || m2) ? (int32_t)v : NO_RANK;  // (an empty slot is all ones and matches no key: ids are < 2^21 - 1)
 }
+// one slot against a pair: does it hold it?
+TD_HD bool pair_slot_is(uint64_t e, uint32_t left, uint32_t right) { return ((e >> ID_BITS) & PAIR_KEY_MASK) == (((uint64_t)left << ID_BITS) | right); }
 TD_HD int32_t pair_lookup(const Tables& T, uint32_t left, uint32_t right) {
     const uint64_t e1 = T.pair_slots[hash_pair(left, right) & T.pair_mask];
     const uint64_t e2 = T.pair_slots[hash_pair2(left, right) & T.pair_mask];
@@ -1134,9 +1142,18 @@ TD_HD bool mg_round_t(const Tables& T, uint32_t* keys, uint32_t* ids, MergeState
     typedef const uint64_t __attribute__((address_space(1)))* gpair_t;  // (global loads, not flat ones)
     gpair_t const ps = (gpair_t)(uintptr_t)T.pair_slots;
     uint64_t e1 = PAIR_EMPTY, e2 = PAIR_EMPTY, e3 = PAIR_EMPTY, e4 = PAIR_EMPTY;
+#ifdef TD_MG_FOUR_PROBES  // (rounds 2-4: both seats of both pairs in flight at once)
     if (nn < 64u) { e1 = ps[hash_pair(r, id_nn) & T.pair_mask]; e2 = ps[hash_pair2(r, id_nn) & T.pair_mask]; }
     if (pw < 64u) { e3 = ps[hash_pair(id_pw, r) & T.pair_mask]; e4 = ps[hash_pair2(id_pw, r) & T.pair_mask]; }
     asm volatile("" : "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4));  // all four are in flight before the first one is looked at
+#else
+    // the first seats of both pairs; a second seat only where the first one neither holds the pair nor says it is final
+    if (nn < 64u) e1 = ps[hash_pair(r, id_nn) & T.pair_mask];
+    if (pw < 64u) e3 = ps[hash_pair(id_pw, r) & T.pair_mask];
+    asm volatile("" : "+v"(e1), "+v"(e3));
+    if (nn < 64u && !(e1 & PAIR_FINAL) && !pair_slot_is(e1, r, id_nn)) e2 = ps[hash_pair2(r, id_nn) & T.pair_mask];
+    if (pw < 64u && !(e3 & PAIR_FINAL) && !pair_slot_is(e3, id_pw, r)) e4 = ps[hash_pair2(id_pw, r) & T.pair_mask];
+#endif
 #else
     const uint64_t e1 = T.pair_slots[hash_pair(r, id_nn) & T.pair_mask], e2 = T.pair_slots[hash_pair2(r, id_nn) & T.pair_mask];
     const uint64_t e3 = T.pair_slots[hash_pair(id_pw, r) & T.pair_mask], e4 = T.pair_slots[hash_pair2(id_pw, r) & T.pair_mask];

@@ -95,6 +95,7 @@ __device__ __forceinline__ Tables uniform_tables(const Tables* p) {
     t.ucls2 = uni_ptr(p->ucls2);
     t.byte_id = uni_ptr(p->byte_id);
     t.byte_pair = uni_ptr(p->byte_pair);
+    t.byte_pair_id = uni_ptr(p->byte_pair_id);
     t.piece_slots = uni_ptr(p->piece_slots);
     t.pair_slots = uni_ptr(p->pair_slots);
     t.piece12_slots = uni_ptr(p->piece12_slots);
@@ -361,17 +362,19 @@ __device__ __forceinline__ void load_piece_window(const uint8_t* text, int64_t n
 }
 
 // parts + keys of the piece text[g, g + st.len) into the lane's units: the piece's bytes 16 at a time in registers (+ the
-// byte behind them), so that the sixteen byte-pair ranks of a unit are independent loads that go out back to back
-__device__ __forceinline__ void mg_init_piece(const uint8_t* text, int64_t n_text, const Tables& T, const int32_t* s_byteid, uint32_t* keys, uint32_t* ids,
+// byte behind them), so that the sixteen loads of a unit are independent and go out back to back.  One 8-byte load per part:
+// the rank of the byte pair that starts there AND the id of its first byte (Tables::byte_pair_id) — the ids from a table of
+// their own were sixteen more requests to the vector L1 per unit (+18 % of td_merge_pieces), in LDS the kilobyte that keeps a
+// fifth workgroup off the CU.
+__device__ __forceinline__ void mg_init_piece(const uint8_t* text, int64_t n_text, const Tables& T, uint32_t* keys, uint32_t* ids,
                                               const MergeState& st, int64_t g) {
     for (uint32_t c = 0; c * 16u < st.len; ++c) {
         uint32_t w[5];
         load_piece_window(text, n_text, g + 16 * c, w);
-        // all sixteen byte-pair ranks first (loads only: with the LDS stores of mg_put in between, every load waited for
-        // the one before it), then the slots
-        int32_t rk[16];
-        typedef const int32_t __attribute__((address_space(1)))* gbp_t;  // (global loads, not flat ones)
-        gbp_t const bp = (gbp_t)(uintptr_t)T.byte_pair;
+        // all sixteen loads first (with the LDS stores in between, every load waited for the one before it), then the slots
+        uint64_t rk[16];
+        typedef const uint64_t __attribute__((address_space(1)))* gbp_t;  // (global loads, not flat ones)
+        gbp_t const bp = (gbp_t)(uintptr_t)T.byte_pair_id;
 #pragma unroll
         for (uint32_t j = 0; j < 16; ++j) {
             const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
@@ -382,10 +385,10 @@ __device__ __forceinline__ void mg_init_piece(const uint8_t* text, int64_t n_tex
         for (uint32_t j = 0; j < 16; ++j) {
             const uint32_t jj = 16u * c + j;
             if (jj < st.len) {
-                const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                 const uint32_t sl = mg_slot(st.t, jj);
-                ids[sl] = (uint32_t)s_byteid[b];
-                keys[sl] = (jj + 1 < st.len && rk[j] != NO_RANK) ? (((uint32_t)rk[j] << 6) | jj) : MG_DEAD;  // (= mg_put)
+                const int32_t r = (int32_t)(uint32_t)rk[j];
+                ids[sl] = (uint32_t)(rk[j] >> 32);
+                keys[sl] = (jj + 1 < st.len && r != NO_RANK) ? (((uint32_t)r << 6) | jj) : MG_DEAD;  // (= mg_put)
             }
         }
     }
@@ -408,7 +411,7 @@ __device__ __forceinline__ uint32_t fz_merge_piece(const Tables* Tp, const uint8
     st.t = wave_incl_scan(units, lane) - units;
     const uint32_t pos = (rec >> 7) & 0xFFFu;
     const int64_t gpos = tile_g0 + (int64_t)hh * K_TILE + pos;
-    if (st.len) mg_init_piece(text, n_text, T, T.byte_id, keys, ids, st, gpos);
+    if (st.len) mg_init_piece(text, n_text, T, keys, ids, st, gpos);
     for (;;) {
         const bool more = mg_round_t<uint64_t>(T, keys, ids, st);
         if (!__any(more)) break;
@@ -2125,16 +2128,17 @@ static_assert(MG_LISTS <= 64, "a lane per list");
 #ifndef TD_MERGE_MIN_WAVES
 #define TD_MERGE_MIN_WAVES 4
 #endif
-__global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces(const EncodeArgs a) {
-    constexpr int NW = K_THREADS / 64;
+#ifndef TD_MERGE_THREADS
+#define TD_MERGE_THREADS 256
+#endif
+constexpr int MG_THREADS = TD_MERGE_THREADS;  // (a wavefront's key + id arrays are 8 KB)
+__global__ __launch_bounds__(MG_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces(const EncodeArgs a) {
+    constexpr int NW = MG_THREADS / 64;
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[NW][64 * MG_UNIT];
     __shared__ __attribute__((aligned(16))) uint32_t s_ids[NW][64 * MG_UNIT];
-    __shared__ int32_t s_byteid[256];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Tables T = uniform_tables(a.Tp);
-    for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
-    __syncthreads();
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t* const keys = s_keys[wv];
     uint32_t* const ids = s_ids[wv];
@@ -2157,7 +2161,7 @@ __global__ __launch_bounds__(K_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces
         st.alive = st.len >= 64u ? ~0ull : ((1ull << st.len) - 1ull);
         const uint32_t tile = (uint32_t)(rec >> 32), pos = ((uint32_t)rec >> 7) & 0xFFFu;
         const int64_t gpos = (int64_t)tile * K_TILE + pos;
-        if (st.len) mg_init_piece(a.text, a.n, T, s_byteid, keys, ids, st, gpos);
+        if (st.len) mg_init_piece(a.text, a.n, T, keys, ids, st, gpos);
         TD_TICK(t_init)
         for (;;) {  // (pieces of at most 32 bytes: the part mask is one register)
             if (TD_STOP(41)) break;
@@ -3572,15 +3576,15 @@ hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream) {
 
 // ------------------------------------------------------------------ launches ----------------
 static int g_blocks_split = 0, g_blocks_encode = 0, g_blocks_merge = 0, g_blocks_long = 0;
-static int resident_blocks(const void* fn, int fallback_per_cu) {
+static int resident_blocks(const void* fn, int fallback_per_cu, int threads = K_THREADS, int max_per_cu = 0) {
     // persistent grid = exactly the workgroups that are resident at once (a larger grid would run in
     // uneven rounds: tiles are dealt round-robin to blockIdx)
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K_THREADS, 0) == hipSuccess && per_cu > 0) {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) == hipSuccess && per_cu > 0) {
         if (getenv("TD_DEBUG_GRID")) fprintf(stderr, "[tokendagger] persistent grid: %d CUs x %d workgroups\n", prop.multiProcessorCount, per_cu);
-        return prop.multiProcessorCount * per_cu;
+        return prop.multiProcessorCount * (max_per_cu > 0 && per_cu > max_per_cu ? max_per_cu : per_cu);
     }
     return 256 * fallback_per_cu;
 }
@@ -3591,7 +3595,9 @@ int encode_grid_blocks() {
     return g_blocks_encode;
 }
 int merge_grid_blocks() {
-    if (!g_blocks_merge) g_blocks_merge = resident_blocks((const void*)td_merge_pieces, 4);
+    // (four workgroups per CU, measured: the occupancy query says five fit — 5 x 32 KB is all of the LDS — but with a grid of five
+    // per CU the kernel is 10-20 % slower, as it is with four workgroups of five wavefronts: the fifth does not run beside the others)
+    if (!g_blocks_merge) g_blocks_merge = resident_blocks((const void*)td_merge_pieces, 4, MG_THREADS, 4);
     const char* e = getenv("TD_MERGE_BLOCKS_PER_CU");
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_merge;
@@ -3699,7 +3705,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         const int wtiles = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
         const int mblocks = wtiles < merge_grid_blocks() ? wtiles : merge_grid_blocks();
         hipLaunchKernelGGL(td_collect_misses, dim3(wtiles < 256 * 8 ? wtiles : 256 * 8), dim3(K_THREADS), 0, stream, a);
-        hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(K_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(MG_THREADS), 0, stream, a);
     }
     if (ev) (void)hipEventRecord(ev[4], stream);
     if (tokens) {

@@ -1,5 +1,7 @@
 // Host-side table construction.  See td_tables.h.
 #include "td_tables.h"
+#include <cstdio>
+#include <cstdlib>
 #include "td_regex.h"
 
 #include <string.h>
@@ -82,6 +84,7 @@ Tables HostTables::view() const {
     T.ucls2 = ucls2_remap.empty() ? td_ucls_stage2 : ucls2_remap.data();
     T.byte_id = byte_id.data();
     T.byte_pair = byte_pair.data();
+    T.byte_pair_id = byte_pair_id.data();
     T.piece_slots = piece_slots.data();
     T.piece12_slots = piece12_slots.data();
     T.piece12_mask = piece12_mask;
@@ -178,7 +181,7 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
     for (int64_t s = 0; s < n_special; ++s) max_id = std::max(max_id, special_ranks[s]);
     H.max_rank = max_rank;
     H.pseudo_base = max_id + 1;
-    if ((int64_t)H.pseudo_base + 256 >= (1ll << ID_BITS)) {
+    if ((int64_t)H.pseudo_base + 256 >= (1ll << ID_BITS) - 1) {  // (the id 2^21 - 1 is the empty pair slot's)
         err = "token ids must be < 2^21 - 256";
         return TD_E_VOCAB;
     }
@@ -239,6 +242,9 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
         if (len == 1) H.byte_id[p[0]] = ranks[v];
         if (len == 2) H.byte_pair[((uint32_t)p[0] << 8) | p[1]] = ranks[v];
     }
+
+    H.byte_pair_id.resize(65536);
+    for (uint32_t q = 0; q < 65536; ++q) H.byte_pair_id[q] = (uint64_t)(uint32_t)H.byte_pair[q] | ((uint64_t)(uint32_t)H.byte_id[q >> 8] << 32);
 
     // exact-key table for the tokens of 1..12 bytes (the hot probe loop of td_probe_tiles: one 16-byte load per piece, first
     // slot only).  Inserted in RANK order: a key leaves its home slot only when a lower-rank (as a rule: more frequent) key
@@ -307,6 +313,25 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
         }
         if (ok) break;
         if (qcap >= (1u << 28)) { err = "pair table construction failed"; return TD_E_VOCAB; }
+    }
+    // PAIR_FINAL (td_common.h): a slot nobody was pushed out of says so
+    {
+        std::vector<uint8_t> pushed(H.pair_slots.size(), 0);
+        for (size_t sl = 0; sl < H.pair_slots.size(); ++sl) {
+            const uint64_t e = H.pair_slots[sl];
+            if (e == PAIR_EMPTY) continue;
+            const uint32_t l = (uint32_t)(e >> (2 * ID_BITS)), r = (uint32_t)((e >> ID_BITS) & ((1u << ID_BITS) - 1));
+            const uint32_t h1 = hash_pair(l, r) & H.pair_mask;
+            if (h1 != sl) { pushed[h1] = 1; ++H.n_pairs_second_seat; }
+        }
+        size_t open_slots = 0;
+        for (size_t sl = 0; sl < H.pair_slots.size(); ++sl) {
+            if (pushed[sl]) { H.pair_slots[sl] &= ~PAIR_FINAL; ++open_slots; }
+            else H.pair_slots[sl] |= PAIR_FINAL;
+        }
+        if (getenv("TD_DEBUG_TABLES"))
+            fprintf(stderr, "[tokendagger] pair table: %llu pairs in %zu slots, %llu in their second seat, %zu first seats not final\n",
+                    (unsigned long long)H.n_pairs, H.pair_slots.size(), (unsigned long long)H.n_pairs_second_seat, open_slots);
     }
 
     // Is the whole-piece fast path redundant (encode == encode_ordinary on every input)?

@@ -38,6 +38,7 @@ struct HostTables {
     std::vector<uint8_t> ucls2_remap;  // stage-2 class table with the pattern's class remaps applied (empty: the static one)
     std::vector<int32_t> byte_id;
     std::vector<int32_t> byte_pair;
+    std::vector<uint64_t> byte_pair_id;
     std::vector<PieceSlot> piece_slots;
     std::vector<Piece12Slot> piece12_slots;
     uint32_t piece12_mask = 0;
@@ -50,6 +51,7 @@ struct HostTables {
     int32_t pseudo_base = 0;
     uint32_t max_token_len = 0;
     uint64_t n_pairs = 0;
+    uint64_t n_pairs_second_seat = 0;  // pairs that sit in their second seat (hash_pair2): their first seats are not PAIR_FINAL
     bool merge_closed = false;  // every multi-byte token is what the merge loop produces from its own bytes
     std::vector<std::string> special_strs;
     std::vector<int32_t> special_ids;
