@@ -643,7 +643,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     // global-memory round trip at the top of every tile and another one in front of the document slots: 13 % + 5 % of the
     // fused loop.)
     uint32_t pfd0 = 0, pfd1 = 0, pffd0 = 0xFFFFFFFFu, pffd1 = 0xFFFFFFFFu;
+#ifdef TD_TEXT_L2_PREFETCH
     uint32_t pft = 0;  // (FUSED) one byte of every 64-byte line of the next window: pulls the text into the L2, see load_window
+#endif
     static_assert(K_WIN / 32 <= 2 * K_THREADS, "two prefetched document words per lane cover the window");
     auto load_window = [&](int64_t w0) {
         {
@@ -760,7 +762,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             stw = (pkind == 1u && idx0 >= 0) ? __hip_atomic_load(&a.tile_state[idx0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (TS_PREFIX << 62);
         }
         if (have) {
+#ifdef TD_TEXT_L2_PREFETCH
         if (FUSED) asm volatile("" :: "v"(pft));  // (see load_window: the prefetch byte's register is free from here on)
+#endif
 
         // ---- phase 0: stage the text window and the document bits (two-kernel form: the text was requested one iteration ago,
         //      registers pf[]; FUSED: now, see NPRE) --------------
