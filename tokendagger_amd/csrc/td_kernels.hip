@@ -307,8 +307,71 @@ __device__ __forceinline__ uint32_t mq_units(uint32_t cls) { return cls < 2u ? 1
 #define TD_PROBE_MIN_WAVES 8  // (measured on 256 MiB of English: 0.49 ms at 8 waves/SIMD, 0.66 ms at 5..7)
 #endif
 
+// A piece of the text window in LDS as dwords (zero behind its end): what the cold route hashes and compares.  (Until round 4 it
+// took the piece byte by byte — hash_bytes over an LDS byte getter, then piece_lookup's check of a matching slot against the
+// token's bytes one global byte load after the other, each waiting for the one before it: 20 % of the fused loop's cycles on
+// mixed-script text and on code, where identifiers of 13..30 bytes that ARE tokens paid 13..30 dependent round trips.)
+#ifndef TD_COLD_CMP
+#define TD_COLD_CMP 2  // dwords of a token compared per step
+#endif
+struct PieceWords {
+    const uint32_t* wp;  // the aligned dword that holds the piece's first byte
+    uint32_t sh, len;    // bit offset of that byte in it; bytes
+    __device__ __forceinline__ uint32_t tail(uint32_t j) const {  // mask of the piece's bytes in its dword j
+        const int nb = (int)len - 4 * (int)j;
+        return nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : (1u << (8 * nb)) - 1u;
+    }
+    __device__ __forceinline__ uint32_t word(uint32_t j) const { return __funnelshift_r(wp[j], wp[j + 1], sh) & tail(j); }
+};
+__device__ __forceinline__ uint64_t hash_piece_words(const PieceWords& P) {  // = hash_bytes (td_common.h) over the piece's bytes
+    uint64_t k = 0x243F6A8885A308D3ull ^ P.len;
+#pragma unroll 1
+    for (uint32_t j = 0; 4u * j < P.len; j += 2) {
+        const uint64_t w = (uint64_t)P.word(j) | ((uint64_t)P.word(j + 1) << 32);
+        k = ((k << 23) | (k >> 41)) ^ w;
+        k *= 0x9E3779B97F4A7C15ull;
+    }
+    return k ^ (k >> 31);
+}
+// = piece_lookup (td_common.h); a slot whose key and length match is checked against the token's bytes sixteen at a time
+// (independent loads; tok_bytes is padded behind its last token)
+__device__ __forceinline__ int32_t piece_lookup_words(const Tables& T, uint64_t key, const PieceWords& P) {
+    uint32_t h = hash_piece(key, P.len) & T.piece_mask;
+    for (;;) {
+        const PieceSlot s = T.piece_slots[h];
+        if (s.len == 0) return NO_RANK;
+        if (s.key == key && s.len == P.len) {
+            if (P.len <= 8) return (int32_t)s.rank;
+            const uintptr_t tb = (uintptr_t)(T.tok_bytes + T.tok_off[s.rank]);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(tb & ~(uintptr_t)3);
+            const uint32_t tsh = (uint32_t)(tb & 3) * 8u;
+            uint32_t diff = 0;
+#pragma unroll 1
+            for (uint32_t j = 0; 4u * j < P.len; j += TD_COLD_CMP) {  // (rolled: unrolled to sixteen bytes a step the fused loop spilled 12 more VGPRs, and 3 more with the lookup out of line: +2 % on English)
+                uint32_t t[TD_COLD_CMP + 1];
+#pragma unroll
+                for (int u = 0; u <= TD_COLD_CMP; ++u) t[u] = q[j + u];
+#pragma unroll
+                for (int u = 0; u < TD_COLD_CMP; ++u) diff |= (__funnelshift_r(t[u], t[u + 1], tsh) & P.tail(j + u)) ^ P.word(j + u);
+            }
+            if (!diff) return (int32_t)s.rank;
+        }
+        h = (h + 1) & T.piece_mask;
+    }
+}
+
+__device__ __forceinline__ int32_t cold_lookup(const Tables& T, const uint32_t* wp, uint32_t sh, uint32_t len) {
+    PieceWords P;
+    P.wp = wp;
+    P.sh = sh;
+    P.len = len;
+    const uint64_t key = len <= 8 ? ((uint64_t)P.word(0) | ((uint64_t)P.word(1) << 32)) : hash_piece_words(P);
+    return piece_lookup_words(T, key, P);
+}
+
 // everything the hot probe path leaves out: keys longer than 16 bytes (hashed + verified against the token bytes), probe
 // sequences longer than one slot, pieces longer than K_MAXSHORT (handed to td_long_pieces).  Returns the piece's slot.
+template <bool WORDS>  // (the fused loop: true; td_probe_tiles keeps the byte-wise form — with the other one it spills 94 VGPRs instead of 14)
 __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const Tables& T, const uint8_t* s_txt, const int32_t* s_byteid,
                                                      uint32_t* s_flags, int64_t wg0, int i, uint32_t len) {
     if (len > (uint32_t)K_MAXSHORT) {
@@ -329,15 +392,20 @@ __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const 
         return (uint32_t)id;
     }
     if (a.use_fastpath) {
-        auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
-        uint64_t key;
-        if (len <= 8) {
-            key = 0;
-            for (uint32_t q = 0; q < len; ++q) key |= (uint64_t)pb[q] << (8 * q);
+        int32_t r;
+        if constexpr (WORDS) {
+            r = cold_lookup(T, reinterpret_cast<const uint32_t*>(s_txt) + (i >> 2), (uint32_t)(i & 3) * 8u, len);  // (s_txt is 16-byte aligned)
         } else {
-            key = hash_bytes(get, len);
+            auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
+            uint64_t key;
+            if (len <= 8) {
+                key = 0;
+                for (uint32_t q = 0; q < len; ++q) key |= (uint64_t)pb[q] << (8 * q);
+            } else {
+                key = hash_bytes(get, len);
+            }
+            r = piece_lookup(T, key, len, get);
         }
-        const int32_t r = piece_lookup(T, key, len, get);
         if (r != NO_RANK) return (uint32_t)r;
     }
     return TOK_MISS | ((uint32_t)i << 7) | len;  // (the caller notes it: note_miss)
@@ -1427,7 +1495,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                         const int i = s_plist[k];
                         const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
                         const uint32_t h = k >= n0 ? 1u : 0u;
-                        uint32_t res = probe_piece_cold(a, T, s_txt, T.byte_id, &s_hflags[h], wg0, i, len);
+                        uint32_t res = probe_piece_cold<true>(a, T, s_txt, T.byte_id, &s_hflags[h], wg0, i, len);
                         if ((res & 0xC0000000u) == TOK_MISS) { res = miss_marker(i, len); note_miss(k, res); }
                         (h ? dst1 : dst0)[k] = res;
                     }
@@ -1924,7 +1992,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
                     const long long l = ext_end - (wg0 + i);
                     len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
                 }
-                res = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);  // (more than 256 of them in one tile)
+                res = probe_piece_cold<false>(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);  // (more than 256 of them in one tile)
                 if ((res & 0xC0000000u) == TOK_MISS) note_miss(k, res);
             }
             dst[k] = res;
@@ -1940,7 +2008,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
                     const long long l = ext_end - (wg0 + i);
                     len = l > 0x7FFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
                 }
-                const uint32_t res = probe_piece_cold(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);
+                const uint32_t res = probe_piece_cold<false>(a, T, s_txt, s_byteid, &s_flags, wg0, i, len);
                 if ((res & 0xC0000000u) == TOK_MISS) note_miss(k, res);
                 dst[k] = res;
             }

@@ -209,7 +209,7 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
     }
     H.tok_off.assign((size_t)max_id + 2, 0);
     for (int32_t id = 0; id <= max_id; ++id) H.tok_off[id + 1] = H.tok_off[id] + len_of[id];
-    H.tok_bytes.assign((size_t)H.tok_off[max_id + 1] + 16, 0);
+    H.tok_bytes.assign((size_t)H.tok_off[max_id + 1] + 32, 0);  // (the device compares 16 bytes at a time from an aligned dword: reads up to 23 bytes behind a token)
     for (int32_t id = 0; id <= max_id; ++id) {
         if (src_of[id] >= 0)
             memcpy(&H.tok_bytes[H.tok_off[id]], token_bytes + token_offsets[src_of[id]], len_of[id]);
