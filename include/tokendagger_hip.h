@@ -196,11 +196,15 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
                                     step is launched kernel by kernel; same results either way. */
 #define TD_OPT_DEVICE_SPECIALS 8  /* 0: td_encode_batch_with_special* always search for the allowed specials on host threads (default 1:
                                     batches of a MiB and more search on the device, td_special.hip; same results) */
-#define TD_OPT_DIRECT 9            /* 0: every tile's ids are staged and packed by td_pack_tokens (rounds 1-3).  Default 1: the fused tile loop
+#define TD_OPT_DIRECT 9            /* 0 (default): every tile's ids are staged and packed (rounds 1-3).  1 (measured slower): the fused tile loop
                                     writes a tile's ids straight to the output when the tile's base is known in time (decoupled look-back
                                     over per-tile id counts; tiles that are not — and everything behind a tile whose count cannot be settled
-                                    inside the loop — are staged as before).  Same results either way; TD_DIRECT=0 in the environment at
-                                    td_create time also turns it off. */
+                                    inside the loop — are staged as before).  Same results either way; TD_DIRECT=1 in the environment at
+                                    td_create time also turns it on. */
+#define TD_OPT_PACK_SPLIT 10       /* 1 (default): the ids are placed by a pair of kernels — td_pack_plain, a wavefront per tile that has no long
+                                    piece and at most a few merged ones (nearly a copy: 5 TB/s), and td_pack_rest for the others; 0: one
+                                    kernel for all tiles (td_pack_tokens, rounds 2-4).  Same results either way; TD_PACK_SPLIT=0 in the
+                                    environment at td_create time also turns it off. */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 16) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 

@@ -42,13 +42,17 @@ def tok():
 
 def _both(tok, text: bytes, offs):
     """-> (fused loop with direct placement, TD_OPT_DIRECT = 1), (two-kernel form); the fused loop with every tile staged (the
-    default) is run in between and must agree with the first."""
+    default) is run in between, with the pair of pack kernels (the default) and with the single one, and must agree with the first."""
     offs = np.asarray(offs, dtype=np.int64)
     tok.set_option(TD_OPT_FUSED, 1)
     tok.set_option(capi.TD_OPT_DIRECT, 1)
     ft, fo = tok.encode_batch(text, offs)
     tok.set_option(capi.TD_OPT_DIRECT, 0)
     st, so = tok.encode_batch(text, offs)
+    tok.set_option(capi.TD_OPT_PACK_SPLIT, 0)  # one pack kernel for all tiles (rounds 2-4) instead of td_pack_plain + td_pack_rest
+    pt, po = tok.encode_batch(text, offs)
+    tok.set_option(capi.TD_OPT_PACK_SPLIT, 1)
+    assert np.array_equal(po, so) and np.array_equal(pt, st), "the pair of pack kernels and the single one differ"
     tok.set_option(TD_OPT_FUSED, 0)
     ut, uo = tok.encode_batch(text, offs)
     tok.set_option(TD_OPT_FUSED, 1)

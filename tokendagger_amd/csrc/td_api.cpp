@@ -199,7 +199,7 @@ struct td_tokenizer {
     uint32_t sp_n = 0, sp_maxlen = 0;
     bool device_specials = true;     // host-buffer batches of a MiB and more search on the device (TD_OPT_DEVICE_SPECIALS)
     bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
-    bool pack_split = false;  // (TD_PACK_SPLIT=1 at td_create time: A/B)
+    bool pack_split = true;   // td_pack_plain + td_pack_rest instead of td_pack_tokens (TD_OPT_PACK_SPLIT; TD_PACK_SPLIT=0 at td_create time turns it off)
     int coll_shrink = 1;      // (TD_COLL_SHRINK=<k> at td_create time, tests: td_collect_misses' lists 1/k of their size)
     // generic patterns with left-context assertions behind special cuts: per document of the NEXT host batch, the bytes at its
     // start that are context only (set around encode_batch_locked by encode_special_locked)
@@ -1800,6 +1800,11 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     }
     if (what == TD_OPT_DEVICE_SPECIALS) {
         t->device_specials = value != 0;
+        return TD_OK;
+    }
+    if (what == TD_OPT_PACK_SPLIT) {
+        t->pack_split = value != 0;
+        drop_graph(t); t->has_last_key = false;
         return TD_OK;
     }
     if (what == TD_OPT_GRAPH) {

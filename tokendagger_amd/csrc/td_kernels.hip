@@ -3070,6 +3070,13 @@ constexpr int PK_ECAP = 256;  // merged pieces the expansion list holds
 // PLAIN_ONLY: only the pipelined path of the plain tiles (every slot an id, at most 1024 of them); SKIP_PLAIN: everything else.
 // Launched as a pair (a.pack_split): the first has none of the marker path's registers — 8 wavefronts per SIMD instead of 4 —
 // the second finds next to nothing to do on plain text.  <false, false>: one kernel for all tiles (rounds 2-3).
+// td_pack_plain's tiles (the pair td_pack_plain / td_pack_rest, a.pack_split): no long piece, at most a few merged ones (the tiles
+// the tile loops flag for their many missed pieces are pack_body's: measured, its row groups are faster on them), not placed by
+// the fused loop, at most 1024 slots, all of its ids inside the output
+__device__ __forceinline__ bool pk_simple(uint32_t tc, int64_t base, uint32_t extra, int64_t out_cap) {
+    const uint32_t cnt = tc & TILE_COUNT_MASK;
+    return !(tc & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_DIRECT)) && cnt <= 1024u && base + (int64_t)(int32_t)(cnt + extra) <= out_cap;
+}
 template <bool PLAIN_ONLY, bool SKIP_PLAIN>
 __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long long (*s_elist)[PK_ECAP]) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -3094,8 +3101,9 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
     (void)base_of;
     const int tile_first = (int)uni32((uint32_t)(blockIdx.x * (K_THREADS / 64) + wv));
     uint32_t tcA = 0, dfA = 0, tcB = 0, dfB = 0, tcC = 0, dfC = 0;          // A = this tile, B = the next one, C = the one after
+    uint32_t exA = 0, exB = 0, exC = 0;
     int64_t baseA = 0, baseB = 0, baseC = 0;
-#define PK_FETCH(t, X) { tc##X = a.tile_count[t]; base##X = a.tile_base[t] + a.chunk_pref[(t) / K_SCAN_CHUNK]; df##X = a.tile_first_doc[t]; }
+#define PK_FETCH(t, X) { tc##X = a.tile_count[t]; base##X = a.tile_base[t] + a.chunk_pref[(t) / K_SCAN_CHUNK]; df##X = a.tile_first_doc[t]; if (SKIP_PLAIN) ex##X = a.tile_extra[t]; }
 #define PK_FAST(X) (!(tc##X & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_MISS_LISTED | TILE_DIRECT)) && (tc##X & TILE_COUNT_MASK) <= 1024u && \
                     base##X + (int64_t)(tc##X & TILE_COUNT_MASK) <= a.out_cap)
     uint4 cx0 = make_uint4(0, 0, 0, 0), cx1 = cx0, cx2 = cx0, cx3 = cx0, nx0 = cx0, nx1 = cx0, nx2 = cx0, nx3 = cx0;
@@ -3133,10 +3141,12 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
         const uint4 sx0 = cx0, sx1 = cx1, sx2 = cx2, sx3 = cx3;
         const uint32_t sh0 = ch0, stl = ctl, sdsl = cdsl;
         const int64_t sdpos = cdpos;
-        tcA = tcB; baseA = baseB; dfA = dfB; tcB = tcC; baseB = baseC; dfB = dfC;
+        const uint32_t ex = exA;
+        tcA = tcB; baseA = baseB; dfA = dfB; exA = exB; tcB = tcC; baseB = baseC; dfB = dfC; exB = exC;
         fast_cur = fast_next;
         cx0 = nx0; cx1 = nx1; cx2 = nx2; cx3 = nx3; ch0 = nh0; ctl = ntl; cdsl = ndsl; cdpos = ndpos;
-        if (SKIP_PLAIN && fast_this) continue;       // (the other kernel of the pair; the closing offsets with it when this is the last tile)
+        if (SKIP_PLAIN && pk_simple(tc, base, ex, a.out_cap)) continue;  // (the other kernel of the pair; the closing offsets with it when this is the last tile)
+        (void)ex;
         if (PLAIN_ONLY && !fast_this) continue;
         if (tc & TILE_DIRECT) {  // the fused tile loop wrote this tile's ids and document offsets itself
             if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
@@ -3364,8 +3374,98 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) 
     __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];  // dst offset << 32 | tile position << 7 | ids
     pack_body<false, false>(a, s_elist);
 }
-__global__ __launch_bounds__(K_THREADS, 8) void td_pack_plain(const EncodeArgs a) {
-    pack_body<true, false>(a, nullptr);
+// The tiles without long pieces (every slot an id or the marker of a merged piece, at most 1024 slots, inside the output:
+// pk_simple) nearly as a copy: a WAVEFRONT per tile in a grid of short workgroups (no persistent loop, no pipeline, no
+// alignment of the stores to the destination); what depends on the tile index only goes out in ONE round trip, then all
+// sixteen dwords per lane and the documents, then the stores.  A row of 64 slots that holds a marker takes one add-scan
+// (a marker stands for its piece's ids: 0..64 of them, in merge_out at the piece's own bytes' slots).
+// (Round 4: torch's strided copy moves 840 of every 4160 slots to a dense array at 5.3 TB/s on this box —
+// tools/gpu_copy_ceiling.py — where the pipelined path of pack_body reaches 3.1; a first form of this kernel with a workgroup
+// per tile and three dependent round trips before the stores was latency-bound at 2.7; this one runs the plain tiles of
+// 1 GiB of English at 5.5.)
+#ifndef TD_PACK_PLAIN_WAVES
+#define TD_PACK_PLAIN_WAVES 6  // (measured on 1 GiB of English: 0.392 ms at 4 wavefronts per SIMD, 0.371 at 6, 0.646 at 8: its marker rows spill there)
+#endif
+__global__ __launch_bounds__(K_THREADS, TD_PACK_PLAIN_WAVES) void td_pack_plain(const EncodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * (K_THREADS / 64);
+    for (int tile = blockIdx.x * (K_THREADS / 64) + (threadIdx.x >> 6); tile < a.n_tiles; tile += nwaves) {
+        const uint32_t tc = a.tile_count[tile], ex = a.tile_extra[tile];
+        const int64_t tb = a.tile_base[tile], cp = a.chunk_pref[tile / K_SCAN_CHUNK];
+        const int64_t dfirst = (int64_t)a.tile_first_doc[tile];
+        const uint32_t cnt = tc & TILE_COUNT_MASK;
+        const int64_t base = tb + cp;
+        if (!pk_simple(tc, base, ex, a.out_cap)) continue;  // (td_pack_rest's)
+        const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
+        int32_t* dst = a.out_tokens + base;
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t k = (uint32_t)lane + 64u * q;
+            v[q] = k < cnt ? src[k] : 0u;
+        }
+        const int64_t g_lo = (int64_t)tile * K_TILE;
+        const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
+        const bool marks = (tc & TILE_MISS_LISTED) != 0;  // (uniform)
+        if (!marks) {
+            for (int64_t d = dfirst + lane; d < a.n_docs; d += 64) {
+                if (a.doc_offsets[d] >= g_hi) break;
+                a.out_offsets[d] = base + a.doc_slot[d];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint32_t k = (uint32_t)lane + 64u * q;
+                if (k < cnt) dst[k] = (int32_t)v[q];
+            }
+        } else {
+            uint32_t sh[16], carry = 0;  // ids of the tile in front of my slot of row q, minus the slot's index (modulo 2^32: a marker may stand for no id)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool m = (v[q] & 0xC0000000u) == TOK_MISS;
+                uint32_t excl = 0, rowsum = 0;
+                if (__ballot(m)) {
+                    const uint32_t dlt = m ? (v[q] & 127u) - 1u : 0u;
+                    const uint32_t incl = wave_incl_scan(dlt, lane);
+                    excl = incl - dlt;
+                    rowsum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+                sh[q] = carry + excl;
+                carry += rowsum;
+            }
+            for (int64_t d = dfirst + lane; __any(d < a.n_docs); d += 64) {  // (every lane stays in: the shuffles below)
+                const bool mine = d < a.n_docs && a.doc_offsets[d < a.n_docs ? d : 0] < g_hi;
+                if (!__any(mine)) break;
+                const uint32_t ks = mine ? a.doc_slot[d] : 0u;
+                uint32_t s0 = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t t = (uint32_t)__shfl((int)sh[q], (int)(ks & 63u));
+                    if ((ks >> 6) == (uint32_t)q) s0 = t;
+                }
+                if (mine) a.out_offsets[d] = base + (int64_t)(int32_t)(ks + (ks < cnt ? s0 : carry));  // (a document that starts behind the tile's last slot)
+                if (!__all(mine)) break;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint32_t k = (uint32_t)lane + 64u * q;
+                if (k < cnt) {
+                    int32_t* o = dst + (int64_t)(int32_t)(k + sh[q]);
+                    if ((v[q] & 0xC0000000u) == TOK_MISS) {
+                        const uint32_t* mo = a.merge_out + (size_t)tile * K_STAGE + ((v[q] >> 7) & 0xFFFu);
+                        const uint32_t nt = v[q] & 127u;
+                        for (uint32_t i = 0; i < nt; ++i) o[i] = (int32_t)mo[i];
+                    } else {
+                        *o = (int32_t)v[q];
+                    }
+                }
+            }
+        }
+        if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
+            const int64_t total = a.tile_base[a.n_tiles];
+            const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
+            for (int64_t d = d_end + lane; d <= a.n_docs; d += 64) a.out_offsets[d] = total;
+        }
+    }
 }
 __global__ __launch_bounds__(K_THREADS) void td_pack_rest(const EncodeArgs a) {
     __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];
@@ -3794,8 +3894,13 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
         if (ev) (void)hipEventRecord(ev[5], stream);
         if (a.pack_split) {
-            hipLaunchKernelGGL(td_pack_plain, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
-            hipLaunchKernelGGL(td_pack_rest, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
+            const int pwg = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
+            hipLaunchKernelGGL(td_pack_plain, dim3(pwg < (1 << 20) ? pwg : (1 << 20)), dim3(K_THREADS), 0, stream, a);
+            // (a grid of 16 384 workgroups, eight times the resident ones: on mixed-script text 0.45 -> 0.36 ms per 256 MiB against
+            // the 2048 of rounds 2-4 — a wavefront that walks fewer tiles ends its pipeline sooner — and the 47 us it takes to find
+            // nothing to do on English are the walk over the tiles' count words)
+            static const int rest_max = getenv("TD_PACK_REST_BLOCKS") ? atoi(getenv("TD_PACK_REST_BLOCKS")) : 16384;
+            hipLaunchKernelGGL(td_pack_rest, dim3(pwg < rest_max ? pwg : rest_max), dim3(K_THREADS), 0, stream, a);
         } else {
             hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
         }
