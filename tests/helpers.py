@@ -276,6 +276,16 @@ class Twin:
         bad = self._lib.twin_arrmask_check(self._h, data, len(data), offs.ctypes.data, len(offs) - 1, ctypes.byref(ck))
         return int(bad), ck.value
 
+    def pair_probe_check(self, n_random: int = 200000, seed: int = 1) -> tuple[int, list[int]]:
+        """-> (mismatches, [pairs, second-seat probes for them, other pairs tried, second-seat probes for those, bad byte_pair_id
+        entries]) of the pair table probed in the device's order (first seat, the second one on demand: PAIR_FINAL) against both
+        seats"""
+        st = (ctypes.c_int64 * 5)()
+        self._lib.twin_pair_probe_check.restype = ctypes.c_int64
+        self._lib.twin_pair_probe_check.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p]
+        bad = self._lib.twin_pair_probe_check(self._h, n_random, seed, st)
+        return int(bad), list(st)
+
     def encode_batch(self, data: bytes, offs=None, mode: int = 0):
         offs = self._offs(data, offs)
         out = np.empty(max(len(data), 1), dtype=np.int32)

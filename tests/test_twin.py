@@ -134,3 +134,16 @@ def test_incomplete_vocab_semantics():
             tw.encode_batch(bad)
         with pytest.raises(port.OracleError):
             O.encode(bad)
+
+
+def test_pair_table_probed_in_the_devices_order():
+    """td_merge_pieces probes a pair's first seat and its second one only where the first neither holds the pair nor is marked
+    final (PAIR_FINAL, set by build_tables for the slots nobody was pushed out of); a part is set up from ONE load of
+    Tables::byte_pair_id.  Both against the plain tables: every pair of the vocabulary, every one of them with its halves
+    swapped, random id pairs."""
+    for tw in (H.twin_llama4(), H.twin_gpt2()):
+        bad, st = tw.pair_probe_check(300000, seed=3)
+        assert bad == 0, st
+        assert st[0] > 1000 and st[4] == 0
+        assert st[1] < 0.4 * st[0], f"more than 40 % of the pairs sit in their second seat: {st}"
+        assert st[3] < 0.25 * st[2], f"the first seat is final for fewer than three in four of the pairs that are none: {st}"

@@ -119,6 +119,43 @@ int64_t twin_info(void* h, int what) {
     return -1;
 }
 
+// The pair table as the DEVICE's merge rounds probe it (mg_round_t, td_common.h): the first seat; the second one only where the first
+// neither holds the pair nor is marked PAIR_FINAL.  Checked against pair_lookup (both seats) on every pair of the table, on every
+// pair with its halves swapped and on n_random random id pairs.  -> mismatches; stats: [pairs, second-seat probes for them,
+// other pairs tried, second-seat probes for those, byte_pair_id entries that differ from byte_pair / byte_id]
+int64_t twin_pair_probe_check(void* h, int64_t n_random, uint64_t seed, int64_t* stats5) {
+    Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
+    int64_t bad = 0, st[5] = {0, 0, 0, 0, 0};
+    auto device_order = [&](uint32_t l, uint32_t r, int64_t& second) -> int32_t {
+        const uint64_t e1 = T.pair_slots[hash_pair(l, r) & T.pair_mask];
+        uint64_t e2 = PAIR_EMPTY;
+        if (!(e1 & PAIR_FINAL) && !pair_slot_is(e1, l, r)) { e2 = T.pair_slots[hash_pair2(l, r) & T.pair_mask]; ++second; }
+        return pair_match(e1, e2, l, r);
+    };
+    for (size_t sl = 0; sl <= T.pair_mask; ++sl) {
+        const uint64_t e = T.pair_slots[sl];
+        if ((e | PAIR_FINAL) == PAIR_EMPTY) continue;
+        const uint32_t l = (uint32_t)((e >> (2 * ID_BITS)) & ((1u << ID_BITS) - 1)), r = (uint32_t)((e >> ID_BITS) & ((1u << ID_BITS) - 1));
+        ++st[0];
+        const int32_t want = pair_lookup(T, l, r);
+        if (want == NO_RANK || want != (int32_t)(e & ((1u << ID_BITS) - 1)) || device_order(l, r, st[1]) != want) ++bad;
+        ++st[2];
+        if (device_order(r, l, st[3]) != pair_lookup(T, r, l)) ++bad;
+    }
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    for (int64_t i = 0; i < n_random; ++i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const uint32_t l = (uint32_t)(x % (uint64_t)(t->H.max_id + 1)), r = (uint32_t)((x >> 32) % (uint64_t)(t->H.max_id + 1));
+        ++st[2];
+        if (device_order(l, r, st[3]) != pair_lookup(T, l, r)) ++bad;
+    }
+    for (uint32_t q = 0; q < 65536; ++q)
+        if ((uint32_t)T.byte_pair_id[q] != (uint32_t)T.byte_pair[q] || (uint32_t)(T.byte_pair_id[q] >> 32) != (uint32_t)T.byte_id[q >> 8]) { ++st[4]; ++bad; }
+    for (int i = 0; i < 5; ++i) stats5[i] = st[i];
+    return bad;
+}
+
 // per-byte class + F_CONT + F_DOC exactly as phase 1 of the kernel defines them
 void twin_classify(void* h, const uint8_t* text, int64_t n, const int64_t* offs, int64_t n_docs, uint8_t* out) {
     Twin* t = (Twin*)h;
