@@ -173,7 +173,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf coll_ctr, tile_state, slab, docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, gapbits, gx_exit, gx_state, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf rest_mask, coll_ctr, tile_state, slab, docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, gapbits, gx_exit, gx_state, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -384,6 +384,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs, bool dense = false) {
     if ((rc = ensure(t, t->stage2, (size_t)std::max<int64_t>(n_tiles, 1) * K_STAGE * 4))) return rc;  // ids of merged pieces
     if ((rc = ensure(t, t->tile_count, (size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_extra, (size_t)(n_tiles + 1) * 4))) return rc;
+    if ((rc = ensure(t, t->rest_mask, (size_t)((n_tiles + 15) / 16 + 4) * 2))) return rc;
     if ((rc = ensure(t, t->flagged_list, (size_t)(n_tiles + 64) * 4))) return rc;
     if ((rc = ensure(t, t->deferred_list, (size_t)(n_tiles + 64) * 4))) return rc;
     if (t->H.pattern_kind == PATTERN_GENERIC) {
@@ -441,6 +442,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.merge_out = (uint32_t*)t->stage2.p;
     a.tile_count = (uint32_t*)t->tile_count.p;
     a.tile_extra = (uint32_t*)t->tile_extra.p;
+    a.rest_mask = (uint16_t*)t->rest_mask.p;
     a.tile_base = (int64_t*)t->tile_base.p;
     a.doc_slot = (uint32_t*)t->doc_slot.p;
     a.tile_first_doc = (uint32_t*)t->tile_first_doc.p;
@@ -758,7 +760,7 @@ void td_destroy(td_tokenizer* t) {
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
         if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->coll_ctr, &t->gx_prefix, &t->tile_state, &t->slab, &t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->rest_mask, &t->coll_ctr, &t->gx_prefix, &t->tile_state, &t->slab, &t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)

@@ -90,6 +90,7 @@ struct EncodeArgs {
     uint32_t* coll_count;
     uint32_t coll_cap[K_MISS_CLASSES];
     unsigned long long coll_base[K_MISS_CLASSES];
+    uint16_t* rest_mask;        // [(n_tiles + 15) / 16] bit k of word g: tile 16 g + k is td_pack_rest's whatever its base (td_scan_tiles -> td_pack_rest)
     uint32_t* ovf_count;        // tiles with a class whose records found no room (tile_count bits TILE_OVF_SHIFT..: td_merge_pieces scans those)
     // generic split patterns (PV_GENERIC; td_generic.hip)
     const RxProgram* rx;        // the compiled pattern

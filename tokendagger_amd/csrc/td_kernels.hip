@@ -2989,6 +2989,15 @@ __global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a
 // LDS hop) and publishes the chunk total; the workgroup that finishes last scans the chunk totals (chunk_pref).  A
 // tile's token base is tile_base[tile] + chunk_pref[tile / 4096].
 constexpr int K_SCAN_CHUNK = 4096;
+// td_pack_plain's tiles (the pair td_pack_plain / td_pack_rest, a.pack_split): no long piece, at most a few merged ones (the tiles
+// the tile loops flag for their many missed pieces are pack_body's: measured, its row groups are faster on them), not placed by
+// the fused loop, at most 1024 slots, all of its ids inside the output
+__device__ __forceinline__ bool pk_rest_tile(uint32_t tc) {  // (what td_scan_tiles notes in rest_mask: the part that needs no base)
+    return (tc & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_DIRECT)) != 0u || (tc & TILE_COUNT_MASK) > 1024u;
+}
+__device__ __forceinline__ bool pk_simple(uint32_t tc, int64_t base, uint32_t extra, int64_t out_cap) {
+    return !pk_rest_tile(tc) && base + (int64_t)(int32_t)((tc & TILE_COUNT_MASK) + extra) <= out_cap;
+}
 __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
     __shared__ unsigned long long s_wsum[16];
     __shared__ uint32_t s_last;
@@ -2998,14 +3007,24 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
         const int c0 = blockIdx.x * K_SCAN_CHUNK;
         const int e0 = c0 + tid * 4;
         uint32_t v[4] = {0, 0, 0, 0};
+        uint32_t nib = 0;  // bit k: tile e0 + k is td_pack_rest's whatever its base (pk_rest_tile)
         if (e0 + 4 <= a.n_tiles) {
             const uint4 cnt = *reinterpret_cast<const uint4*>(a.tile_count + e0);
             const uint4 ext = *reinterpret_cast<const uint4*>(a.tile_extra + e0);
             v[0] = (cnt.x & TILE_COUNT_MASK) + ext.x; v[1] = (cnt.y & TILE_COUNT_MASK) + ext.y;
             v[2] = (cnt.z & TILE_COUNT_MASK) + ext.z; v[3] = (cnt.w & TILE_COUNT_MASK) + ext.w;
+            nib = (pk_rest_tile(cnt.x) ? 1u : 0u) | (pk_rest_tile(cnt.y) ? 2u : 0u) | (pk_rest_tile(cnt.z) ? 4u : 0u) | (pk_rest_tile(cnt.w) ? 8u : 0u);
         } else {
             for (int k = 0; k < 4; ++k)
-                if (e0 + k < a.n_tiles) v[k] = (a.tile_count[e0 + k] & TILE_COUNT_MASK) + a.tile_extra[e0 + k];
+                if (e0 + k < a.n_tiles) {
+                    const uint32_t tc = a.tile_count[e0 + k];
+                    v[k] = (tc & TILE_COUNT_MASK) + a.tile_extra[e0 + k];
+                    nib |= (pk_rest_tile(tc) ? 1u : 0u) << k;
+                }
+        }
+        {   // ... sixteen tiles a word: td_pack_rest walks these instead of every tile's count word
+            const uint32_t m16 = nib | ((uint32_t)__shfl_down((int)nib, 1) << 4) | ((uint32_t)__shfl_down((int)nib, 2) << 8) | ((uint32_t)__shfl_down((int)nib, 3) << 12);
+            if ((lane & 3) == 0 && e0 < a.n_tiles) a.rest_mask[e0 >> 4] = (uint16_t)m16;
         }
         const unsigned long long mine = (unsigned long long)v[0] + v[1] + v[2] + v[3];
         unsigned long long x = mine;
@@ -3070,13 +3089,6 @@ constexpr int PK_ECAP = 256;  // merged pieces the expansion list holds
 // PLAIN_ONLY: only the pipelined path of the plain tiles (every slot an id, at most 1024 of them); SKIP_PLAIN: everything else.
 // Launched as a pair (a.pack_split): the first has none of the marker path's registers — 8 wavefronts per SIMD instead of 4 —
 // the second finds next to nothing to do on plain text.  <false, false>: one kernel for all tiles (rounds 2-3).
-// td_pack_plain's tiles (the pair td_pack_plain / td_pack_rest, a.pack_split): no long piece, at most a few merged ones (the tiles
-// the tile loops flag for their many missed pieces are pack_body's: measured, its row groups are faster on them), not placed by
-// the fused loop, at most 1024 slots, all of its ids inside the output
-__device__ __forceinline__ bool pk_simple(uint32_t tc, int64_t base, uint32_t extra, int64_t out_cap) {
-    const uint32_t cnt = tc & TILE_COUNT_MASK;
-    return !(tc & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_DIRECT)) && cnt <= 1024u && base + (int64_t)(int32_t)(cnt + extra) <= out_cap;
-}
 template <bool PLAIN_ONLY, bool SKIP_PLAIN>
 __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long long (*s_elist)[PK_ECAP]) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -3101,9 +3113,8 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
     (void)base_of;
     const int tile_first = (int)uni32((uint32_t)(blockIdx.x * (K_THREADS / 64) + wv));
     uint32_t tcA = 0, dfA = 0, tcB = 0, dfB = 0, tcC = 0, dfC = 0;          // A = this tile, B = the next one, C = the one after
-    uint32_t exA = 0, exB = 0, exC = 0;
     int64_t baseA = 0, baseB = 0, baseC = 0;
-#define PK_FETCH(t, X) { tc##X = a.tile_count[t]; base##X = a.tile_base[t] + a.chunk_pref[(t) / K_SCAN_CHUNK]; df##X = a.tile_first_doc[t]; if (SKIP_PLAIN) ex##X = a.tile_extra[t]; }
+#define PK_FETCH(t, X) { tc##X = a.tile_count[t]; base##X = a.tile_base[t] + a.chunk_pref[(t) / K_SCAN_CHUNK]; df##X = a.tile_first_doc[t]; }
 #define PK_FAST(X) (!(tc##X & (TILE_HAS_LONG | TILE_HAS_MISS | TILE_MISS_LISTED | TILE_DIRECT)) && (tc##X & TILE_COUNT_MASK) <= 1024u && \
                     base##X + (int64_t)(tc##X & TILE_COUNT_MASK) <= a.out_cap)
     uint4 cx0 = make_uint4(0, 0, 0, 0), cx1 = cx0, cx2 = cx0, cx3 = cx0, nx0 = cx0, nx1 = cx0, nx2 = cx0, nx3 = cx0;
@@ -3126,26 +3137,80 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
         if ((uint32_t)lane + 192 < g_nv) { const u32x4a4 v = *reinterpret_cast<const u32x4a4*>(g_src + g_head + 4 * (lane + 192)); P##x3 = make_uint4(v.x, v.y, v.z, v.w); } \
         const int64_t g_dm = (int64_t)df##X + lane;                                                                   \
         if (g_dm < a.n_docs) { P##dpos = a.doc_offsets[g_dm]; P##dsl = a.doc_slot[g_dm]; } }
-    if (tile_first < a.n_tiles) PK_FETCH(tile_first, A)
-    if (tile_first + nwaves < a.n_tiles) PK_FETCH(tile_first + nwaves, B)
-    bool fast_cur = tile_first < a.n_tiles && PK_FAST(A);
-    if (fast_cur && !SKIP_PLAIN) PK_LOAD(tile_first, A, c)
-    for (int tile = tile_first; tile < a.n_tiles; tile += nwaves) {
-        if (tile + 2 * nwaves < a.n_tiles) PK_FETCH(tile + 2 * nwaves, C)
-        const bool fast_next = tile + nwaves < a.n_tiles && PK_FAST(B);
-        if (fast_next && !SKIP_PLAIN) PK_LOAD(tile + nwaves, B, n)  // (in front of this tile's stores)
-        const uint32_t tc = tcA;
-        const int64_t base = baseA;
-        const int64_t dfirst = (int64_t)dfA;
-        const bool fast_this = fast_cur;
-        const uint4 sx0 = cx0, sx1 = cx1, sx2 = cx2, sx3 = cx3;
-        const uint32_t sh0 = ch0, stl = ctl, sdsl = cdsl;
-        const int64_t sdpos = cdpos;
-        const uint32_t ex = exA;
-        tcA = tcB; baseA = baseB; dfA = dfB; exA = exB; tcB = tcC; baseB = baseC; dfB = dfC; exB = exC;
-        fast_cur = fast_next;
-        cx0 = nx0; cx1 = nx1; cx2 = nx2; cx3 = nx3; ch0 = nh0; ctl = ntl; cdsl = ndsl; cdpos = ndpos;
-        if (SKIP_PLAIN && pk_simple(tc, base, ex, a.out_cap)) continue;  // (the other kernel of the pair; the closing offsets with it when this is the last tile)
+    bool fast_cur = false;
+    if constexpr (!SKIP_PLAIN) {
+        if (tile_first < a.n_tiles) PK_FETCH(tile_first, A)
+        if (tile_first + nwaves < a.n_tiles) PK_FETCH(tile_first + nwaves, B)
+        fast_cur = tile_first < a.n_tiles && PK_FAST(A);
+        if (fast_cur) PK_LOAD(tile_first, A, c)
+    }
+    // SKIP_PLAIN (td_pack_rest): the wavefront's tiles are the same as above (its index, then every nwaves-th), FOUR at a time: their bits
+    // of td_scan_tiles' masks of the tiles that are not td_pack_plain's first (four independent loads: on plain text next to none
+    // is set, and reading every tile's count word to find that out was 48 us per GiB), then what depends on the tile index only
+    // for all of the four that are (one more round trip), then the tiles.  When the output is too small (total > out_cap)
+    // every tile is looked at: the ones behind the end of the output are nobody's otherwise.
+    const bool walk_all = SKIP_PLAIN && total > a.out_cap;  // (uniform)
+    int t0 = tile_first - 4 * nwaves;
+    uint32_t cmask = 0, c_tc[4] = {0, 0, 0, 0}, c_df[4] = {0, 0, 0, 0}, c_ex[4] = {0, 0, 0, 0};
+    int64_t c_base[4] = {0, 0, 0, 0};
+    int tile = tile_first - nwaves;
+    for (;;) {
+        uint32_t tc, ex = 0;
+        int64_t base, dfirst;
+        bool fast_this = false;
+        uint4 sx0 = cx0, sx1 = cx0, sx2 = cx0, sx3 = cx0;
+        uint32_t sh0 = 0, stl = 0, sdsl = 0;
+        int64_t sdpos = 0;
+        if constexpr (SKIP_PLAIN) {
+            if (!cmask) {
+                t0 += 4 * nwaves;
+                if (t0 >= a.n_tiles) break;
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tq = t0 + q * nwaves;
+                    if (tq < a.n_tiles) w[q] = walk_all ? 0xFFFFu : (uint32_t)a.rest_mask[tq >> 4];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tq = t0 + q * nwaves;
+                    if (tq < a.n_tiles && ((w[q] >> (tq & 15)) & 1u)) cmask |= 1u << q;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tq = t0 + q * nwaves;
+                    if ((cmask >> q) & 1u) {
+                        c_tc[q] = a.tile_count[tq]; c_ex[q] = a.tile_extra[tq]; c_df[q] = a.tile_first_doc[tq];
+                        c_base[q] = a.tile_base[tq] + a.chunk_pref[tq / K_SCAN_CHUNK];
+                    }
+                }
+                if (!cmask) continue;
+            }
+            const int q = (int)td_ctz32(cmask);
+            cmask &= cmask - 1u;
+            tile = t0 + q * nwaves;
+            tc = q == 0 ? c_tc[0] : q == 1 ? c_tc[1] : q == 2 ? c_tc[2] : c_tc[3];
+            ex = q == 0 ? c_ex[0] : q == 1 ? c_ex[1] : q == 2 ? c_ex[2] : c_ex[3];
+            dfirst = (int64_t)(q == 0 ? c_df[0] : q == 1 ? c_df[1] : q == 2 ? c_df[2] : c_df[3]);
+            base = q == 0 ? c_base[0] : q == 1 ? c_base[1] : q == 2 ? c_base[2] : c_base[3];
+            if (pk_simple(tc, base, ex, a.out_cap)) continue;  // (the other kernel of the pair; the closing offsets with it when this is the last tile)
+        } else {
+            tile += nwaves;
+            if (tile >= a.n_tiles) break;
+            if (tile + 2 * nwaves < a.n_tiles) PK_FETCH(tile + 2 * nwaves, C)
+            const bool fast_next = tile + nwaves < a.n_tiles && PK_FAST(B);
+            if (fast_next) PK_LOAD(tile + nwaves, B, n)  // (in front of this tile's stores)
+            tc = tcA;
+            base = baseA;
+            dfirst = (int64_t)dfA;
+            fast_this = fast_cur;
+            sx0 = cx0; sx1 = cx1; sx2 = cx2; sx3 = cx3;
+            sh0 = ch0; stl = ctl; sdsl = cdsl;
+            sdpos = cdpos;
+            tcA = tcB; baseA = baseB; dfA = dfB; tcB = tcC; baseB = baseC; dfB = dfC;
+            fast_cur = fast_next;
+            cx0 = nx0; cx1 = nx1; cx2 = nx2; cx3 = nx3; ch0 = nh0; ctl = ntl; cdsl = ndsl; cdpos = ndpos;
+        }
         (void)ex;
         if (PLAIN_ONLY && !fast_this) continue;
         if (tc & TILE_DIRECT) {  // the fused tile loop wrote this tile's ids and document offsets itself
@@ -3370,7 +3435,7 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
                (unsigned long long)(__builtin_readcyclecounter() - t_total0), t_meta, t_plainpath, n_pt, n_mt, t_rows, t_scan, t_plain, t_list, t_flush, t_docs);
 #endif
 }
-__global__ __launch_bounds__(K_THREADS) void td_pack_tokens(const EncodeArgs a) {
+__global__ __launch_bounds__(K_THREADS, 4) void td_pack_tokens(const EncodeArgs a) {
     __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];  // dst offset << 32 | tile position << 7 | ids
     pack_body<false, false>(a, s_elist);
 }
