@@ -205,6 +205,11 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
                                     piece and at most a few merged ones (nearly a copy: 5 TB/s), and td_pack_rest for the others; 0: one
                                     kernel for all tiles (td_pack_tokens, rounds 2-4).  Same results either way; TD_PACK_SPLIT=0 in the
                                     environment at td_create time also turns it off. */
+#define TD_OPT_DEDUPE 11           /* 1 (default): a piece that is not a token is merged ONCE per call however often its bytes occur in it — the
+                                    pieces of the tiles with many missed pieces are looked up in a table of the call's distinct ones (bytes
+                                    compared, not hashes) and the repeats copy the ids; 0: every piece is merged (rounds 1-4).  Same results
+                                    either way (bpe_merge reads nothing but the piece, tiktoken.cpp:298-368); TD_DEDUPE=0 in the environment at
+                                    td_create time also turns it off. */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 16) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 

@@ -33,6 +33,26 @@ def pytest_collection_modifyitems(session, config, items):
     items.sort(key=key)  # (stable: the order inside a file and among unlisted files stays)
 
 
+# VERDICT r4 (parity evidence must not be skippable): the reference-parity tests are `skipif(not ref.available())` because the compiled
+# reference (oracle/_ref/libtdref.so, git-ignored) can only be built where /root/reference exists.  On a CPU-only checkout that is a
+# skip; in a GPU run (`-m gpu`) it is a FAILURE — a green GPU suite must mean "compared with the reference", never "skipped".
+@pytest.hookimpl(tryfirst=True)
+def pytest_runtest_setup(item):
+    if item.get_closest_marker("gpu") is None:
+        return
+    for m in item.iter_markers(name="skipif"):
+        if m.args and m.args[0] and "oracle/_ref" in str(m.kwargs.get("reason", "")):
+            pytest.fail("GPU parity test without its checker: oracle/_ref is missing (build it where /root/reference exists: "
+                        "oracle/build_ref.sh; the prebuilt .so travels with the snapshot).  " + str(m.kwargs.get("reason")), pytrace=False)
+
+
+@pytest.fixture(scope="session")
+def fullsize_hashes():
+    """Hashes of the compiled reference's ids and offsets on the full-size corpora (tools/make_fullsize_golden.py): one per 2^18 ids."""
+    import numpy as np
+    return np.load(ROOT / "tests" / "golden" / "fullsize_hashes.npz")
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -19,6 +19,23 @@ def tok():
     return capi.HipTokenizer(pat, mr, special, device=0)
 
 
+def _check_small_documents_against_the_reference(text: bytes, offs, toks, toffs, limit=1024):
+    """The documents below `limit` bytes once more against the COMPILED REFERENCE (the restatement and the kernels
+    share generated Unicode tables; longer documents hold single pieces of kilobytes, where the reference's merge loop is quadratic)."""
+    from oracle import ref
+    assert ref.available(), "oracle/_ref/libtdref.so is missing (build it where /root/reference exists: oracle/build_ref.sh)"
+    R = H.ref_tokenizer()
+    offs = np.asarray(offs, dtype=np.int64)
+    small = np.flatnonzero(np.diff(offs) < limit)
+    docs = [text[int(offs[d]):int(offs[d + 1])] for d in small]
+    st, so = H.pack_docs(docs)
+    _, et, eo = R.encode_batch(np.frombuffer(st, dtype=np.uint8) if st else np.zeros(0, np.uint8), so, n_threads=8, want_tokens=True)
+    for j, d in enumerate(small):
+        got = toks[int(toffs[d]):int(toffs[d + 1])]
+        assert np.array_equal(got, et[int(eo[j]):int(eo[j + 1])]), f"document {int(d)} differs from the compiled reference: {docs[j][:80]!r}"
+    return len(small)
+
+
 def _check_batch(tok, O, text: bytes, offs, mode=0):
     toks, toffs = tok.encode_batch(text, offs, mode=mode)
     etoks, eoffs = O.encode_batch(text, offs)
@@ -59,6 +76,7 @@ def test_survey_known_answers(tok):
 def test_fuzz_batches_vs_oracle(tok):
     O = H.port_tokenizer()
     rng = random.Random(2025)
+    n_ref = 0
     for it in range(12):
         docs = []
         for _ in range(rng.randint(1, 400)):
@@ -73,6 +91,9 @@ def test_fuzz_batches_vs_oracle(tok):
                 docs.append("".join(H.fuzz_string(rng) for _ in range(rng.randint(1, 40))).encode("utf-8"))
         text, offs = H.pack_docs(docs)
         _check_batch(tok, O, text, offs, mode=it % 2)
+        toks, toffs = tok.encode_batch(text, offs, mode=it % 2)
+        n_ref += _check_small_documents_against_the_reference(text, offs, toks, toffs)
+    assert n_ref > 1000, "the fuzz documents below 1 KiB were compared with the compiled reference"
 
 
 @pytest.mark.parametrize("gen,size", [("english", 8 << 20), ("mixed", 4 << 20), ("code", 4 << 20)])

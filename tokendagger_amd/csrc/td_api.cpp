@@ -173,7 +173,7 @@ struct td_tokenizer {
     std::string err;
     std::mutex mu;
     // workspace (grown on demand)
-    DevBuf rest_mask, coll_ctr, tile_state, slab, docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, gapbits, gx_exit, gx_state, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
+    DevBuf dd_table, rest_mask, coll_ctr, tile_state, slab, docbits, startbits, slow_list, tile_flag, tile_carry, stage, stage2, tile_count, tile_extra, miss_list, flagged_list, deferred_list, gap_list, gapbits, gx_exit, gx_state, tile_base, doc_slot, long_list, pool, ctl, tile_first_doc, chunk_pref;
     DevBuf h2d_text, h2d_offs, d_tokens, d_offsets;  // host-API staging
     DevBuf dec_tokens, dec_off, dec_out;
     int64_t pool_bytes_opt = 0;
@@ -199,6 +199,8 @@ struct td_tokenizer {
     uint32_t sp_n = 0, sp_maxlen = 0;
     bool device_specials = true;     // host-buffer batches of a MiB and more search on the device (TD_OPT_DEVICE_SPECIALS)
     bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
+    uint32_t dd_entries_opt = 0;  // (TD_DD_ENTRIES=<power of two> at td_create time, tests: seats of the table of distinct missed pieces)
+    bool dedupe = true;       // a missed piece whose bytes another one of the call has is merged once (TD_OPT_DEDUPE; TD_DEDUPE=0 at td_create time turns it off)
     bool pack_split = true;   // td_pack_plain + td_pack_rest instead of td_pack_tokens (TD_OPT_PACK_SPLIT; TD_PACK_SPLIT=0 at td_create time turns it off)
     int coll_shrink = 1;      // (TD_COLL_SHRINK=<k> at td_create time, tests: td_collect_misses' lists 1/k of their size)
     // generic patterns with left-context assertions behind special cuts: per document of the NEXT host batch, the bytes at its
@@ -343,18 +345,21 @@ int upload(td_tokenizer* t, const V* src, size_t count, const V** dst) {
 
 // The miss lists in one buffer: the tile loops' five (room for K_MISS_LISTED_MAX per tile each), then td_collect_misses'
 // K_MISS_CLASSES x COLL_SUBS.  A class gets room for the most records n bytes can hold up to 64 Ki, beyond that for a fixed share
-// of n: a miss of <= 8 bytes every 8 bytes of text, 9..16 every 18, 17..32 every 34, longer ones whatever fits (2.1 bytes of list
-// per byte of text; mixed-script text has a miss every 51 bytes over all classes).  What finds no room is merged by the slow scan
+// of n: a miss of <= 8 bytes every 24 bytes of text, 9..16 every 48, 17..32 every 96, 33..48 every 128, longer ones every 160 (0.7 bytes
+// of list per byte of text — round 4 had 2.1; mixed-script text has a miss every 51 bytes over all classes, the reference's code
+// file set one of <= 8 bytes every 33, and since round 5 only the DISTINCT pieces of a call are listed).  What finds no room is merged by the slow scan
 // at the end of td_merge_pieces.  dense (encode_ordinary with a vocabulary whose tokens the merge loop does not all reproduce: no
 // whole-piece lookup, EVERY piece of two bytes or more is merged): the worst case, 5.8 bytes per byte of text.  TD_COLL_SHRINK=<k>
 // (tests): 1/k of that.
 struct CollLayout {
     unsigned long long base[K_MISS_CLASSES];
     uint32_t cap[K_MISS_CLASSES];
+    unsigned long long dup_base;  // the lists of repeats behind them: COLL_SUBS x dup_cap entries
+    uint32_t dup_cap;
     unsigned long long total;
 };
 static CollLayout coll_layout(const td_tokenizer* t, int64_t n, int64_t n_tiles, bool dense) {
-    static const int minlen[K_MISS_CLASSES] = {2, 9, 17, 33, 49}, share[K_MISS_CLASSES] = {8, 18, 34, 33, 49};
+    static const int minlen[K_MISS_CLASSES] = {2, 9, 17, 33, 49}, share[K_MISS_CLASSES] = {24, 48, 96, 128, 160};
     CollLayout L;
     unsigned long long at = (unsigned long long)(n_tiles + 1) * K_MISS_LISTED_MAX * K_MISS_CLASSES;
     for (int c = 0; c < K_MISS_CLASSES; ++c) {
@@ -366,8 +371,29 @@ static CollLayout coll_layout(const td_tokenizer* t, int64_t n, int64_t n_tiles,
         L.cap[c] = (uint32_t)per_list;
         at += (unsigned long long)per_list * COLL_SUBS;
     }
+    // the repeats (round 5; 8 bytes each): room for as many as the lists of the classes hold records — a missed piece is on one or the other
+    L.dup_base = at;
+    const unsigned long long coll_records = at - (unsigned long long)(n_tiles + 1) * K_MISS_LISTED_MAX * K_MISS_CLASSES;
+    L.dup_cap = (uint32_t)std::min<unsigned long long>(coll_records / COLL_SUBS + 64, 0x7FFFFFF0ull);
+    at += (unsigned long long)L.dup_cap * COLL_SUBS;
     L.total = at;
     return L;
+}
+
+// seats of the table of distinct missed pieces (EncodeArgs::dd_table): a power of two, about one per 128 bytes of text
+// ... as many as an entry of the list of repeats can name next to its tile (39 bits for both: 2 Mi seats up to 1 GiB of text)
+static uint32_t dd_tile_bits(int64_t n) {
+    const int64_t n_tiles = (n + K_TILE - 1) / K_TILE;
+    uint32_t b = 1;
+    while (b < 39 && (1ll << b) < n_tiles) ++b;
+    return b;
+}
+static uint32_t dd_entries(const td_tokenizer* t, int64_t n) {
+    const uint32_t most = 1u << std::min<uint32_t>(39 - dd_tile_bits(n), 24);
+    if (t->dd_entries_opt) return std::min(t->dd_entries_opt, most);
+    uint32_t e = 4096;
+    while (e < (2u << 20) && e < most && (int64_t)e * 128 < n) e <<= 1;
+    return std::min(e, most);
 }
 
 int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs, bool dense = false) {
@@ -396,8 +422,9 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs, bool dense = false) {
     {
         CollLayout L = coll_layout(t, n, n_tiles, dense);
         if ((rc = ensure(t, t->miss_list, (size_t)L.total * 8))) return rc;
-        if ((rc = ensure(t, t->coll_ctr, (size_t)K_MISS_CLASSES * COLL_SUBS * COLL_STRIDE * 4))) return rc;
+        if ((rc = ensure(t, t->coll_ctr, (size_t)(K_MISS_CLASSES + 1) * COLL_SUBS * COLL_STRIDE * 4))) return rc;
     }
+    if ((rc = ensure(t, t->dd_table, (size_t)dd_entries(t, n) * 8))) return rc;
     if ((rc = ensure(t, t->tile_base, (size_t)(n_tiles + 2) * 8))) return rc;
     if ((rc = ensure(t, t->doc_slot, (size_t)(n_docs + 1) * 4))) return rc;
     if ((rc = ensure(t, t->tile_first_doc, (size_t)(n_tiles + 1) * 4))) return rc;
@@ -463,9 +490,15 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     {
         const CollLayout L = coll_layout(t, n, n_tiles, dense);
         for (int c = 0; c < K_MISS_CLASSES; ++c) { a.coll_base[c] = L.base[c]; a.coll_cap[c] = L.cap[c]; }
+        a.dup_list = a.miss_list + L.dup_base;
+        a.dup_cap = L.dup_cap;
         a.coll_count = (uint32_t*)t->coll_ctr.p;
         a.ovf_count = &ctl->ovf_count;
     }
+    a.dedupe = (t->dedupe && n_tiles < (1ll << 24)) ? 1 : 0;  // (a table entry keeps the tile in 24 bits)
+    a.dd_seat_bits = std::min<uint32_t>(39 - dd_tile_bits(n), 24);
+    a.dd_table = a.dedupe ? (unsigned long long*)t->dd_table.p : nullptr;
+    a.dd_mask = a.dedupe ? dd_entries(t, n) - 1u : 0u;
     a.flagged_count = &ctl->flagged_count;
     a.rx = t->d_rx;
     a.rx_stage1 = t->d_rx_s1;
@@ -637,6 +670,8 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if (const char* e = getenv("TD_GRAPH")) t->graphs = atoi(e) != 0;
     if (const char* e = getenv("TD_DIRECT")) t->direct = atoi(e) != 0;
     if (const char* e = getenv("TD_PACK_SPLIT")) t->pack_split = atoi(e) != 0;
+    if (const char* e = getenv("TD_DEDUPE")) t->dedupe = atoi(e) != 0;
+    if (const char* e = getenv("TD_DD_ENTRIES")) { const long v = atol(e); if (v >= 2 && v <= (1l << 24) && !(v & (v - 1))) t->dd_entries_opt = (uint32_t)v; }
     if (const char* e = getenv("TD_COLL_SHRINK")) t->coll_shrink = std::max(1, atoi(e));
     std::string err;
     int rc = build_tables(pat_str, n_vocab, token_bytes, token_offsets, ranks, n_special, special_bytes, special_offsets,
@@ -722,7 +757,7 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t = new td_tokenizer(src->shared);
         t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
         t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
-        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->coll_shrink = src->coll_shrink;
+        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->dd_entries_opt = src->dd_entries_opt; t->coll_shrink = src->coll_shrink;
         t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }
@@ -760,7 +795,7 @@ void td_destroy(td_tokenizer* t) {
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
         if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
         if (t->small_out) (void)hipHostFree(t->small_out);
-        DevBuf* bufs[] = {&t->rest_mask, &t->coll_ctr, &t->gx_prefix, &t->tile_state, &t->slab, &t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
+        DevBuf* bufs[] = {&t->dd_table, &t->rest_mask, &t->coll_ctr, &t->gx_prefix, &t->tile_state, &t->slab, &t->docbits, &t->startbits, &t->slow_list, &t->tile_flag, &t->tile_carry, &t->stage, &t->stage2, &t->tile_count, &t->tile_extra, &t->miss_list, &t->flagged_list, &t->deferred_list, &t->gap_list, &t->gapbits, &t->gx_exit, &t->gx_state, &t->sp_bytes, &t->sp_off, &t->sp_len, &t->sp_id, &t->sp_parent, &t->sp_first2, &t->sp_hit, &t->sp_acc, &t->sp_cpos, &t->sp_clit, &t->sp_ccount, &t->tile_base, &t->doc_slot, &t->long_list,
                           &t->pool, &t->ctl, &t->tile_first_doc, &t->chunk_pref, &t->h2d_text, &t->h2d_offs, &t->d_tokens, &t->d_offsets, &t->dec_tokens,
                           &t->dec_off, &t->dec_out};
         for (DevBuf* b : bufs)
@@ -779,7 +814,9 @@ const char* td_last_error(const td_tokenizer* t) {
 
 int td_reserve(td_tokenizer* t, int64_t max_bytes, int64_t max_docs) {
     if (!t || max_bytes < 0 || max_docs < 0) return TD_E_INVALID;
-    return locked(t, [&] { return reserve_ws(t, std::max<int64_t>(max_bytes, 1), max_docs); });
+    // (an encode_ordinary call on a vocabulary the merge loop does not reproduce merges EVERY piece: reserve for that, so that no
+    // call after td_reserve allocates — ADVICE r4)
+    return locked(t, [&] { return reserve_ws(t, std::max<int64_t>(max_bytes, 1), max_docs, !t->H.merge_closed); });
 }
 
 int td_encode_device(td_tokenizer* t, const void* d_text, int64_t n_bytes, const void* d_doc_offsets, int64_t n_docs,
@@ -1806,6 +1843,11 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     }
     if (what == TD_OPT_PACK_SPLIT) {
         t->pack_split = value != 0;
+        drop_graph(t); t->has_last_key = false;
+        return TD_OK;
+    }
+    if (what == TD_OPT_DEDUPE) {
+        t->dedupe = value != 0;
         drop_graph(t); t->has_last_key = false;
         return TD_OK;
     }

@@ -92,6 +92,15 @@ struct EncodeArgs {
     unsigned long long coll_base[K_MISS_CLASSES];
     uint16_t* rest_mask;        // [(n_tiles + 15) / 16] bit k of word g: tile 16 g + k is td_pack_rest's whatever its base (td_scan_tiles -> td_pack_rest)
     uint32_t* ovf_count;        // tiles with a class whose records found no room (tile_count bits TILE_OVF_SHIFT..: td_merge_pieces scans those)
+    // round 5: a missed piece whose bytes another missed piece of the call has is not merged again.  dd_table: open addressing, a slot
+    // = the record (tile << 32 | slot << 19 | position << 7 | length) of the FIRST piece with those bytes to arrive | hash tag << 56;
+    // zeroed by td_prepare; the bytes are compared, the tag only saves most of the comparisons.  0 entries: off.
+    unsigned long long* dd_table;
+    uint32_t dd_mask;           // entries - 1 (a power of two)
+    uint32_t dd_seat_bits;      // bits of a seat number in an entry of dup_list (>= log2(entries); the tile number gets the other 39 - this)
+    int dedupe;
+    unsigned long long* dup_list;  // the repeats: COLL_SUBS lists of dup_cap entries (tile | slot (13 bits) | tile position (12) | seat of dd_table that
+    uint32_t dup_cap;              // names the piece whose ids it gets); coll_count[(K_MISS_CLASSES * COLL_SUBS + s) * COLL_STRIDE] = entries on list s (td_copy_dups)
     // generic split patterns (PV_GENERIC; td_generic.hip)
     const RxProgram* rx;        // the compiled pattern
     const uint16_t* rx_stage1;  // general-category table (generated/unicode_gc.inc)

@@ -183,7 +183,11 @@ __global__ void td_prepare(const EncodeArgs a) {
         a.tile_state[i] = TS_NONE;
     }
     if (gid < a.ctl_reset_words) a.ctl_reset[gid] = 0;
-    if (gid < K_MISS_CLASSES * COLL_SUBS) a.coll_count[gid * COLL_STRIDE] = 0;
+    if (gid < (K_MISS_CLASSES + 1) * COLL_SUBS) a.coll_count[gid * COLL_STRIDE] = 0;  // (the lists of td_collect_misses: records by class, repeats)
+    if (a.dedupe) {
+        uint4* t4 = reinterpret_cast<uint4*>(a.dd_table);
+        for (int64_t i = gid; i < ((int64_t)a.dd_mask + 1) / 2; i += gsz) t4[i] = make_uint4(0, 0, 0, 0);
+    }
 }
 
 // ------------------------------------------------------------------ shared helpers ----------
@@ -413,15 +417,20 @@ __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const 
 
 // ---- (used by td_merge_pieces and, for the few missed pieces of a tile it places itself, by the fused tile loop) ----
 // 17 text bytes at global offset g as five dwords (byte k = bits 8(k&3).. of w[k>>2]); zero past the end of the text
+typedef uint32_t U32x4a __attribute__((ext_vector_type(4), aligned(4)));  // (a 16-byte global load needs dword alignment only)
+typedef uint32_t U32x2a __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ void load_piece_window(const uint8_t* text, int64_t n_text, int64_t g, uint32_t (&w)[5]) {
     const uintptr_t addr = (uintptr_t)(text + g);
     const int64_t g4 = g - (int64_t)(addr & 3);  // text offset of the aligned dword that holds byte g
     if (g4 >= 0 && g4 + 24 <= n_text) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(text + g4);
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
+        // six dwords as two loads (round 5; they were six requests to the vector L1 per lane)
+        typedef const U32x4a __attribute__((address_space(1)))* g4_t;
+        typedef const U32x2a __attribute__((address_space(1)))* g2_t;
+        const U32x4a a = *(g4_t)(uintptr_t)(text + g4);
+        const U32x2a b = *(g2_t)(uintptr_t)(text + g4 + 16);
         const uint32_t sh = (uint32_t)(addr & 3) * 8;
-        w[0] = __funnelshift_r(d0, d1, sh); w[1] = __funnelshift_r(d1, d2, sh); w[2] = __funnelshift_r(d2, d3, sh);
-        w[3] = __funnelshift_r(d3, d4, sh); w[4] = __funnelshift_r(d4, d5, sh);
+        w[0] = __funnelshift_r(a.x, a.y, sh); w[1] = __funnelshift_r(a.y, a.z, sh); w[2] = __funnelshift_r(a.z, a.w, sh);
+        w[3] = __funnelshift_r(a.w, b.x, sh); w[4] = __funnelshift_r(b.x, b.y, sh);
     } else {
         for (int k = 0; k < 5; ++k) w[k] = 0;
         for (int k = 0; k < 17; ++k)
@@ -2099,63 +2108,198 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
 // counters of one class are COLL_SUBS different cache lines), pass 2 writes the records — no LDS, full occupancy.  A class that
 // finds no room (lists are sized for a few times the density of real text, not for the worst case of a miss every two bytes)
 // is noted in the tile's count word; td_merge_pieces scans those tiles for those classes after the rows.
+// Round 5: ... and a piece is merged ONCE per call however often its bytes occur.  The tile's missed slots are compacted into LDS (a
+// group of eight rows at a time; what is left of a group waits for the next one, so the dense part always runs with 64 lanes), then a
+// lane per piece: hash of its bytes, a look at the table of the pieces seen so far in this call (EncodeArgs::dd_table), and either the
+// piece is the first one with these bytes (its record goes into the table with one compare-and-swap, and onto a list), or the table
+// names a piece with the same hash tag and length whose bytes ARE the same (compared, 16 bytes a step): then the pair (this record,
+// that record) goes on the list of repeats and td_copy_dups copies the ids when td_merge_pieces is done.  Equal bytes have equal ids
+// (bpe_merge reads nothing but the piece, tiktoken.cpp:298-368), so this changes no result; missed words repeat (8 MiB of mixed-script
+// text: 168 000 missed pieces, 14 000 distinct; the reference's code file set: 290 000 / 4 500).  A full table (or two occupied seats)
+// only means the piece is merged itself.  Records and repeats are held back in LDS until a wavefront has 64 of a kind: one atomic
+// per 64 whatever the tiles were.
+constexpr int DD_BUF = 512 + 64;   // compacted slots of eight rows + what the group before left over
+constexpr int DD_UCAP = 128;       // records per class (and repeats) a wavefront holds back (at most 63 + 64)
+__device__ __forceinline__ void dd_chunk(const uint8_t* text, int64_t n_text, int64_t g, uint32_t left, uint32_t (&w)[4]) {  // 16 bytes at g, zero from byte `left` on
+    uint32_t t[5];
+    load_piece_window(text, n_text, g, t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int32_t l = (int32_t)left - 4 * i;
+        w[i] = l >= 4 ? t[i] : l <= 0 ? 0u : (t[i] & ((1u << (8 * l)) - 1u));
+    }
+}
+__device__ __forceinline__ uint32_t dd_mix(uint32_t h, uint32_t w) {  // (murmur3's mixing)
+    uint32_t k = w * 0xCC9E2D51u;
+    k = (k << 15) | (k >> 17);
+    h ^= k * 0x1B873593u;
+    return ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
+}
+__device__ __forceinline__ uint32_t dd_fmix(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ bool dd_same_from(const uint8_t* text, int64_t n_text, int64_t g, int64_t g2, uint32_t len, uint32_t from) {
+    uint32_t diff = 0;
+    for (uint32_t c = from; c < len; c += 16u) {
+        uint32_t w[4], v[4];
+        dd_chunk(text, n_text, g + c, len - c, w);
+        dd_chunk(text, n_text, g2 + c, len - c, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) diff |= w[i] ^ v[i];
+    }
+    return diff == 0u;
+}
+constexpr unsigned long long DD_REC_MASK = (1ull << 56) - 1ull;  // (a record's tile stays below 2^24: dedupe is off above 64 GiB of text)
+constexpr int DD_CTR = K_MISS_CLASSES * COLL_SUBS;  // coll_count[(DD_CTR + s) * COLL_STRIDE]: entries on list s of the repeats
+
 __global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * (K_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (K_THREADS / 64);
+    __shared__ uint32_t s_m[K_THREADS / 64][DD_BUF];
+    __shared__ unsigned long long s_u[K_THREADS / 64][K_MISS_CLASSES][DD_UCAP];
+    __shared__ unsigned long long s_d[K_THREADS / 64][DD_UCAP];
+    __shared__ uint32_t s_dv[K_THREADS / 64][DD_UCAP];  // (their tile position << 7 | length: only what finds no room on the list needs it)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = blockIdx.x * (K_THREADS / 64) + wv, nw = gridDim.x * (K_THREADS / 64);
     const int n_flagged = (int)*a.flagged_count;
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t sub = (uint32_t)gw % (uint32_t)COLL_SUBS;
-    for (int f = gw; f < n_flagged; f += nw) {
-        const uint32_t tile = a.flagged_list[f];
-        const uint32_t tc = a.tile_count[tile];
-        const uint32_t cnt = tc & TILE_COUNT_MASK;
-        const uint32_t* slots = a.stage + (size_t)tile * K_STAGE;
-        const uint32_t rows = (cnt + 63u) >> 6;
-        // pass 1: misses per class (a lane counts its own, 8 bits a class: at most 65 rows)
-        uint64_t mine = 0;
-        for (uint32_t row = 0; row < rows; row += 8) {
-            uint32_t v[8];
+    uint32_t* const mb = s_m[wv];
+    unsigned long long* const db = s_d[wv];
+    uint32_t ucnt[K_MISS_CLASSES], dcnt = 0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t k = (row + r) * 64u + lane;
-                v[r] = k < cnt ? slots[k] : 0u;
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if ((v[r] & 0xC0000000u) == TOK_MISS) mine += 1ull << (8u * mq_class(v[r] & 127u));
-        }
-        uint32_t n[K_MISS_CLASSES];
-#pragma unroll
-        for (int c = 0; c < K_MISS_CLASSES; ++c)
-            n[c] = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)(mine >> (8 * c)) & 0xFFu, lane), 63);
-        // one atomic per class (lane c)
-        uint32_t myn = 0, mycap = 0;
-#pragma unroll
-        for (int c = 0; c < K_MISS_CLASSES; ++c)
-            if (lane == c) { myn = n[c]; mycap = a.coll_cap[c]; }
+    for (int c = 0; c < K_MISS_CLASSES; ++c) ucnt[c] = 0;
+
+    // no room on a list: the pieces are marked for the scan behind td_merge_pieces' rows (lists are sized for a few times the density of
+    // real text, not for a miss every two bytes)
+    auto to_scan = [&](const unsigned long long rec) {
+        const uint32_t tile = (uint32_t)(rec >> 32), k = ((uint32_t)rec >> 19) & 0x1FFFu;
+        a.stage[(size_t)tile * K_STAGE + k] = TOK_MISS | TOK_OVF | ((uint32_t)rec & 0x7FFFFu);
+        atomicOr(&a.tile_count[tile], 1u << (TILE_OVF_SHIFT + mq_class((uint32_t)rec & 127u)));
+    };
+    // `take` records of class c from the front of the wavefront's buffer to its list of that class, the others move up
+    auto flush = [&](const int c, const uint32_t take) {
+        const uint32_t cap = a.coll_cap[c];
+        unsigned long long* const dst = a.miss_list + a.coll_base[c] + (size_t)sub * cap;
         uint32_t at = 0;
-        if (myn) at = atomicAdd(&a.coll_count[((uint32_t)lane * COLL_SUBS + sub) * COLL_STRIDE], myn);
-        const bool full = myn && (at > mycap || myn > mycap - at);
-        const uint32_t ovf = (uint32_t)__ballot(full) & ((1u << K_MISS_CLASSES) - 1u);
-        uint32_t atc[K_MISS_CLASSES];
-        unsigned long long* dstc[K_MISS_CLASSES];
+        if (lane == 0) at = atomicAdd(&a.coll_count[((uint32_t)c * COLL_SUBS + sub) * COLL_STRIDE], take);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        const unsigned long long rec = (uint32_t)lane < take ? s_u[wv][c][lane] : 0ull;
+        if (at <= cap && take <= cap - at) {
+            if ((uint32_t)lane < take) dst[at + (uint32_t)lane] = rec;
+        } else {  // the places taken before the end of the list hold empty records (length 0: the lane that gets one idles)
+            if ((uint32_t)lane < take) {
+                if (at < cap && (uint32_t)lane < cap - at) dst[at + (uint32_t)lane] = 0ull;
+                to_scan(rec);
+            }
+            if (lane == 0) atomicAdd(a.ovf_count, 1u);
+        }
+        const uint32_t rem = ucnt[c] - take;
+        const unsigned long long x = (uint32_t)lane < rem ? s_u[wv][c][take + (uint32_t)lane] : 0ull;
+        wave_sync_lds();
+        if ((uint32_t)lane < rem) s_u[wv][c][lane] = x;
+        ucnt[c] = rem;
+        wave_sync_lds();
+    };
+    // (a repeat = tile << (25 + seat bits) | slot << (12 + seat bits) | tile position << seat bits | the table seat that names the piece whose
+    // ids it gets; seat bits = a.dd_seat_bits: what the tile number leaves of 39 bits)
+    const uint32_t sb = a.dd_seat_bits;
+    auto flush_dups = [&](const uint32_t take) {
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&a.coll_count[((uint32_t)DD_CTR + sub) * COLL_STRIDE], take);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        const unsigned long long ent = (uint32_t)lane < take ? db[lane] : 0ull;
+        if ((uint32_t)lane < take) {
+            if (at < a.dup_cap && (uint32_t)lane < a.dup_cap - at) a.dup_list[(size_t)sub * a.dup_cap + at + (uint32_t)lane] = ent;
+            else to_scan(((unsigned long long)(uint32_t)(ent >> (25u + sb)) << 32) | (((uint32_t)(ent >> (12u + sb)) & 0x1FFFu) << 19) | s_dv[wv][lane]);  // (no room: merged by the scan after all)
+        }
+        if (at > a.dup_cap || take > a.dup_cap - at) { if (lane == 0) atomicAdd(a.ovf_count, 1u); }
+        const uint32_t rem = dcnt - take;
+        const unsigned long long x = (uint32_t)lane < rem ? db[take + (uint32_t)lane] : 0ull;
+        const uint32_t xv = (uint32_t)lane < rem ? s_dv[wv][take + (uint32_t)lane] : 0u;
+        wave_sync_lds();
+        if ((uint32_t)lane < rem) { db[lane] = x; s_dv[wv][lane] = xv; }
+        dcnt = rem;
+        wave_sync_lds();
+    };
+    // the dense part: entries mb[head .. head + cnt) of `tile`, a lane each
+    auto process = [&](const uint32_t tile, const uint32_t head, const uint32_t cnt) {
+        const bool act = (uint32_t)lane < cnt;
+        const uint32_t e = act ? mb[head + (uint32_t)lane] : 0u;  // slot << 19 | tile position << 7 | length
+        const uint32_t len = e & 127u, pos = (e >> 7) & 0xFFFu;
+        const unsigned long long rec = ((unsigned long long)tile << 32) | e;
+        unsigned long long other = 0ull;
+        uint32_t seat = 0;
+        if (act && a.dedupe) {
+            const int64_t g = (int64_t)tile * K_TILE + pos;
+            // hash over the piece's dwords; its first 16 bytes stay in registers for the comparison
+            uint32_t w0[4];
+            dd_chunk(a.text, a.n, g, len, w0);
+            uint32_t h = 0x9747B28Cu ^ len;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h = dd_mix(h, w0[i]);
+            for (uint32_t c = 16u; c < len; c += 16u) {
+                uint32_t w[4];
+                dd_chunk(a.text, a.n, g + c, len - c, w);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h = dd_mix(h, w[i]);
+            }
+            h = dd_fmix(h);
+            const unsigned long long mine = rec | ((unsigned long long)(h >> 24) << 56);
+            uint32_t i = h & a.dd_mask;
+            for (int probe = 0; probe < 2; ++probe, i ^= 1u) {
+                // (a plain load first: the seats of frequent pieces are taken early and then only ever read, out of the CU's own cache;
+                // atomics on one address are served one after the other.  A stale zero only costs the compare-and-swap it leads to.)
+                unsigned long long cur = a.dd_table[i];
+                if (cur == 0ull) {
+                    cur = atomicCAS(&a.dd_table[i], 0ull, mine);
+                    if (cur == 0ull) break;  // the first piece with these bytes (as far as the table knows): merged, and named to the others
+                }
+                if ((cur >> 56) == (mine >> 56) && ((uint32_t)cur & 127u) == len) {
+                    const int64_t g2 = (int64_t)(uint32_t)((cur & DD_REC_MASK) >> 32) * K_TILE + (((uint32_t)cur >> 7) & 0xFFFu);
+                    uint32_t v0[4];
+                    dd_chunk(a.text, a.n, g2, len, v0);
+                    if (((w0[0] ^ v0[0]) | (w0[1] ^ v0[1]) | (w0[2] ^ v0[2]) | (w0[3] ^ v0[3])) == 0u && dd_same_from(a.text, a.n, g, g2, len, 16u)) {
+                        other = cur & DD_REC_MASK;
+                        seat = i;
+                        break;
+                    }
+                }
+            }
+        }
+        const bool dup = other != 0ull, uq = act && !dup;
+        const uint32_t cls = mq_class(len);
 #pragma unroll
         for (int c = 0; c < K_MISS_CLASSES; ++c) {
-            atc[c] = (uint32_t)__builtin_amdgcn_readlane((int)at, c);
-            dstc[c] = a.miss_list + a.coll_base[c] + (size_t)sub * a.coll_cap[c];
-        }
-        if (ovf) {
-            // the places this tile took before the end of a full list hold no records: empty ones (length 0: the lane that gets one idles)
-#pragma unroll
-            for (int c = 0; c < K_MISS_CLASSES; ++c)
-                if ((ovf >> c) & 1u)
-                    for (uint32_t k = atc[c] + lane; k < a.coll_cap[c] && k < atc[c] + n[c]; k += 64u) dstc[c][k] = 0ull;
-            if (lane == 0) {
-                a.tile_count[tile] = tc | (ovf << TILE_OVF_SHIFT);
-                atomicAdd(a.ovf_count, 1u);
+            const uint64_t b = __ballot(uq && cls == (uint32_t)c);
+            if (b) {
+                if (uq && cls == (uint32_t)c) s_u[wv][c][ucnt[c] + (uint32_t)__popcll((unsigned long long)(b & lt))] = rec;
+                ucnt[c] += (uint32_t)__popcll((unsigned long long)b);
             }
         }
-        // pass 2: the records (the tile's slots come from the L2 this time)
+        {
+            const uint64_t b = __ballot(dup);
+            if (b) {
+                if (dup) {
+                    const uint32_t at = dcnt + (uint32_t)__popcll((unsigned long long)(b & lt));
+                    db[at] = ((((unsigned long long)tile << 13 | (e >> 19)) << 12 | pos) << sb) | seat;
+                    s_dv[wv][at] = e & 0x7FFFFu;
+                }
+                dcnt += (uint32_t)__popcll((unsigned long long)b);
+            }
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int c = 0; c < K_MISS_CLASSES; ++c)
+            if (ucnt[c] >= 64u) flush(c, 64u);
+        if (dcnt >= 64u) flush_dups(64u);
+    };
+
+    for (int f = gw; f < n_flagged; f += nw) {
+        const uint32_t tile = a.flagged_list[f];
+        const uint32_t cnt = a.tile_count[tile] & TILE_COUNT_MASK;
+        const uint32_t* slots = a.stage + (size_t)tile * K_STAGE;
+        const uint32_t rows = (cnt + 63u) >> 6;
+        uint32_t tail = 0;
         for (uint32_t row = 0; row < rows; row += 8) {
             uint32_t v[8];
 #pragma unroll
@@ -2166,18 +2310,75 @@ __global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs 
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const bool miss = (v[r] & 0xC0000000u) == TOK_MISS;
-                if (!__ballot(miss)) continue;
-                const uint32_t cls = mq_class(v[r] & 127u);
-                const unsigned long long rec =
-                    ((unsigned long long)tile << 32) | ((((row + r) * 64u + lane) & 0x1FFFu) << 19) | (v[r] & 0x7FFFFu);
+                const uint64_t b = __ballot(miss);
+                if (miss) mb[tail + (uint32_t)__popcll((unsigned long long)(b & lt))] = ((((row + r) * 64u + lane) & 0x1FFFu) << 19) | (v[r] & 0x7FFFFu);
+                tail += (uint32_t)__popcll((unsigned long long)b);
+            }
+            wave_sync_lds();
+            uint32_t head = 0;
+            for (; tail - head >= 64u; head += 64u) process(tile, head, 64u);
+            if (head) {
+                const uint32_t rem = tail - head;
+                const uint32_t x = (uint32_t)lane < rem ? mb[head + (uint32_t)lane] : 0u;
+                wave_sync_lds();
+                if ((uint32_t)lane < rem) mb[lane] = x;
+                tail = rem;
+                wave_sync_lds();
+            }
+        }
+        if (tail) process(tile, 0u, tail);
+        wave_sync_lds();
+    }
 #pragma unroll
-                for (int c = 0; c < K_MISS_CLASSES; ++c) {
-                    const uint64_t b = __ballot(miss && cls == (uint32_t)c);
-                    if (b) {
-                        if (miss && cls == (uint32_t)c && !((ovf >> c) & 1u)) dstc[c][atc[c] + (uint32_t)__popcll((unsigned long long)(b & lt))] = rec;
-                        atc[c] += (uint32_t)__popcll((unsigned long long)b);
-                    }
+    for (int c = 0; c < K_MISS_CLASSES; ++c)
+        if (ucnt[c]) flush(c, ucnt[c]);
+    if (dcnt) flush_dups(dcnt);
+}
+
+// td_copy_dups (behind td_merge_pieces): a lane per repeat — the other piece's finished slot (its id count), its ids to this piece's
+// place in merge_out, this piece's slot, and the tile's extra ids with one atomic per tile of the wavefront's 64 repeats (they come
+// from two or three tiles).
+__global__ __launch_bounds__(K_THREADS) void td_copy_dups(const EncodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = (blockIdx.x * (uint32_t)K_THREADS + threadIdx.x) >> 6, nw = gridDim.x * (uint32_t)(K_THREADS / 64);
+    for (uint32_t sub = 0; sub < (uint32_t)COLL_SUBS; ++sub) {
+        const uint32_t c0 = a.coll_count[((uint32_t)DD_CTR + sub) * COLL_STRIDE];
+        const uint32_t cnt = c0 < a.dup_cap ? c0 : a.dup_cap;
+        for (uint32_t base = gw * 64u; base < cnt; base += nw * 64u) {
+            const uint32_t idx = base + (uint32_t)lane;
+            uint32_t tile = 0xFFFFFFFFu, extra = 0;
+            if (idx < cnt) {
+                const unsigned long long ent = a.dup_list[(size_t)sub * a.dup_cap + idx];
+                const uint32_t sb = a.dd_seat_bits;
+                tile = (uint32_t)(ent >> (25u + sb));
+                const uint32_t k = (uint32_t)(ent >> (12u + sb)) & 0x1FFFu, pos = (uint32_t)(ent >> sb) & 0xFFFu;
+                const unsigned long long other = a.dd_table[(uint32_t)ent & ((1u << sb) - 1u)] & DD_REC_MASK;
+                const uint32_t r_tile = (uint32_t)(other >> 32), r_k = ((uint32_t)other >> 19) & 0x1FFFu, r_pos = ((uint32_t)other >> 7) & 0xFFFu;
+                const uint32_t rs = a.stage[(size_t)r_tile * K_STAGE + r_k];
+                uint32_t nt = rs & 127u;
+                if ((rs & (0xC0000000u | TOK_MERGED)) != (TOK_MISS | TOK_MERGED) || nt == 0u) {
+                    raise(a, TD_E_HIP, (int64_t)tile * K_TILE + pos);  // (cannot happen: the other piece was on a list or marked for the scan)
+                    nt = 1u;
                 }
+                const uint32_t* const src = a.merge_out + (size_t)r_tile * K_STAGE + r_pos;
+                uint32_t* const mo = a.merge_out + (size_t)tile * K_STAGE + pos;
+                for (uint32_t i = 0; i < nt; i += 4u) {
+                    const uint32_t x0 = src[i], x1 = i + 1u < nt ? src[i + 1u] : 0u, x2 = i + 2u < nt ? src[i + 2u] : 0u, x3 = i + 3u < nt ? src[i + 3u] : 0u;
+                    mo[i] = x0;
+                    if (i + 1u < nt) mo[i + 1u] = x1;
+                    if (i + 2u < nt) mo[i + 2u] = x2;
+                    if (i + 3u < nt) mo[i + 3u] = x3;
+                }
+                a.stage[(size_t)tile * K_STAGE + k] = TOK_MISS | TOK_MERGED | (pos << 7) | nt;
+                extra = nt - 1u;
+            }
+            for (uint64_t pend = __ballot(extra != 0); pend;) {
+                const int l = td_ctz64(pend);
+                const uint32_t tl = (uint32_t)__shfl((int)tile, l);
+                const bool same = extra != 0 && tile == tl;
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(same ? extra : 0u, lane), 63);
+                if (lane == l) atomicAdd(&a.tile_extra[tl], tot);
+                pend &= ~__ballot(same);
             }
         }
     }
@@ -2335,7 +2536,7 @@ __global__ __launch_bounds__(MG_THREADS, TD_MERGE_MIN_WAVES) void td_merge_piece
                 }
                 const uint32_t k = o_row * 64u + (uint32_t)lane;
                 o_v = k < o_cnt ? a.stage[(size_t)o_tile * K_STAGE + k] : 0u;
-                o_pend = __ballot((o_v & (0xC0000000u | TOK_MERGED)) == TOK_MISS && ((o_mask >> mq_class(o_v & 127u)) & 1u));  // (not merged by a row meanwhile)
+                o_pend = __ballot((o_v & (0xC0000000u | TOK_MERGED | TOK_OVF)) == (TOK_MISS | TOK_OVF));  // (the slots whose records found no room)
                 continue;
             }
             const uint32_t rank = (uint32_t)__popcll((unsigned long long)(o_pend & lt));
@@ -3943,6 +4144,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         const int mblocks = wtiles < merge_grid_blocks() ? wtiles : merge_grid_blocks();
         hipLaunchKernelGGL(td_collect_misses, dim3(wtiles < 256 * 8 ? wtiles : 256 * 8), dim3(K_THREADS), 0, stream, a);
         hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(MG_THREADS), 0, stream, a);
+        if (a.dedupe) hipLaunchKernelGGL(td_copy_dups, dim3(wtiles < 256 * 4 ? wtiles : 256 * 4), dim3(K_THREADS), 0, stream, a);
     }
     if (ev) (void)hipEventRecord(ev[4], stream);
     if (tokens) {
