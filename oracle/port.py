@@ -87,6 +87,16 @@ class OracleTokenizer:
     def encode(self, data: bytes) -> np.ndarray:
         return self._enc(data, 0)
 
+    def merge_piece(self, piece: bytes) -> np.ndarray:
+        """byte_pair_encode of one piece as given (tiktoken.cpp:371-378): no split, no whole-piece lookup."""
+        out = np.empty(max(len(piece), 1), dtype=np.int32)
+        self._lib.tdo_merge_piece.restype = ctypes.c_int64
+        self._lib.tdo_merge_piece.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+        n = self._lib.tdo_merge_piece(self._h, piece, len(piece), out.ctypes.data, out.size)
+        if n < 0:
+            raise OracleError(self._lib.tdo_last_error().decode())
+        return out[:n].copy()
+
     def encode_ordinary(self, data: bytes) -> np.ndarray:
         return self._enc(data, 1)
 

@@ -527,6 +527,23 @@ int64_t tdo_encode(void* h, const uint8_t* text, int64_t n, int32_t* out, int64_
     return k;
 }
 
+/* byte_pair_encode (tiktoken.cpp:371-378) of ONE piece as given: no split, no whole-piece lookup; the reference's quadratic loop.
+ * (tests/test_char_seeds.py: the merge of a piece from seeded parts against the merge from its bytes.)  -> ids or < 0 */
+int64_t tdo_merge_piece(void* h, const uint8_t* piece, int64_t len, int32_t* out, int64_t cap) {
+    const tdo_t* t = (const tdo_t*)h;
+    int64_t k = 0;
+    if (len <= 0) return 0;
+    if (len == 1) {
+        int32_t r = lookup(t, piece, 1);
+        if (r == INT_MAX) { snprintf(g_err, sizeof g_err, "byte 0x%02x is not in the vocabulary", piece[0]); return -1; }
+        if (cap < 1) return -2;
+        out[0] = r;
+        return 1;
+    }
+    int rc = tdo_merge(t, piece, len, out, &k, cap);
+    return rc < 0 ? rc : k;
+}
+
 /* tiktoken.cpp:236-255 (regular tokens only; specials are looked up by the caller's table) */
 int64_t tdo_decode(void* h, const int32_t* toks, int64_t n, uint8_t* out, int64_t cap) {
     const tdo_t* t = (const tdo_t*)h;

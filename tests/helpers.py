@@ -163,6 +163,19 @@ def rx_split(pattern: str, data: bytes):
 class Twin:
     """CPU twin of the device algorithm (tests/twin/td_twin.cpp)."""
 
+    def seeded_merge(self, pieces: list[bytes]):
+        """-> (list of id arrays, characters entered whole, parts at the start): the pieces merged from their seeded parts
+        (td_common.h: character seeds), as td_long_pieces sets them up."""
+        blob, offs = pack_docs(pieces)
+        cap = len(blob) + 1
+        ids = np.empty(cap, dtype=np.int32)
+        io = np.empty(len(pieces) + 1, dtype=np.int64)
+        st = np.zeros(2, dtype=np.int64)
+        n = self._lib.twin_seeded_merge(self._h, blob, offs.ctypes.data, len(pieces), ids.ctypes.data, cap, io.ctypes.data, st.ctypes.data)
+        if n < 0:
+            raise RuntimeError(f"twin_seeded_merge: bookkeeping check {n} failed")
+        return [ids[io[i]:io[i + 1]] for i in range(len(pieces))], int(st[0]), int(st[1])
+
     def __init__(self, pat_str: str, mergeable_ranks: dict[bytes, int], special: dict[str, int] | None = None):
         build_twin()
         lib = ctypes.CDLL(str(TWIN_SO))
@@ -190,6 +203,9 @@ class Twin:
         lib.twin_encode.restype = ctypes.c_int64
         lib.twin_encode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        lib.twin_seeded_merge.restype = ctypes.c_int64
+        lib.twin_seeded_merge.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                          ctypes.c_void_p, ctypes.c_void_p]
         self._lib = lib
         special = special or {}
         b, o, r = pack_vocab(mergeable_ranks)

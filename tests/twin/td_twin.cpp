@@ -115,8 +115,64 @@ int64_t twin_info(void* h, int what) {
         case 3: return t->H.max_id;
         case 4: return t->H.piece_mask + 1;
         case 5: return t->H.pair_mask + 1;
+        case 6: return t->H.n_char_seeds;
     }
     return -1;
+}
+
+// Character seeds (td_common.h): the pieces pieces[offs[i] .. offs[i+1]) merged from the SEEDED parts — cseed_part_at at every byte, as
+// td_long_pieces' set-up asks it, then the reference's loop (lowest rank, leftmost; tiktoken.cpp:322-343) over those parts through the
+// pair table.  ids_out / id_offs as usual; stats2 = [characters entered whole, parts at the start summed over the pieces].
+// Also checks the set-up's own bookkeeping: the part in front of every part start, found the way the kernel finds it.  -> ids or -1.
+int64_t twin_seeded_merge(void* h, const uint8_t* pieces, const int64_t* offs, int64_t n_pieces, int32_t* ids_out, int64_t cap,
+                          int64_t* id_offs, int64_t* stats2) {
+    Twin* t = (Twin*)h;
+    const Tables T = t->H.view();
+    int64_t n_out = 0, seeded = 0, parts0 = 0;
+    std::vector<uint32_t> ids, start;
+    for (int64_t i = 0; i < n_pieces; ++i) {
+        const uint8_t* p = pieces + offs[i];
+        const uint32_t len = (uint32_t)(offs[i + 1] - offs[i]);
+        auto get = [p](uint32_t k) { return (uint32_t)p[k]; };
+        ids.clear(); start.clear();
+        uint32_t expect = 0;  // next part start when walking parts left to right
+        for (uint32_t q = 0; q < len; ++q) {
+            const SeedPart sp = cseed_part_at(T, get, len, q);
+            if (sp.kind == 0u) {
+                if (q >= expect || sp.back == 0u || start.empty() || start.back() != q - sp.back) return -2;  // the inside of a character that was not seen to start
+                continue;
+            }
+            if (q != expect) return -3;  // a part starts inside another one
+            if (q) {  // the kernel's way to the part in front
+                const SeedPart pp = cseed_part_at(T, get, len, q - 1u);
+                if (start.empty() || q - 1u - pp.back != start.back()) return -4;
+            }
+            start.push_back(q);
+            ids.push_back(sp.kind == 2u ? sp.id : (uint32_t)T.byte_id[p[q]]);
+            seeded += sp.kind == 2u;
+            expect = q + sp.k;
+        }
+        if (expect != len) return -5;
+        parts0 += (int64_t)ids.size();
+        for (;;) {
+            int32_t best = NO_RANK; size_t bi = 0;
+            for (size_t k = 0; k + 1 < ids.size(); ++k) {
+                const int32_t r = pair_lookup(T, ids[k], ids[k + 1]);
+                if (r < best) { best = r; bi = k; }
+            }
+            if (best == NO_RANK) break;
+            ids[bi] = (uint32_t)best;
+            ids.erase(ids.begin() + (long)bi + 1);
+        }
+        id_offs[i] = n_out;
+        for (uint32_t v : ids) {
+            if (n_out >= cap) return -1;
+            ids_out[n_out++] = (int32_t)v;
+        }
+    }
+    id_offs[n_pieces] = n_out;
+    stats2[0] = seeded; stats2[1] = parts0;
+    return n_out;
 }
 
 // The pair table as the DEVICE's merge rounds probe it (mg_round_t, td_common.h): the first seat; the second one only where the first

@@ -731,6 +731,12 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if ((rc = upload(t, H.pair_slots.data(), H.pair_slots.size(), &d.pair_slots))) return fail(rc);
     if ((rc = upload(t, H.tok_off.data(), H.tok_off.size(), &d.tok_off))) return fail(rc);
     if ((rc = upload(t, H.tok_bytes.data(), H.tok_bytes.size(), &d.tok_bytes))) return fail(rc);
+    d.cseed = nullptr; d.cseed_pm = nullptr; d.cseed_nm = nullptr;
+    if (!H.cseed.empty()) {  // characters that enter the merge loop whole (td_common.h: character seeds)
+        if ((rc = upload(t, H.cseed.data(), H.cseed.size(), &d.cseed))) return fail(rc);
+        if ((rc = upload(t, H.cseed_pm.data(), H.cseed_pm.size(), &d.cseed_pm))) return fail(rc);
+        if ((rc = upload(t, H.cseed_nm.data(), H.cseed_nm.size(), &d.cseed_nm))) return fail(rc);
+    }
     if (H.pattern_kind == PATTERN_GENERIC) {
         size_t n1 = 0, n2 = 0;
         const uint16_t* s1 = rx_stage1(&n1);

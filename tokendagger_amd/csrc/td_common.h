@@ -115,6 +115,10 @@ struct Tables {
     uint32_t max_token_len;
     uint32_t piece12_mask;
     uint32_t pat_flags;           // PV_* bits: which member of the split-pattern family the scanners implement
+    // character seeds (round 5, below): null = none
+    const uint64_t* cseed;        // [65536] by code point (characters of 2 and 3 bytes): CS_VALID | row of cseed_nm << 29 | row of cseed_pm << 21 | id
+    const uint32_t* cseed_pm;     // [rows][8] 256-bit sets: a byte that must not stand in FRONT of the character for it to be seeded
+    const uint32_t* cseed_nm;     // [rows][8] ... BEHIND it
 };
 
 // The split patterns the scanners implement are one family: the Llama-4 / o200k pattern (reference src/main.cpp:114)
@@ -199,6 +203,83 @@ TD_HD int32_t pair_lookup(const Tables& T, uint32_t left, uint32_t right) {
     const uint64_t e1 = T.pair_slots[hash_pair(left, right) & T.pair_mask];
     const uint64_t e2 = T.pair_slots[hash_pair2(left, right) & T.pair_mask];
     return pair_match(e1, e2, left, right);
+}
+
+// ------------------------------------------------------------------ character seeds (round 5) ----
+// The merge loop (bpe_merge, tiktoken.cpp:298-368) starts from single bytes: a CJK sentence of 27 characters is 81 parts and ~75
+// rounds, most of which only put the characters together.  A multi-byte character c whose bytes merge to ONE token C may be entered
+// as the single part C when that provably changes nothing.  Conditions (td_tables.cpp: build_char_seeds checks 1, 3, 4 per vocabulary;
+// 2 is checked per occurrence, here):
+//   1. the merge loop on c's bytes alone ends with [C];
+//   2. no token of the vocabulary OCCURS in the piece overlapping c partially (some of c's bytes and at least one byte outside): such
+//      a token ends with a proper prefix of c preceded by the byte in front of c, or starts with a proper suffix of c followed by the
+//      byte behind c — per character two 256-bit sets of bytes that must not stand in front of / behind it (exact in the adjacent
+//      byte, conservative beyond it);
+//   3. every pair of the pair table with C as its left or right part ranks ABOVE every merge inside c (rho(c) = the highest rank
+//      among the merges of 1.; in a vocabulary that BPE training produced, rank(C) itself);
+//   4. C's id is its rank (a regular token).
+// Why that is exact.  Every part the loop ever holds is a token (or a byte) that occurs in the piece where the part stands.  By 2. no
+// part covers c partially, so until c is complete its bytes merge only among themselves, in the order of 1., whatever happens around
+// them, and the loop cannot end before c is complete.  Let R be the reference's run on bytes and S the run with every seeded character
+// entered whole.  Claim: R's merges that are not inside an incomplete seeded character are S's merges, in S's order.  Induction: let e
+// be S's next merge (lowest rank, leftmost).  R's ranked pairs outside incomplete characters are a subset of S's (pairs between a part
+// and a piece of an incomplete character have no rank by 2.), so none of them ranks below e or ties left of it.  If e's parts exist
+// in R, R merges e next, possibly after merges inside incomplete characters; a character C' they complete only adds pairs S had
+// all along.  If e involves a character C that R has not completed, e is C's first merge in S, so rank(e) > rho(c) by 3., i.e. above
+// every pending merge inside c: R, which takes the globally lowest rank, completes c (and nothing ranked >= rank(e) elsewhere) first,
+// and then is in the first case.  When S ends, R has only merges inside characters left.  Same parts at the end.
+// tests/test_char_seeds.py: the CPU twin's seeded merge against the reference's loop on a few hundred thousand pieces of all scripts.
+constexpr uint64_t CS_VALID = 1ull << 63;
+// Does a seeded character start at byte q of the piece get(0..len)?  -> its length in k, its id in id.
+template <class Get>
+TD_HD bool cseed_char_at(const Tables& T, Get get, uint32_t len, uint32_t q, uint32_t& k, uint32_t& id) {
+    const uint32_t b0 = get(q);
+    if (b0 < 0xC2u || b0 >= 0xF0u) return false;
+    k = b0 < 0xE0u ? 2u : 3u;
+    if (q + k > len) return false;
+    const uint32_t b1 = get(q + 1u);
+    if ((b1 & 0xC0u) != 0x80u) return false;
+    uint32_t cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
+    if (k == 3u) {
+        const uint32_t b2 = get(q + 2u);
+        if ((b2 & 0xC0u) != 0x80u) return false;
+        cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+        if (cp < 0x800u) return false;  // (an overlong form is not the character's bytes)
+    }
+    const uint64_t e = T.cseed[cp];
+    if (!(e & CS_VALID)) return false;
+    if (q > 0u) {
+        const uint32_t pb = get(q - 1u);
+        if ((T.cseed_pm[(uint32_t)((e >> 21) & 0xFFu) * 8u + (pb >> 5)] >> (pb & 31u)) & 1u) return false;
+    }
+    if (q + k < len) {
+        const uint32_t nb = get(q + k);
+        if ((T.cseed_nm[(uint32_t)((e >> 29) & 0xFFu) * 8u + (nb >> 5)] >> (nb & 31u)) & 1u) return false;
+    }
+    id = (uint32_t)e & 0x1FFFFFu;
+    return true;
+}
+// What stands at byte q: kind 0 = inside a seeded character (no part starts here), 1 = a single byte is a part, 2 = a seeded
+// character of k bytes with id `id` starts here.  back = bytes from q back to the start of the part that holds q (kind 0) or 0.
+struct SeedPart { uint32_t kind, k, id, back; };
+template <class Get>
+TD_HD SeedPart cseed_part_at(const Tables& T, Get get, uint32_t len, uint32_t q) {
+    SeedPart sp{1u, 1u, 0u, 0u};
+    if (!T.cseed) return sp;
+    const uint32_t b = get(q);
+    if (b >= 0xC2u) {
+        uint32_t k = 0, id = 0;
+        if (cseed_char_at(T, get, len, q, k, id)) { sp.kind = 2u; sp.k = k; sp.id = id; }
+    } else if ((b & 0xC0u) == 0x80u) {
+        for (uint32_t d = 1; d <= 2u && d <= q; ++d) {
+            const uint32_t lb = get(q - d);
+            if ((lb & 0xC0u) == 0x80u) continue;  // (another continuation byte: the lead may be one further back)
+            uint32_t k = 0, id = 0;
+            if (lb >= 0xC2u && cseed_char_at(T, get, len, q - d, k, id) && k > d) { sp.kind = 0u; sp.back = d; }
+            break;
+        }
+    }
+    return sp;
 }
 
 // piece bytes -> rank, NO_RANK if the piece is not a token.  `get(i)` returns byte i of the piece.

@@ -101,6 +101,9 @@ __device__ __forceinline__ Tables uniform_tables(const Tables* p) {
     t.piece12_slots = uni_ptr(p->piece12_slots);
     t.tok_off = uni_ptr(p->tok_off);
     t.tok_bytes = uni_ptr(p->tok_bytes);
+    t.cseed = uni_ptr(p->cseed);
+    t.cseed_pm = uni_ptr(p->cseed_pm);
+    t.cseed_nm = uni_ptr(p->cseed_nm);
     t.piece_mask = uni32(p->piece_mask);
     t.pair_mask = uni32(p->pair_mask);
     t.max_id = (int32_t)uni32((uint32_t)p->max_id);
@@ -416,7 +419,7 @@ __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const 
 }
 
 // ---- (used by td_merge_pieces and, for the few missed pieces of a tile it places itself, by the fused tile loop) ----
-// 17 text bytes at global offset g as five dwords (byte k = bits 8(k&3).. of w[k>>2]); zero past the end of the text
+// 20 text bytes at global offset g as five dwords (byte k = bits 8(k&3).. of w[k>>2]); zero past the end of the text
 typedef uint32_t U32x4a __attribute__((ext_vector_type(4), aligned(4)));  // (a 16-byte global load needs dword alignment only)
 typedef uint32_t U32x2a __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ void load_piece_window(const uint8_t* text, int64_t n_text, int64_t g, uint32_t (&w)[5]) {
@@ -433,7 +436,7 @@ __device__ __forceinline__ void load_piece_window(const uint8_t* text, int64_t n
         w[3] = __funnelshift_r(a.w, b.x, sh); w[4] = __funnelshift_r(b.x, b.y, sh);
     } else {
         for (int k = 0; k < 5; ++k) w[k] = 0;
-        for (int k = 0; k < 17; ++k)
+        for (int k = 0; k < 20; ++k)  // (all twenty bytes, as the fast path has them: lp_seed_setup reads bytes 17..19 too)
             if (g + k >= 0 && g + k < n_text) w[k >> 2] |= (uint32_t)text[g + k] << (8 * (k & 3));
     }
 }
@@ -2656,14 +2659,139 @@ __device__ __forceinline__ void lp_do_piece(const EncodeArgs& a, const Tables& T
     }
 }
 
+// Set-up of a linked piece with character seeds (td_common.h): a lane takes 16 CONSECUTIVE bytes and every step is a batch of
+// independent loads, because a first form — every position asking cseed_part_at about itself, the part in front of it and the part
+// behind it, one dependent load after the other — cost more than the rounds the seeds save (td_long_pieces 0.94 -> 1.13 ms per 256 MiB
+// of mixed-script text).  Pass 1: is a seeded character starting at each of my bytes?  (the table entries of all sixteen, then their two
+// neighbour-byte words, then the verdicts: to rk[], with the byte's own id in id[]).  Pass 2, behind a fence: what stands in front of
+// and behind each of my part starts, read from the verdicts (all reads into registers, another fence), then the pair ranks of all my
+// parts as one batch of lookups, then the writes.  Returns the number of parts.  (= cseed_part_at at every byte; tests/test_char_seeds.py
+// holds that function to the reference's loop, the GPU parity tests hold this one to the reference.)
+constexpr int LP_TINY = 128;      // eight lanes per piece up to here
+constexpr int LP_LINKED = 255;    // sixteen lanes per piece up to here (links are bytes)
+constexpr uint32_t LP_END = 255;  // "no neighbour" in the link arrays
+constexpr uint32_t LPS_SEEDED = 0x80000000u;  // verdict: a seeded character starts here | its length << 21 | its id
+template <int G>
+__device__ __forceinline__ uint32_t lp_seed_setup(const EncodeArgs& a, const Tables& T, int64_t gs, uint32_t len, uint32_t* id, uint32_t* rk,
+                                                  uint8_t* nx, uint8_t* pv, int gl) {
+    const uint32_t c = (uint32_t)gl * 16u;
+    uint32_t w[5];
+    load_piece_window(a.text, a.n, gs + (int64_t)c - 1, w);  // bytes c - 1 .. c + 18 of the piece (what lies outside the piece is never looked at)
+#define LPS_W(i) ((w[(i) >> 2] >> (8 * ((i) & 3))) & 0xFFu)  /* byte c - 1 + i */
+    uint32_t dec[16], bid[16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // (eight bytes at a time: the batches' registers)
+        uint64_t e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int jj = 8 * h + u;
+            const uint32_t q = c + jj, b0 = LPS_W(jj + 1), b1 = LPS_W(jj + 2), b2 = LPS_W(jj + 3);
+            const uint32_t k = b0 < 0xE0u ? 2u : 3u;
+            uint32_t cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
+            bool ok = q < len && b0 >= 0xC2u && b0 < 0xF0u && q + k <= len && (b1 & 0xC0u) == 0x80u;
+            if (k == 3u) {
+                cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+                ok = ok && (b2 & 0xC0u) == 0x80u && cp >= 0x800u;
+            }
+            e[u] = ok ? T.cseed[cp] : 0ull;
+            bid[jj] = q < len ? (uint32_t)T.byte_id[b0] : 0u;
+        }
+        uint32_t pmw[8], nmw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int jj = 8 * h + u;
+            const uint32_t q = c + jj, k = LPS_W(jj + 1) < 0xE0u ? 2u : 3u;
+            const uint32_t pb = LPS_W(jj), nb = k == 2u ? LPS_W(jj + 3) : LPS_W(jj + 4);
+            const bool v = (e[u] & CS_VALID) != 0ull;
+            pmw[u] = (v && q > 0u) ? T.cseed_pm[(uint32_t)((e[u] >> 21) & 0xFFu) * 8u + (pb >> 5)] : 0u;
+            nmw[u] = (v && q + k < len) ? T.cseed_nm[(uint32_t)((e[u] >> 29) & 0xFFu) * 8u + (nb >> 5)] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int jj = 8 * h + u;
+            const uint32_t q = c + jj, k = LPS_W(jj + 1) < 0xE0u ? 2u : 3u;
+            const uint32_t pb = LPS_W(jj), nb = k == 2u ? LPS_W(jj + 3) : LPS_W(jj + 4);
+            const bool v = (e[u] & CS_VALID) != 0ull && !(((pmw[u] >> (pb & 31u)) | (nmw[u] >> (nb & 31u))) & 1u);
+            dec[jj] = v ? (LPS_SEEDED | (k << 21) | ((uint32_t)e[u] & 0x1FFFFFu)) : 0u;
+            if (q < len) { rk[q] = dec[jj]; id[q] = bid[jj]; }
+        }
+    }
+    wave_sync_lds();
+    // pass 2: my part starts, the parts behind and in front of them
+    uint32_t my_id[16], nid[16], meta[16];  // meta: next part start | previous part start << 8 | 1 << 16 (a part starts here) | 1 << 17 (both parts single bytes)
+    uint32_t starts = 0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const uint32_t q = c + jj;
+        my_id[jj] = 0; nid[jj] = 0; meta[jj] = 0;
+        if (q < len) {
+            const uint32_t dm1 = jj >= 1 ? dec[jj >= 1 ? jj - 1 : 0] : (q >= 1u ? rk[q - 1u] : 0u);
+            const uint32_t dm2 = jj >= 2 ? dec[jj >= 2 ? jj - 2 : 0] : (q >= 2u ? rk[q - 2u] : 0u);
+            const uint32_t dm3 = jj >= 3 ? dec[jj >= 3 ? jj - 3 : 0] : (q >= 3u ? rk[q - 3u] : 0u);
+            const bool inside = (dm1 & LPS_SEEDED) || ((dm2 & LPS_SEEDED) && ((dm2 >> 21) & 3u) == 3u);
+            if (!inside) {
+                const uint32_t d0 = dec[jj];
+                const uint32_t k0 = (d0 & LPS_SEEDED) ? ((d0 >> 21) & 3u) : 1u;
+                const uint32_t nq = q + k0;
+                uint32_t dn = 0, nb_id = 0;
+                if (nq < len) { dn = rk[nq]; nb_id = id[nq]; }
+                my_id[jj] = (d0 & LPS_SEEDED) ? (d0 & 0x1FFFFFu) : bid[jj];
+                nid[jj] = (dn & LPS_SEEDED) ? (dn & 0x1FFFFFu) : nb_id;
+                // the part in front: the byte in front, or the seeded character it is the inside of
+                const uint32_t pq = q == 0u ? LP_END : (dm2 & LPS_SEEDED) ? q - 2u : ((dm3 & LPS_SEEDED) && ((dm3 >> 21) & 3u) == 3u) ? q - 3u : q - 1u;
+                meta[jj] = (nq < len ? nq : LP_END) | (pq << 8) | (1u << 16) | ((!(d0 & LPS_SEEDED) && !(dn & LPS_SEEDED)) ? (1u << 17) : 0u);
+                ++starts;
+            }
+        }
+    }
+    wave_sync_lds();  // (every lane has read the verdicts: rk[] and id[] take their final contents now)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        uint64_t e1[4], e2[4];
+        uint32_t bp[4];
+        typedef const uint64_t __attribute__((address_space(1)))* gpair_t;
+        gpair_t const ps = (gpair_t)(uintptr_t)T.pair_slots;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = 4 * h + u;
+            const bool st = (meta[jj] >> 16) & 1u, has_next = (meta[jj] & 0xFFu) != LP_END, plain = (meta[jj] >> 17) & 1u;
+            e1[u] = PAIR_EMPTY; e2[u] = PAIR_EMPTY; bp[u] = (uint32_t)NO_RANK;
+            if (st && has_next) {
+                if (plain) bp[u] = (uint32_t)T.byte_pair[(LPS_W(jj + 1) << 8) | LPS_W(jj + 2)];
+                else { e1[u] = ps[hash_pair(my_id[jj], nid[jj]) & T.pair_mask]; e2[u] = ps[hash_pair2(my_id[jj], nid[jj]) & T.pair_mask]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = 4 * h + u;
+            const uint32_t q = c + jj;
+            if (q < len) {
+                const bool st = (meta[jj] >> 16) & 1u, plain = (meta[jj] >> 17) & 1u;
+                if (st) {
+                    id[q] = my_id[jj];
+                    rk[q] = plain ? bp[u] : (uint32_t)pair_match(e1[u], e2[u], my_id[jj], nid[jj]);
+                    nx[q] = (uint8_t)(meta[jj] & 0xFFu);
+                    pv[q] = (uint8_t)((meta[jj] >> 8) & 0xFFu);
+                } else {
+                    id[q] = TOK_NONE;
+                    rk[q] = (uint32_t)NO_RANK;
+                    nx[q] = (uint8_t)LP_END;
+                    pv[q] = (uint8_t)LP_END;
+                }
+            }
+        }
+    }
+#undef LPS_W
+#pragma unroll
+    for (int d = G / 2; d >= 1; d >>= 1) starts += (uint32_t)__shfl_xor((int)starts, d, G);
+    return starts;
+}
+
 // Pieces of 65..LP_TINY bytes (the bulk of the long pieces: comment rulers, CJK sentences): eight lanes per piece,
 // eight pieces per wavefront, parts as a doubly linked list in LDS — a merge touches a handful of entries instead of
 // shifting the tail, so a round is: strided min over the rank array (dead parts carry NO_RANK), 3-step shuffle reduce,
 // relink, two pair-table probes (one lane each).  The rounds are bound by the probe latency; pieces in flight per
 // wavefront are what buys throughput.
-constexpr int LP_TINY = 128;      // eight lanes per piece up to here
-constexpr int LP_LINKED = 255;    // sixteen lanes per piece up to here (links are bytes)
-constexpr uint32_t LP_END = 255;  // "no neighbour" in the link arrays
 template <int G>
 __device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Tables& T, uint32_t j, volatile uint32_t* vid,
                                                    volatile uint32_t* vrk, volatile uint8_t* vnx, volatile uint8_t* vpv, int grp, int gl) {
@@ -2689,6 +2817,19 @@ __device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Ta
         m = 1;
         if (gl == 0) { id[0] = (uint32_t)whole; nx[0] = (uint8_t)LP_END; }
     } else {
+        // Round 5: characters that may be entered whole (td_common.h: character seeds) are ONE part from the start — a CJK sentence
+        // of 27 characters begins with ~30 parts instead of 81.  Every position settles by itself what stands there (a byte, a seeded
+        // character, the inside of one), what part stands in front of it and what part follows: the answers depend on the piece's
+        // bytes only, so the lanes agree without talking.  Pieces without a byte above 0xC1 take the plain set-up.
+        bool multi = false;
+        if (T.cseed) {
+            bool mine = false;
+            for (uint32_t q = gl; q < len; q += G) mine = mine || p[q] >= 0xC2u;
+            multi = (((uint32_t)(__ballot(mine) >> (grp * G))) & ((1u << G) - 1u)) != 0u;
+        }
+        if (multi) {
+            m = lp_seed_setup<G>(a, T, gs, len, id, rk, nx, pv, gl);
+        } else
         for (uint32_t q = gl; q < len; q += G) {
             const uint32_t b = p[q];
             id[q] = (uint32_t)T.byte_id[b];
@@ -2854,7 +2995,7 @@ __device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Ta
 
 constexpr int LP_WAVE_WORDS = 8 * (2 * LP_TINY + 2 * LP_TINY / 4);  // LDS words per wavefront: 8 pieces x (ids, ranks, links)
 static_assert(LP_WAVE_WORDS >= 2 * LP_MEDIUM, "the wavefront-per-piece pass reuses the same LDS");
-__global__ __launch_bounds__(256) void td_long_pieces(const EncodeArgs a) {
+__global__ __launch_bounds__(256, 4) void td_long_pieces(const EncodeArgs a) {  // (four wavefronts per SIMD is what the LDS allows: the registers must not allow less)
     __shared__ uint32_t s_parts[4][LP_WAVE_WORDS];  // per wavefront: ids | ranks (| links)
     const Tables T = uniform_tables(a.Tp);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 
 #include "generated/unicode_classes.inc"
 
@@ -97,6 +98,9 @@ Tables HostTables::view() const {
     T.max_id = max_id;
     T.pseudo_base = pseudo_base;
     T.max_token_len = max_token_len;
+    T.cseed = cseed.empty() ? nullptr : cseed.data();
+    T.cseed_pm = cseed_pm.empty() ? nullptr : cseed_pm.data();
+    T.cseed_nm = cseed_nm.empty() ? nullptr : cseed_nm.data();
     return T;
 }
 
@@ -129,6 +133,128 @@ int merge_piece_host(const Tables& T, const uint8_t* piece, uint32_t n, std::vec
         out.push_back(v);
     }
     return TD_OK;
+}
+
+// Character seeds (td_common.h: "character seeds"): which characters of 2 and 3 bytes may be entered into the merge loop as one
+// part, and the bytes that must not stand next to them.  Conditions 1, 3 and 4 of the comment there are settled here per character,
+// condition 2 becomes two 256-bit sets per character: pm = the bytes in front of c with which some token ends in a proper prefix of
+// c, nm = the bytes behind c with which some token starts with a proper suffix of c.  TD_CHAR_SEEDS=0 in the environment: none.
+namespace {
+struct Bits256 {
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void set(uint32_t b) { w[b >> 5] |= 1u << (b & 31); }
+    void join(const Bits256& o) { for (int i = 0; i < 8; ++i) w[i] |= o.w[i]; }
+    bool operator<(const Bits256& o) const { return memcmp(w, o.w, sizeof w) < 0; }
+};
+uint32_t key_of(const uint8_t* p, uint32_t n) {  // up to three bytes and their number
+    uint32_t k = n;
+    for (uint32_t i = 0; i < n; ++i) k = (k << 8) | p[i];
+    return k;
+}
+}  // namespace
+static void build_char_seeds(HostTables& H, int64_t n_vocab, const uint8_t* token_bytes, const int64_t* token_offsets, const int32_t* ranks,
+                             const std::vector<std::pair<uint64_t, uint32_t>>& pairs) {
+    H.cseed.clear(); H.cseed_pm.clear(); H.cseed_nm.clear(); H.n_char_seeds = 0;
+    if (const char* e = getenv("TD_CHAR_SEEDS")) if (atoi(e) == 0) return;
+    const Tables T = H.view();
+    // candidates: the tokens that are one character of 2 or 3 bytes in its shortest form, whose bytes merge to exactly that token (1.)
+    // and whose id is the rank (4.: always so for the regular vocabulary); rho = the highest rank among those merges
+    struct Cand { uint32_t cp, k, id, rho; uint8_t b[3]; bool ok; };
+    std::vector<Cand> cands;
+    std::vector<int32_t> cand_of((size_t)H.max_id + 1, -1);
+    for (int64_t v = 0; v < n_vocab; ++v) {
+        const uint8_t* p = token_bytes + token_offsets[v];
+        const uint32_t len = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
+        if (len != 2 && len != 3) continue;
+        uint32_t cp;
+        if (len == 2) {
+            if (p[0] < 0xC2 || p[0] >= 0xE0 || (p[1] & 0xC0) != 0x80) continue;
+            cp = ((p[0] & 0x1Fu) << 6) | (p[1] & 0x3Fu);
+        } else {
+            if (p[0] < 0xE0 || p[0] >= 0xF0 || (p[1] & 0xC0) != 0x80 || (p[2] & 0xC0) != 0x80) continue;
+            cp = ((p[0] & 0x0Fu) << 12) | ((p[1] & 0x3Fu) << 6) | (p[2] & 0x3Fu);
+            if (cp < 0x800) continue;
+        }
+        if ((uint32_t)ranks[v] >= (1u << 21)) continue;
+        // the merge loop on the character's bytes (tiktoken.cpp:322-343): lowest rank, leftmost
+        uint32_t part[3], np = len, rho = 0;
+        bool fail = false;
+        for (uint32_t i = 0; i < len; ++i) part[i] = (uint32_t)H.byte_id[p[i]];
+        while (np > 1) {
+            int32_t best = NO_RANK; uint32_t bi = 0;
+            for (uint32_t i = 0; i + 1 < np; ++i) {
+                const int32_t r = pair_lookup(T, part[i], part[i + 1]);
+                if (r < best) { best = r; bi = i; }
+            }
+            if (best == NO_RANK) { fail = true; break; }
+            rho = std::max<uint32_t>(rho, (uint32_t)best);
+            part[bi] = (uint32_t)best;
+            for (uint32_t i = bi + 1; i + 1 < np; ++i) part[i] = part[i + 1];
+            --np;
+        }
+        if (fail || part[0] != (uint32_t)ranks[v]) continue;
+        Cand c{cp, len, (uint32_t)ranks[v], rho, {p[0], p[1], len == 3 ? p[2] : (uint8_t)0}, true};
+        cand_of[ranks[v]] = (int32_t)cands.size();
+        cands.push_back(c);
+    }
+    if (cands.empty()) return;
+    // 3.: a pair with the character as one of its parts must rank above every merge inside the character
+    for (const auto& pr : pairs) {
+        const uint32_t l = (uint32_t)(pr.first >> ID_BITS), r = (uint32_t)(pr.first & ((1u << ID_BITS) - 1));
+        if (l <= (uint32_t)H.max_id && cand_of[l] >= 0 && pr.second <= cands[cand_of[l]].rho) cands[cand_of[l]].ok = false;
+        if (r <= (uint32_t)H.max_id && cand_of[r] >= 0 && pr.second <= cands[cand_of[r]].rho) cands[cand_of[r]].ok = false;
+    }
+    // 2.: every token that ends in a proper prefix of some character (a lead byte and up to two continuation bytes short of the
+    // character's length) with at least one byte in front of it, and every token that starts with continuation bytes followed by at
+    // least one more byte (proper suffixes of characters: every prefix of the run of continuation bytes counts)
+    std::map<uint32_t, Bits256> tails, heads;
+    for (int64_t v = 0; v < n_vocab; ++v) {
+        const uint8_t* p = token_bytes + token_offsets[v];
+        const uint32_t len = (uint32_t)(token_offsets[v + 1] - token_offsets[v]);
+        if (len < 2) continue;
+        {   // tail: ... x | lead cont*   (shorter than the lead's character)
+            uint32_t i = len - 1, nc = 0;
+            while (i > 0 && (p[i] & 0xC0) == 0x80 && nc < 3) { --i; ++nc; }
+            const uint32_t lead = p[i];
+            const uint32_t need = lead >= 0xC2 && lead < 0xE0 ? 2u : lead >= 0xE0 && lead < 0xF0 ? 3u : lead >= 0xF0 && lead < 0xF8 ? 4u : 0u;
+            if (need && nc + 1 < need && i > 0 && need <= 3) tails[key_of(p + i, nc + 1)].set(p[i - 1]);
+        }
+        {   // heads: cont{j} y ...
+            uint32_t j = 0;
+            while (j < len && j < 3 && (p[j] & 0xC0) == 0x80) ++j;
+            for (uint32_t jj = 1; jj <= j && jj < len; ++jj)
+                if (jj <= 2) heads[key_of(p, jj)].set(p[jj]);
+        }
+    }
+    std::map<Bits256, uint32_t> pm_rows, nm_rows;
+    auto row_of = [](std::map<Bits256, uint32_t>& rows, std::vector<uint32_t>& store, const Bits256& b) -> int {
+        auto it = rows.find(b);
+        if (it != rows.end()) return (int)it->second;
+        if (rows.size() >= 256) return -1;
+        const uint32_t r = (uint32_t)rows.size();
+        rows.emplace(b, r);
+        store.insert(store.end(), b.w, b.w + 8);
+        return (int)r;
+    };
+    H.cseed.assign(65536, 0);
+    for (const Cand& c : cands) {
+        if (!c.ok) continue;
+        Bits256 pm, nm;
+        for (uint32_t i = 1; i < c.k; ++i) {
+            auto t = tails.find(key_of(c.b, i));
+            if (t != tails.end()) pm.join(t->second);
+            auto h = heads.find(key_of(c.b + i, c.k - i));
+            if (h != heads.end()) nm.join(h->second);
+        }
+        const int pr = row_of(pm_rows, H.cseed_pm, pm), nr = row_of(nm_rows, H.cseed_nm, nm);
+        if (pr < 0 || nr < 0) continue;  // (more distinct sets than an entry can name: the character is entered byte by byte)
+        H.cseed[c.cp] = CS_VALID | ((uint64_t)nr << 29) | ((uint64_t)pr << 21) | c.id;
+        ++H.n_char_seeds;
+    }
+    if (getenv("TD_DEBUG_TABLES"))
+        fprintf(stderr, "[tokendagger] character seeds: %u of %zu one-character tokens of 2..3 bytes, %zu + %zu sets of neighbour bytes\n",
+                H.n_char_seeds, cands.size(), pm_rows.size(), nm_rows.size());
+    if (!H.n_char_seeds) { H.cseed.clear(); H.cseed_pm.clear(); H.cseed_nm.clear(); }
 }
 
 int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_bytes, const int64_t* token_offsets,
@@ -333,6 +459,8 @@ int build_tables(const char* pattern, int64_t n_vocab, const uint8_t* token_byte
             fprintf(stderr, "[tokendagger] pair table: %llu pairs in %zu slots, %llu in their second seat, %zu first seats not final\n",
                     (unsigned long long)H.n_pairs, H.pair_slots.size(), (unsigned long long)H.n_pairs_second_seat, open_slots);
     }
+
+    build_char_seeds(H, n_vocab, token_bytes, token_offsets, ranks, pairs);
 
     // Is the whole-piece fast path redundant (encode == encode_ordinary on every input)?
     T = H.view();

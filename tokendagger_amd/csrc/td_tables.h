@@ -53,6 +53,10 @@ struct HostTables {
     uint64_t n_pairs = 0;
     uint64_t n_pairs_second_seat = 0;  // pairs that sit in their second seat (hash_pair2): their first seats are not PAIR_FINAL
     bool merge_closed = false;  // every multi-byte token is what the merge loop produces from its own bytes
+    // character seeds (td_common.h: cseed_char_at): empty = none
+    std::vector<uint64_t> cseed;      // [65536]
+    std::vector<uint32_t> cseed_pm, cseed_nm;  // [rows][8]
+    uint32_t n_char_seeds = 0;        // characters that may be entered whole (statistics)
     std::vector<std::string> special_strs;
     std::vector<int32_t> special_ids;
 
