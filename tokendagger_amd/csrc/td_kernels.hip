@@ -2462,6 +2462,9 @@ __global__ __launch_bounds__(MG_THREADS, TD_MERGE_MIN_WAVES) void td_merge_piece
                 if ((int32_t)id >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gpos + j);
                 out[nt++] = id;
             }
+            // (a piece of >= 2 bytes always keeps a part: nt >= 1.  td_pack_plain shifts by ids - 1 per marker and the count here adds
+            // nt - 1: the two sides agree only for nt >= 1, so a marker of td_merge_pieces with no id is an error, not a shift — ADVICE r4)
+            if (nt == 0u) raise(a, TD_E_HIP, gpos);
             a.stage[(size_t)tile * K_STAGE + (((uint32_t)rec >> 19) & 0x1FFFu)] = TOK_MISS | TOK_MERGED | (pos << 7) | nt;
             extra = nt > 1 ? nt - 1 : 0;
         }

@@ -177,9 +177,10 @@ class Tokenizer:
         disallowed_special: Literal["all"] | Collection[str] = set(),
     ) -> list[list[int]]:
         allowed, disallowed = self._special_sets(allowed_special, disallowed_special)
-        texts = list(text)
-        for t in texts:
-            self._check_disallowed(t, disallowed)
+        texts = text if isinstance(text, (list, tuple)) else list(text)  # (the binding takes a private tuple of the items itself)
+        if disallowed:  # (nothing to look for otherwise: the loop alone was 0.2 us per document)
+            for t in texts:
+                self._check_disallowed(t, disallowed)
         try:
             if allowed:  # every text is cut at its allowed special tokens on the host; all ordinary segments of all
                 return self._core_bpe.encode_batch_special(texts, allowed)  # texts run on the GPU as one batch
