@@ -184,6 +184,9 @@ struct td_tokenizer {
     // host waits for, table uploads and the host-buffer entry points run on `s_own` (non-blocking, private to the handle);
     // small results come back through `h_ctl` (pinned).
     hipStream_t s_own = nullptr;
+    hipStream_t s_aux = nullptr;       // the long pieces beside the short ones (LaunchAux, td_kernels.h); with its two events
+    hipEvent_t e_fork = nullptr, e_join = nullptr;
+    bool overlap = true;               // TD_OPT_OVERLAP (TD_OVERLAP=0 at td_create time turns it off)
     hipStream_t s_cap = nullptr;       // hipGraph capture only (non-blocking: the CALLER's stream is never put into capture)
     void* h_ctl = nullptr;             // pinned, 256 B: the control block / an 8-byte total on their way to the host
     // the last step as a hipGraph (encode_device_locked): opt-in (TD_OPT_GRAPH, TD_GRAPH=1)
@@ -199,6 +202,7 @@ struct td_tokenizer {
     uint32_t sp_n = 0, sp_maxlen = 0;
     bool device_specials = true;     // host-buffer batches of a MiB and more search on the device (TD_OPT_DEVICE_SPECIALS)
     bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
+    uint32_t dd_minlen = 9;       // (TD_DD_MINLEN at td_create time, tuning: pieces below this many bytes are merged without a look at the table)
     uint32_t dd_entries_opt = 0;  // (TD_DD_ENTRIES=<power of two> at td_create time, tests: seats of the table of distinct missed pieces)
     bool dedupe = true;       // a missed piece whose bytes another one of the call has is merged once (TD_OPT_DEDUPE; TD_DEDUPE=0 at td_create time turns it off)
     bool pack_split = true;   // td_pack_plain + td_pack_rest instead of td_pack_tokens (TD_OPT_PACK_SPLIT; TD_PACK_SPLIT=0 at td_create time turns it off)
@@ -295,7 +299,7 @@ int zero_wait(td_tokenizer* t, void* dst, size_t bytes, hipStream_t s) {
 // stream itself may be gone by now, the event is ours).
 void drain(td_tokenizer* t) {
     if (t->has_last && t->last_done) (void)hipEventSynchronize(t->last_done);
-    for (hipStream_t st : {t->s_own, t->s_h2d, t->s_k, t->s_d2h}) if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {t->s_own, t->s_h2d, t->s_k, t->s_d2h, t->s_aux}) if (st) (void)hipStreamSynchronize(st);
 }
 
 // Runs f() with the handle locked and its device current; a failure's message is published to this thread's slot.
@@ -497,6 +501,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     }
     a.dedupe = (t->dedupe && n_tiles < (1ll << 24)) ? 1 : 0;  // (a table entry keeps the tile in 24 bits)
     a.dd_seat_bits = std::min<uint32_t>(39 - dd_tile_bits(n), 24);
+    a.dd_minlen = t->dd_minlen;
     a.dd_table = a.dedupe ? (unsigned long long*)t->dd_table.p : nullptr;
     a.dd_mask = a.dedupe ? dd_entries(t, n) - 1u : 0u;
     a.flagged_count = &ctl->flagged_count;
@@ -567,6 +572,20 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     // the caller's stream only ever sees hipGraphLaunch: no stream of the application is in capture because of this library,
     // other threads' legacy-stream work (torch's default stream) stays legal, and a failed capture costs nothing but itself:
     // it is ended, the error is cleared and the step is launched kernel by kernel.
+    LaunchAux aux_v{nullptr, nullptr, nullptr};
+    const LaunchAux* aux = nullptr;
+    // ... when the handle has SEEN long pieces: the fork and the join cost a step without any ~13 us (English: -2 % at 256 MiB), a step
+    // with a hundred thousand of them gains 4-7 %.  What the last call whose counters were read had (td_device_status, every host-buffer
+    // entry point) decides; a handle that never reads them stays in line.
+    if (t->overlap && t->last_long >= 2048) {
+        hipError_t ae = hipSuccess;
+        if (!t->s_aux) ae = hipStreamCreateWithFlags(&t->s_aux, hipStreamNonBlocking);
+        if (ae == hipSuccess && !t->e_fork) ae = hipEventCreateWithFlags(&t->e_fork, hipEventDisableTiming);
+        if (ae == hipSuccess && !t->e_join) ae = hipEventCreateWithFlags(&t->e_join, hipEventDisableTiming);
+        if (ae == hipSuccess) { aux_v = LaunchAux{t->s_aux, t->e_fork, t->e_join}; aux = &aux_v; }
+        else (void)hipGetLastError();  // (no second stream: everything in line)
+    }
+    a.overlap = aux ? 1 : 0;
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing(stream, &cap_status) != hipSuccess) { cap_status = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
     // (a caller that is capturing this stream into a graph of its own gets the plain launches captured there)
@@ -583,7 +602,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
             hipError_t ce = t->s_cap ? hipSuccess : hipStreamCreateWithFlags(&t->s_cap, hipStreamNonBlocking);
             if (ce == hipSuccess) ce = hipStreamBeginCapture(t->s_cap, hipStreamCaptureModeThreadLocal);
             if (ce == hipSuccess) {
-                const hipError_t le = launch_encode(a, t->s_cap, nullptr);
+                const hipError_t le = launch_encode(a, t->s_cap, nullptr, aux);
                 ce = hipStreamEndCapture(t->s_cap, &g);  // (always: also ends a capture that was invalidated)
                 if (le != hipSuccess) ce = le;
             }
@@ -607,7 +626,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
             t->has_last_key = true;
         }
     }
-    HIP_TRY(t, launch_encode(a, stream, t->profile ? ev.e : nullptr));
+    HIP_TRY(t, launch_encode(a, stream, t->profile ? ev.e : nullptr, aux));
     return order_after(t, stream);
 }
 
@@ -671,6 +690,8 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if (const char* e = getenv("TD_DIRECT")) t->direct = atoi(e) != 0;
     if (const char* e = getenv("TD_PACK_SPLIT")) t->pack_split = atoi(e) != 0;
     if (const char* e = getenv("TD_DEDUPE")) t->dedupe = atoi(e) != 0;
+    if (const char* e = getenv("TD_OVERLAP")) t->overlap = atoi(e) != 0;
+    if (const char* e = getenv("TD_DD_MINLEN")) t->dd_minlen = (uint32_t)std::max(2, atoi(e));
     if (const char* e = getenv("TD_DD_ENTRIES")) { const long v = atol(e); if (v >= 2 && v <= (1l << 24) && !(v & (v - 1))) t->dd_entries_opt = (uint32_t)v; }
     if (const char* e = getenv("TD_COLL_SHRINK")) t->coll_shrink = std::max(1, atoi(e));
     std::string err;
@@ -763,7 +784,7 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t = new td_tokenizer(src->shared);
         t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
         t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
-        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->dd_entries_opt = src->dd_entries_opt; t->coll_shrink = src->coll_shrink;
+        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->overlap = src->overlap; t->dd_entries_opt = src->dd_entries_opt; t->dd_minlen = src->dd_minlen; t->coll_shrink = src->coll_shrink;
         t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }
@@ -795,7 +816,8 @@ void td_destroy(td_tokenizer* t) {
             for (DevBuf* b : {&sl.d_text, &sl.d_offs, &sl.d_tok, &sl.d_toff}) if (b->p) (void)hipFree(b->p);
             for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_off, sl.ev_tok}) if (e) (void)hipEventDestroy(e);
         }
-        for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h, t->s_own, t->s_cap}) if (st) (void)hipStreamDestroy(st);
+        for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h, t->s_own, t->s_cap, t->s_aux}) if (st) (void)hipStreamDestroy(st);
+        for (hipEvent_t e : {t->e_fork, t->e_join}) if (e) (void)hipEventDestroy(e);
         if (t->h_ctl) (void)hipHostFree(t->h_ctl);
         if (t->small_in) (void)hipHostFree(t->small_in);
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
@@ -1849,6 +1871,11 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     }
     if (what == TD_OPT_PACK_SPLIT) {
         t->pack_split = value != 0;
+        drop_graph(t); t->has_last_key = false;
+        return TD_OK;
+    }
+    if (what == TD_OPT_OVERLAP) {
+        t->overlap = value != 0;
         drop_graph(t); t->has_last_key = false;
         return TD_OK;
     }

@@ -99,6 +99,8 @@ struct EncodeArgs {
     uint32_t dd_mask;           // entries - 1 (a power of two)
     uint32_t dd_seat_bits;      // bits of a seat number in an entry of dup_list (>= log2(entries); the tile number gets the other 39 - this)
     int dedupe;
+    uint32_t dd_minlen;         // pieces below this many bytes are not looked up (merged themselves)
+    int overlap;                // (host only: the long pieces run beside the short ones in this call — part of the key a captured graph is reused by)
     unsigned long long* dup_list;  // the repeats: COLL_SUBS lists of dup_cap entries (tile | slot (13 bits) | tile position (12) | seat of dd_table that
     uint32_t dup_cap;              // names the piece whose ids it gets); coll_count[(K_MISS_CLASSES * COLL_SUBS + s) * COLL_STRIDE] = entries on list s (td_copy_dups)
     // generic split patterns (PV_GENERIC; td_generic.hip)
@@ -208,7 +210,12 @@ hipError_t launch_small_decode(const SmallDecArgs& a, hipStream_t stream);
 // ev[2] | td_probe_tiles (fused: the deferred tiles only) | ev[3] | td_merge_pieces | ev[4] | td_long_pieces, td_giant_pieces,
 // td_scan_tiles | ev[5] | td_pack_tokens | ev[6]
 constexpr int TD_PROF_EVENTS = 7;
-hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev = nullptr);
+// aux (optional; round 5): a second stream and two events of the handle.  td_long_pieces / td_giant_pieces touch nothing the chain
+// td_collect_misses -> td_merge_pieces -> td_copy_dups touches (other pieces, other outputs; both add to tile_extra atomically), and both
+// sides are bound by dependent round trips, not by issue or bandwidth: with `aux` the long pieces run on aux->s BESIDE that chain (fork
+// behind td_probe_tiles, join in front of td_scan_tiles; inside a capture the two become parallel branches of the graph).
+struct LaunchAux { hipStream_t s; hipEvent_t fork, join; };
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev = nullptr, const LaunchAux* aux = nullptr);
 // generic split patterns (td_generic.hip), called by launch_encode in place of td_split_tiles / ahead of td_scan_tiles
 hipError_t launch_generic_split(const EncodeArgs& a, hipStream_t stream);
 hipError_t launch_generic_gaps(const EncodeArgs& a, hipStream_t stream);

@@ -2232,7 +2232,7 @@ __global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs 
         const unsigned long long rec = ((unsigned long long)tile << 32) | e;
         unsigned long long other = 0ull;
         uint32_t seat = 0;
-        if (act && a.dedupe) {
+        if (act && a.dedupe && len >= a.dd_minlen) {  // (shorter pieces are merged in fewer rounds than the detour through the table costs)
             const int64_t g = (int64_t)tile * K_TILE + pos;
             // hash over the piece's dwords; its first 16 bytes stay in registers for the comparison
             uint32_t w0[4];
@@ -4211,7 +4211,7 @@ static int split_grid_blocks() {
     return g_blocks_split;
 }
 
-hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev) {
+hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev, const LaunchAux* aux) {
     if (a.n_tiles <= 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], stream);
     {   // one launch clears what was seven memsets: document bits, per-tile long-piece counts, first-document
@@ -4283,6 +4283,16 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         }
     }
     if (ev) (void)hipEventRecord(ev[3], stream);
+    // the long pieces beside the chain of the short ones (see LaunchAux); with per-segment events (ev) everything stays in line
+    const bool fork = aux && !ev && tokens;
+    if (fork) {
+        hipError_t fe = hipEventRecord(aux->fork, stream);
+        if (fe == hipSuccess) fe = hipStreamWaitEvent(aux->s, aux->fork, 0);
+        if (fe != hipSuccess) return fe;
+        hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, aux->s, a);
+        hipLaunchKernelGGL(td_giant_pieces, dim3(128), dim3(GP_THREADS), 0, aux->s, a);
+        if ((fe = hipEventRecord(aux->join, aux->s)) != hipSuccess) return fe;
+    }
     if (tokens && merges) {
         const int wtiles = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
         const int mblocks = wtiles < merge_grid_blocks() ? wtiles : merge_grid_blocks();
@@ -4292,8 +4302,13 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     }
     if (ev) (void)hipEventRecord(ev[4], stream);
     if (tokens) {
-        hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(td_giant_pieces, dim3(128), dim3(GP_THREADS), 0, stream, a);
+        if (fork) {
+            const hipError_t je = hipStreamWaitEvent(stream, aux->join, 0);
+            if (je != hipSuccess) return je;
+        } else {
+            hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(td_giant_pieces, dim3(128), dim3(GP_THREADS), 0, stream, a);
+        }
         if (a.pat_flags & PV_GENERIC) {  // text the pattern skips gets no tokens
             const hipError_t ge = launch_generic_gaps(a, stream);
             if (ge != hipSuccess) return ge;

@@ -22,8 +22,11 @@ for pdir in sorted(glob.glob(os.path.join(root, "*"))):
 A = {k: {c: acc[k][c] / cnt[k][c] for c in acc[k]} for k in acc}
 SIMDS = 256 * 4
 print(f"# {title}\n# per kernel LAUNCH (averages over the launches of the run); separate rocprofv3 --kernel-trace --pmc passes (tools/pmc_workload.sh)")
-print("# wave cycles = SQ_WAVE_CYCLES x 4 (quad-cycles); busy% = share of the chip's SIMD-cycles (GRBM_GUI_ACTIVE x 1024 SIMDs) a VALU instruction was issuing")
-hdr = f"{'kernel':<34} {'waves':>9} {'VALU/wave':>10} {'SALU/wave':>10} {'LDS/wave':>9} {'VMEM/wave':>10} {'cyc/wave':>10} {'active%':>8} {'issue-stall%':>12} {'parked%':>8} {'VALU busy%':>10} {'lanes/VALU':>10} {'LDS confl%':>10} {'occ waves/SIMD':>14} {'L2 hit%':>8} {'Mcycles':>9}"
+print("# rocprofv3 sums a counter over the 8 XCDs: GRBM_GUI_ACTIVE / 8 = the kernel's duration in cycles (x 1/2.4 GHz = the kernel-trace duration);")
+print("# cyc/wave = SQ_WAVE_CYCLES x 4 / waves (SQ_*_CYCLES and SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles); VALU busy% = SQ_ACTIVE_INST_VALU x 4 / (duration x 1024 SIMDs):")
+print("# the share of the chip's SIMD issue cycles that issued a vector instruction; lanes/VALU = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64);")
+print("# active / issue-stall / parked = SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY / SQ_WAIT_ANY as shares of the wavefronts' resident cycles (parked = s_waitcnt or barrier)")
+hdr = f"{'kernel':<34} {'waves':>9} {'VALU/wave':>10} {'SALU/wave':>10} {'LDS/wave':>9} {'VMEM/wave':>10} {'cyc/wave':>10} {'active%':>8} {'issue-stall%':>12} {'parked%':>8} {'VALU busy%':>10} {'lanes/VALU':>10} {'LDS confl%':>10} {'occ waves/SIMD':>14} {'L2 hit%':>8} {'us @2.4GHz':>10}"
 print(hdr)
 def g(d, k, default=0.0):
     return d.get(k, default)
@@ -36,14 +39,12 @@ for k in sorted(A, key=lambda k: -g(A[k], "GRBM_GUI_ACTIVE")):
     valu = g(d, "SQ_INSTS_VALU")
     vmem = g(d, "SQ_INSTS_VMEM_RD") + g(d, "SQ_INSTS_VMEM_WR") + g(d, "SQ_INSTS_FLAT")
     pct = lambda x, y: f"{100.0 * x / y:.1f}" if y else "-"
-    lanes = f"{g(d, 'SQ_THREAD_CYCLES_VALU') / g(d, 'SQ_ACTIVE_INST_VALU') / 4 * 64 / 64:.1f}" if g(d, "SQ_ACTIVE_INST_VALU") else "-"
-    # SQ_THREAD_CYCLES_VALU: lane-cycles of VALU work; / (SQ_ACTIVE_INST_VALU x 4 cycles) = lanes active per VALU cycle
-    lanes = f"{g(d, 'SQ_THREAD_CYCLES_VALU') / (g(d, 'SQ_ACTIVE_INST_VALU') * 4):.1f}" if g(d, "SQ_ACTIVE_INST_VALU") else "-"
-    occ = f"{g(d, 'SQ_LEVEL_WAVES') / gui / SIMDS:.2f}" if gui and g(d, "SQ_LEVEL_WAVES") else (f"{wc * 4 / gui / SIMDS:.2f}" if gui else "-")
+    lanes = f"{g(d, 'SQ_THREAD_CYCLES_VALU') / g(d, 'SQ_ACTIVE_INST_VALU'):.1f}" if g(d, "SQ_ACTIVE_INST_VALU") else "-"
+    occ = f"{wc * 4 / (gui / 8) / SIMDS:.2f}" if gui else "-"
     l2 = pct(g(d, "TCC_HIT_sum"), g(d, "TCC_HIT_sum") + g(d, "TCC_MISS_sum"))
     print(f"{k[:34]:<34} {w:>9.0f} {valu / w:>10.1f} {g(d, 'SQ_INSTS_SALU') / w:>10.1f} {g(d, 'SQ_INSTS_LDS') / w:>9.1f} {vmem / w:>10.1f} {wc * 4 / w:>10.0f} "
           f"{pct(g(d, 'SQ_ACTIVE_INST_ANY'), wc):>8} {pct(g(d, 'SQ_WAIT_INST_ANY'), wc):>12} {pct(g(d, 'SQ_WAIT_ANY'), wc):>8} "
-          f"{pct(g(d, 'SQ_ACTIVE_INST_VALU') * 4, gui * SIMDS):>10} {lanes:>10} {pct(g(d, 'SQ_LDS_BANK_CONFLICT'), g(d, 'SQ_LDS_IDX_ACTIVE')):>10} {occ:>14} {l2:>8} {gui / 1e6:>9.3f}")
+          f"{pct(g(d, 'SQ_ACTIVE_INST_VALU') * 4, gui / 8 * SIMDS):>10} {lanes:>10} {pct(g(d, 'SQ_LDS_BANK_CONFLICT'), g(d, 'SQ_LDS_IDX_ACTIVE')):>10} {occ:>14} {l2:>8} {gui / 8 / 2400:>9.1f}")
 print("\n# raw averages per launch")
 for k in sorted(A):
     print(f"{k:<34} " + "  ".join(f"{c}={A[k][c]:.4g}" for c in sorted(A[k])))

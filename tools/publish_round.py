@@ -18,7 +18,12 @@ t = json.loads((src / "hbm_traffic.json").read_text())
 lines = ["# fabric traffic of the L2s per launch, rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the bench command (tools/measure_workload.sh)",
          "# bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (counter unit KiB; factor 2: the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md), averaged over the launches",
          f"# kernel sources {t['kernel_source_sha']} ({t['source']})", ""]
-ALG = {"english_llama4_1024": 1970829960}  # text + 4 x ids + 8 x (documents + 1)
+ALG = {}  # text + 4 x ids + 8 x (documents + 1), of the bench line's own corpus
+try:
+    bj = json.loads((src / "bench_default.json").read_text().strip().splitlines()[-1])
+    ALG["english_llama4_1024"] = int(bj["roofline"]["algorithmic_bytes_per_launch"])
+except Exception:  # noqa: BLE001
+    pass
 for key in sorted(k for k, v in t.items() if isinstance(v, dict)):
     tot = t[key]["_all"]
     head = f"## {key}: all kernels of a step {tot / 1e9:.3f} GB"
@@ -30,9 +35,12 @@ for key in sorted(k for k, v in t.items() if isinstance(v, dict)):
     lines.append("")
 (prof / f"r{rn}_03_hbm_traffic.txt").write_text("\n".join(lines))
 shutil.copy(src / "hbm_traffic.json", prof / "hbm_traffic.json")
+for i, name in enumerate(("pmc_english_1024.txt", "pmc_mixed_256.txt", "pmc_code_files_256.txt")):
+    if (src / name).exists():
+        shutil.copy(src / name, prof / f"r{rn}_0{4 + i}_{name}")
 bdir = prof / f"r{rn}_bench"
 bdir.mkdir(exist_ok=True)
-for name in ("bench_default.json", "bench_default.time", "bench_2rank_same_gpu_gloo.json", "pybatch.txt", "host.txt", "pytest_gpu.log", "smoke.log"):
+for name in ("bench_default.json", "bench_default.time", "bench_2rank_same_gpu_gloo.json", "pybatch.txt", "host.txt", "pytest_gpu.log", "smoke.log", "latency.txt", "hostpath.txt", "bench_128_weak.json"):
     if (src / name).exists():
         shutil.copy(src / name, bdir / name)
 print("published", src, "->", prof)

@@ -17,7 +17,7 @@ SEG = {"td_prepare": "td_prepare+td_mark_docs", "td_mark_docs": "td_prepare+td_m
        "td_probe_tiles": "td_probe_tiles", "td_merge_pieces": "td_merge_pieces",  # (segments = the events of TD_OPT_PROFILE)
        "td_long_pieces": "td_long_pieces+td_giant_pieces+td_scan_tiles", "td_giant_pieces": "td_long_pieces+td_giant_pieces+td_scan_tiles",
        "td_scan_tiles": "td_long_pieces+td_giant_pieces+td_scan_tiles", "td_pack_tokens": "td_pack_tokens",
-       "td_pack_plain": "td_pack_tokens", "td_pack_rest": "td_pack_tokens", "td_collect_misses": "td_merge_pieces"}
+       "td_pack_plain": "td_pack_tokens", "td_pack_rest": "td_pack_tokens", "td_collect_misses": "td_merge_pieces", "td_copy_dups": "td_merge_pieces"}
 def per_kernel(counter):
     acc, cnt = defaultdict(float), defaultdict(int)
     for f in glob.glob(os.path.join(root, counter, "**", "*counter_collection.csv"), recursive=True):
