@@ -202,7 +202,8 @@ struct td_tokenizer {
     uint32_t sp_n = 0, sp_maxlen = 0;
     bool device_specials = true;     // host-buffer batches of a MiB and more search on the device (TD_OPT_DEVICE_SPECIALS)
     bool sp_active = false;          // this call cuts allowed specials (set around encode_device_locked)
-    uint32_t dd_minlen = 9;       // (TD_DD_MINLEN at td_create time, tuning: pieces below this many bytes are merged without a look at the table)
+    uint32_t dd_replicas = 4;     // (TD_DD_REPLICAS at td_create time, tuning: a power of two)
+    uint32_t dd_minlen = 2;       // (TD_DD_MINLEN at td_create time, tuning: pieces below this many bytes are merged without a look at the table)
     uint32_t dd_entries_opt = 0;  // (TD_DD_ENTRIES=<power of two> at td_create time, tests: seats of the table of distinct missed pieces)
     bool dedupe = true;       // a missed piece whose bytes another one of the call has is merged once (TD_OPT_DEDUPE; TD_DEDUPE=0 at td_create time turns it off)
     bool pack_split = true;   // td_pack_plain + td_pack_rest instead of td_pack_tokens (TD_OPT_PACK_SPLIT; TD_PACK_SPLIT=0 at td_create time turns it off)
@@ -502,6 +503,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.dedupe = (t->dedupe && n_tiles < (1ll << 24)) ? 1 : 0;  // (a table entry keeps the tile in 24 bits)
     a.dd_seat_bits = std::min<uint32_t>(39 - dd_tile_bits(n), 24);
     a.dd_minlen = t->dd_minlen;
+    a.dd_replicas = t->dd_replicas;
     a.dd_table = a.dedupe ? (unsigned long long*)t->dd_table.p : nullptr;
     a.dd_mask = a.dedupe ? dd_entries(t, n) - 1u : 0u;
     a.flagged_count = &ctl->flagged_count;
@@ -691,6 +693,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if (const char* e = getenv("TD_PACK_SPLIT")) t->pack_split = atoi(e) != 0;
     if (const char* e = getenv("TD_DEDUPE")) t->dedupe = atoi(e) != 0;
     if (const char* e = getenv("TD_OVERLAP")) t->overlap = atoi(e) != 0;
+    if (const char* e = getenv("TD_DD_REPLICAS")) { const int v = atoi(e); if (v >= 1 && v <= 16 && !(v & (v - 1))) t->dd_replicas = (uint32_t)v; }
     if (const char* e = getenv("TD_DD_MINLEN")) t->dd_minlen = (uint32_t)std::max(2, atoi(e));
     if (const char* e = getenv("TD_DD_ENTRIES")) { const long v = atol(e); if (v >= 2 && v <= (1l << 24) && !(v & (v - 1))) t->dd_entries_opt = (uint32_t)v; }
     if (const char* e = getenv("TD_COLL_SHRINK")) t->coll_shrink = std::max(1, atoi(e));
@@ -784,7 +787,7 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t = new td_tokenizer(src->shared);
         t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
         t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
-        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->overlap = src->overlap; t->dd_entries_opt = src->dd_entries_opt; t->dd_minlen = src->dd_minlen; t->coll_shrink = src->coll_shrink;
+        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->overlap = src->overlap; t->dd_entries_opt = src->dd_entries_opt; t->dd_minlen = src->dd_minlen; t->dd_replicas = src->dd_replicas; t->coll_shrink = src->coll_shrink;
         t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }
@@ -1276,6 +1279,12 @@ extern "C" {
 int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
                     int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
     if (!t || !doc_offsets || n_docs < 0 || !out_offsets || out_capacity < 0) return TD_E_INVALID;
+    if ((mode == TD_MODE_ENCODE || mode == TD_MODE_ORDINARY) && doc_offsets[0] == 0 && doc_offsets[n_docs] == 0) {
+        // nothing but empty documents: no ids, and no reason to wake the device (enc.encode("") was 48 us)
+        for (int64_t d = 0; d <= n_docs; ++d) out_offsets[d] = 0;
+        if (n_tokens) *n_tokens = 0;
+        return TD_OK;
+    }
     return locked(t, [&] { return encode_batch_locked(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens); });
 }
 

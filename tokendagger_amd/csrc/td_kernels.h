@@ -100,6 +100,7 @@ struct EncodeArgs {
     uint32_t dd_seat_bits;      // bits of a seat number in an entry of dup_list (>= log2(entries); the tile number gets the other 39 - this)
     int dedupe;
     uint32_t dd_minlen;         // pieces below this many bytes are not looked up (merged themselves)
+    uint32_t dd_replicas;       // seats a piece may take, one per group of workgroups (a power of two)
     int overlap;                // (host only: the long pieces run beside the short ones in this call — part of the key a captured graph is reused by)
     unsigned long long* dup_list;  // the repeats: COLL_SUBS lists of dup_cap entries (tile | slot (13 bits) | tile position (12) | seat of dd_table that
     uint32_t dup_cap;              // names the piece whose ids it gets); coll_count[(K_MISS_CLASSES * COLL_SUBS + s) * COLL_STRIDE] = entries on list s (td_copy_dups)

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r5_ml; mkdir -p $O
-for ml in 2 9 17; do
+for ml in 2 9; do
 for c in "mixed none" "code_files none" "chat all"; do set -- $c
 TD_DD_MINLEN=$ml timeout 300 python bench.py --corpus $1 --allowed-special $2 --size-mb 256 --no-cpu-baseline --no-verify --steps 20 --warmup 3 > $O/b.json 2> $O/b.err
 python - $O/b.json $ml $1 <<'PY'
