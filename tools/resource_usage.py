@@ -9,7 +9,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import bench
 
-out = [f"# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage on the round-4 sources (kernel source sha {bench.kernel_source_sha()})",
+out = [f"# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage on these sources (kernel source sha {bench.kernel_source_sha()})",
        "# kernel | VGPRs | spilled VGPRs | scratch B/lane | waves/SIMD | LDS B/workgroup"]
 for src in ("td_kernels.hip", "td_generic.hip", "td_special.hip"):
     p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT / 'include'}", "-c",
