@@ -210,10 +210,11 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
                                     compared, not hashes) and the repeats copy the ids; 0: every piece is merged (rounds 1-4).  Same results
                                     either way (bpe_merge reads nothing but the piece, tiktoken.cpp:298-368); TD_DEDUPE=0 in the environment at
                                     td_create time also turns it off. */
-#define TD_OPT_OVERLAP 12          /* 1 (default): the kernels of the pieces above 64 bytes run on a second stream of the handle beside the
-                                    kernels of the shorter ones (fork behind the lookups, join in front of the scan; parallel branches when the
-                                    step is captured into a graph); 0: one kernel after the other.  Same results either way; TD_OVERLAP=0 in the
-                                    environment at td_create time also turns it off. */
+#define TD_OPT_OVERLAP 12          /* 1 (default): once the handle has seen long pieces (>= 2048 in the last call whose counters were read:
+                                    td_device_status and every host-buffer entry point read them), the kernels of the pieces above 64 bytes run on
+                                    a second stream of the handle beside the kernels of the shorter ones (fork behind the lookups, join in front of
+                                    the scan; parallel branches when the step is captured into a graph); 0: always one kernel after the other.
+                                    Same results either way; TD_OVERLAP=0 in the environment at td_create time also turns it off. */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 16) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 
