@@ -394,7 +394,7 @@ static uint32_t dd_tile_bits(int64_t n) {
     return b;
 }
 static uint32_t dd_entries(const td_tokenizer* t, int64_t n) {
-    const uint32_t most = 1u << std::min<uint32_t>(39 - dd_tile_bits(n), 24);
+    const uint32_t most = 1u << std::min<uint32_t>(39 - dd_tile_bits(n), 21);  // (21 bits: what a TOK_DUPREF slot has for the seat)
     if (t->dd_entries_opt) return std::min(t->dd_entries_opt, most);
     uint32_t e = 4096;
     while (e < (2u << 20) && e < most && (int64_t)e * 128 < n) e <<= 1;
@@ -501,7 +501,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
         a.ovf_count = &ctl->ovf_count;
     }
     a.dedupe = (t->dedupe && n_tiles < (1ll << 24)) ? 1 : 0;  // (a table entry keeps the tile in 24 bits)
-    a.dd_seat_bits = std::min<uint32_t>(39 - dd_tile_bits(n), 24);
+    a.dd_seat_bits = std::min<uint32_t>(39 - dd_tile_bits(n), 21);
     a.dd_minlen = t->dd_minlen;
     a.dd_replicas = t->dd_replicas;
     a.dd_table = a.dedupe ? (unsigned long long*)t->dd_table.p : nullptr;

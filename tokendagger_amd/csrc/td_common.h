@@ -65,6 +65,9 @@ constexpr uint32_t TOK_LONGREF = 0x80000000u; // | index into the long-piece lis
 constexpr uint32_t TOK_MISS = 0x40000000u;    // | tile position << 7 | length: a piece of 2..64 bytes that is not a token; td_merge_tiles
                                               // replaces the slot by the ids its byte-pair merge produces
 constexpr uint32_t TOK_MERGED = 0x20000000u;  // in a TOK_MISS slot: the piece is merged, the low 7 bits count its ids (position << 7 stays)
+constexpr uint32_t TOK_DUPREF = 0x10000000u;  // in a merged TOK_MISS slot (td_copy_dups): the piece repeats another one — bits 7..27 name the seat of the table of
+                                              // distinct pieces (EncodeArgs::dd_table) whose record says where that piece's ids are (instead of a tile position):
+                                              // the pack kernels copy them from there, nothing was copied in between
 constexpr uint32_t TOK_OVF = 0x08000000u;     // in a TOK_MISS slot: its record found no room on a list; td_merge_pieces' scan behind the rows merges it
 // tile_count[]: slots of the tile (bits 0..12) | length classes that found no room on td_collect_misses' lists (bits 13..17) | flags
 constexpr uint32_t TILE_HAS_LONG = 0x80000000u, TILE_HAS_MISS = 0x40000000u, TILE_COUNT_MASK = 0x1FFFu;

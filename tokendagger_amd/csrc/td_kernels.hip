@@ -2346,12 +2346,15 @@ __global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs 
     if (dcnt) flush_dups(dcnt);
 }
 
-// td_copy_dups (behind td_merge_pieces): a lane per repeat — the other piece's finished slot (its id count), its ids to this piece's
-// place in merge_out, this piece's slot, and the tile's extra ids with one atomic per tile of the wavefront's 64 repeats (they come
-// from two or three tiles).
+// td_copy_dups (behind td_merge_pieces): a lane per repeat — the other piece's finished slot (its id count), this piece's slot (TOK_DUPREF:
+// the seat that names the other piece + the count; the ids themselves are NOT copied, the pack kernels read them where they are), and the tile's
+// extra ids with one atomic per tile of the wavefront's 64 repeats (they come from two or three tiles).
 __global__ __launch_bounds__(K_THREADS) void td_copy_dups(const EncodeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t gw = (blockIdx.x * (uint32_t)K_THREADS + threadIdx.x) >> 6, nw = gridDim.x * (uint32_t)(K_THREADS / 64);
+    // With allowed special tokens (td_special_ids puts a literal's id where its first piece's ids were) or a generic pattern (markers of its
+    // own behind this kernel) a piece's place in merge_out does not keep its ids until the pack kernels run: the ids are copied here then.
+    const bool by_ref = a.sp.n == 0u && !(a.pat_flags & PV_GENERIC);
     for (uint32_t sub = 0; sub < (uint32_t)COLL_SUBS; ++sub) {
         const uint32_t c0 = a.coll_count[((uint32_t)DD_CTR + sub) * COLL_STRIDE];
         const uint32_t cnt = c0 < a.dup_cap ? c0 : a.dup_cap;
@@ -2364,23 +2367,28 @@ __global__ __launch_bounds__(K_THREADS) void td_copy_dups(const EncodeArgs a) {
                 tile = (uint32_t)(ent >> (25u + sb));
                 const uint32_t k = (uint32_t)(ent >> (12u + sb)) & 0x1FFFu, pos = (uint32_t)(ent >> sb) & 0xFFFu;
                 const unsigned long long other = a.dd_table[(uint32_t)ent & ((1u << sb) - 1u)] & DD_REC_MASK;
-                const uint32_t r_tile = (uint32_t)(other >> 32), r_k = ((uint32_t)other >> 19) & 0x1FFFu, r_pos = ((uint32_t)other >> 7) & 0xFFFu;
+                const uint32_t r_tile = (uint32_t)(other >> 32), r_k = ((uint32_t)other >> 19) & 0x1FFFu;
                 const uint32_t rs = a.stage[(size_t)r_tile * K_STAGE + r_k];
                 uint32_t nt = rs & 127u;
                 if ((rs & (0xC0000000u | TOK_MERGED)) != (TOK_MISS | TOK_MERGED) || nt == 0u) {
                     raise(a, TD_E_HIP, (int64_t)tile * K_TILE + pos);  // (cannot happen: the other piece was on a list or marked for the scan)
                     nt = 1u;
                 }
-                const uint32_t* const src = a.merge_out + (size_t)r_tile * K_STAGE + r_pos;
-                uint32_t* const mo = a.merge_out + (size_t)tile * K_STAGE + pos;
-                for (uint32_t i = 0; i < nt; i += 4u) {
-                    const uint32_t x0 = src[i], x1 = i + 1u < nt ? src[i + 1u] : 0u, x2 = i + 2u < nt ? src[i + 2u] : 0u, x3 = i + 3u < nt ? src[i + 3u] : 0u;
-                    mo[i] = x0;
-                    if (i + 1u < nt) mo[i + 1u] = x1;
-                    if (i + 2u < nt) mo[i + 2u] = x2;
-                    if (i + 3u < nt) mo[i + 3u] = x3;
+                if (by_ref) {
+                    // (the ids stay where they are: the slot names the seat, the pack kernels read them there — marker_ids)
+                    a.stage[(size_t)tile * K_STAGE + k] = TOK_MISS | TOK_MERGED | TOK_DUPREF | (((uint32_t)ent & ((1u << sb) - 1u)) << 7) | nt;
+                } else {
+                    const uint32_t* const src = a.merge_out + (size_t)r_tile * K_STAGE + (((uint32_t)other >> 7) & 0xFFFu);
+                    uint32_t* const mo = a.merge_out + (size_t)tile * K_STAGE + pos;
+                    for (uint32_t i = 0; i < nt; i += 4u) {
+                        const uint32_t x0 = src[i], x1 = i + 1u < nt ? src[i + 1u] : 0u, x2 = i + 2u < nt ? src[i + 2u] : 0u, x3 = i + 3u < nt ? src[i + 3u] : 0u;
+                        mo[i] = x0;
+                        if (i + 1u < nt) mo[i + 1u] = x1;
+                        if (i + 2u < nt) mo[i + 2u] = x2;
+                        if (i + 3u < nt) mo[i + 3u] = x3;
+                    }
+                    a.stage[(size_t)tile * K_STAGE + k] = TOK_MISS | TOK_MERGED | (pos << 7) | nt;
                 }
-                a.stage[(size_t)tile * K_STAGE + k] = TOK_MISS | TOK_MERGED | (pos << 7) | nt;
                 extra = nt - 1u;
             }
             for (uint64_t pend = __ballot(extra != 0); pend;) {
@@ -3437,6 +3445,16 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
 //   wavefront); the documents that start in the tile pick their offset out of the row scan their slot falls in.
 // (A workgroup-per-tile version of the marker path with the tile's offsets in LDS cost 14-17 us per tile: five barriers
 // and six dependent global loads in a row; plain English has a marker in every third tile.)
+// Where the ids of a merged marker are: at the piece's own bytes' slots of merge_out, or — a repeat (TOK_DUPREF) — at the bytes' slots of the
+// piece it repeats, which the table of distinct pieces names (one more load; the seats of frequent pieces are hot in every cache).
+__device__ __forceinline__ const uint32_t* marker_ids(const EncodeArgs& a, uint32_t tile, uint32_t v) {
+    if (v & TOK_DUPREF) {
+        const unsigned long long other = a.dd_table[(v >> 7) & 0x1FFFFFu];
+        return a.merge_out + (size_t)((uint32_t)(other >> 32) & 0xFFFFFFu) * K_STAGE + (((uint32_t)other >> 7) & 0xFFFu);
+    }
+    return a.merge_out + (size_t)tile * K_STAGE + ((v >> 7) & 0xFFFu);
+}
+
 constexpr int PK_G = 8;       // rows of 64 slots per group of the marker path
 constexpr int PK_ECAP = 256;  // merged pieces the expansion list holds
 // PLAIN_ONLY: only the pipelined path of the plain tiles (every slot an id, at most 1024 of them); SKIP_PLAIN: everything else.
@@ -3664,7 +3682,7 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
                 for (uint32_t c0 = 0; c0 < ecount; c0 += 64) {
                     const unsigned long long e = c0 + lane < ecount ? elist[c0 + lane] : 0ull;
                     const uint32_t n = (uint32_t)e & 127u;
-                    const uint32_t* ps = a.merge_out + (size_t)tile * K_STAGE + (((uint32_t)e >> 7) & 0xFFFu);
+                    const uint32_t* ps = marker_ids(a, (uint32_t)tile, (uint32_t)e);
                     const int64_t o = base + (int64_t)(uint32_t)(e >> 32);
                     for (uint32_t j = 0; __any(j < n); j += 4) {
                         uint32_t t[4];
@@ -3736,7 +3754,7 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
                     const bool m = (mmask >> q) & 1u;
                     const uint64_t bm = __ballot(m);
                     if (bm) {
-                        if (m) elist[ecount + (uint32_t)__popcll((unsigned long long)(bm & lt))] = ((unsigned long long)off[q] << 32) | (v[q] & 0x7FFFFu);
+                        if (m) elist[ecount + (uint32_t)__popcll((unsigned long long)(bm & lt))] = ((unsigned long long)off[q] << 32) | (v[q] & 0x1FFFFFFFu);  // (ids | position or seat << 7 | TOK_DUPREF)
                         ecount += (uint32_t)__popcll((unsigned long long)bm);
                         if (ecount > (uint32_t)PK_ECAP - 64u) flush();
                     }
@@ -3869,7 +3887,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PACK_PLAIN_WAVES) void td_pack_plain(
                 if (k < cnt) {
                     int32_t* o = dst + (int64_t)(int32_t)(k + sh[q]);
                     if ((v[q] & 0xC0000000u) == TOK_MISS) {
-                        const uint32_t* mo = a.merge_out + (size_t)tile * K_STAGE + ((v[q] >> 7) & 0xFFFu);
+                        const uint32_t* mo = marker_ids(a, (uint32_t)tile, v[q]);
                         const uint32_t nt = v[q] & 127u;
                         for (uint32_t i = 0; i < nt; ++i) o[i] = (int32_t)mo[i];
                     } else {
