@@ -163,6 +163,9 @@ int td_encode_batch_with_special_strs(td_tokenizer* t, const uint8_t* text, cons
 #define TD_INFO_DEFERRED_TILES 9 /* token tiles (4 KiB) the fused tile loop left to td_probe_tiles, last call (as of the last td_device_status) */
 #define TD_INFO_FLAGGED_TILES 10 /* token tiles whose missed pieces went to td_merge_pieces, last call */
 #define TD_INFO_LB_TIMEOUTS 12   /* ... and tiles it staged because their output base was not known in time (bounded look-back), last call */
+#define TD_INFO_REPEATS 13       /* missed pieces whose ids were taken from another piece with the same bytes (TD_OPT_DEDUPE), last call */
+#define TD_INFO_LISTED_PIECES 14 /* ... and missed pieces of the same tiles that were merged themselves, last call */
+#define TD_INFO_CHAR_SEEDS 15    /* characters of 2..3 bytes this vocabulary allows to enter the merge of a long piece as one part (td_common.h) */
 #define TD_INFO_DIRECT_TILES 11  /* pre-tokenizer tiles (8 KiB) whose ids the fused tile loop wrote straight to the output (TD_OPT_DIRECT), last call */
 int64_t td_info(const td_tokenizer* t, int what);
 

@@ -54,6 +54,7 @@ def test_long_pieces_of_seedable_characters_equal_the_reference():
     R = H.ref_tokenizer()
     rng = random.Random(17)
     on, off = _tok(), _tok(TD_CHAR_SEEDS=0)
+    assert on.info(capi.TD_INFO_CHAR_SEEDS) > 5000 and off.info(capi.TD_INFO_CHAR_SEEDS) == 0, "the Llama-4 vocabulary has 5 675 seedable characters"
     try:
         for rep in range(6):
             runs = _runs(rng, 1500)

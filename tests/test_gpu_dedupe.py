@@ -84,6 +84,14 @@ def test_dedupe_changes_no_id():
                         assert np.array_equal(go, eo), f"{name}, fused={fused}, dedupe={dd}, {k}: document offsets differ from the reference"
                         bad = np.flatnonzero(gt != et) if len(gt) == len(et) else np.asarray([min(len(gt), len(et))])
                         assert bad.size == 0, f"{name}, fused={fused}, dedupe={dd}, {k}: ids differ from the reference, first at token {bad[:1]}"
+                        # ... and the table does what it is there for (a switch that silently did nothing would pass everything above)
+                        rep, listed = t.info(capi.TD_INFO_REPEATS), t.info(capi.TD_INFO_LISTED_PIECES)
+                        if not dd:
+                            assert rep == 0, f"{name}, {k}: repeats with the table off"
+                        elif name == "default" and k in ("five words", "code file set", "mixed-script 3 MiB"):
+                            assert rep > 4 * listed, f"{name}, fused={fused}, {k}: {rep} repeats, {listed} pieces merged themselves"
+                        elif name == "default" and k == "random words":
+                            assert rep < listed // 4, f"{name}, {k}: {rep} repeats among random words ({listed} merged)"
     finally:
         for t in toks.values():
             t.close()

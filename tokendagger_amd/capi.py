@@ -35,6 +35,7 @@ TD_OPT_OVERLAP = 12
 TD_INFO_DEFERRED_TILES, TD_INFO_FLAGGED_TILES = 9, 10
 TD_INFO_DIRECT_TILES = 11
 TD_INFO_LB_TIMEOUTS = 12
+TD_INFO_REPEATS, TD_INFO_LISTED_PIECES, TD_INFO_CHAR_SEEDS = 13, 14, 15
 
 EXPORTS = [
     "td_create", "td_clone", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",

@@ -144,6 +144,7 @@ struct Ctl {  // small control block in device memory
     uint32_t direct_tiles;   // (statistics) pre-tokenizer tiles whose ids the fused loop wrote straight to the output
     uint32_t lb_timeouts;    // ... and tiles it staged because their base was not known in time (behind direct_tiles)
     uint32_t ovf_count;      // td_collect_misses: tiles with a length class that found its lists full
+    uint32_t dd_stats[2];    // (statistics) repeats, pieces listed for the merge (td_copy_dups)
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 }  // namespace
@@ -217,6 +218,7 @@ struct td_tokenizer {
     bool fused = true;  // pre-tokenizer and lookup in one pass over the text (TD_OPT_FUSED; TD_FUSED=0 in the environment turns it off)
     struct Ev3 { hipEvent_t e[TD_PROF_EVENTS]; };
     std::vector<Ev3> ev_pending, ev_free;
+    int64_t last_repeats = 0, last_listed = 0;
     int64_t last_long = 0, last_far = 0, last_deferred = 0, last_flagged = 0, last_direct = 0, last_timeouts = 0;
     const RxProgram* d_rx = nullptr;      // generic split pattern: the compiled program and its tables in HBM
     const uint16_t* d_rx_s1 = nullptr;
@@ -504,6 +506,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.dd_seat_bits = std::min<uint32_t>(39 - dd_tile_bits(n), 21);
     a.dd_minlen = t->dd_minlen;
     a.dd_replicas = t->dd_replicas;
+    a.dd_stats = ctl->dd_stats;
     a.dd_table = a.dedupe ? (unsigned long long*)t->dd_table.p : nullptr;
     a.dd_mask = a.dedupe ? dd_entries(t, n) - 1u : 0u;
     a.flagged_count = &ctl->flagged_count;
@@ -648,6 +651,8 @@ int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) 
     t->last_flagged = c.flagged_count;
     t->last_direct = c.direct_tiles;
     t->last_timeouts = c.lb_timeouts;
+    t->last_repeats = c.dd_stats[0];
+    t->last_listed = c.dd_stats[1];
     if (err_pos) *err_pos = c.err_pos;
     if (c.err != 0) {
         if ((rc0 = zero_wait(t, t->ctl.p, sizeof(Ctl), stream))) return rc0;
@@ -1849,6 +1854,9 @@ int64_t td_info(const td_tokenizer* t, int what) {
         case TD_INFO_FLAGGED_TILES: return t->last_flagged;
         case TD_INFO_DIRECT_TILES: return t->last_direct;
         case TD_INFO_LB_TIMEOUTS: return t->last_timeouts;
+        case TD_INFO_REPEATS: return t->last_repeats;
+        case TD_INFO_LISTED_PIECES: return t->last_listed;
+        case TD_INFO_CHAR_SEEDS: return (int64_t)t->H.n_char_seeds;
     }
     return -1;
 }

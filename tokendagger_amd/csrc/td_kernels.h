@@ -100,6 +100,7 @@ struct EncodeArgs {
     uint32_t dd_seat_bits;      // bits of a seat number in an entry of dup_list (>= log2(entries); the tile number gets the other 39 - this)
     int dedupe;
     uint32_t dd_minlen;         // pieces below this many bytes are not looked up (merged themselves)
+    uint32_t* dd_stats;         // [2] (statistics) repeats / pieces listed for the merge by td_collect_misses, written by td_copy_dups
     uint32_t dd_replicas;       // seats a piece may take, one per group of workgroups (a power of two)
     int overlap;                // (host only: the long pieces run beside the short ones in this call — part of the key a captured graph is reused by)
     unsigned long long* dup_list;  // the repeats: COLL_SUBS lists of dup_cap entries (tile | slot (13 bits) | tile position (12) | seat of dd_table that

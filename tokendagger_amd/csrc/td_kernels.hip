@@ -7,12 +7,17 @@
 //   td_split_far_pieces/_tiles pieces longer than the LDS window (normally none): a wavefront per piece, same matcher over HBM
 //   td_probe_tiles             4 KiB tiles: dense piece list -> ONE slot per piece: the id when the piece is a token
 //                              (whole-piece table probe), a TOK_MISS marker when it is not, TOK_LONGREF above 64 bytes
-//   td_merge_pieces            the TOK_MISS pieces: byte-pair merge, one LANE per piece (every lane advances its own merge
-//                              chain, a merge per round), batches of one length class filled across tiles
-//   td_long_pieces             pieces longer than 64 bytes: lane groups / a wavefront per piece, parts in LDS
+//   td_collect_misses          the TOK_MISS pieces of the tiles that have many: onto lists by length class — once per DISTINCT piece of the
+//                              call (a table of the pieces seen so far, bytes compared); repeats onto a list of their own (round 5)
+//   td_merge_pieces            the listed pieces: byte-pair merge, one LANE per piece (every lane advances its own merge
+//                              chain, a merge per round), rows of one length class
+//   td_copy_dups               the repeats: id count from the piece they repeat; the pack kernels read the ids there (round 5)
+//   td_long_pieces             pieces longer than 64 bytes: lane groups / a wavefront per piece, parts in LDS; multi-byte characters that
+//                              provably merge first enter as one part (character seeds, td_common.h; round 5).  With td_giant_pieces on a
+//                              second stream beside the three kernels above when the handle has seen long pieces (LaunchAux, td_kernels.h)
 //   td_giant_pieces            pieces above 1 KiB: rounds over the whole piece (every pair of the lowest rank at once)
 //   td_scan_tiles              device-wide exclusive scan of the per-tile id counts
-//   td_pack_tokens             per-tile slots -> densely packed int32 ids + int64 per-document token offsets
+//   td_pack_plain, td_pack_rest   per-tile slots -> densely packed int32 ids + int64 per-document token offsets (td_pack_tokens: both in one)
 //
 // Reference behaviour being reproduced: /root/reference/src/tiktoken/tiktoken.cpp:70-128
 // (split_text), :169-234 (encode), :282-378 (get_rank / bpe_merge / byte_pair_encode).
@@ -2355,6 +2360,16 @@ __global__ __launch_bounds__(K_THREADS) void td_copy_dups(const EncodeArgs a) {
     // With allowed special tokens (td_special_ids puts a literal's id where its first piece's ids were) or a generic pattern (markers of its
     // own behind this kernel) a piece's place in merge_out does not keep its ids until the pack kernels run: the ids are copied here then.
     const bool by_ref = a.sp.n == 0u && !(a.pat_flags & PV_GENERIC);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (statistics: TD_INFO_REPEATS, TD_INFO_LISTED_PIECES)
+        uint32_t rep = 0, listed = 0;
+        for (uint32_t q = 0; q < (uint32_t)(K_MISS_CLASSES + 1) * COLL_SUBS; ++q) {
+            const uint32_t c = a.coll_count[q * COLL_STRIDE];
+            if (q >= (uint32_t)DD_CTR) rep += c < a.dup_cap ? c : a.dup_cap;
+            else listed += c < a.coll_cap[q / COLL_SUBS] ? c : a.coll_cap[q / COLL_SUBS];
+        }
+        a.dd_stats[0] = rep;
+        a.dd_stats[1] = listed;
+    }
     for (uint32_t sub = 0; sub < (uint32_t)COLL_SUBS; ++sub) {
         const uint32_t c0 = a.coll_count[((uint32_t)DD_CTR + sub) * COLL_STRIDE];
         const uint32_t cnt = c0 < a.dup_cap ? c0 : a.dup_cap;
