@@ -2360,15 +2360,13 @@ __global__ __launch_bounds__(K_THREADS) void td_copy_dups(const EncodeArgs a) {
     // With allowed special tokens (td_special_ids puts a literal's id where its first piece's ids were) or a generic pattern (markers of its
     // own behind this kernel) a piece's place in merge_out does not keep its ids until the pack kernels run: the ids are copied here then.
     const bool by_ref = a.sp.n == 0u && !(a.pat_flags & PV_GENERIC);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (statistics: TD_INFO_REPEATS, TD_INFO_LISTED_PIECES)
-        uint32_t rep = 0, listed = 0;
-        for (uint32_t q = 0; q < (uint32_t)(K_MISS_CLASSES + 1) * COLL_SUBS; ++q) {
-            const uint32_t c = a.coll_count[q * COLL_STRIDE];
-            if (q >= (uint32_t)DD_CTR) rep += c < a.dup_cap ? c : a.dup_cap;
-            else listed += c < a.coll_cap[q / COLL_SUBS] ? c : a.coll_cap[q / COLL_SUBS];
-        }
-        a.dd_stats[0] = rep;
-        a.dd_stats[1] = listed;
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(K_MISS_CLASSES + 1) * COLL_SUBS) {  // (statistics: TD_INFO_REPEATS, TD_INFO_LISTED_PIECES; a thread per list)
+        const uint32_t q = threadIdx.x, c = a.coll_count[q * COLL_STRIDE];
+        uint32_t cap = a.dup_cap;
+#pragma unroll
+        for (int k = 0; k < K_MISS_CLASSES; ++k)
+            if (q / COLL_SUBS == (uint32_t)k) cap = a.coll_cap[k];
+        if (c) atomicAdd(&a.dd_stats[q >= (uint32_t)DD_CTR ? 0 : 1], c < cap ? c : cap);
     }
     for (uint32_t sub = 0; sub < (uint32_t)COLL_SUBS; ++sub) {
         const uint32_t c0 = a.coll_count[((uint32_t)DD_CTR + sub) * COLL_STRIDE];
