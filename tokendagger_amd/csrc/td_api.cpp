@@ -1828,6 +1828,11 @@ int td_encode_with_special_strs(td_tokenizer* t, const uint8_t* text, int64_t n_
                                 int64_t* n_tokens, int32_t* last_piece_token_len) {
     if (!t || n_bytes < 0 || (n_bytes > 0 && !text) || n_allowed < 0 || (n_allowed > 0 && (!allowed_bytes || !allowed_offsets)) || out_capacity < 0)
         return TD_E_INVALID;
+    if (n_bytes == 0 && n_allowed == 0) {  // (no text, nothing allowed to validate: no ids, and no reason to wake the device)
+        if (n_tokens) *n_tokens = 0;
+        if (last_piece_token_len) *last_piece_token_len = 0;
+        return TD_OK;
+    }
     static const int64_t no_offs[1] = {0};
     return locked(t, [&] {
         const int64_t doc[2] = {0, n_bytes};

@@ -3928,8 +3928,9 @@ __global__ __launch_bounds__(K_THREADS) void td_pack_rest(const EncodeArgs a) {
 // bytes, scan_piece on the class bytes in LDS), looks the pieces up, merges the misses one lane per piece (mg_round), packs
 // and writes ids + offsets + status back into pinned host memory, and releases a sequence number the host spins on.
 // (The batch pipeline is thirteen launches: ~160 us for "Hello, world!", against microseconds on the reference's CPU path.)
-// A piece above 64 bytes makes the kernel hand the call back (fallback = 1) to the general path.
+// A piece above 1 KiB (or more than SM_LONG_MAX pieces above 64 bytes) makes the kernel hand the call back (fallback = 1) to the general path.
 constexpr int SM_MAXBYTES = K_TILE;
+constexpr int SM_LONG_MAX = 64;  // pieces above 64 bytes td_small_encode merges itself (more: the general path)
 struct SmallCfAcc {  // scanner accessor over the class bytes in LDS; positions >= n read as end of subject
     using pos_t = int;
     const uint8_t* cfs;
@@ -3953,6 +3954,8 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
     __shared__ int32_t s_byteid[256];
     __shared__ uint32_t s_wave[8];
     __shared__ uint32_t s_nmiss, s_err, s_errpos, s_fallback;
+    __shared__ uint32_t s_nlong;
+    __shared__ uint16_t s_long[SM_LONG_MAX];  // pieces of 65..1024 bytes (indices into s_plist)
 
     const int tid = threadIdx.x;
     const Tables T = uniform_tables(a.Tp);
@@ -3968,7 +3971,7 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
     }
     for (int q = tid; q < SM_MAXBYTES / 32 + 4; q += K_THREADS) { s_doc[q] = 0; s_start[q] = 0; }
     for (int q = tid; q < (SM_MAXBYTES + 64) / 4; q += K_THREADS) reinterpret_cast<uint4*>(s_tok)[q] = make_uint4(TOK_NONE, TOK_NONE, TOK_NONE, TOK_NONE);
-    if (tid == 0) { s_nmiss = 0; s_err = 0; s_errpos = 0; s_fallback = 0; }
+    if (tid == 0) { s_nmiss = 0; s_err = 0; s_errpos = 0; s_fallback = 0; s_nlong = 0; }
     __syncthreads();
     for (int d = tid; d < a.n_docs; d += K_THREADS) {
         const int64_t p = a.doc_offsets[d];
@@ -4034,7 +4037,14 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
             s_tok[i] = (uint32_t)id;
             continue;
         }
-        if (len > (uint32_t)K_MAXSHORT) { s_fallback = 1; continue; }
+        if (len > (uint32_t)K_MAXSHORT) {
+            // (round 5: pieces of 65..1024 bytes are merged here too, a wavefront per piece behind the short ones — the general path
+            // costs a dozen launches and four copies, 0.37 ms for a line of a hundred blanks; above that, or more than SM_LONG_MAX of them: hand back)
+            uint32_t at = (uint32_t)SM_LONG_MAX;
+            if (len <= (uint32_t)LP_MEDIUM) at = atomicAdd(&s_nlong, 1u);
+            if (at < (uint32_t)SM_LONG_MAX) s_long[at] = (uint16_t)k; else s_fallback = 1;
+            continue;
+        }
         int32_t r = NO_RANK;
         if (a.use_fastpath) {
             auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
@@ -4091,6 +4101,49 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
                 }
                 __syncthreads();
             }
+        }
+    }
+    __syncthreads();
+    // ---- pieces of 65..1024 bytes: a wavefront each, parts dense in LDS (the arrays of the lane-per-piece merge are free now) ----
+    if (s_nlong && !s_fallback) {
+        const int wv = tid >> 6, lane = tid & 63;
+        uint32_t* const base = (wv < 2 ? s_keys : s_ids) + (wv & 1) * 2 * LP_MEDIUM;
+        static_assert(K_THREADS * MG_UNIT >= 4 * LP_MEDIUM, "two wavefronts' ids + ranks per array");
+        volatile uint32_t* const id = base;
+        volatile uint32_t* const rk = base + LP_MEDIUM;
+        const uint32_t nlong = s_nlong < (uint32_t)SM_LONG_MAX ? s_nlong : (uint32_t)SM_LONG_MAX;
+        for (uint32_t e = (uint32_t)wv; e < nlong; e += K_THREADS / 64) {
+            const uint32_t k = s_long[e];
+            const int pos = s_plist[k];
+            const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)pos;
+            const uint8_t* pb = s_txt + pos;
+            int32_t whole = NO_RANK;
+            if (a.use_fastpath && len <= T.max_token_len) {  // whole-piece table first (CoreBPE::encode, tiktoken.cpp:209-215)
+                if (lane == 0) {
+                    auto get = [pb](uint32_t q) { return (uint32_t)pb[q]; };
+                    whole = piece_lookup(T, hash_bytes(get, len), len, get);
+                }
+                whole = __shfl(whole, 0);
+            }
+            uint32_t m = 1;
+            if (whole != NO_RANK) {
+                if (lane == 0) id[0] = (uint32_t)whole;
+            } else {
+                for (uint32_t q = (uint32_t)lane; q < len; q += 64u) {
+                    const uint32_t b = pb[q];
+                    id[q] = (uint32_t)s_byteid[b];
+                    rk[q] = (q + 1 < len) ? (uint32_t)T.byte_pair[(b << 8) | pb[q + 1]] : (uint32_t)NO_RANK;
+                }
+                wave_sync_lds();
+                m = lp_merge_lds<64>(T, id, rk, len, lane);
+            }
+            wave_sync_lds();
+            for (uint32_t q = (uint32_t)lane; q < m; q += 64u) {
+                const uint32_t v = id[q];
+                if ((int32_t)v >= T.pseudo_base) fail(TD_E_UNKNOWN_BYTE, pos);
+                s_tok[pos + q] = v;  // (a piece has at most as many ids as bytes: its own bytes' places, in order)
+            }
+            wave_sync_lds();
         }
     }
     __syncthreads();
