@@ -21,8 +21,9 @@ for T in (8, 32, 256):
     co = td_corpus.chunk_offsets(n, T * 10)
     chunks = [text[co[i]:co[i + 1]] for i in range(T * 10)]
     enc.encode_batch(chunks[:2], num_threads=T)
-    best = 1e9
+    best, res = 1e9, None
     for _ in range(3):
+        res = None  # (the previous result is freed OUTSIDE the timed region, as oracle/ref_pybench.py frees the reference's)
         t0 = time.perf_counter(); res = enc.encode_batch(chunks, num_threads=T); best = min(best, time.perf_counter() - t0)
     ntok = sum(len(r) for r in res)
     toks, toffs = enc.encode_batch_to_numpy(x, np.asarray(co, dtype=np.int64))
