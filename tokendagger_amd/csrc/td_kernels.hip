@@ -2127,7 +2127,6 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
 // only means the piece is merged itself.  Records and repeats are held back in LDS until a wavefront has 64 of a kind: one atomic
 // per 64 whatever the tiles were.
 constexpr int DD_BUF = 512 + 64;   // compacted slots of eight rows + what the group before left over
-constexpr int DD_UCAP = 128;       // records per class (and repeats) a wavefront holds back (at most 63 + 64)
 __device__ __forceinline__ void dd_chunk(const uint8_t* text, int64_t n_text, int64_t g, uint32_t left, uint32_t (&w)[4]) {  // 16 bytes at g, zero from byte `left` on
     uint32_t t[5];
     load_piece_window(text, n_text, g, t);
@@ -2161,21 +2160,20 @@ __device__ __forceinline__ bool dd_same_from(const uint8_t* text, int64_t n_text
 constexpr unsigned long long DD_REC_MASK = (1ull << 56) - 1ull;  // (a record's tile stays below 2^24: dedupe is off above 64 GiB of text)
 constexpr int DD_CTR = K_MISS_CLASSES * COLL_SUBS;  // coll_count[(DD_CTR + s) * COLL_STRIDE]: entries on list s of the repeats
 
-__global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs a) {
+#ifndef TD_COLLECT_MIN_WAVES
+#define TD_COLLECT_MIN_WAVES 6
+#endif
+__global__ __launch_bounds__(K_THREADS, TD_COLLECT_MIN_WAVES) void td_collect_misses(const EncodeArgs a) {
     __shared__ uint32_t s_m[K_THREADS / 64][DD_BUF];
-    __shared__ unsigned long long s_u[K_THREADS / 64][K_MISS_CLASSES][DD_UCAP];
-    __shared__ unsigned long long s_d[K_THREADS / 64][DD_UCAP];
-    __shared__ uint32_t s_dv[K_THREADS / 64][DD_UCAP];  // (their tile position << 7 | length: only what finds no room on the list needs it)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gw = blockIdx.x * (K_THREADS / 64) + wv, nw = gridDim.x * (K_THREADS / 64);
     const int n_flagged = (int)*a.flagged_count;
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t sub = (uint32_t)gw % (uint32_t)COLL_SUBS;
     uint32_t* const mb = s_m[wv];
-    unsigned long long* const db = s_d[wv];
-    uint32_t ucnt[K_MISS_CLASSES], dcnt = 0;
-#pragma unroll
-    for (int c = 0; c < K_MISS_CLASSES; ++c) ucnt[c] = 0;
+    // (a repeat = tile << (25 + seat bits) | slot << (12 + seat bits) | tile position << seat bits | the table seat that names the piece whose
+    // ids it gets; seat bits = a.dd_seat_bits: what the tile number leaves of 39 bits)
+    const uint32_t sb = a.dd_seat_bits;
 
     // no room on a list: the pieces are marked for the scan behind td_merge_pieces' rows (lists are sized for a few times the density of
     // real text, not for a miss every two bytes)
@@ -2183,51 +2181,6 @@ __global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs 
         const uint32_t tile = (uint32_t)(rec >> 32), k = ((uint32_t)rec >> 19) & 0x1FFFu;
         a.stage[(size_t)tile * K_STAGE + k] = TOK_MISS | TOK_OVF | ((uint32_t)rec & 0x7FFFFu);
         atomicOr(&a.tile_count[tile], 1u << (TILE_OVF_SHIFT + mq_class((uint32_t)rec & 127u)));
-    };
-    // `take` records of class c from the front of the wavefront's buffer to its list of that class, the others move up
-    auto flush = [&](const int c, const uint32_t take) {
-        const uint32_t cap = a.coll_cap[c];
-        unsigned long long* const dst = a.miss_list + a.coll_base[c] + (size_t)sub * cap;
-        uint32_t at = 0;
-        if (lane == 0) at = atomicAdd(&a.coll_count[((uint32_t)c * COLL_SUBS + sub) * COLL_STRIDE], take);
-        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-        const unsigned long long rec = (uint32_t)lane < take ? s_u[wv][c][lane] : 0ull;
-        if (at <= cap && take <= cap - at) {
-            if ((uint32_t)lane < take) dst[at + (uint32_t)lane] = rec;
-        } else {  // the places taken before the end of the list hold empty records (length 0: the lane that gets one idles)
-            if ((uint32_t)lane < take) {
-                if (at < cap && (uint32_t)lane < cap - at) dst[at + (uint32_t)lane] = 0ull;
-                to_scan(rec);
-            }
-            if (lane == 0) atomicAdd(a.ovf_count, 1u);
-        }
-        const uint32_t rem = ucnt[c] - take;
-        const unsigned long long x = (uint32_t)lane < rem ? s_u[wv][c][take + (uint32_t)lane] : 0ull;
-        wave_sync_lds();
-        if ((uint32_t)lane < rem) s_u[wv][c][lane] = x;
-        ucnt[c] = rem;
-        wave_sync_lds();
-    };
-    // (a repeat = tile << (25 + seat bits) | slot << (12 + seat bits) | tile position << seat bits | the table seat that names the piece whose
-    // ids it gets; seat bits = a.dd_seat_bits: what the tile number leaves of 39 bits)
-    const uint32_t sb = a.dd_seat_bits;
-    auto flush_dups = [&](const uint32_t take) {
-        uint32_t at = 0;
-        if (lane == 0) at = atomicAdd(&a.coll_count[((uint32_t)DD_CTR + sub) * COLL_STRIDE], take);
-        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-        const unsigned long long ent = (uint32_t)lane < take ? db[lane] : 0ull;
-        if ((uint32_t)lane < take) {
-            if (at < a.dup_cap && (uint32_t)lane < a.dup_cap - at) a.dup_list[(size_t)sub * a.dup_cap + at + (uint32_t)lane] = ent;
-            else to_scan(((unsigned long long)(uint32_t)(ent >> (25u + sb)) << 32) | (((uint32_t)(ent >> (12u + sb)) & 0x1FFFu) << 19) | s_dv[wv][lane]);  // (no room: merged by the scan after all)
-        }
-        if (at > a.dup_cap || take > a.dup_cap - at) { if (lane == 0) atomicAdd(a.ovf_count, 1u); }
-        const uint32_t rem = dcnt - take;
-        const unsigned long long x = (uint32_t)lane < rem ? db[take + (uint32_t)lane] : 0ull;
-        const uint32_t xv = (uint32_t)lane < rem ? s_dv[wv][take + (uint32_t)lane] : 0u;
-        wave_sync_lds();
-        if ((uint32_t)lane < rem) { db[lane] = x; s_dv[wv][lane] = xv; }
-        dcnt = rem;
-        wave_sync_lds();
     };
     // the dense part: entries mb[head .. head + cnt) of `tile`, a lane each
     auto process = [&](const uint32_t tile, const uint32_t head, const uint32_t cnt) {
@@ -2264,8 +2217,7 @@ __global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs 
                 unsigned long long cur = a.dd_table[i];
                 if (cur == 0ull) {
                     // (the zero may be this CU's stale cache line, or the kernel has only just begun and every wavefront finds the seats
-                    // of the few most frequent pieces empty at once — chat markup: 10^5 compare-and-swaps on a dozen addresses, served one
-                    // after the other, were a millisecond per 256 MiB.  A load that bypasses the vector cache first: it is not serialised.)
+                    // of the few most frequent pieces empty at once.  A load that bypasses the vector cache first: it is not serialised.)
                     cur = __hip_atomic_load(&a.dd_table[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cur == 0ull) cur = atomicCAS(&a.dd_table[i], 0ull, mine);
                     if (cur == 0ull) break;  // the first piece with these bytes (as far as the table knows): merged, and named to the others
@@ -2282,32 +2234,44 @@ __global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs 
                 }
             }
         }
+        // Onto the lists: ONE atomic instruction per 64 pieces — lane c reserves the places of class c on this wavefront's list of that class,
+        // lane K_MISS_CLASSES those of the repeats (six different addresses) — then every lane writes its own record.  (Round 5's first form
+        // held records back in LDS until 64 of a kind were there: 26 KB of LDS per workgroup kept the kernel at 4 wavefronts per SIMD, and
+        // it waits for memory 72 % of the time.)
         const bool dup = other != 0ull, uq = act && !dup;
         const uint32_t cls = mq_class(len);
+        uint64_t bc[K_MISS_CLASSES + 1];
+        uint32_t myn = 0;
 #pragma unroll
         for (int c = 0; c < K_MISS_CLASSES; ++c) {
-            const uint64_t b = __ballot(uq && cls == (uint32_t)c);
-            if (b) {
-                if (uq && cls == (uint32_t)c) s_u[wv][c][ucnt[c] + (uint32_t)__popcll((unsigned long long)(b & lt))] = rec;
-                ucnt[c] += (uint32_t)__popcll((unsigned long long)b);
-            }
+            bc[c] = __ballot(uq && cls == (uint32_t)c);
+            if (lane == c) myn = (uint32_t)__popcll((unsigned long long)bc[c]);
         }
-        {
-            const uint64_t b = __ballot(dup);
-            if (b) {
-                if (dup) {
-                    const uint32_t at = dcnt + (uint32_t)__popcll((unsigned long long)(b & lt));
-                    db[at] = ((((unsigned long long)tile << 13 | (e >> 19)) << 12 | pos) << sb) | seat;
-                    s_dv[wv][at] = e & 0x7FFFFu;
-                }
-                dcnt += (uint32_t)__popcll((unsigned long long)b);
-            }
-        }
-        wave_sync_lds();
+        bc[K_MISS_CLASSES] = __ballot(dup);
+        if (lane == K_MISS_CLASSES) myn = (uint32_t)__popcll((unsigned long long)bc[K_MISS_CLASSES]);
+        uint32_t at = 0;
+        if (myn) at = atomicAdd(&a.coll_count[((uint32_t)lane < (uint32_t)K_MISS_CLASSES ? (uint32_t)lane * COLL_SUBS + sub : (uint32_t)DD_CTR + sub) * COLL_STRIDE], myn);
+        uint32_t ats[K_MISS_CLASSES + 1];  // (every lane learns all six answers: uniform)
 #pragma unroll
-        for (int c = 0; c < K_MISS_CLASSES; ++c)
-            if (ucnt[c] >= 64u) flush(c, 64u);
-        if (dcnt >= 64u) flush_dups(64u);
+        for (int c = 0; c <= K_MISS_CLASSES; ++c) ats[c] = (uint32_t)__builtin_amdgcn_readlane((int)at, c);
+        bool lost = false;  // my piece found no room
+        if (uq) {
+            uint32_t at_c = 0, cap = 0, rank = 0;
+            unsigned long long base = 0;
+#pragma unroll
+            for (int c = 0; c < K_MISS_CLASSES; ++c)
+                if (cls == (uint32_t)c) { at_c = ats[c]; cap = a.coll_cap[c]; base = a.coll_base[c]; rank = (uint32_t)__popcll((unsigned long long)(bc[c] & lt)); }
+            const uint32_t idx = at_c + rank;
+            if (idx < cap && idx >= at_c) a.miss_list[base + (size_t)sub * cap + idx] = rec;
+            else { to_scan(rec); lost = true; }
+        }
+        if (dup) {
+            const uint32_t at_d = ats[K_MISS_CLASSES];
+            const uint32_t idx = at_d + (uint32_t)__popcll((unsigned long long)(bc[K_MISS_CLASSES] & lt));
+            if (idx < a.dup_cap && idx >= at_d) a.dup_list[(size_t)sub * a.dup_cap + idx] = ((((unsigned long long)tile << 13 | (e >> 19)) << 12 | pos) << sb) | seat;
+            else { to_scan(rec); lost = true; }  // (merged by the scan after all)
+        }
+        if (__ballot(lost) && lane == 0) atomicAdd(a.ovf_count, 1u);
     };
 
     for (int f = gw; f < n_flagged; f += nw) {
@@ -2345,10 +2309,6 @@ __global__ __launch_bounds__(K_THREADS) void td_collect_misses(const EncodeArgs 
         if (tail) process(tile, 0u, tail);
         wave_sync_lds();
     }
-#pragma unroll
-    for (int c = 0; c < K_MISS_CLASSES; ++c)
-        if (ucnt[c]) flush(c, ucnt[c]);
-    if (dcnt) flush_dups(dcnt);
 }
 
 // td_copy_dups (behind td_merge_pieces): a lane per repeat — the other piece's finished slot (its id count), this piece's slot (TOK_DUPREF:
