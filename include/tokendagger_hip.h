@@ -218,6 +218,10 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
                                     a second stream of the handle beside the kernels of the shorter ones (fork behind the lookups, join in front of
                                     the scan; parallel branches when the step is captured into a graph); 0: always one kernel after the other.
                                     Same results either way; TD_OVERLAP=0 in the environment at td_create time also turns it off. */
+#define TD_OPT_GIANT_COOP_MIN 13   /* bytes (default 16384, at least 1024): a single piece above this length is merged by ALL workgroups of
+                                    td_giant_pieces together (grid barriers between the sweeps; a megabyte of random letters: 0.55 s on one
+                                    workgroup); shorter pieces above 1 KiB get a workgroup each as before.  Same results either way;
+                                    TD_GP_COOP_MIN in the environment at td_create time sets it too. */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 16) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 

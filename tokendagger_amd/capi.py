@@ -32,6 +32,7 @@ TD_OPT_DIRECT = 9
 TD_OPT_PACK_SPLIT = 10
 TD_OPT_DEDUPE = 11
 TD_OPT_OVERLAP = 12
+TD_OPT_GIANT_COOP_MIN = 13
 TD_INFO_DEFERRED_TILES, TD_INFO_FLAGGED_TILES = 9, 10
 TD_INFO_DIRECT_TILES = 11
 TD_INFO_LB_TIMEOUTS = 12

@@ -145,8 +145,11 @@ struct Ctl {  // small control block in device memory
     uint32_t lb_timeouts;    // ... and tiles it staged because their base was not known in time (behind direct_tiles)
     uint32_t ovf_count;      // td_collect_misses: tiles with a length class that found its lists full
     uint32_t dd_stats[2];    // (statistics) repeats, pieces listed for the merge (td_copy_dups)
+    uint32_t gp_ctl[3];      // td_giant_pieces over all workgroups: barrier arrivals, pieces listed, a barrier gave up
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
+constexpr size_t CTL_BYTES = 256;  // the control block's place in its buffer; behind it: td_giant_pieces' scratch (TD_GP_SCRATCH_BYTES)
+static_assert(sizeof(Ctl) <= CTL_BYTES, "Ctl");
 }  // namespace
 
 // What td_create builds and no call changes afterwards: the host tables and their copies in HBM (~30 MB for a 200 000-entry
@@ -188,6 +191,7 @@ struct td_tokenizer {
     hipStream_t s_aux = nullptr;       // the long pieces beside the short ones (LaunchAux, td_kernels.h); with its two events
     hipEvent_t e_fork = nullptr, e_join = nullptr;
     bool overlap = true;               // TD_OPT_OVERLAP (TD_OVERLAP=0 at td_create time turns it off)
+    uint32_t gp_coop_min = 16384;      // TD_OPT_GIANT_COOP_MIN (TD_GP_COOP_MIN at td_create time): pieces above this many bytes get all workgroups of td_giant_pieces
     hipStream_t s_cap = nullptr;       // hipGraph capture only (non-blocking: the CALLER's stream is never put into capture)
     void* h_ctl = nullptr;             // pinned, 256 B: the control block / an 8-byte total on their way to the host
     // the last step as a hipGraph (encode_device_locked): opt-in (TD_OPT_GRAPH, TD_GRAPH=1)
@@ -439,7 +443,7 @@ int reserve_ws(td_tokenizer* t, int64_t n, int64_t n_docs, bool dense = false) {
     if ((rc = ensure(t, t->long_list, (size_t)(n / (K_MAXSHORT + 1) + n_tiles + 16) * sizeof(LongEntry)))) return rc;
     const int64_t pool_bytes = t->pool_bytes_opt > 0 ? t->pool_bytes_opt : std::max<int64_t>(64ll << 20, 2 * n);
     if ((rc = ensure(t, t->pool, (size_t)pool_bytes))) return rc;
-    if ((rc = ensure(t, t->ctl, sizeof(Ctl)))) return rc;
+    if ((rc = ensure(t, t->ctl, CTL_BYTES + TD_GP_SCRATCH_BYTES))) return rc;
     return TD_OK;
 }
 
@@ -485,6 +489,9 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     Ctl* ctl = (Ctl*)t->ctl.p;
     a.long_count = &ctl->long_count;
     a.giant_count = &ctl->giant_count;
+    a.gp_ctl = ctl->gp_ctl;
+    a.gp_scratch = (uint32_t*)((char*)t->ctl.p + CTL_BYTES);  // (behind the control block; needs no reset)
+    a.gp_coop_min = t->gp_coop_min;
     a.tile_draw = &ctl->tile_draw;
     a.slow_count = &ctl->slow_count;
     a.pool = (uint32_t*)t->pool.p;
@@ -698,6 +705,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if (const char* e = getenv("TD_PACK_SPLIT")) t->pack_split = atoi(e) != 0;
     if (const char* e = getenv("TD_DEDUPE")) t->dedupe = atoi(e) != 0;
     if (const char* e = getenv("TD_OVERLAP")) t->overlap = atoi(e) != 0;
+    if (const char* e = getenv("TD_GP_COOP_MIN")) { if (atol(e) >= 1024) t->gp_coop_min = (uint32_t)std::min<long>(atol(e), 0x7FFFFFFF); }
     if (const char* e = getenv("TD_DD_REPLICAS")) { const int v = atoi(e); if (v >= 1 && v <= 16 && !(v & (v - 1))) t->dd_replicas = (uint32_t)v; }
     if (const char* e = getenv("TD_DD_MINLEN")) t->dd_minlen = (uint32_t)std::max(2, atoi(e));
     if (const char* e = getenv("TD_DD_ENTRIES")) { const long v = atol(e); if (v >= 2 && v <= (1l << 24) && !(v & (v - 1))) t->dd_entries_opt = (uint32_t)v; }
@@ -776,7 +784,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     }
     t->dT = d;
     if ((rc = upload(t, &t->dT, 1, &t->dTp))) return fail(rc);
-    if ((rc = ensure(t, t->ctl, sizeof(Ctl)))) return fail(rc);
+    if ((rc = ensure(t, t->ctl, CTL_BYTES + TD_GP_SCRATCH_BYTES))) return fail(rc);
     if ((rc = zero_wait(t, t->ctl.p, sizeof(Ctl), t->s_own))) return fail(rc);
     *out = t;
     return TD_OK;
@@ -792,13 +800,13 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t = new td_tokenizer(src->shared);
         t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
         t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
-        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->overlap = src->overlap; t->dd_entries_opt = src->dd_entries_opt; t->dd_minlen = src->dd_minlen; t->dd_replicas = src->dd_replicas; t->coll_shrink = src->coll_shrink;
+        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->overlap = src->overlap; t->gp_coop_min = src->gp_coop_min; t->dd_entries_opt = src->dd_entries_opt; t->dd_minlen = src->dd_minlen; t->dd_replicas = src->dd_replicas; t->coll_shrink = src->coll_shrink;
         t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }
     DeviceGuard dg(t->device);
     int rc = own_streams(t);
-    if (rc == TD_OK) rc = ensure(t, t->ctl, sizeof(Ctl));
+    if (rc == TD_OK) rc = ensure(t, t->ctl, CTL_BYTES + TD_GP_SCRATCH_BYTES);
     if (rc == TD_OK) rc = zero_wait(t, t->ctl.p, sizeof(Ctl), t->s_own);
     if (rc != TD_OK) {
         g_create_err = t->err;
@@ -1898,6 +1906,11 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     }
     if (what == TD_OPT_OVERLAP) {
         t->overlap = value != 0;
+        drop_graph(t); t->has_last_key = false;
+        return TD_OK;
+    }
+    if (what == TD_OPT_GIANT_COOP_MIN && value >= 1024) {
+        t->gp_coop_min = (uint32_t)std::min<int64_t>(value, 0x7FFFFFFF);
         drop_graph(t); t->has_last_key = false;
         return TD_OK;
     }

@@ -9,6 +9,7 @@ namespace td {
 
 struct RxProgram;       // td_regex.h: a compiled generic split pattern
 
+constexpr int TD_GP_SCRATCH_BYTES = 8192;  // td_giant_pieces: (1024 listed pieces + 2 x 256 x 2 slots) x 4
 struct LongEntry {      // a piece longer than K_MAXSHORT bytes, merged by td_long_pieces
     int64_t gs;         // global byte offset of the piece
     uint32_t len;       // bytes
@@ -74,6 +75,9 @@ struct EncodeArgs {
     uint32_t long_cap;
     uint32_t* long_count;
     uint32_t* giant_count;      // entries of long_list above 1 KiB (td_giant_pieces)
+    uint32_t* gp_ctl;           // td_giant_pieces over all workgroups (round 5): [0] grid-barrier arrivals, [1] pieces listed, [2] a barrier gave up — zero at launch
+    uint32_t* gp_scratch;       // [TD_GP_SCRATCH_BYTES / 4] the listed pieces | two slots per workgroup and parity
+    uint32_t gp_coop_min;       // pieces above this many bytes are swept by all workgroups of the launch together
     uint32_t* tile_draw;        // fused tile loop: counter the workgroups draw their tiles from (0 at launch)
     uint32_t* pool;             // long-piece scratch + token store
     uint64_t pool_cap;          // in u32

@@ -1754,15 +1754,64 @@ struct FarScan {  // one wavefront's view of the text for the far kernels
     __device__ __forceinline__ int64_t mark_to_tile_end(int64_t p, bool first_is_marked) const {
         const int64_t tile_end = (p - (p % KS_TILE) + KS_TILE < a.n) ? p - (p % KS_TILE) + KS_TILE : a.n;
         bool skip = first_is_marked;
+        const int stride = digit_stride();
         while (p < tile_end) {
             if (!skip) {
                 if (fast_lane_starts_at(p)) return -1;
                 if (lane == 0) atomicOr(&a.startbits[p >> 5], 1u << (p & 31));
             }
             skip = false;
+            if (stride) {
+                const int64_t q = digit_run_skip(p, tile_end, stride);
+                if (q > p) { p = q; continue; }
+            }
             p = piece_end(p);
         }
         return p;
+    }
+    // Inside a run of digits nothing is a synchronisation point (is_sync): under \p{N}{1,3} a piece start is the run's start + 3 k, so
+    // the tiles of a long run are a chain walked by ONE wavefront — piece by piece that was ~2 us per piece: 15 ms for 20 KB of
+    // digits, 0.75 s for a megabyte.  Round 5: when the piece at p starts with an ASCII digit, the end of the run of ASCII digits
+    // (no document start inside) is searched 256 bytes per step, as far as the tile end, and the piece starts p + stride k in
+    // front of it are marked a word of START bits per lane (stride 3; 1 for the patterns that take digits one by one; GPT-2's
+    // digit run is one piece: td_split_far_pieces).  A digit that is not ASCII ends the search: the walk goes on piece by piece
+    // from the last start in front of it.  -> the last of those starts (unmarked: the walk checks and marks it), or p: no shortcut
+    __device__ __forceinline__ int digit_stride() const {
+        const uint32_t pf = T.pat_flags;
+        return (pf & (PV_GPT2 | PV_GENERIC)) ? 0 : (pf & PV_SINGLE_DIGIT) ? 1 : 3;
+    }
+    __device__ __forceinline__ int64_t digit_run_skip(int64_t p, int64_t tile_end, int stride) const {
+        if ((uint32_t)a.text[p] - (uint32_t)'0' > 9u) return p;
+        const int64_t lim = tile_end + stride - 1 < a.n ? tile_end + stride - 1 : a.n;
+        int64_t e = lim;
+        for (int64_t w = p; w < lim; w += 256) {
+            uint64_t b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t pos = w + 64 * q + lane;
+                bool ok = pos < lim;
+                if (ok) ok = (uint32_t)a.text[pos] - (uint32_t)'0' <= 9u && !(pos > p && ((a.docbits[pos >> 5] >> (pos & 31)) & 1u));
+                b[q] = __ballot(ok);
+            }
+            int64_t stop = -1;
+#pragma unroll
+            for (int q = 3; q >= 0; --q)
+                if (~b[q]) stop = w + 64 * q + td_ctz64(~b[q]);
+            if (stop >= 0) { e = stop < lim ? stop : lim; break; }
+        }
+        const int64_t K = (e - p) / stride;
+        if (K < 2) return p;
+        const int64_t first = p + stride, last = p + stride * K;  // starts first, first + stride, ... in front of `last` (and of the tile end)
+        const int64_t stop_at = last < tile_end ? last : tile_end;
+        for (int64_t w = (first >> 5) + lane; w <= ((stop_at - 1) >> 5); w += 64) {
+            uint32_t bits = 0;
+            for (int bpos = 0; bpos < 32; ++bpos) {
+                const int64_t pos = w * 32 + bpos;
+                if (pos >= first && pos < stop_at && (pos - p) % stride == 0) bits |= 1u << bpos;
+            }
+            if (bits) atomicOr(&a.startbits[w], bits);
+        }
+        return last;
     }
     __device__ __forceinline__ void carry_to(int64_t from_tile, int64_t p) const {  // tiles (from_tile, tile of p]: first piece start = p
         const int64_t last = p >= a.n ? (int64_t)a.n_stiles - 1 : p / KS_TILE;
@@ -3105,21 +3154,380 @@ __device__ __forceinline__ uint32_t gp_block_min(uint32_t x, uint32_t* s_m) {  /
 constexpr uint32_t GP_INF = 0x00FFFFFFu;   // rank word: low 24 bits = rank of the pair that starts here (GP_INF: none)
 constexpr uint32_t GP_BASE = 0x40000000u;  //            the pair is a candidate of this round
 constexpr int GP_E = 4;                    // parts per thread and step
+constexpr uint32_t GP_STEP = GP_THREADS * GP_E;
 // (the scope of the loads of what other lanes wrote: workgroup — a piece is one workgroup's, and a CU's waves share its L1;
 // agent scope sends every one of these loads to the memory side of the fabric: 554 -> ? ms for a megabyte of random letters)
 #ifndef GP_LD_SCOPE
 #define GP_LD_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 #endif
-__device__ __forceinline__ uint32_t gp_ld(const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, GP_LD_SCOPE); }  // (written by other lanes of this workgroup)
+// COOP (round 5, below): what the workgroups of a launch exchange is written and read at agent scope (write-through stores, loads
+// that pass the L1 and the XCD's L2): no cache write-back or invalidation at the grid barriers — with release / acquire fences
+// around them (buffer_wbl2 / buffer_inv by 4096 wavefronts) a barrier cost ~260 us, a megabyte of random letters 94 ms
+template <bool COOP>
+__device__ __forceinline__ uint32_t gp_ld(const uint32_t* q) {
+    if constexpr (COOP) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __hip_atomic_load(q, __ATOMIC_RELAXED, GP_LD_SCOPE);  // (written by other lanes of this workgroup)
+}
+template <bool COOP>
+__device__ __forceinline__ void gp_st(uint32_t* q, uint32_t v) {
+    if constexpr (COOP) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *q = v;
+}
 __device__ __forceinline__ uint32_t gp_rank(const Tables& T, uint32_t l, uint32_t r) {
     const int32_t v = pair_lookup(T, l, r);
     return v == NO_RANK ? GP_INF : (uint32_t)v;
+}
+
+// Round 5: ONE piece over ALL workgroups of the launch (a megabyte of random letters was 0.55 s on one CU).
+// The rule and its three kinds of sweeps are the ones above; what changes is who sweeps what.  The parts of a generation are cut
+// into one stretch per workgroup (a multiple of GP_STEP positions; positions stay global, so a stretch reads its neighbours'
+// border parts like its own); a phase ends in a grid barrier (one counter in the control block; the arrays are written and
+// read at agent scope, see gp_ld / gp_st); the three workgroup-wide combinations become grid-wide ones through a slot per workgroup in HBM:
+//   run start in front of a stretch   each workgroup's last run start -> barrier -> maximum over the workgroups in front
+//   the bound's vmin / smax           a pair of slots per workgroup -> barrier -> every wavefront reduces the slots itself
+//   compaction                        survivors counted per stretch -> barrier -> sum over the workgroups in front = where
+//                                     the stretch's survivors go (a pass more than the single workgroup, which compacts in place)
+// and the ranks of the pairs the merges create go to an array of their own (in place they would land in a stretch another
+// workgroup has not read yet): 5 x len words of the pool instead of 4.  The slots are double-buffered by the parity of a
+// sequence number every thread counts alike: between two uses of one parity lies the barrier of the other.
+// A launch's workgroups are resident together (launch_encode: at most one per CU) — a barrier that is not passed within
+// GP_BAR_TIMEOUT (other work of the process holding the CUs that long, or a fault) raises TD_E_HIP and lets every workgroup go.
+constexpr int GP_MAX_BLOCKS = 256;
+constexpr uint32_t GP_LIST_CAP = 1024;  // pieces for all workgroups together, per call (further ones: a workgroup each)
+constexpr uint32_t GP_SCRATCH_WORDS = GP_LIST_CAP + 2u * GP_MAX_BLOCKS * 2u;  // the list | 2 parities x workgroups x 2 slots
+static_assert(GP_SCRATCH_WORDS * 4u == (uint32_t)TD_GP_SCRATCH_BYTES, "td_kernels.h");
+constexpr unsigned long long GP_BAR_TIMEOUT = 400000000ull;  // wall_clock64 ticks (100 MHz): 4 s
+struct GpCoop {
+    uint32_t* bar;     // a.gp_ctl[0]: arrivals (zero at launch; counts up)
+    uint32_t* stop;    // a.gp_ctl[2]: a barrier timed out
+    uint32_t* slots;
+    uint32_t nblk, seq;
+    int* s_flag;
+};
+__device__ __forceinline__ bool gp_grid_barrier(const GpCoop& c) {
+    __builtin_amdgcn_s_waitcnt(0);  // (this wavefront's write-through stores have arrived)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t target = (old / c.nblk + 1u) * c.nblk;
+        const unsigned long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(c.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(c.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+            if (wall_clock64() - t0 > GP_BAR_TIMEOUT) {
+                __hip_atomic_store(c.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *c.s_flag = ok;
+    }
+    __syncthreads();
+    return *c.s_flag != 0;
+}
+__device__ __forceinline__ uint32_t* gp_slot(const GpCoop& c, uint32_t blk, uint32_t k) {
+    return c.slots + (((c.seq & 1u) * GP_MAX_BLOCKS + blk) * 2u + k);
+}
+__device__ __forceinline__ uint32_t gp_slot_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// minimum of x0 and of x1 over the whole grid (x0, x1: this workgroup's values, the same in all its threads)
+__device__ __forceinline__ bool gp_grid_min2(GpCoop& c, uint32_t& x0, uint32_t& x1) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(gp_slot(c, blockIdx.x, 0), x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gp_slot(c, blockIdx.x, 1), x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!gp_grid_barrier(c)) return false;
+    uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
+    for (uint32_t k = threadIdx.x & 63u; k < c.nblk; k += 64u) {
+        const uint32_t v0 = gp_slot_ld(gp_slot(c, k, 0)), v1 = gp_slot_ld(gp_slot(c, k, 1));
+        m0 = v0 < m0 ? v0 : m0;
+        m1 = v1 < m1 ? v1 : m1;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o0 = __shfl_xor(m0, d), o1 = __shfl_xor(m1, d);
+        m0 = o0 < m0 ? o0 : m0;
+        m1 = o1 < m1 ? o1 : m1;
+    }
+    x0 = m0; x1 = m1;
+    ++c.seq;
+    return true;
+}
+// x = this workgroup's value -> before = the maximum (IS_MAX) or the sum of the workgroups' in front of it (identity 0), total = of all
+template <bool IS_MAX>
+__device__ __forceinline__ bool gp_grid_prefix(GpCoop& c, uint32_t x, uint32_t& before, uint32_t& total) {
+    if (threadIdx.x == 0) __hip_atomic_store(gp_slot(c, blockIdx.x, 0), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!gp_grid_barrier(c)) return false;
+    uint32_t bf = 0, tt = 0;
+    for (uint32_t k = threadIdx.x & 63u; k < c.nblk; k += 64u) {
+        const uint32_t v = gp_slot_ld(gp_slot(c, k, 0));
+        if (IS_MAX) { tt = v > tt ? v : tt; if (k < blockIdx.x) bf = v > bf ? v : bf; }
+        else { tt += v; if (k < blockIdx.x) bf += v; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t ob = __shfl_xor(bf, d), ot = __shfl_xor(tt, d);
+        if (IS_MAX) { bf = ob > bf ? ob : bf; tt = ot > tt ? ot : tt; }
+        else { bf += ob; tt += ot; }
+    }
+    before = bf; total = tt;
+    ++c.seq;
+    return true;
+}
+
+struct GpShared {
+    int* s_w;
+    uint32_t* s_m;
+};
+
+// One piece: the `len` bytes at p, arrays at `base` in the pool (4 x len words; COOP: 5 x len).  COOP = false: this workgroup alone
+// (what rounds 2-4 had); COOP = true: every workgroup of the launch, all in the same control flow (m, g, B are grid-wide values).
+// -> false: a grid barrier gave up (c.stop): leave the kernel.
+template <bool COOP>
+__device__ bool gp_piece(const EncodeArgs& a, const Tables& T, const uint32_t j, uint32_t* base, const GpShared sh, GpCoop& co) {
+    int* const s_w = sh.s_w;
+    uint32_t* const s_m = sh.s_m;
+    const int tid = threadIdx.x;
+    const uint32_t len = a.long_list[j].len;
+    const int64_t gs = a.long_list[j].gs;
+    const uint8_t* p = a.text + gs;
+    const uint32_t blk = COOP ? blockIdx.x : 0u, nblk = COOP ? co.nblk : 1u;
+    uint32_t* id_cur = base;               // two generations of (ids, rank words): a round reads one, writes the other
+    uint32_t* rk_cur = id_cur + len;
+    uint32_t* id_nxt = rk_cur + len;
+    uint32_t* rk_nxt = id_nxt + len;
+    uint32_t* const rk_own = rk_nxt + len;  // (COOP) the ranks of the pairs the merges create
+    // (one workgroup: they go to rk_nxt, where the compaction takes them from, in place)
+    // generation 0: one part per byte, rank of every byte pair
+    uint32_t m = len, lmin = GP_INF;
+    for (uint32_t i = blk * GP_THREADS + tid; i < len; i += nblk * GP_THREADS) {
+        const uint32_t b = p[i];
+        const int32_t r0 = (i + 1 < len) ? T.byte_pair[(b << 8) | p[i + 1]] : NO_RANK;
+        const uint32_t r = r0 == NO_RANK ? GP_INF : (uint32_t)r0;
+        gp_st<COOP>(id_cur + i, (uint32_t)T.byte_id[b]);
+        gp_st<COOP>(rk_cur + i, r);
+        lmin = r < lmin ? r : lmin;
+    }
+    if (!COOP) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t g = gp_block_min(lmin, s_m);
+    if constexpr (COOP) {
+        uint32_t dummy = 0;
+        if (!gp_grid_min2(co, g, dummy)) return false;
+    }
+    while (g != GP_INF) {
+        uint32_t* const rk_new = COOP ? rk_own : rk_nxt;
+        // this workgroup's stretch of the generation
+        uint32_t lo = 0, hi = m;
+        if constexpr (COOP) {
+            const uint32_t per = ((m + nblk - 1u) / nblk + GP_STEP - 1u) / GP_STEP * GP_STEP;
+            const unsigned long long l64 = (unsigned long long)blk * per;
+            lo = l64 < m ? (uint32_t)l64 : m;
+            hi = m - lo < per ? m : lo + per;
+        }
+        // ---- sweep 1: the round's candidates.  rank word i gets GP_BASE when pair i ranks below its left neighbour pair's
+        //      run start ... (see above): r_i <= r_{i+1}, the run of equal ranks it lies in starts at rs with r_rs < r_{rs-1},
+        //      and i - rs is even ----
+        int carry = -1;  // last position so far where the rank differs from the one in front of it (run start)
+        if constexpr (COOP) {  // ... in front of the stretch: the last run start of the workgroups in front of this one
+            uint32_t last1 = 0;  // (position + 1; 0: none)
+            for (uint32_t q = lo + (uint32_t)tid; q < hi; q += GP_THREADS) {
+                const uint32_t r = gp_ld<COOP>(rk_cur + q) & GP_INF;
+                if (q == 0u || r != (gp_ld<COOP>(rk_cur + q - 1) & GP_INF)) last1 = q + 1u;  // (q grows: the last one stays)
+            }
+            last1 = ~gp_block_min(~last1, s_m);
+            uint32_t before, total;
+            if (!gp_grid_prefix<true>(co, last1, before, total)) return false;
+            carry = (int)before - 1;
+        }
+        for (uint32_t i0 = lo; i0 < hi; i0 += GP_STEP) {
+            const uint32_t i = i0 + (uint32_t)tid * GP_E;
+            uint32_t r[GP_E + 2];  // r[0] = rank at i - 1 ... r[GP_E + 1] = rank at i + GP_E
+#pragma unroll
+            for (int e = 0; e < GP_E + 2; ++e) {
+                const uint32_t q = i + (uint32_t)e - 1u;
+                r[e] = (q < m) ? (gp_ld<COOP>(rk_cur + q) & GP_INF) : GP_INF;  // (q = i - 1 wraps for i = 0: >= m)
+            }
+            int last = -1;  // my last run start
+#pragma unroll
+            for (int e = 0; e < GP_E; ++e)
+                if (i + (uint32_t)e < m && (i + (uint32_t)e == 0u || r[e + 1] != r[e])) last = (int)(i + (uint32_t)e);
+            int tot;
+            const int incl = gp_block_scan<true>(last, s_w, tot);  // (max-scan: identity 0x80000000 < -1)
+            int before = __shfl_up(incl, 1);                       // run start in front of my first part: the thread before me ...
+            if ((tid & 63) == 0) before = -1;
+            {   // ... (across wavefronts: the scan's own prefix) — recomputed from the totals
+                int pre = carry;
+                for (int w = 0; w < (tid >> 6); ++w) pre = s_w[w] > pre ? s_w[w] : pre;
+                before = before > pre ? before : pre;
+            }
+            int rs = before;
+#pragma unroll
+            for (int e = 0; e < GP_E; ++e) {
+                const uint32_t q = i + (uint32_t)e;
+                if (q < m) {
+                    if (q == 0u || r[e + 1] != r[e]) rs = (int)q;
+                    const uint32_t rq = r[e + 1];
+                    bool cand = rq != GP_INF && rq <= r[e + 2] && !(((int)q - rs) & 1);
+                    if (cand) {  // the run's start ranks strictly below the pair in front of it
+                        const uint32_t rl = rs > 0 ? (gp_ld<COOP>(rk_cur + rs - 1) & GP_INF) : GP_INF;
+                        cand = rq < rl;
+                    }
+                    gp_st<COOP>(rk_cur + q, rq | (cand ? GP_BASE : 0u));  // (others read the low 24 bits of this word meanwhile: they do not change)
+                }
+            }
+            carry = tot > carry ? tot : carry;
+            __syncthreads();  // (s_w is read above after the scan's last barrier)
+        }
+        if constexpr (COOP) {
+            if (!gp_grid_barrier(co)) return false;
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+        }
+        // ---- sweeps 2: the bound.  sel_i = GP_BASE and rank < B; lowered until the two conditions hold ----
+        uint32_t B = GP_INF;       // merge the candidates that rank below B
+        uint32_t first_sel = 0;    // B == 0: the plain sequential step — only this pair merges
+        for (;;) {
+            auto sel_of = [&](uint32_t q, uint32_t w) { return B ? ((w & GP_BASE) && (w & GP_INF) < B) : (q == first_sel); };
+            uint32_t vmin = GP_INF, smax = 0;  // lowest rank that has to stay above the merged ones; highest merged rank
+            for (uint32_t q = lo + (uint32_t)tid; q < hi; q += GP_THREADS) {
+                const uint32_t w0 = gp_ld<COOP>(rk_cur + q), r0 = w0 & GP_INF;
+                const uint32_t wm1 = q >= 1 ? gp_ld<COOP>(rk_cur + q - 1) : GP_INF, wp1 = q + 1 < m ? gp_ld<COOP>(rk_cur + q + 1) : GP_INF;
+                const bool s0 = sel_of(q, w0), sm1 = q >= 1 && sel_of(q - 1, wm1), sp1 = q + 1 < m && sel_of(q + 1, wp1);
+                if (!s0) {
+                    if (!sm1 && !sp1 && r0 < vmin) vmin = r0;  // a pair that is left over and not overlapped by a merging one
+                    continue;
+                }
+                smax = r0 > smax ? r0 : smax;
+                const uint32_t wp2 = q + 2 < m ? gp_ld<COOP>(rk_cur + q + 2) : GP_INF, wm2 = q >= 2 ? gp_ld<COOP>(rk_cur + q - 2) : GP_INF;
+                const bool sp2 = q + 2 < m && sel_of(q + 2, wp2), sm2 = q >= 2 && sel_of(q - 2, wm2);
+                if (q + 2 < m) {  // the pair my merged part makes with what follows it
+                    const uint32_t idn = gp_ld<COOP>(id_cur + q + 2);
+                    const uint32_t nr = gp_rank(T, r0, sp2 ? (wp2 & GP_INF) : idn);
+                    gp_st<COOP>(rk_new + q, nr);
+                    vmin = nr < vmin ? nr : vmin;
+                    if (sp2) {  // two merges one part apart: the pair the sequential order sees in between
+                        const uint32_t tr = r0 <= (wp2 & GP_INF) ? gp_rank(T, r0, idn) : gp_rank(T, gp_ld<COOP>(id_cur + q + 1), wp2 & GP_INF);
+                        vmin = tr < vmin ? tr : vmin;
+                    }
+                } else {
+                    gp_st<COOP>(rk_new + q, GP_INF);
+                }
+                if (q >= 1 && !sm2) {  // ... and with the (unchanged) part in front of it
+                    const uint32_t nl = gp_rank(T, gp_ld<COOP>(id_cur + q - 1), r0);
+                    gp_st<COOP>(rk_new + q - 1, nl);
+                    vmin = nl < vmin ? nl : vmin;
+                }
+            }
+            vmin = gp_block_min(vmin, s_m);
+            smax = ~gp_block_min(~smax, s_m);
+            if constexpr (COOP) {
+                uint32_t nsmax = ~smax;
+                if (!gp_grid_min2(co, vmin, nsmax)) return false;
+                smax = ~nsmax;
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+            }
+            if (B == 0u || smax < vmin) break;       // (the sequential step needs no check)
+            B = vmin;
+            if (B <= g) {  // nothing but the lowest rank is left below the bound: its leftmost pair alone
+                B = 0u;
+                uint32_t f = 0xFFFFFFFFu;
+                for (uint32_t q = lo + (uint32_t)tid; q < hi; q += GP_THREADS)
+                    if ((gp_ld<COOP>(rk_cur + q) & GP_INF) == g && q < f) f = q;
+                first_sel = gp_block_min(f, s_m);
+                if constexpr (COOP) {
+                    uint32_t dummy = 0;
+                    if (!gp_grid_min2(co, first_sel, dummy)) return false;
+                }
+            }
+        }
+        // ---- sweep 3: next generation — surviving parts compacted, the new ranks taken from rk_new ----
+        {
+            auto sel_of = [&](uint32_t q, uint32_t w) { return B ? ((w & GP_BASE) && (w & GP_INF) < B) : (q == first_sel); };
+            uint32_t out_base = 0, m_next = 0;
+            if constexpr (COOP) {  // where this stretch's survivors go: the survivors of the stretches in front of it
+                uint32_t cnt = 0;
+                for (uint32_t q = lo + (uint32_t)tid; q < hi; q += GP_THREADS)
+                    cnt += (q >= 1 && sel_of(q - 1, gp_ld<COOP>(rk_cur + q - 1))) ? 0u : 1u;
+                int tot;
+                (void)gp_block_scan<false>((int)cnt, s_w, tot);
+                if (!gp_grid_prefix<false>(co, (uint32_t)tot, out_base, m_next)) return false;
+            }
+            lmin = GP_INF;
+            for (uint32_t i0 = lo; i0 < hi; i0 += GP_STEP) {
+                const uint32_t i = i0 + (uint32_t)tid * GP_E;
+                uint32_t A[GP_E], nr[GP_E];
+                bool surv[GP_E];
+                uint32_t cnt = 0;
+                uint32_t wprev = i >= 1 && i - 1 < m ? gp_ld<COOP>(rk_cur + i - 1) : GP_INF;
+                bool sprev = i >= 1 && i - 1 < m && sel_of(i - 1, wprev);
+#pragma unroll
+                for (int e = 0; e < GP_E; ++e) {
+                    const uint32_t q = i + (uint32_t)e;
+                    surv[e] = false; A[e] = 0; nr[e] = GP_INF;
+                    if (q < m) {
+                        const uint32_t w0 = gp_ld<COOP>(rk_cur + q);
+                        const bool s0 = sel_of(q, w0);
+                        surv[e] = !sprev;
+                        if (surv[e]) {
+                            const bool sn = q + 1 < m && sel_of(q + 1, gp_ld<COOP>(rk_cur + q + 1));
+                            A[e] = s0 ? (w0 & GP_INF) : gp_ld<COOP>(id_cur + q);
+                            nr[e] = (s0 || sn) ? gp_ld<COOP>(rk_new + q) : (w0 & GP_INF);  // (a merged part's pairs: looked up by the sweeps above)
+                            if (s0 && q + 2 >= m) nr[e] = GP_INF;
+                            if (!s0 && q + 1 >= m) nr[e] = GP_INF;
+                            ++cnt;
+                        }
+                        sprev = s0;
+                    }
+                }
+                int tot;
+                const int incl = gp_block_scan<false>((int)cnt, s_w, tot);
+                uint32_t o = out_base + (uint32_t)incl - cnt;
+#pragma unroll
+                for (int e = 0; e < GP_E; ++e)
+                    if (surv[e]) {
+                        gp_st<COOP>(id_nxt + o, A[e]);
+                        gp_st<COOP>(rk_nxt + o, nr[e]);
+                        lmin = nr[e] < lmin ? nr[e] : lmin;
+                        ++o;
+                    }
+                out_base += (uint32_t)tot;
+            }
+            if (!COOP) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            g = gp_block_min(lmin, s_m);
+            if constexpr (COOP) {
+                uint32_t dummy = 0;
+                if (!gp_grid_min2(co, g, dummy)) return false;
+                m = m_next;
+            } else {
+                m = out_base;
+            }
+            uint32_t* t0 = id_cur; id_cur = id_nxt; id_nxt = t0;
+            uint32_t* t1 = rk_cur; rk_cur = rk_nxt; rk_nxt = t1;
+            if (!COOP) __syncthreads();
+        }
+    }
+    // the ids of the piece: generation `cur`
+    for (uint32_t i = blk * GP_THREADS + tid; i < m; i += nblk * GP_THREADS) {
+        const uint32_t v = gp_ld<COOP>(id_cur + i);
+        if ((int32_t)v >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gs);
+    }
+    if (tid == 0 && blk == 0u) {
+        a.long_list[j].ntok = m;
+        a.long_list[j].pool_off = (unsigned long long)(id_cur - a.pool);
+        if (m > 1) atomicAdd(&a.tile_extra[gs / K_TILE], m - 1);
+    }
+    if (!COOP) __syncthreads();
+    return true;
 }
 
 __global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a) {
     __shared__ int s_w[GP_THREADS / 64];
     __shared__ uint32_t s_m[GP_THREADS / 64];
     __shared__ unsigned long long s_off;
+    __shared__ int s_flag;
     const Tables T = uniform_tables(a.Tp);
     const int tid = threadIdx.x;
     static_assert(K_GIANT_MIN == LP_MEDIUM, "what td_long_pieces leaves");
@@ -3127,194 +3535,60 @@ __global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a
     // of mixed-script text, 128 workgroups with a dependent load per entry, was 0.27 ms for nothing)
     if (*a.giant_count == 0u) return;
     const uint32_t nlong = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
+    const GpShared sh{s_w, s_m};
+    GpCoop co{a.gp_ctl, a.gp_ctl + 2, a.gp_scratch + GP_LIST_CAP, gridDim.x, 0u, &s_flag};
+    const bool grid_ok = gridDim.x > 1u && gridDim.x <= (uint32_t)GP_MAX_BLOCKS;
+    const uint32_t coop_min = grid_ok ? (a.gp_coop_min > (uint32_t)LP_MEDIUM ? a.gp_coop_min : (uint32_t)LP_MEDIUM) : 0xFFFFFFFFu;
+    // ---- the pieces up to coop_min bytes: a workgroup each; the longer ones are listed for all workgroups together ----
     for (uint32_t j = blockIdx.x; j < nlong; j += gridDim.x) {
         const uint32_t len = a.long_list[j].len;
         if (len <= (uint32_t)LP_MEDIUM) continue;  // (uniform: td_long_pieces')
-        const int64_t gs = a.long_list[j].gs;
-        const uint8_t* p = a.text + gs;
+        if (len > coop_min) {
+            if (tid == 0) s_off = atomicAdd(a.gp_ctl + 1, 1u);
+            __syncthreads();
+            const uint32_t k = (uint32_t)s_off;
+            __syncthreads();
+            if (k < GP_LIST_CAP) {
+                if (tid == 0) __hip_atomic_store(a.gp_scratch + k, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }  // (the list is full: this workgroup alone)
+        }
         if (tid == 0) s_off = atomicAdd(a.pool_used, 4ull * len);
         __syncthreads();
         const unsigned long long off = s_off;
         __syncthreads();
         if (off + 4ull * len > a.pool_cap) {
-            if (tid == 0) raise(a, TD_E_SCRATCH, gs);
+            if (tid == 0) raise(a, TD_E_SCRATCH, a.long_list[j].gs);
             continue;
         }
-        uint32_t* id_cur = a.pool + off;       // two generations of (ids, rank words): a round reads one, writes the other
-        uint32_t* rk_cur = id_cur + len;
-        uint32_t* id_nxt = rk_cur + len;
-        uint32_t* rk_nxt = id_nxt + len;       // (during a round: the ranks of the pairs the merges create, where the compaction takes them from)
-        // generation 0: one part per byte, rank of every byte pair
-        uint32_t m = len, lmin = GP_INF;
-        for (uint32_t i = tid; i < len; i += GP_THREADS) {
-            const uint32_t b = p[i];
-            const int32_t r0 = (i + 1 < len) ? T.byte_pair[(b << 8) | p[i + 1]] : NO_RANK;
-            const uint32_t r = r0 == NO_RANK ? GP_INF : (uint32_t)r0;
-            id_cur[i] = (uint32_t)T.byte_id[b];
-            rk_cur[i] = r;
-            lmin = r < lmin ? r : lmin;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        uint32_t g = gp_block_min(lmin, s_m);
-        while (g != GP_INF) {
-            // ---- sweep 1: the round's candidates.  rank word i gets GP_BASE when pair i ranks below its left neighbour pair's
-            //      run start ... (see above): r_i <= r_{i+1}, the run of equal ranks it lies in starts at rs with r_rs < r_{rs-1},
-            //      and i - rs is even ----
-            int carry = -1;  // last position so far where the rank differs from the one in front of it (run start)
-            for (uint32_t i0 = 0; i0 < m; i0 += GP_THREADS * GP_E) {
-                const uint32_t i = i0 + (uint32_t)tid * GP_E;
-                uint32_t r[GP_E + 2];  // r[0] = rank at i - 1 ... r[GP_E + 1] = rank at i + GP_E
-#pragma unroll
-                for (int e = 0; e < GP_E + 2; ++e) {
-                    const uint32_t q = i + (uint32_t)e - 1u;
-                    r[e] = (q < m) ? (gp_ld(rk_cur + q) & GP_INF) : GP_INF;  // (q = i - 1 wraps for i = 0: >= m)
-                }
-                int last = -1;  // my last run start
-#pragma unroll
-                for (int e = 0; e < GP_E; ++e)
-                    if (i + (uint32_t)e < m && (i + (uint32_t)e == 0u || r[e + 1] != r[e])) last = (int)(i + (uint32_t)e);
-                int tot;
-                const int incl = gp_block_scan<true>(last, s_w, tot);  // (max-scan: identity 0x80000000 < -1)
-                int before = __shfl_up(incl, 1);                       // run start in front of my first part: the thread before me ...
-                if ((tid & 63) == 0) before = -1;
-                {   // ... (across wavefronts: the scan's own prefix) — recomputed from the totals
-                    int pre = carry;
-                    for (int w = 0; w < (tid >> 6); ++w) pre = s_w[w] > pre ? s_w[w] : pre;
-                    before = before > pre ? before : pre;
-                }
-                int rs = before;
-#pragma unroll
-                for (int e = 0; e < GP_E; ++e) {
-                    const uint32_t q = i + (uint32_t)e;
-                    if (q < m) {
-                        if (q == 0u || r[e + 1] != r[e]) rs = (int)q;
-                        const uint32_t rq = r[e + 1];
-                        bool base = rq != GP_INF && rq <= r[e + 2] && !(((int)q - rs) & 1);
-                        if (base) {  // the run's start ranks strictly below the pair in front of it
-                            const uint32_t rl = rs > 0 ? (gp_ld(rk_cur + rs - 1) & GP_INF) : GP_INF;
-                            base = rq < rl;
-                        }
-                        rk_cur[q] = rq | (base ? GP_BASE : 0u);
-                    }
-                }
-                carry = tot > carry ? tot : carry;
-                __syncthreads();  // (s_w is read above after the scan's last barrier)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            // ---- sweeps 2: the bound.  sel_i = GP_BASE and rank < B; lowered until the two conditions hold ----
-            uint32_t B = GP_INF;       // merge the candidates that rank below B
-            uint32_t first_sel = 0;    // B == 0: the plain sequential step — only this pair merges
-            for (;;) {
-                auto sel_of = [&](uint32_t q, uint32_t w) { return B ? ((w & GP_BASE) && (w & GP_INF) < B) : (q == first_sel); };
-                uint32_t vmin = GP_INF, smax = 0;  // lowest rank that has to stay above the merged ones; highest merged rank
-                for (uint32_t q = tid; q < m; q += GP_THREADS) {
-                    const uint32_t w0 = gp_ld(rk_cur + q), r0 = w0 & GP_INF;
-                    const uint32_t wm1 = q >= 1 ? gp_ld(rk_cur + q - 1) : GP_INF, wp1 = q + 1 < m ? gp_ld(rk_cur + q + 1) : GP_INF;
-                    const bool s0 = sel_of(q, w0), sm1 = q >= 1 && sel_of(q - 1, wm1), sp1 = q + 1 < m && sel_of(q + 1, wp1);
-                    if (!s0) {
-                        if (!sm1 && !sp1 && r0 < vmin) vmin = r0;  // a pair that is left over and not overlapped by a merging one
-                        continue;
-                    }
-                    smax = r0 > smax ? r0 : smax;
-                    const uint32_t wp2 = q + 2 < m ? gp_ld(rk_cur + q + 2) : GP_INF, wm2 = q >= 2 ? gp_ld(rk_cur + q - 2) : GP_INF;
-                    const bool sp2 = q + 2 < m && sel_of(q + 2, wp2), sm2 = q >= 2 && sel_of(q - 2, wm2);
-                    if (q + 2 < m) {  // the pair my merged part makes with what follows it
-                        const uint32_t idn = gp_ld(id_cur + q + 2);
-                        const uint32_t nr = gp_rank(T, r0, sp2 ? (wp2 & GP_INF) : idn);
-                        rk_nxt[q] = nr;
-                        vmin = nr < vmin ? nr : vmin;
-                        if (sp2) {  // two merges one part apart: the pair the sequential order sees in between
-                            const uint32_t tr = r0 <= (wp2 & GP_INF) ? gp_rank(T, r0, idn) : gp_rank(T, gp_ld(id_cur + q + 1), wp2 & GP_INF);
-                            vmin = tr < vmin ? tr : vmin;
-                        }
-                    } else {
-                        rk_nxt[q] = GP_INF;
-                    }
-                    if (q >= 1 && !sm2) {  // ... and with the (unchanged) part in front of it
-                        const uint32_t nl = gp_rank(T, gp_ld(id_cur + q - 1), r0);
-                        rk_nxt[q - 1] = nl;
-                        vmin = nl < vmin ? nl : vmin;
-                    }
-                }
-                vmin = gp_block_min(vmin, s_m);
-                smax = ~gp_block_min(~smax, s_m);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __syncthreads();
-                if (B == 0u || smax < vmin) break;       // (the sequential step needs no check)
-                B = vmin;
-                if (B <= g) {  // nothing but the lowest rank is left below the bound: its leftmost pair alone
-                    B = 0u;
-                    uint32_t f = 0xFFFFFFFFu;
-                    for (uint32_t q = tid; q < m; q += GP_THREADS)
-                        if ((gp_ld(rk_cur + q) & GP_INF) == g && q < f) f = q;
-                    first_sel = gp_block_min(f, s_m);
-                }
-            }
-            // ---- sweep 3: next generation — surviving parts compacted, the new ranks taken from rk_nxt ----
-            {
-                auto sel_of = [&](uint32_t q, uint32_t w) { return B ? ((w & GP_BASE) && (w & GP_INF) < B) : (q == first_sel); };
-                uint32_t out_base = 0;
-                lmin = GP_INF;
-                for (uint32_t i0 = 0; i0 < m; i0 += GP_THREADS * GP_E) {
-                    const uint32_t i = i0 + (uint32_t)tid * GP_E;
-                    uint32_t A[GP_E], nr[GP_E];
-                    bool surv[GP_E];
-                    uint32_t cnt = 0;
-                    uint32_t wprev = i >= 1 && i - 1 < m ? gp_ld(rk_cur + i - 1) : GP_INF;
-                    bool sprev = i >= 1 && i - 1 < m && sel_of(i - 1, wprev);
-#pragma unroll
-                    for (int e = 0; e < GP_E; ++e) {
-                        const uint32_t q = i + (uint32_t)e;
-                        surv[e] = false; A[e] = 0; nr[e] = GP_INF;
-                        if (q < m) {
-                            const uint32_t w0 = gp_ld(rk_cur + q);
-                            const bool s0 = sel_of(q, w0);
-                            surv[e] = !sprev;
-                            if (surv[e]) {
-                                const bool sn = q + 1 < m && sel_of(q + 1, gp_ld(rk_cur + q + 1));
-                                A[e] = s0 ? (w0 & GP_INF) : gp_ld(id_cur + q);
-                                nr[e] = (s0 || sn) ? gp_ld(rk_nxt + q) : (w0 & GP_INF);  // (a merged part's pairs: looked up by the sweeps above)
-                                if (s0 && q + 2 >= m) nr[e] = GP_INF;
-                                if (!s0 && q + 1 >= m) nr[e] = GP_INF;
-                                ++cnt;
-                            }
-                            sprev = s0;
-                        }
-                    }
-                    int tot;
-                    const int incl = gp_block_scan<false>((int)cnt, s_w, tot);
-                    uint32_t o = out_base + (uint32_t)incl - cnt;
-#pragma unroll
-                    for (int e = 0; e < GP_E; ++e)
-                        if (surv[e]) {
-                            id_nxt[o] = A[e];
-                            rk_nxt[o] = nr[e];
-                            lmin = nr[e] < lmin ? nr[e] : lmin;
-                            ++o;
-                        }
-                    out_base += (uint32_t)tot;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                g = gp_block_min(lmin, s_m);
-                m = out_base;
-                uint32_t* t0 = id_cur; id_cur = id_nxt; id_nxt = t0;
-                uint32_t* t1 = rk_cur; rk_cur = rk_nxt; rk_nxt = t1;
-                __syncthreads();
-            }
-        }
-        // the ids of the piece: generation `cur`
-        for (uint32_t i = tid; i < m; i += GP_THREADS) {
-            const uint32_t v = gp_ld(id_cur + i);
-            if ((int32_t)v >= T.pseudo_base) raise(a, TD_E_UNKNOWN_BYTE, gs);
-        }
-        if (tid == 0) {
-            a.long_list[j].ntok = m;
-            a.long_list[j].pool_off = (unsigned long long)(id_cur - a.pool);
-            if (m > 1) atomicAdd(&a.tile_extra[gs / K_TILE], m - 1);
-        }
-        __syncthreads();
+        (void)gp_piece<false>(a, T, j, a.pool + off, sh, co);
     }
+    if (!grid_ok) return;
+    // ---- the listed pieces: all workgroups on one after the other (every workgroup passes the same barriers) ----
+    if (!gp_grid_barrier(co)) {
+        if (tid == 0) raise(a, TD_E_HIP, 0);
+        return;
+    }
+    uint32_t ncoop = gp_slot_ld(a.gp_ctl + 1);
+    ncoop = ncoop < GP_LIST_CAP ? ncoop : GP_LIST_CAP;
+    // (nothing else takes from the pool from here on: every workgroup computes the same offsets)
+    const unsigned long long used0 = __hip_atomic_load(a.pool_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long off = used0;
+    for (uint32_t k = 0; k < ncoop; ++k) {
+        const uint32_t j = gp_slot_ld(a.gp_scratch + k);
+        const uint32_t len = a.long_list[j].len;
+        if (off + 5ull * len > a.pool_cap) {
+            if (tid == 0 && blockIdx.x == 0u) raise(a, TD_E_SCRATCH, a.long_list[j].gs);
+            continue;
+        }
+        if (!gp_piece<true>(a, T, j, a.pool + off, sh, co)) {
+            if (tid == 0) raise(a, TD_E_HIP, a.long_list[j].gs);
+            return;
+        }
+        off += 5ull * len;
+    }
+    // (every workgroup has read pool_used before the first listed piece's first barrier, which workgroup 0 is behind by now)
+    if (ncoop && tid == 0 && blockIdx.x == 0u) atomicAdd(a.pool_used, off - used0);
 }
 
 // ------------------------------------------------------------------ td_scan_tiles -----------
@@ -4242,6 +4516,22 @@ static int long_grid_blocks() {  // (work is dealt round-robin to the wavefronts
     if (e && atoi(e) > 0) return 256 * atoi(e);
     return g_blocks_long;
 }
+static int giant_grid_blocks() {
+    // (a piece above gp_coop_min bytes is swept by ALL workgroups with grid barriers in between: the grid has to be resident at once —
+    // one 1024-thread workgroup per CU at most, whatever the occupancy query says fits)
+    static int blocks = 0;
+    if (!blocks) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        blocks = 1;  // (no grid barrier without knowing what is resident)
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)td_giant_pieces, GP_THREADS, 0) == hipSuccess && per_cu > 0)
+            blocks = prop.multiProcessorCount < GP_MAX_BLOCKS ? prop.multiProcessorCount : GP_MAX_BLOCKS;
+        const char* e = getenv("TD_GIANT_BLOCKS");
+        if (e && atoi(e) > 0 && atoi(e) <= blocks) blocks = atoi(e);
+    }
+    return blocks;
+}
 static int g_blocks_fused = 0;
 int fused_grid_blocks() {
     if (!g_blocks_fused) g_blocks_fused = resident_blocks((const void*)td_split_tiles<0u, true, false>, 3);
@@ -4342,7 +4632,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         if (fe == hipSuccess) fe = hipStreamWaitEvent(aux->s, aux->fork, 0);
         if (fe != hipSuccess) return fe;
         hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, aux->s, a);
-        hipLaunchKernelGGL(td_giant_pieces, dim3(128), dim3(GP_THREADS), 0, aux->s, a);
+        hipLaunchKernelGGL(td_giant_pieces, dim3(giant_grid_blocks()), dim3(GP_THREADS), 0, aux->s, a);
         if ((fe = hipEventRecord(aux->join, aux->s)) != hipSuccess) return fe;
     }
     if (tokens && merges) {
@@ -4363,7 +4653,7 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
             if (je != hipSuccess) return je;
         } else {
             hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, stream, a);
-            hipLaunchKernelGGL(td_giant_pieces, dim3(128), dim3(GP_THREADS), 0, stream, a);
+            hipLaunchKernelGGL(td_giant_pieces, dim3(giant_grid_blocks()), dim3(GP_THREADS), 0, stream, a);
         }
         if (a.pat_flags & PV_GENERIC) {  // text the pattern skips gets no tokens
             const hipError_t ge = launch_generic_gaps(a, stream);
