@@ -388,7 +388,8 @@ def test_giant_pieces_are_not_quadratic(tok):
             assert one < 0.05, f"{one * 1e3:.1f} ms for a run of {len(d)} bytes"
         print(f"giant pieces: {len(text)} bytes in {dt * 1e3:.1f} ms")
         # many DISTINCT ranks ("a megabyte of random letters: seconds" — one round per distinct rank): round 4
-        # merges bands of ranks per round (td_giant_pieces), ~45 rounds for a megabyte
+        # merges bands of ranks per round (td_giant_pieces), ~45 rounds for a megabyte — 0.55 s on one workgroup; round 5 sweeps a
+        # piece above 16 KiB with all workgroups of the launch (28 ms; VERDICT r4 item 8: <= 100 ms, as an assertion)
         for name, d in (("1 MB of random letters", "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(1_000_000)).encode()),
                         ("400 KB of skewed letters", "".join(rng.choice("eeeeeeetttttaaaaooooiiinnnssshhrrdlcumwfgypbvkjxqz") for _ in range(400_000)).encode()),
                         ("300 KB of runs of a, b, c", b"".join(bytes([rng.choice(b"abc")]) * rng.randrange(1, 9) for _ in range(66_000)))):
@@ -399,7 +400,7 @@ def test_giant_pieces_are_not_quadratic(tok):
             one = time.perf_counter() - t0
             assert np.array_equal(ids, want), name
             print(f"giant pieces: {name}: {one * 1e3:.1f} ms")
-            assert one < 1.0, f"{name}: {one * 1e3:.0f} ms"
+            assert one < 0.1, f"{name}: {one * 1e3:.0f} ms"
     finally:
         port.set_heap_threshold(4096)
 

@@ -145,7 +145,7 @@ struct Ctl {  // small control block in device memory
     uint32_t lb_timeouts;    // ... and tiles it staged because their base was not known in time (behind direct_tiles)
     uint32_t ovf_count;      // td_collect_misses: tiles with a length class that found its lists full
     uint32_t dd_stats[2];    // (statistics) repeats, pieces listed for the merge (td_copy_dups)
-    uint32_t gp_ctl[3];      // td_giant_pieces over all workgroups: barrier arrivals, pieces listed, a barrier gave up
+    uint32_t gp_ctl[4];      // td_giant_pieces over all workgroups: barrier arrivals, pieces listed, a barrier gave up, pieces above the limit
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 constexpr size_t CTL_BYTES = 256;  // the control block's place in its buffer; behind it: td_giant_pieces' scratch (TD_GP_SCRATCH_BYTES)

@@ -75,7 +75,7 @@ struct EncodeArgs {
     uint32_t long_cap;
     uint32_t* long_count;
     uint32_t* giant_count;      // entries of long_list above 1 KiB (td_giant_pieces)
-    uint32_t* gp_ctl;           // td_giant_pieces over all workgroups (round 5): [0] grid-barrier arrivals, [1] pieces listed, [2] a barrier gave up — zero at launch
+    uint32_t* gp_ctl;           // td_giant_pieces over all workgroups (round 5): [0] grid-barrier arrivals, [1] pieces listed, [2] a barrier gave up, [3] pieces above gp_coop_min (counted by the lookups) — zero at launch
     uint32_t* gp_scratch;       // [TD_GP_SCRATCH_BYTES / 4] the listed pieces | two slots per workgroup and parity
     uint32_t gp_coop_min;       // pieces above this many bytes are swept by all workgroups of the launch together
     uint32_t* tile_draw;        // fused tile loop: counter the workgroups draw their tiles from (0 at launch)

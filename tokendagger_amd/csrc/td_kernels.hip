@@ -394,6 +394,7 @@ __device__ __forceinline__ uint32_t probe_piece_cold(const EncodeArgs& a, const 
         le.gs = wg0 + i; le.len = len; le.ntok = 0; le.pool_off = 0;
         a.long_list[idx] = le;
         if (len > (uint32_t)K_GIANT_MIN) atomicAdd(a.giant_count, 1u);  // (td_giant_pieces looks at the list only when there is one)
+        if (len > (uint32_t)K_GIANT_MIN && len > a.gp_coop_min) atomicAdd(a.gp_ctl + 3, 1u);  // (... and its workgroups meet at a grid barrier only when one is for all of them)
         atomicOr(s_flags, TILE_HAS_LONG);
         return TOK_LONGREF | idx;
     }
@@ -3537,7 +3538,7 @@ __global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a
     const uint32_t nlong = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
     const GpShared sh{s_w, s_m};
     GpCoop co{a.gp_ctl, a.gp_ctl + 2, a.gp_scratch + GP_LIST_CAP, gridDim.x, 0u, &s_flag};
-    const bool grid_ok = gridDim.x > 1u && gridDim.x <= (uint32_t)GP_MAX_BLOCKS;
+    const bool grid_ok = gridDim.x > 1u && gridDim.x <= (uint32_t)GP_MAX_BLOCKS && a.gp_ctl[3] != 0u;  // (a.gp_ctl[3]: pieces above gp_coop_min, counted where they were listed)
     const uint32_t coop_min = grid_ok ? (a.gp_coop_min > (uint32_t)LP_MEDIUM ? a.gp_coop_min : (uint32_t)LP_MEDIUM) : 0xFFFFFFFFu;
     // ---- the pieces up to coop_min bytes: a workgroup each; the longer ones are listed for all workgroups together ----
     for (uint32_t j = blockIdx.x; j < nlong; j += gridDim.x) {

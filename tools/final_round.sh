@@ -25,4 +25,5 @@ bash tools/prof_workload.sh $tag code_files 256 > $O/prof_code_files.log 2>&1; t
 cp $R/profiles/hbm_traffic.json $O/hbm_traffic.json
 timeout 200 python tools/gpu_pybatch.py 256 > $O/pybatch.txt 2>&1; grep -v amdgpu $O/pybatch.txt
 timeout 200 python tools/gpu_latency.py > $O/latency.txt 2>&1; grep -v amdgpu $O/latency.txt | tail -12
+timeout 200 python tools/gpu_giant.py > $O/giant_pieces.txt 2>&1; grep -v amdgpu $O/giant_pieces.txt | tail -16
 find $O -name "*.db" -size +20M -delete
