@@ -187,8 +187,9 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
 #define TD_OPT_LONG_POOL_BYTES 1 /* scratch for pieces longer than 64 bytes (default max(64 MiB, 2 x input)) */
 #define TD_OPT_PROFILE 2         /* 1: bracket the kernels of every td_encode_device call with HIP events on the
                                     call's stream (td_profile_read_ex) */
-#define TD_OPT_PIPE_CHUNK_BYTES 3 /* td_encode_batch cuts inputs of at least two chunks into chunks of whole documents of about
-                                    this many bytes (default 16 MiB) and overlaps host copies, PCIe transfers and kernels */
+#define TD_OPT_PIPE_CHUNK_BYTES 3 /* td_encode_batch cuts inputs of at least HALF this many bytes (default 64 MiB) into chunks of whole
+                                    documents of about this size — a sixth of the input, down to an eighth of the size, when the input
+                                    is less than six chunks — and overlaps host copies, PCIe transfers (both directions) and kernels */
 #define TD_OPT_SMALL_PATH 5       /* 0: never take the one-launch path for inputs of at most 4 KiB (default 1: on) */
 #define TD_OPT_FUSED 6            /* 0: pre-tokenizer and lookup as two kernels, two passes over the text (default 1: one fused pass;
                                     TD_FUSED=0 in the environment at td_create time also turns it off).  Same results either way. */

@@ -417,7 +417,7 @@ def test_pipelined_host_batches_equal_the_plain_path():
     big = (b"z" * 700_000)  # one document larger than a chunk
     text = np.concatenate([x, np.frombuffer(big, dtype=np.uint8), y])
     offs = np.concatenate([o, [o[-1] + len(big)], o[-1] + len(big) + p[1:]]).astype(np.int64)
-    want_t, want_o = tok.encode_batch(text, offs)                 # below two chunks of 32 MiB: the plain path
+    want_t, want_o = tok.encode_batch(text, offs)                 # below half of TD_OPT_PIPE_CHUNK_BYTES (32 MiB): the plain path
     tok.set_option(capi.TD_OPT_PIPE_CHUNK_BYTES, 512 << 10)
     for threads in (1, 3):
         tok.set_option(capi.TD_OPT_PIPE_THREADS, threads)

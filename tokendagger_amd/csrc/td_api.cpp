@@ -21,6 +21,8 @@
 #include "td_tables.h"
 #include "td_vocab.h"
 
+namespace td { hipError_t launch_pipe_copy_out(const void* src, void* dst, int64_t n_words, int blocks, hipStream_t stream); }  // td_special.hip
+namespace td { hipError_t launch_pipe_publish(const void* ctl, uint32_t ctl_bytes, void* h_ctl, const int64_t* d_toff, int64_t n_off, int64_t* h_toff, hipStream_t stream); }  // td_special.hip
 using namespace td;
 
 namespace {
@@ -234,7 +236,7 @@ struct td_tokenizer {
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     std::vector<void*> graveyard;  // workspace buffers replaced by larger ones; freed at the next synchronisation point
-    // host-buffer pipeline (td_encode_batch on large inputs): three slots of pinned bounce buffers + device buffers, three
+    // host-buffer pipeline (td_encode_batch on large inputs): four slots of pinned bounce buffers + device buffers, three
     // streams (H2D, kernels, D2H)
     struct PipeSlot {
         void* h_text = nullptr; size_t h_text_cap = 0;   // pinned
@@ -244,9 +246,10 @@ struct td_tokenizer {
         hipEvent_t ev_h2d = nullptr, ev_k = nullptr, ev_off = nullptr, ev_tok = nullptr;
         Ctl* h_ctl = nullptr;                            // pinned copy of the device control block after the chunk's kernels
     };
-    PipeSlot pipe[3];
-    hipStream_t s_h2d = nullptr, s_k = nullptr, s_d2h = nullptr;
-    int64_t pipe_chunk_bytes = 16ll << 20;
+    static constexpr int PIPE_SLOTS = 4;
+    PipeSlot pipe[PIPE_SLOTS];
+    hipStream_t s_h2d = nullptr, s_k = nullptr, s_d2h = nullptr, s_h2d_b = nullptr, s_d2h_b = nullptr;  // (_b: the odd chunks' copies, TD_PIPE_STREAMS=2)
+    int64_t pipe_chunk_bytes = 64ll << 20;  // (a GiB of English host to host: 16 MiB chunks 33 GB/s, 32 MiB 39, 64 MiB 40.5, profiles/r5_bench/e2e_sweep.txt)
     int pipe_threads = 16;
     std::unique_ptr<CopyPool> pool_threads;
     // one-launch path for inputs of at most 4 KiB: pinned host buffers the kernel reads and writes directly
@@ -306,7 +309,7 @@ int zero_wait(td_tokenizer* t, void* dst, size_t bytes, hipStream_t s) {
 // stream itself may be gone by now, the event is ours).
 void drain(td_tokenizer* t) {
     if (t->has_last && t->last_done) (void)hipEventSynchronize(t->last_done);
-    for (hipStream_t st : {t->s_own, t->s_h2d, t->s_k, t->s_d2h, t->s_aux}) if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {t->s_own, t->s_h2d, t->s_k, t->s_d2h, t->s_h2d_b, t->s_d2h_b, t->s_aux}) if (st) (void)hipStreamSynchronize(st);
 }
 
 // Runs f() with the handle locked and its device current; a failure's message is published to this thread's slot.
@@ -832,7 +835,7 @@ void td_destroy(td_tokenizer* t) {
             for (DevBuf* b : {&sl.d_text, &sl.d_offs, &sl.d_tok, &sl.d_toff}) if (b->p) (void)hipFree(b->p);
             for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_off, sl.ev_tok}) if (e) (void)hipEventDestroy(e);
         }
-        for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h, t->s_own, t->s_cap, t->s_aux}) if (st) (void)hipStreamDestroy(st);
+        for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h, t->s_h2d_b, t->s_d2h_b, t->s_own, t->s_cap, t->s_aux}) if (st) (void)hipStreamDestroy(st);
         for (hipEvent_t e : {t->e_fork, t->e_join}) if (e) (void)hipEventDestroy(e);
         if (t->h_ctl) (void)hipHostFree(t->h_ctl);
         if (t->small_in) (void)hipHostFree(t->small_in);
@@ -1027,6 +1030,8 @@ int pipe_init(td_tokenizer* t) {
     HIP_TRY(t, hipStreamCreateWithFlags(&t->s_h2d, hipStreamNonBlocking));
     HIP_TRY(t, hipStreamCreateWithFlags(&t->s_k, hipStreamNonBlocking));
     HIP_TRY(t, hipStreamCreateWithFlags(&t->s_d2h, hipStreamNonBlocking));
+    HIP_TRY(t, hipStreamCreateWithFlags(&t->s_h2d_b, hipStreamNonBlocking));
+    HIP_TRY(t, hipStreamCreateWithFlags(&t->s_d2h_b, hipStreamNonBlocking));
     for (auto& sl : t->pipe) {
         for (hipEvent_t* e : {&sl.ev_h2d, &sl.ev_k, &sl.ev_off, &sl.ev_tok}) HIP_TRY(t, hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_TRY(t, hipHostMalloc((void**)&sl.h_ctl, sizeof(Ctl), hipHostMallocDefault));
@@ -1040,14 +1045,17 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
     if ((rc = pipe_init(t))) return rc;
     if (!t->pool_threads || t->pool_threads->size() != std::max(t->pipe_threads - 1, 1)) t->pool_threads.reset(new CopyPool(std::max(t->pipe_threads - 1, 1)));
     if ((rc = order_before(t, t->s_k))) return rc;
-    // chunks: whole documents, about pipe_chunk_bytes each
+    // chunks: whole documents, about pipe_chunk_bytes each (inputs of less than six such chunks: a sixth of the input, down to an
+    // eighth of pipe_chunk_bytes — the pipeline needs a few chunks in flight to hide anything)
+    const int64_t n_all = doc_offsets[n_docs] - doc_offsets[0];
+    const int64_t chunk_bytes = std::min(t->pipe_chunk_bytes, std::max<int64_t>(t->pipe_chunk_bytes / 8, n_all / 6));
     std::vector<int64_t> cd{0};
     for (int64_t d = 0; d < n_docs;) {
         const int64_t lo = doc_offsets[d];
         int64_t e = d + 1;
         // (binary search for the last document that still fits)
         int64_t a = d + 1, b = n_docs;
-        while (a < b) { const int64_t mid = (a + b + 1) >> 1; if (doc_offsets[mid] - lo <= t->pipe_chunk_bytes) a = mid; else b = mid - 1; }
+        while (a < b) { const int64_t mid = (a + b + 1) >> 1; if (doc_offsets[mid] - lo <= chunk_bytes) a = mid; else b = mid - 1; }
         e = std::max(e, a);
         cd.push_back(e);
         d = e;
@@ -1059,36 +1067,73 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
     int64_t tok_base = 0;
     bool capacity_miss = false;
     int first_err = TD_OK;
+    constexpr int NS = td_tokenizer::PIPE_SLOTS;
+    const bool timing = getenv("TD_PIPE_TIMING") != nullptr;
+    static const bool publish = !(getenv("TD_PIPE_PUBLISH") && atoi(getenv("TD_PIPE_PUBLISH")) == 0);
+    // A chunk's ids leave the device by a KERNEL that stores them into the pinned buffer (32 workgroups; TD_PIPE_D2H_KERNEL=0: by
+    // hipMemcpyAsync).  As SDMA copies on their own stream they did not run beside the H2D copies of the next chunks on this box — a
+    // GiB of English took the SUM of the two directions, 37 ms, whatever the chunk size, the copy threads, a second pair of streams,
+    // HSA_ENABLE_SDMA_GANG=0 or the small dependent copies (profiles/r5_bench/e2e_sweep.txt) — although two streams of queued copies
+    // alone do overlap (tools/gpu_pcie_duplex.py: 20 ms).  Stores over PCIe from a kernel do: 27 ms.
+    static const int d2h_blocks = getenv("TD_PIPE_D2H_KERNEL") ? atoi(getenv("TD_PIPE_D2H_KERNEL")) : 32;
+    static const bool two_streams = getenv("TD_PIPE_STREAMS") && atoi(getenv("TD_PIPE_STREAMS")) == 2;
+    double tm[6] = {0, 0, 0, 0, 0, 0};  // wait for the text copy | enqueue | wait for a chunk's kernels | wait for an out-copy | wait for its ids | start copies
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](int k, std::chrono::steady_clock::time_point t0) { if (timing) tm[k] += std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    std::shared_ptr<CopyPool::Job> in_job[NS], out_job[NS];
+    // chunk i's text starts its way into the slot's pinned buffer (the pool copies; nobody waits here).  The slot was chunk
+    // i - NS's, whose H2D copy was over before its kernels were, and those were waited for in fetch(i - NS)
+    auto start_in = [&](int i) -> int {
+        td_tokenizer::PipeSlot& sl = t->pipe[i % NS];
+        const int64_t d0 = cd[(size_t)i], d1 = cd[(size_t)i + 1], b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0;
+        const auto t0 = now();
+        int r;
+        if ((r = pinned_ensure(t, sl.h_text, sl.h_text_cap, (size_t)nb + 64))) return r;
+        in_job[i % NS] = t->pool_threads->copy(sl.h_text, text + b0, (size_t)nb);
+        lap(5, t0);
+        return TD_OK;
+    };
     auto submit = [&](int i) -> int {
-        td_tokenizer::PipeSlot& sl = t->pipe[i % 3];
+        td_tokenizer::PipeSlot& sl = t->pipe[i % NS];
         const int64_t d0 = cd[(size_t)i], d1 = cd[(size_t)i + 1], b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0, nd = d1 - d0;
         pend[(size_t)i] = {d0, d1, b0, nb, 0};
         int r;
-        if ((r = pinned_ensure(t, sl.h_text, sl.h_text_cap, (size_t)nb + 64))) return r;
+        auto t0 = now();
         if ((r = pinned_ensure(t, sl.h_offs, sl.h_offs_cap, (size_t)(nd + 1) * 8))) return r;
         if ((r = ensure(t, sl.d_text, (size_t)nb + 64))) return r;
         if ((r = ensure(t, sl.d_offs, (size_t)(nd + 1) * 8))) return r;
         if ((r = ensure(t, sl.d_toff, (size_t)(nd + 1) * 8))) return r;
         if ((r = ensure(t, sl.d_tok, (size_t)std::max<int64_t>(nb, 1) * 4))) return r;  // worst case one id per byte
-        auto in_job = t->pool_threads->copy(sl.h_text, text + b0, (size_t)nb);
         int64_t* ho = (int64_t*)sl.h_offs;
         for (int64_t k = 0; k <= nd; ++k) ho[k] = doc_offsets[d0 + k] - b0;
-        t->pool_threads->wait(in_job);
-        if (nb > 0) HIP_TRY(t, hipMemcpyAsync(sl.d_text.p, sl.h_text, (size_t)nb, hipMemcpyHostToDevice, t->s_h2d));
-        HIP_TRY(t, hipMemcpyAsync(sl.d_offs.p, sl.h_offs, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, t->s_h2d));
-        HIP_TRY(t, hipEventRecord(sl.ev_h2d, t->s_h2d));
+        lap(1, t0);
+        t0 = now();
+        if (in_job[i % NS]) { t->pool_threads->wait(in_job[i % NS]); in_job[i % NS].reset(); }
+        lap(0, t0);
+        t0 = now();
+        hipStream_t sh = (two_streams && (i & 1)) ? t->s_h2d_b : t->s_h2d;
+        if (nb > 0) HIP_TRY(t, hipMemcpyAsync(sl.d_text.p, sl.h_text, (size_t)nb, hipMemcpyHostToDevice, sh));
+        HIP_TRY(t, hipMemcpyAsync(sl.d_offs.p, sl.h_offs, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, sh));
+        HIP_TRY(t, hipEventRecord(sl.ev_h2d, sh));
         HIP_TRY(t, hipStreamWaitEvent(t->s_k, sl.ev_h2d, 0));
         if ((r = encode_device_locked(t, sl.d_text.p, nb, sl.d_offs.p, nd, mode, sl.d_tok.p, std::max<int64_t>(nb, 1), sl.d_toff.p, t->s_k))) return r;
         // the chunk's error word and the workspace counters travel with its offsets (the next chunk resets the counters)
-        HIP_TRY(t, hipMemcpyAsync(sl.h_ctl, t->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, t->s_k));
-        HIP_TRY(t, hipMemcpyAsync(sl.h_offs, sl.d_toff.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, t->s_k));
+        if (publish) {
+            HIP_TRY(t, launch_pipe_publish(t->ctl.p, (uint32_t)sizeof(Ctl), sl.h_ctl, (const int64_t*)sl.d_toff.p, nd + 1, (int64_t*)sl.h_offs, t->s_k));
+        } else {
+            HIP_TRY(t, hipMemcpyAsync(sl.h_ctl, t->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, t->s_k));
+            HIP_TRY(t, hipMemcpyAsync(sl.h_offs, sl.d_toff.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, t->s_k));
+        }
         HIP_TRY(t, hipEventRecord(sl.ev_off, t->s_k));
+        lap(1, t0);
         return TD_OK;
     };
     auto fetch = [&](int i) -> int {  // chunk i's kernels are done: its total is known, its ids start their way up
-        td_tokenizer::PipeSlot& sl = t->pipe[i % 3];
+        td_tokenizer::PipeSlot& sl = t->pipe[i % NS];
         Pending& P = pend[(size_t)i];
+        auto t0 = now();
         HIP_TRY(t, hipEventSynchronize(sl.ev_off));
+        lap(2, t0);
         const int64_t nd = P.d1 - P.d0;
         const int64_t* to = (const int64_t*)sl.h_offs;
         P.ntok = to[nd];
@@ -1103,31 +1148,50 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
         for (int64_t k = 0; k < nd; ++k) out_offsets[P.d0 + k] = tok_base + to[k];
         if (tok_base + P.ntok > out_capacity) capacity_miss = true;
         int r;
+        // the slot's pinned id buffer was chunk i - NS's: its ids have to have left it (the pool's copy, started three rounds ago)
+        t0 = now();
+        if (out_job[i % NS]) { t->pool_threads->wait(out_job[i % NS]); out_job[i % NS].reset(); }
+        lap(3, t0);
         if ((r = pinned_ensure(t, sl.h_tok, sl.h_tok_cap, (size_t)std::max<int64_t>(P.ntok, 1) * 4))) return r;
         if (P.ntok > 0 && !capacity_miss && first_err == TD_OK)
-            HIP_TRY(t, hipMemcpyAsync(sl.h_tok, sl.d_tok.p, (size_t)P.ntok * 4, hipMemcpyDeviceToHost, t->s_d2h));
-        HIP_TRY(t, hipEventRecord(sl.ev_tok, t->s_d2h));
+        {
+            hipStream_t sd = (two_streams && (i & 1)) ? t->s_d2h_b : t->s_d2h;
+            if (d2h_blocks > 0) HIP_TRY(t, launch_pipe_copy_out(sl.d_tok.p, sl.h_tok, P.ntok, d2h_blocks, sd));
+            else HIP_TRY(t, hipMemcpyAsync(sl.h_tok, sl.d_tok.p, (size_t)P.ntok * 4, hipMemcpyDeviceToHost, sd));
+        }
+        HIP_TRY(t, hipEventRecord(sl.ev_tok, (two_streams && (i & 1)) ? t->s_d2h_b : t->s_d2h));
         const int64_t base = tok_base;
         tok_base += P.ntok;
         P.nbytes = base;  // (reused: where the chunk's ids go in the caller's buffer)
         return TD_OK;
     };
-    std::shared_ptr<CopyPool::Job> out_job[3];
-    auto deliver = [&](int i) -> int {  // chunk i's ids are in its pinned buffer: the pool copies them out while the next chunk goes in
-        td_tokenizer::PipeSlot& sl = t->pipe[i % 3];
+    auto deliver = [&](int i) -> int {  // chunk i's ids are in its pinned buffer: the pool copies them out while the next chunks go in
+        td_tokenizer::PipeSlot& sl = t->pipe[i % NS];
         const Pending& P = pend[(size_t)i];
+        auto t0 = now();
         HIP_TRY(t, hipEventSynchronize(sl.ev_tok));
-        if (P.ntok > 0 && !capacity_miss && first_err == TD_OK) out_job[i % 3] = t->pool_threads->copy(out_tokens + P.nbytes, sl.h_tok, (size_t)P.ntok * 4);
+        lap(4, t0);
+        t0 = now();
+        if (P.ntok > 0 && !capacity_miss && first_err == TD_OK) out_job[i % NS] = t->pool_threads->copy(out_tokens + P.nbytes, sl.h_tok, (size_t)P.ntok * 4);
+        lap(5, t0);
         return TD_OK;
     };
-    for (int i = 0; i < nchunks + 2; ++i) {
-        // slot i % 3 was chunk i - 3's: its ids left the pinned buffer (out_job), its kernels were done long before
-        if (out_job[i % 3]) { t->pool_threads->wait(out_job[i % 3]); out_job[i % 3].reset(); }
+    // Round 5: the host thread no longer WAITS for a copy it has just started.  The text of chunk i + 1 goes into its pinned buffer
+    // while chunk i is enqueued and chunks i - 1, i - 2 are collected, and a slot's ids have three rounds to leave it (four slots):
+    // with three slots and the text copied inside submit() a round was out-copy + in-copy back to back on this thread (1.1 ms per
+    // 32 MiB chunk: 37 ms per GiB of English = 0.50 of what the two PCIe directions allow side by side).
+    if (nchunks > 0) rc = start_in(0);
+    for (int i = 0; rc == TD_OK && i < nchunks + 2; ++i) {
         if (i < nchunks && (rc = submit(i))) break;
+        if (i + 1 < nchunks && (rc = start_in(i + 1))) break;
         if (i - 1 >= 0 && i - 1 < nchunks && (rc = fetch(i - 1))) break;
         if (i - 2 >= 0 && i - 2 < nchunks && (rc = deliver(i - 2))) break;
     }
+    for (auto& j : in_job) if (j) t->pool_threads->wait(j);
     for (auto& j : out_job) if (j) t->pool_threads->wait(j);
+    if (timing)
+        fprintf(stderr, "[tokendagger] pipeline: %d chunks; host thread ms: wait text copy %.2f | enqueue %.2f | wait kernels %.2f | wait out-copy %.2f | wait ids %.2f | start copies %.2f\n",
+                nchunks, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
     if (rc != TD_OK) {
         // a chunk failed on the host side (allocation, a HIP call): nothing of this call may still be reading the caller's
         // text or writing its output buffers when the error is returned — the copy jobs are done (above), the three streams
@@ -1135,6 +1199,8 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
         (void)hipStreamSynchronize(t->s_h2d);
         (void)hipStreamSynchronize(t->s_k);
         (void)hipStreamSynchronize(t->s_d2h);
+        (void)hipStreamSynchronize(t->s_h2d_b);
+        (void)hipStreamSynchronize(t->s_d2h_b);
         return rc;
     }
     out_offsets[n_docs] = tok_base;
@@ -1225,7 +1291,7 @@ int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc
         rc = encode_batch_small(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
         if (rc != -1) return rc;  // (-1: a piece above 64 bytes; the general path below handles it)
     }
-    if (n >= 2 * t->pipe_chunk_bytes && out_tokens && !with_prefix)
+    if (n >= t->pipe_chunk_bytes / 2 && out_tokens && !with_prefix)  // (default: from 32 MiB on)
         return encode_batch_pipelined(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
     if ((rc = ensure(t, t->h2d_text, (size_t)n + 64))) return rc;
     if ((rc = ensure(t, t->h2d_offs, (size_t)(n_docs + 1) * 8))) return rc;

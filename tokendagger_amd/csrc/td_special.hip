@@ -308,6 +308,35 @@ hipError_t launch_special_cuts(const EncodeArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// td_encode_batch's pipeline (td_api.cpp): a chunk's control block and token offsets written straight into pinned host memory
+// by a kernel behind the chunk's kernels — as copies they were SDMA commands that wait for those kernels inside a copy engine's queue
+__global__ void td_pipe_publish(const uint32_t* ctl, uint32_t ctl_words, uint32_t* h_ctl, const int64_t* d_toff, int64_t n_off, int64_t* h_toff) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    if (gid < ctl_words) h_ctl[gid] = ctl[gid];
+    for (int64_t i = gid; i < n_off; i += gsz) h_toff[i] = d_toff[i];
+    __threadfence_system();
+}
+// ... and a chunk's ids: device buffer -> pinned host buffer by a kernel (stores over PCIe), TD_PIPE_D2H_KERNEL=1
+__global__ __launch_bounds__(256) void td_pipe_copy_out(const uint32_t* src, uint32_t* dst, int64_t n_words) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n_words >> 2;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (int64_t i = gid; i < n4; i += gsz) d4[i] = s4[i];
+    if (gid < (n_words & 3)) dst[(n4 << 2) + gid] = src[(n4 << 2) + gid];
+    __threadfence_system();
+}
+hipError_t launch_pipe_copy_out(const void* src, void* dst, int64_t n_words, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(td_pipe_copy_out, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, n_words);
+    return hipGetLastError();
+}
+hipError_t launch_pipe_publish(const void* ctl, uint32_t ctl_bytes, void* h_ctl, const int64_t* d_toff, int64_t n_off, int64_t* h_toff, hipStream_t stream) {
+    int64_t blocks = (n_off + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 512 ? 512 : blocks;
+    hipLaunchKernelGGL(td_pipe_publish, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint32_t*)ctl, ctl_bytes / 4u, (uint32_t*)h_ctl, d_toff, n_off, h_toff);
+    return hipGetLastError();
+}
+
 hipError_t launch_special_ids(const EncodeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(td_special_ids, dim3(2048), dim3(256), 0, stream, a);
     return hipGetLastError();
