@@ -248,7 +248,7 @@ struct td_tokenizer {
     };
     static constexpr int PIPE_SLOTS = 4;
     PipeSlot pipe[PIPE_SLOTS];
-    hipStream_t s_h2d = nullptr, s_k = nullptr, s_d2h = nullptr, s_h2d_b = nullptr, s_d2h_b = nullptr;  // (_b: the odd chunks' copies, TD_PIPE_STREAMS=2)
+    hipStream_t s_h2d = nullptr, s_k = nullptr, s_d2h = nullptr;
     int64_t pipe_chunk_bytes = 64ll << 20;  // (a GiB of English host to host: 16 MiB chunks 33 GB/s, 32 MiB 39, 64 MiB 40.5, profiles/r5_bench/e2e_sweep.txt)
     int pipe_threads = 16;
     std::unique_ptr<CopyPool> pool_threads;
@@ -309,7 +309,7 @@ int zero_wait(td_tokenizer* t, void* dst, size_t bytes, hipStream_t s) {
 // stream itself may be gone by now, the event is ours).
 void drain(td_tokenizer* t) {
     if (t->has_last && t->last_done) (void)hipEventSynchronize(t->last_done);
-    for (hipStream_t st : {t->s_own, t->s_h2d, t->s_k, t->s_d2h, t->s_h2d_b, t->s_d2h_b, t->s_aux}) if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {t->s_own, t->s_h2d, t->s_k, t->s_d2h, t->s_aux}) if (st) (void)hipStreamSynchronize(st);
 }
 
 // Runs f() with the handle locked and its device current; a failure's message is published to this thread's slot.
@@ -835,7 +835,7 @@ void td_destroy(td_tokenizer* t) {
             for (DevBuf* b : {&sl.d_text, &sl.d_offs, &sl.d_tok, &sl.d_toff}) if (b->p) (void)hipFree(b->p);
             for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_off, sl.ev_tok}) if (e) (void)hipEventDestroy(e);
         }
-        for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h, t->s_h2d_b, t->s_d2h_b, t->s_own, t->s_cap, t->s_aux}) if (st) (void)hipStreamDestroy(st);
+        for (hipStream_t st : {t->s_h2d, t->s_k, t->s_d2h, t->s_own, t->s_cap, t->s_aux}) if (st) (void)hipStreamDestroy(st);
         for (hipEvent_t e : {t->e_fork, t->e_join}) if (e) (void)hipEventDestroy(e);
         if (t->h_ctl) (void)hipHostFree(t->h_ctl);
         if (t->small_in) (void)hipHostFree(t->small_in);
@@ -1030,8 +1030,6 @@ int pipe_init(td_tokenizer* t) {
     HIP_TRY(t, hipStreamCreateWithFlags(&t->s_h2d, hipStreamNonBlocking));
     HIP_TRY(t, hipStreamCreateWithFlags(&t->s_k, hipStreamNonBlocking));
     HIP_TRY(t, hipStreamCreateWithFlags(&t->s_d2h, hipStreamNonBlocking));
-    HIP_TRY(t, hipStreamCreateWithFlags(&t->s_h2d_b, hipStreamNonBlocking));
-    HIP_TRY(t, hipStreamCreateWithFlags(&t->s_d2h_b, hipStreamNonBlocking));
     for (auto& sl : t->pipe) {
         for (hipEvent_t* e : {&sl.ev_h2d, &sl.ev_k, &sl.ev_off, &sl.ev_tok}) HIP_TRY(t, hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_TRY(t, hipHostMalloc((void**)&sl.h_ctl, sizeof(Ctl), hipHostMallocDefault));
@@ -1076,7 +1074,6 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
     // HSA_ENABLE_SDMA_GANG=0 or the small dependent copies (profiles/r5_bench/e2e_sweep.txt) — although two streams of queued copies
     // alone do overlap (tools/gpu_pcie_duplex.py: 20 ms).  Stores over PCIe from a kernel do: 27 ms.
     static const int d2h_blocks = getenv("TD_PIPE_D2H_KERNEL") ? atoi(getenv("TD_PIPE_D2H_KERNEL")) : 32;
-    static const bool two_streams = getenv("TD_PIPE_STREAMS") && atoi(getenv("TD_PIPE_STREAMS")) == 2;
     double tm[6] = {0, 0, 0, 0, 0, 0};  // wait for the text copy | enqueue | wait for a chunk's kernels | wait for an out-copy | wait for its ids | start copies
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](int k, std::chrono::steady_clock::time_point t0) { if (timing) tm[k] += std::chrono::duration<double, std::milli>(now() - t0).count(); };
@@ -1111,10 +1108,9 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
         if (in_job[i % NS]) { t->pool_threads->wait(in_job[i % NS]); in_job[i % NS].reset(); }
         lap(0, t0);
         t0 = now();
-        hipStream_t sh = (two_streams && (i & 1)) ? t->s_h2d_b : t->s_h2d;
-        if (nb > 0) HIP_TRY(t, hipMemcpyAsync(sl.d_text.p, sl.h_text, (size_t)nb, hipMemcpyHostToDevice, sh));
-        HIP_TRY(t, hipMemcpyAsync(sl.d_offs.p, sl.h_offs, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, sh));
-        HIP_TRY(t, hipEventRecord(sl.ev_h2d, sh));
+        if (nb > 0) HIP_TRY(t, hipMemcpyAsync(sl.d_text.p, sl.h_text, (size_t)nb, hipMemcpyHostToDevice, t->s_h2d));
+        HIP_TRY(t, hipMemcpyAsync(sl.d_offs.p, sl.h_offs, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, t->s_h2d));
+        HIP_TRY(t, hipEventRecord(sl.ev_h2d, t->s_h2d));
         HIP_TRY(t, hipStreamWaitEvent(t->s_k, sl.ev_h2d, 0));
         if ((r = encode_device_locked(t, sl.d_text.p, nb, sl.d_offs.p, nd, mode, sl.d_tok.p, std::max<int64_t>(nb, 1), sl.d_toff.p, t->s_k))) return r;
         // the chunk's error word and the workspace counters travel with its offsets (the next chunk resets the counters)
@@ -1155,11 +1151,10 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
         if ((r = pinned_ensure(t, sl.h_tok, sl.h_tok_cap, (size_t)std::max<int64_t>(P.ntok, 1) * 4))) return r;
         if (P.ntok > 0 && !capacity_miss && first_err == TD_OK)
         {
-            hipStream_t sd = (two_streams && (i & 1)) ? t->s_d2h_b : t->s_d2h;
-            if (d2h_blocks > 0) HIP_TRY(t, launch_pipe_copy_out(sl.d_tok.p, sl.h_tok, P.ntok, d2h_blocks, sd));
-            else HIP_TRY(t, hipMemcpyAsync(sl.h_tok, sl.d_tok.p, (size_t)P.ntok * 4, hipMemcpyDeviceToHost, sd));
+            if (d2h_blocks > 0) HIP_TRY(t, launch_pipe_copy_out(sl.d_tok.p, sl.h_tok, P.ntok, d2h_blocks, t->s_d2h));
+            else HIP_TRY(t, hipMemcpyAsync(sl.h_tok, sl.d_tok.p, (size_t)P.ntok * 4, hipMemcpyDeviceToHost, t->s_d2h));
         }
-        HIP_TRY(t, hipEventRecord(sl.ev_tok, (two_streams && (i & 1)) ? t->s_d2h_b : t->s_d2h));
+        HIP_TRY(t, hipEventRecord(sl.ev_tok, t->s_d2h));
         const int64_t base = tok_base;
         tok_base += P.ntok;
         P.nbytes = base;  // (reused: where the chunk's ids go in the caller's buffer)
@@ -1199,8 +1194,6 @@ int encode_batch_pipelined(td_tokenizer* t, const uint8_t* text, const int64_t* 
         (void)hipStreamSynchronize(t->s_h2d);
         (void)hipStreamSynchronize(t->s_k);
         (void)hipStreamSynchronize(t->s_d2h);
-        (void)hipStreamSynchronize(t->s_h2d_b);
-        (void)hipStreamSynchronize(t->s_d2h_b);
         return rc;
     }
     out_offsets[n_docs] = tok_base;
