@@ -113,3 +113,53 @@ def test_a_megabyte_of_random_letters_within_100_ms(tok):
     assert np.array_equal(ids, want)
     print(f"giant pieces: 1 MB of random letters over the grid: {best * 1e3:.1f} ms (host copies included)")
     assert best < 0.1, f"{best * 1e3:.0f} ms"
+
+
+def test_concurrent_handles_with_listed_pieces_do_not_starve_each_other(tok):
+    """Four handles (td_clone), four host threads, each encoding documents with a piece for all workgroups at the same time.  A launch of
+    td_giant_pieces takes half of the CUs, so two of them run side by side; further ones cannot get all their workgroups resident — their
+    first grid barrier (gp_grid_meet) gives up after 50 ms, for all of the launch's workgroups alike, and each workgroup merges what it had
+    listed alone.  Either way: the reference's ids, no TD_E_HIP, no hang."""
+    import threading
+    from oracle import port
+    O = H.port_tokenizer()
+    rng = random.Random(9)
+    docs = ["".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(n)).encode() for n in (120_000, 60_000, 90_000, 40_000)]
+    port.set_heap_threshold(2048)
+    try:
+        want = [O.encode(d) for d in docs]
+    finally:
+        port.set_heap_threshold(4096)
+    handles = [tok] + [tok.clone() for _ in range(3)]
+    errors, times = [], [0.0] * 4
+    go = threading.Barrier(4)
+
+    def work(k):
+        try:
+            t = handles[k]
+            t.encode(docs[k])  # (workspace)
+            go.wait()
+            t0 = time.perf_counter()
+            for it in range(6):
+                d = (k + it) % 4
+                ids = t.encode(docs[d])
+                if not np.array_equal(ids, want[d]):
+                    errors.append((k, it, "ids differ"))
+            times[k] = time.perf_counter() - t0
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+            try:
+                go.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=120)
+    assert not any(x.is_alive() for x in th), "a thread hangs"
+    for h in handles[1:]:
+        h.close()
+    assert not errors, errors
+    print(f"four handles, six pieces each at the same time: {[round(v * 1e3) for v in times]} ms per thread")

@@ -3191,8 +3191,9 @@ __device__ __forceinline__ uint32_t gp_rank(const Tables& T, uint32_t l, uint32_
 // and the ranks of the pairs the merges create go to an array of their own (in place they would land in a stretch another
 // workgroup has not read yet): 5 x len words of the pool instead of 4.  The slots are double-buffered by the parity of a
 // sequence number every thread counts alike: between two uses of one parity lies the barrier of the other.
-// A launch's workgroups are resident together (launch_encode: at most one per CU) — a barrier that is not passed within
-// GP_BAR_TIMEOUT (other work of the process holding the CUs that long, or a fault) raises TD_E_HIP and lets every workgroup go.
+// A launch's workgroups are resident together (launch_encode: one per CU on half of the CUs; its first barrier finds out whether
+// they really are, gp_grid_meet) — a later barrier that is not passed within GP_BAR_TIMEOUT (a fault) raises TD_E_HIP and lets
+// every workgroup go.
 constexpr int GP_MAX_BLOCKS = 256;
 constexpr uint32_t GP_LIST_CAP = 1024;  // pieces for all workgroups together, per call (further ones: a workgroup each)
 constexpr uint32_t GP_SCRATCH_WORDS = GP_LIST_CAP + 2u * GP_MAX_BLOCKS * 2u;  // the list | 2 parities x workgroups x 2 slots
@@ -3221,6 +3222,42 @@ __device__ __forceinline__ bool gp_grid_barrier(const GpCoop& c) {
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
+        }
+        *c.s_flag = ok;
+    }
+    __syncthreads();
+    return *c.s_flag != 0;
+}
+// The launch's FIRST grid barrier asks what all later ones rely on: are its workgroups resident at the same time?  Next to this
+// step's own kernels they are (those end and make room).  Next to ANOTHER launch of this kernel they need not be — a second handle
+// (td_clone) or process on the device with a listed piece of its own: each launch holds a part of the CUs and waits for the rest
+// of its workgroups, which wait for a CU.  So the first barrier gives up after GP_MEET_TIMEOUT, for ALL workgroups alike: the one
+// that runs out of patience sets GP_BAR_DEAD in the counter with a compare-and-swap against a value that has not reached the
+// target (it has reached it meanwhile: the barrier stands, carry on), and whoever reads or increments the counter afterwards finds
+// the bit.  -> false in every workgroup: each merges the pieces it had listed itself, alone (td_giant_pieces, below).  Once the
+// first barrier stands every workgroup is resident until the kernel ends and the later barriers cannot starve.
+constexpr unsigned long long GP_MEET_TIMEOUT = 5000000ull;  // 50 ms
+constexpr uint32_t GP_BAR_DEAD = 0x80000000u;
+__device__ __forceinline__ bool gp_grid_meet(const GpCoop& c) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const uint32_t old = __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old & GP_BAR_DEAD) {
+            ok = 0;
+        } else {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                uint32_t v = __hip_atomic_load(c.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v & GP_BAR_DEAD) { ok = 0; break; }
+                if (v >= c.nblk) break;  // (the counter is zero at launch)
+                if (wall_clock64() - t0 > GP_MEET_TIMEOUT) {
+                    if (__hip_atomic_compare_exchange_strong(c.bar, &v, v | GP_BAR_DEAD, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+                    continue;  // (somebody arrived meanwhile: look again)
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
         *c.s_flag = ok;
     }
@@ -3566,8 +3603,21 @@ __global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a
     }
     if (!grid_ok) return;
     // ---- the listed pieces: all workgroups on one after the other (every workgroup passes the same barriers) ----
-    if (!gp_grid_barrier(co)) {
-        if (tid == 0) raise(a, TD_E_HIP, 0);
+    if (!gp_grid_meet(co)) {  // this launch's workgroups are not resident together: every one merges what it had listed, alone
+        for (uint32_t j = blockIdx.x; j < nlong; j += gridDim.x) {
+            const uint32_t len = a.long_list[j].len;
+            if (len <= coop_min) continue;
+            if (__hip_atomic_load(&a.long_list[j].ntok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;  // (the list was full: merged above)
+            if (tid == 0) s_off = atomicAdd(a.pool_used, 4ull * len);
+            __syncthreads();
+            const unsigned long long off1 = s_off;
+            __syncthreads();
+            if (off1 + 4ull * len > a.pool_cap) {
+                if (tid == 0) raise(a, TD_E_SCRATCH, a.long_list[j].gs);
+                continue;
+            }
+            (void)gp_piece<false>(a, T, j, a.pool + off1, sh, co);
+        }
         return;
     }
     uint32_t ncoop = gp_slot_ld(a.gp_ctl + 1);
@@ -4519,7 +4569,8 @@ static int long_grid_blocks() {  // (work is dealt round-robin to the wavefronts
 }
 static int giant_grid_blocks() {
     // (a piece above gp_coop_min bytes is swept by ALL workgroups with grid barriers in between: the grid has to be resident at once —
-    // one 1024-thread workgroup per CU at most, whatever the occupancy query says fits)
+    // one 1024-thread workgroup per CU at most, whatever the occupancy query says fits — on half of the CUs, so that two such launches
+    // (two handles of a process, two processes) do not starve each other; a third finds out at its first barrier: gp_grid_meet)
     static int blocks = 0;
     if (!blocks) {
         int dev = 0, per_cu = 0;
@@ -4527,7 +4578,8 @@ static int giant_grid_blocks() {
         blocks = 1;  // (no grid barrier without knowing what is resident)
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)td_giant_pieces, GP_THREADS, 0) == hipSuccess && per_cu > 0)
-            blocks = prop.multiProcessorCount < GP_MAX_BLOCKS ? prop.multiProcessorCount : GP_MAX_BLOCKS;
+            blocks = (prop.multiProcessorCount < GP_MAX_BLOCKS ? prop.multiProcessorCount : GP_MAX_BLOCKS) / 2;  // (two launches side by side fit; 128 workgroups: 29 ms for the megabyte, 256: 28)
+        if (blocks < 1) blocks = 1;
         const char* e = getenv("TD_GIANT_BLOCKS");
         if (e && atoi(e) > 0 && atoi(e) <= blocks) blocks = atoi(e);
     }
