@@ -17,8 +17,8 @@ toks = np.zeros(cap, dtype=np.int32); toff = np.zeros(nd + 1, dtype=np.int64); n
 def call():
     rc = lib.td_encode_batch(tok._h, x.ctypes.data, offs.ctypes.data, nd, 0, toks.ctypes.data, cap, toff.ctypes.data, ctypes.byref(ntok))
     assert rc == 0, rc
-for threads in (16,):
-    for mb in (64,):
+for threads in (16, 32):
+    for mb in (16, 32, 64, 128):
         tok.set_option(capi.TD_OPT_PIPE_THREADS, threads); tok.set_option(capi.TD_OPT_PIPE_CHUNK_BYTES, mb << 20)
         call()
         ts = []
