@@ -22,6 +22,7 @@
 #include <map>
 #include <chrono>
 #include <thread>
+#include <sys/mman.h>
 #include <memory>
 #include <set>
 #include <stdexcept>
@@ -67,12 +68,28 @@ void pack_allowed(const std::set<std::string>& allowed, std::vector<uint8_t>& by
     if (bytes.empty()) bytes.push_back(0);
 }
 
+// Fresh memory of megabytes that is about to be written once from end to end (the packed texts, the ids, the item arrays of long
+// lists): ask for huge pages — 4 KiB at a time it is a page fault per 512 ids, 107 000 of them for the lists of 256 MiB of English,
+// and the faults of a process's threads do not scale with the threads.  Only the 2 MiB-aligned interior; a hint, never an error
+// (transparent huge pages set to "never": nothing happens).
+inline void hint_huge(void* p, size_t bytes) {
+#ifdef MADV_HUGEPAGE
+    constexpr uintptr_t H = (uintptr_t)2 << 20;
+    static const bool on = !(getenv("TD_HUGE_PAGES") && atoi(getenv("TD_HUGE_PAGES")) == 0);
+    if (!on || bytes < 2 * H) return;
+    const uintptr_t lo = ((uintptr_t)p + H - 1) & ~(H - 1), hi = ((uintptr_t)p + bytes) & ~(H - 1);
+    if (hi > lo) (void)madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+#else
+    (void)p; (void)bytes;
+#endif
+}
+
 // uninitialised id buffer sized for the worst case (one id per input byte): no capacity miss, no second encode, and
 // only the pages that receive ids are ever touched
 struct IdBuf {
     std::unique_ptr<int32_t[]> p;
     int64_t cap;
-    explicit IdBuf(size_t n_bytes) : p(new int32_t[n_bytes + 16]), cap((int64_t)n_bytes + 16) {}
+    explicit IdBuf(size_t n_bytes) : p(new int32_t[n_bytes + 16]), cap((int64_t)n_bytes + 16) { hint_huge(p.get(), (n_bytes + 16) * 4); }
     int32_t* data() { return p.get(); }
 };
 
@@ -200,15 +217,27 @@ public:
         // The lists first: a failed allocation then leaves nothing to roll back.  They are taken out of the cycle collector's
         // sight until they are filled — their items are NULL while the GIL is released below, and gc.get_objects() / get_referrers()
         // of another thread must not be handed a half-made list.
+        // Round 5: their item arrays are NOT zeroed first.  PyList_New(len) callocs; for lists of a few hundred KB (2560 slices of
+        // 256 MiB) glibc serves that from recycled heap memory and calloc clears it — 440 MB of memset under the GIL for arrays that
+        // are overwritten from end to end a moment later.  An empty list gets an uninitialised array from the same allocator list_dealloc
+        // frees it with; until it is filled its size stays 0, so a list that is dropped half-way (an allocation fails) frees its
+        // array and touches no item.
         py::list outer((size_t)n_docs);
         std::vector<PyObject**> items((size_t)n_docs, nullptr);
         for (int64_t d = 0; d < n_docs; ++d) {
             const Py_ssize_t len = (Py_ssize_t)(offs[d + 1] - offs[d]);
-            PyObject* l = PyList_New(len);
-            if (!l) throw py::error_already_set();  // (outer owns the ones made so far: lists of NULL items are freed like any other)
+            PyObject* l = PyList_New(0);
+            if (!l) throw py::error_already_set();  // (outer owns the ones made so far: empty lists with an array of their own)
             PyObject_GC_UnTrack(l);
-            items[(size_t)d] = ((PyListObject*)l)->ob_item;
             PyList_SET_ITEM(outer.ptr(), (Py_ssize_t)d, l);
+            if (len > 0) {
+                PyObject** arr = (PyObject**)PyMem_Malloc((size_t)len * sizeof(PyObject*));
+                if (!arr) { PyErr_NoMemory(); throw py::error_already_set(); }
+                hint_huge(arr, (size_t)len * sizeof(PyObject*));
+                ((PyListObject*)l)->ob_item = arr;
+                ((PyListObject*)l)->allocated = len;
+                items[(size_t)d] = arr;
+            }
         }
         lap("PyList_New");
         // the references the lists are about to hold, added per distinct id
@@ -232,7 +261,11 @@ public:
             });
         }
         lap("fill");
-        for (int64_t d = 0; d < n_docs; ++d) PyObject_GC_Track(PyList_GET_ITEM(outer.ptr(), (Py_ssize_t)d));  // (complete now)
+        for (int64_t d = 0; d < n_docs; ++d) {  // (complete now: the size, then back into the collector's sight)
+            PyObject* l = PyList_GET_ITEM(outer.ptr(), (Py_ssize_t)d);
+            Py_SET_SIZE(l, (Py_ssize_t)(offs[d + 1] - offs[d]));
+            PyObject_GC_Track(l);
+        }
         lap("track");
         return outer;
     }
@@ -265,6 +298,7 @@ struct PackedTexts {
         }
         total = (size_t)offs[n];
         buf.reset(new uint8_t[total + 64]);
+        hint_huge(buf.get(), total + 64);
         {
             py::gil_scoped_release rel;
             parallel_ranges(n, pool_threads(total), [&](size_t lo, size_t hi, int) {
