@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
         if (kind == 3) for (uint32_t k = 0; k < nblk / 2; ++k) delay[k] += 1000 + (int)(rng() % 1000);
         std::vector<int> result(nblk, -1);
         std::vector<std::thread> th;
-        const auto start = Clock::now() + std::chrono::microseconds(200);
+        const auto start = Clock::now() + std::chrono::microseconds(3000);  // (every thread exists before the first one arrives)
         for (uint32_t k = 0; k < nblk; ++k)
             th.emplace_back([&, k] {
                 while (Clock::now() < start + std::chrono::microseconds(delay[k])) {}
