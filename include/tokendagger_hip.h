@@ -166,6 +166,7 @@ int td_encode_batch_with_special_strs(td_tokenizer* t, const uint8_t* text, cons
 #define TD_INFO_REPEATS 13       /* missed pieces whose ids were taken from another piece with the same bytes (TD_OPT_DEDUPE), last call */
 #define TD_INFO_LISTED_PIECES 14 /* ... and missed pieces of the same tiles that were merged themselves, last call */
 #define TD_INFO_CHAR_SEEDS 15    /* characters of 2..3 bytes this vocabulary allows to enter the merge of a long piece as one part (td_common.h) */
+#define TD_INFO_SPARSE 16        /* 1: the last td_encode_device call of the handle took the sparse launch sequence (TD_OPT_SPARSE), 0: the dense one */
 #define TD_INFO_DIRECT_TILES 11  /* pre-tokenizer tiles (8 KiB) whose ids the fused tile loop wrote straight to the output (TD_OPT_DIRECT), last call */
 int64_t td_info(const td_tokenizer* t, int what);
 
@@ -223,6 +224,14 @@ int td_encode_device_with_special(td_tokenizer* t, const void* d_text, int64_t n
                                     td_giant_pieces together (grid barriers between the sweeps; a megabyte of random letters: 0.55 s on one
                                     workgroup); shorter pieces above 1 KiB get a workgroup each as before.  Same results either way;
                                     TD_GP_COOP_MIN in the environment at td_create time sets it too. */
+#define TD_OPT_SPARSE 14           /* The launch sequence of a step.  -1 (default): chosen by the counters of the last call that were read
+                                    (td_device_status and every host-buffer entry point read them): text that leaves the kernels for far
+                                    pieces, deferred and flagged tiles and long pieces (nearly) idle — plain prose — takes the SPARSE
+                                    sequence, six launches (td_prepare_mark, td_split_tiles, td_tail, td_giant_scan, td_pack_plain,
+                                    td_pack_rest); other text, and a handle whose counters nobody has read yet, the DENSE one, where those
+                                    kernels are launches of their own at their own occupancies.  1: always sparse, 0: always dense.  Same
+                                    results either way — td_tail walks every phase the dense sequence has kernels for; TD_SPARSE in the
+                                    environment at td_create time sets it too. */
 #define TD_OPT_PIPE_THREADS 4     /* host threads that fill / drain the pinned bounce buffers of that pipeline (default 16) */
 int td_set_option(td_tokenizer* t, int what, int64_t value);
 

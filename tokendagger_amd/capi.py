@@ -33,10 +33,12 @@ TD_OPT_PACK_SPLIT = 10
 TD_OPT_DEDUPE = 11
 TD_OPT_OVERLAP = 12
 TD_OPT_GIANT_COOP_MIN = 13
+TD_OPT_SPARSE = 14
 TD_INFO_DEFERRED_TILES, TD_INFO_FLAGGED_TILES = 9, 10
 TD_INFO_DIRECT_TILES = 11
 TD_INFO_LB_TIMEOUTS = 12
 TD_INFO_REPEATS, TD_INFO_LISTED_PIECES, TD_INFO_CHAR_SEEDS = 13, 14, 15
+TD_INFO_SPARSE = 16
 
 EXPORTS = [
     "td_create", "td_clone", "td_destroy", "td_last_error", "td_encode_batch", "td_encode_device", "td_reserve",

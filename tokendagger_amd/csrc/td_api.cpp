@@ -148,6 +148,9 @@ struct Ctl {  // small control block in device memory
     uint32_t ovf_count;      // td_collect_misses: tiles with a length class that found its lists full
     uint32_t dd_stats[2];    // (statistics) repeats, pieces listed for the merge (td_copy_dups)
     uint32_t gp_ctl[4];      // td_giant_pieces over all workgroups: barrier arrivals, pieces listed, a barrier gave up, pieces above the limit
+    uint32_t far_tiles;      // pre-tokenizer tiles without a synchronisation point in their left halo (td_split_far_tiles)
+    uint32_t ph_bar;         // td_far_probe / td_tail: arrivals at their grid barriers
+    uint32_t gs_done;        // td_giant_scan: workgroups that have left the giant pieces
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 constexpr size_t CTL_BYTES = 256;  // the control block's place in its buffer; behind it: td_giant_pieces' scratch (TD_GP_SCRATCH_BYTES)
@@ -226,6 +229,10 @@ struct td_tokenizer {
     std::vector<Ev3> ev_pending, ev_free;
     int64_t last_repeats = 0, last_listed = 0;
     int64_t last_long = 0, last_far = 0, last_deferred = 0, last_flagged = 0, last_direct = 0, last_timeouts = 0;
+    int64_t last_giant = 0;
+    bool seen_counters = false;   // td_device_status / a host-buffer entry point has read a call's counters (what the launch sequence is chosen by)
+    bool last_sparse = false;     // (TD_INFO_SPARSE)
+    int sparse_opt = -1;          // TD_OPT_SPARSE / TD_SPARSE at td_create time: 1 = always the sparse sequence, 0 = never, -1 = by the last counters
     const RxProgram* d_rx = nullptr;      // generic split pattern: the compiled program and its tables in HBM
     const uint16_t* d_rx_s1 = nullptr;
     const uint8_t* d_rx_s2 = nullptr;
@@ -496,6 +503,9 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.gp_scratch = (uint32_t*)((char*)t->ctl.p + CTL_BYTES);  // (behind the control block; needs no reset)
     a.gp_coop_min = t->gp_coop_min;
     a.tile_draw = &ctl->tile_draw;
+    a.far_count = &ctl->far_tiles;
+    a.ph_bar = &ctl->ph_bar;
+    a.gs_done = &ctl->gs_done;
     a.slow_count = &ctl->slow_count;
     a.pool = (uint32_t*)t->pool.p;
     a.pool_cap = t->pool.cap / 4;
@@ -587,12 +597,23 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     // the caller's stream only ever sees hipGraphLaunch: no stream of the application is in capture because of this library,
     // other threads' legacy-stream work (torch's default stream) stays legal, and a failed capture costs nothing but itself:
     // it is ended, the error is cleared and the step is launched kernel by kernel.
+    // The launch sequence (launch_encode): SPARSE — six launches, everything between the tile loop and the packing in td_tail +
+    // td_giant_scan — when the last call whose counters were read had next to nothing for the kernels that plain text leaves idle (no
+    // deferred or far tiles, few flagged tiles, few long pieces); DENSE — those kernels on their own, at their own occupancies —
+    // otherwise and for a handle whose counters nobody has read yet.  Either sequence is correct for any text: a wrong guess costs time.
+    {
+        bool sparse = t->seen_counters && t->last_far == 0 && t->last_deferred == 0 && t->last_giant == 0 &&
+                      t->last_flagged * 64 <= n_tiles && t->last_long * 16 <= n_tiles;
+        if (t->sparse_opt >= 0) sparse = t->sparse_opt != 0;
+        a.sparse = (sparse && a.fused && !a.direct && !t->sp_active && t->H.pattern_kind != PATTERN_GENERIC && !t->stop_after) ? 1 : 0;
+        t->last_sparse = a.sparse != 0;
+    }
     LaunchAux aux_v{nullptr, nullptr, nullptr};
     const LaunchAux* aux = nullptr;
     // ... when the handle has SEEN long pieces: the fork and the join cost a step without any ~13 us (English: -2 % at 256 MiB), a step
     // with a hundred thousand of them gains 4-7 %.  What the last call whose counters were read had (td_device_status, every host-buffer
     // entry point) decides; a handle that never reads them stays in line.
-    if (t->overlap && t->last_long >= 2048) {
+    if (t->overlap && t->last_long >= 2048 && !a.sparse) {
         hipError_t ae = hipSuccess;
         if (!t->s_aux) ae = hipStreamCreateWithFlags(&t->s_aux, hipStreamNonBlocking);
         if (ae == hipSuccess && !t->e_fork) ae = hipEventCreateWithFlags(&t->e_fork, hipEventDisableTiming);
@@ -656,7 +677,9 @@ int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) 
     Ctl c = *(const Ctl*)t->h_ctl;
     if (c.err == TD_E_BAD_TOKEN) c.err_pos = 0x7FFFFFFFFFFFFFFFll - c.err_pos;  // (td_decode_len keeps the LOWEST invalid index as a maximum)
     t->last_long = c.long_count;
-    t->last_far = c.slow_count;
+    t->last_far = (int64_t)c.slow_count + c.far_tiles;
+    t->last_giant = c.giant_count;
+    t->seen_counters = true;
     t->last_deferred = c.deferred_count;
     t->last_flagged = c.flagged_count;
     t->last_direct = c.direct_tiles;
@@ -708,6 +731,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if (const char* e = getenv("TD_PACK_SPLIT")) t->pack_split = atoi(e) != 0;
     if (const char* e = getenv("TD_DEDUPE")) t->dedupe = atoi(e) != 0;
     if (const char* e = getenv("TD_OVERLAP")) t->overlap = atoi(e) != 0;
+    if (const char* e = getenv("TD_SPARSE")) { const int v = atoi(e); if (v >= -1 && v <= 1) t->sparse_opt = v; }
     if (const char* e = getenv("TD_GP_COOP_MIN")) { if (atol(e) >= 1024) t->gp_coop_min = (uint32_t)std::min<long>(atol(e), 0x7FFFFFFF); }
     if (const char* e = getenv("TD_DD_REPLICAS")) { const int v = atoi(e); if (v >= 1 && v <= 16 && !(v & (v - 1))) t->dd_replicas = (uint32_t)v; }
     if (const char* e = getenv("TD_DD_MINLEN")) t->dd_minlen = (uint32_t)std::max(2, atoi(e));
@@ -803,7 +827,7 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t = new td_tokenizer(src->shared);
         t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
         t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
-        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->overlap = src->overlap; t->gp_coop_min = src->gp_coop_min; t->dd_entries_opt = src->dd_entries_opt; t->dd_minlen = src->dd_minlen; t->dd_replicas = src->dd_replicas; t->coll_shrink = src->coll_shrink;
+        t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->overlap = src->overlap; t->sparse_opt = src->sparse_opt; t->gp_coop_min = src->gp_coop_min; t->dd_entries_opt = src->dd_entries_opt; t->dd_minlen = src->dd_minlen; t->dd_replicas = src->dd_replicas; t->coll_shrink = src->coll_shrink;
         t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }
@@ -1929,6 +1953,7 @@ int64_t td_info(const td_tokenizer* t, int what) {
         case TD_INFO_REPEATS: return t->last_repeats;
         case TD_INFO_LISTED_PIECES: return t->last_listed;
         case TD_INFO_CHAR_SEEDS: return (int64_t)t->H.n_char_seeds;
+        case TD_INFO_SPARSE: return t->last_sparse ? 1 : 0;
     }
     return -1;
 }
@@ -1960,6 +1985,11 @@ int td_set_option(td_tokenizer* t, int what, int64_t value) {
     }
     if (what == TD_OPT_PACK_SPLIT) {
         t->pack_split = value != 0;
+        drop_graph(t); t->has_last_key = false;
+        return TD_OK;
+    }
+    if (what == TD_OPT_SPARSE && value >= -1 && value <= 1) {
+        t->sparse_opt = (int)value;
         drop_graph(t); t->has_last_key = false;
         return TD_OK;
     }

@@ -79,6 +79,10 @@ struct EncodeArgs {
     uint32_t* gp_scratch;       // [TD_GP_SCRATCH_BYTES / 4] the listed pieces | two slots per workgroup and parity
     uint32_t gp_coop_min;       // pieces above this many bytes are swept by all workgroups of the launch together
     uint32_t* tile_draw;        // fused tile loop: counter the workgroups draw their tiles from (0 at launch)
+    uint32_t* far_count;        // pre-tokenizer tiles flagged in tile_flag (td_split_far_tiles looks for chains only when there is one; 0 at launch)
+    uint32_t* ph_bar;           // td_far_probe / td_tail: arrivals at their grid barriers (0 at launch)
+    uint32_t* gs_done;          // td_giant_scan: workgroups that have left the giant pieces (0 at launch)
+    int sparse;                 // the sparse launch sequence (td_tail + td_giant_scan instead of nine kernels): launch_encode
     uint32_t* pool;             // long-piece scratch + token store
     uint64_t pool_cap;          // in u32
     unsigned long long* pool_used;

@@ -198,6 +198,77 @@ __global__ void td_prepare(const EncodeArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ td_prepare_mark ---------
+// td_prepare + td_mark_docs as ONE launch (round 6: a dependent launch costs ~5 us of a step whatever it does, and the zeroed bitmap
+// was written twice).  The bitmap and tile_first_doc are produced by TEXT RANGE, not by document: a workgroup owns PM_RANGE bytes of
+// text (1024 words of docbits, 8 token tiles), finds the first document that starts in its range with a 64-ary search over
+// doc_offsets (one wavefront, 3-4 dependent loads for 1.7 M documents instead of a binary search's 21), ORs the range's document
+// starts into a bitmap in LDS and stores the 1024 words — every word of docbits is written exactly once, whether a document starts
+// in it or not: no zero pass, no atomics in HBM, and the cost does not depend on how long a document is (a thread per document that
+// also clears the words up to the next document would leave a single 1 GiB document to one wavefront).  The other per-call state
+// (tile_extra, tile_flag / tile_carry / tile_state, the counters, the table of distinct pieces) is cleared grid-stride as before.
+constexpr int PM_RANGE = 32768;
+__global__ __launch_bounds__(256) void td_prepare_mark(const EncodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[PM_RANGE / 32];
+    __shared__ uint32_t s_first[PM_RANGE / K_TILE];
+    __shared__ long long s_lo;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + tid, gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = gid; i <= a.n_tiles; i += gsz) a.tile_extra[i] = 0;
+    for (int64_t i = gid; i <= a.n_stiles; i += gsz) {
+        a.tile_flag[i] = 0;
+        a.tile_carry[i] = -1;
+        a.tile_state[i] = TS_NONE;
+    }
+    if (gid < a.ctl_reset_words) a.ctl_reset[gid] = 0;
+    if (gid < (K_MISS_CLASSES + 1) * COLL_SUBS) a.coll_count[gid * COLL_STRIDE] = 0;
+    if (a.dedupe) {
+        uint4* t4 = reinterpret_cast<uint4*>(a.dd_table);
+        for (int64_t i = gid; i < ((int64_t)a.dd_mask + 1) / 2; i += gsz) t4[i] = make_uint4(0, 0, 0, 0);
+    }
+    const int64_t words = (a.n + 31) / 32 + 2;  // (what td_prepare cleared; the buffer is padded to whole 16-byte pieces)
+    const int64_t nranges = (words * 32 + PM_RANGE - 1) / PM_RANGE;
+    const int64_t nd = a.n_docs;
+    for (int64_t r = blockIdx.x; r < nranges; r += gridDim.x) {
+        const int64_t b0 = r * PM_RANGE, b1 = b0 + PM_RANGE;
+        reinterpret_cast<uint4*>(s_bits)[tid] = make_uint4(0, 0, 0, 0);
+        static_assert(PM_RANGE / 32 == 4 * 256, "a 16-byte piece of the range's bitmap per thread");
+        if (tid < PM_RANGE / K_TILE) s_first[tid] = 0xFFFFFFFFu;
+        if (tid < 64) {  // first document d with doc_offsets[d] >= b0 (nd: none)
+            int64_t lo = 0, hi = nd;
+            while (hi - lo > 64) {
+                const int64_t idx = lo + ((hi - lo) * (int64_t)(lane + 1)) / 65;  // lo < idx < hi
+                const uint64_t b = __ballot(a.doc_offsets[idx] < b0);             // (sorted offsets: a prefix of the lanes)
+                const int c = (int)__popcll((unsigned long long)b);
+                const int64_t below = __shfl((long long)idx, c > 0 ? c - 1 : 0), above = __shfl((long long)idx, c < 64 ? c : 63);
+                if (c > 0) lo = below + 1;
+                if (c < 64) hi = above;
+            }
+            const bool less = lo + lane < hi && a.doc_offsets[lo + lane] < b0;
+            lo += (int64_t)__popcll((unsigned long long)__ballot(less));
+            if (lane == 0) s_lo = lo;
+        }
+        __syncthreads();
+        for (int64_t d = (int64_t)s_lo + tid;; d += 256) {
+            const int64_t p = d < nd ? a.doc_offsets[d] : b1;
+            const bool in = p >= b0 && p < b1 && p < a.n;
+            if (in) {
+                atomicOr(&s_bits[(p - b0) >> 5], 1u << (p & 31));
+                atomicMin(&s_first[(p - b0) / K_TILE], (uint32_t)d);
+            }
+            if (!__any(p < b1 && d < nd)) break;  // (sorted: nothing of this wavefront's later rounds lies in the range either)
+        }
+        __syncthreads();
+        {
+            const int64_t gw = (b0 >> 5) + 4 * tid;
+            if (gw < words) reinterpret_cast<uint4*>(a.docbits)[gw >> 2] = reinterpret_cast<const uint4*>(s_bits)[tid];
+            const int64_t t = b0 / K_TILE + tid;
+            if (tid < PM_RANGE / K_TILE && t <= a.n_tiles) a.tile_first_doc[t] = s_first[tid];
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ shared helpers ----------
 constexpr int K_MWORDS = K_WIN / 64;  // 64-byte mask words per window
 
@@ -1302,7 +1373,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                             if (w == 0) m &= ~0xFull;
                             if (m) sp = w * 64 + td_top64(m) - 1;
                         }
-                        if (sp < 0) { a.tile_flag[tile] = 1; if (FUSED) s_defer = 1; }
+                        if (sp < 0) { a.tile_flag[tile] = 1; atomicAdd(a.far_count, 1u); if (FUSED) s_defer = 1; }
                         else p = sp;
                     }
                 }
@@ -1820,13 +1891,15 @@ struct FarScan {  // one wavefront's view of the text for the far kernels
     }
 };
 
-__global__ __launch_bounds__(256) void td_split_far_pieces(const EncodeArgs a) {
+// (bodies: bid / nb = this workgroup's number and the number of workgroups that share the work — blockIdx.x / gridDim.x in the kernels
+// of their own, something else inside td_far_probe / td_tail, where one launch walks several of these phases)
+__device__ __forceinline__ void far_pieces_body(const EncodeArgs& a, const uint32_t bid, const uint32_t nb) {
     const Tables T = uniform_tables(a.Tp);
     const int lane = threadIdx.x & 63;
     const uint32_t nitems = *a.slow_count < a.slow_cap ? *a.slow_count : a.slow_cap;
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t nwaves = nb * (blockDim.x >> 6);
     const FarScan F{a, T, lane};
-    for (uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); j < nitems; j += nwaves) {
+    for (uint32_t j = bid * (blockDim.x >> 6) + (threadIdx.x >> 6); j < nitems; j += nwaves) {
         const int64_t g = a.slow_list[j];  // a piece start the fast kernel marked; its end was beyond the window
 #ifdef TD_FAR_DEBUG
         const unsigned long long t0 = __builtin_readcyclecounter();
@@ -1841,14 +1914,16 @@ __global__ __launch_bounds__(256) void td_split_far_pieces(const EncodeArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void td_split_far_tiles(const EncodeArgs a) {
+__global__ __launch_bounds__(256) void td_split_far_pieces(const EncodeArgs a) { far_pieces_body(a, blockIdx.x, gridDim.x); }
+
+__device__ __forceinline__ void far_tiles_body(const EncodeArgs& a, const uint32_t bid, const uint32_t nb) {
     const Tables T = uniform_tables(a.Tp);
     const int lane = threadIdx.x & 63;
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t nwaves = (int64_t)nb * (blockDim.x >> 6);
     const FarScan F{a, T, lane};
     // (64 tiles per step and wavefront, a lane each, looking for the heads of chains of flagged tiles: one tile per step was
     // 60 us per GiB of text for a kernel that normally finds nothing)
-    for (int64_t t0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; t0 < a.n_stiles; t0 += nwaves * 64) {
+    for (int64_t t0 = ((int64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; t0 < a.n_stiles; t0 += nwaves * 64) {
         const int64_t tl = t0 + lane;
         const bool head = tl < a.n_stiles && a.tile_flag[tl] && !(tl > 0 && a.tile_flag[tl - 1]);
         for (uint64_t hb = __ballot(head); hb; hb &= hb - 1ull) {
@@ -1867,6 +1942,7 @@ __global__ __launch_bounds__(256) void td_split_far_tiles(const EncodeArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(256) void td_split_far_tiles(const EncodeArgs a) { far_tiles_body(a, blockIdx.x, gridDim.x); }
 
 // ------------------------------------------------------------------ td_probe_tiles ----------
 // Token kernel, first half: pieces (from the START bitmap) -> one SLOT per piece, in piece order, in the tile's staging
@@ -1874,7 +1950,7 @@ __global__ __launch_bounds__(256) void td_split_far_tiles(const EncodeArgs a) {
 // single bytes through the 256-entry table), TOK_MISS | position | length when it is not (td_merge_tiles expands those),
 // TOK_LONGREF | index for pieces above 64 bytes (td_long_pieces).  No per-byte token array and no compaction: slot k is
 // piece k, lane k mod 256 stores it, the stores of a wavefront are consecutive.
-__global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(const EncodeArgs a) {
+__device__ __forceinline__ void probe_tiles_body(const EncodeArgs& a, const uint32_t bid, const uint32_t nb) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_BWIN + 16];
     __shared__ uint32_t s_start[K_BWIN / 32 + 3];  // bit i: a piece starts at tile byte i
     __shared__ __attribute__((aligned(16))) uint16_t s_plist[K_TILE + 8];  // tile positions of the piece starts (+ end delimiter)
@@ -1936,13 +2012,13 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
     const uint32_t* const tlist = a.probe_deferred ? a.deferred_list : nullptr;
     const int n_items = tlist ? (int)*a.deferred_count : a.n_tiles;
     auto tile_of = [&](int it) { return tlist ? (int)tlist[it] : it; };
-    if ((int)blockIdx.x < n_items) {
-        const int64_t w0 = (int64_t)tile_of((int)blockIdx.x) * K_TILE;
+    if ((int)bid < n_items) {
+        const int64_t w0 = (int64_t)tile_of((int)bid) * K_TILE;
         pf0 = load_text16(a, w0 + (int64_t)tid * 16);
         if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, w0 + (int64_t)(K_THREADS + tid) * 16);
         pfs = load_startword(w0);
     }
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    for (int item = (int)bid; item < n_items; item += (int)nb) {
         const int tile = tile_of(item);
         const int64_t tile_g0 = (int64_t)tile * K_TILE;
         const int64_t wg0 = tile_g0;                 // window index 0 == first byte of the tile
@@ -1958,8 +2034,8 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
             if (a.n >= g && a.n < g + 32) sw |= 1u << (int)(a.n - g);  // the end of the text delimits the last piece
             s_start[tid] = sw;
         }
-        if (item + (int)gridDim.x < n_items) {
-            const int64_t nwg0 = (int64_t)tile_of(item + (int)gridDim.x) * K_TILE;
+        if (item + (int)nb < n_items) {
+            const int64_t nwg0 = (int64_t)tile_of(item + (int)nb) * K_TILE;
             {
                 pf0 = load_text16(a, nwg0 + (int64_t)tid * 16);
                 if (tid < (K_BWIN + 16) / 16 - K_THREADS) pf1 = load_text16(a, nwg0 + (int64_t)(K_THREADS + tid) * 16);
@@ -2147,6 +2223,7 @@ __global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(
         for (uint32_t q = 0; q < nf; ++q) a.flagged_list[at + q] = s_flagl[q];
     }
 }
+__global__ __launch_bounds__(K_THREADS, TD_PROBE_MIN_WAVES) void td_probe_tiles(const EncodeArgs a) { probe_tiles_body(a, blockIdx.x, gridDim.x); }
 
 // ------------------------------------------------------------------ byte-pair merge, one lane per piece ----
 // Token kernel, second half: the pieces td_probe_tiles marked TOK_MISS (2..64 bytes, not a token).  A piece is merged by ONE
@@ -2213,10 +2290,11 @@ constexpr int DD_CTR = K_MISS_CLASSES * COLL_SUBS;  // coll_count[(DD_CTR + s) *
 #ifndef TD_COLLECT_MIN_WAVES
 #define TD_COLLECT_MIN_WAVES 6
 #endif
-__global__ __launch_bounds__(K_THREADS, TD_COLLECT_MIN_WAVES) void td_collect_misses(const EncodeArgs a) {
-    __shared__ uint32_t s_m[K_THREADS / 64][DD_BUF];
+constexpr int COLLECT_LDS_WORDS = (K_THREADS / 64) * DD_BUF;
+__device__ __forceinline__ void collect_misses_body(const EncodeArgs& a, const uint32_t bid, const uint32_t nb, uint32_t* const lds) {
+    uint32_t (*const s_m)[DD_BUF] = reinterpret_cast<uint32_t (*)[DD_BUF]>(lds);  // [K_THREADS / 64][DD_BUF]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gw = blockIdx.x * (K_THREADS / 64) + wv, nw = gridDim.x * (K_THREADS / 64);
+    const int gw = (int)bid * (K_THREADS / 64) + wv, nw = (int)nb * (K_THREADS / 64);
     const int n_flagged = (int)*a.flagged_count;
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t sub = (uint32_t)gw % (uint32_t)COLL_SUBS;
@@ -2260,7 +2338,7 @@ __global__ __launch_bounds__(K_THREADS, TD_COLLECT_MIN_WAVES) void td_collect_mi
             // pieces are otherwise a few cache lines that every CU of the chip asks one L2 channel for)
             // Measured on 256 MiB (collect + merge + copy): chat markup with all specials 0.89 ms with one seat per piece, 0.40 with four, 0.29
             // with sixteen; mixed-script text 0.64 / 0.72 / 0.78 (more pieces merged); the code file set 0.98 / 0.95 / 1.04.  Four.
-            uint32_t i = (h + ((uint32_t)blockIdx.x & (a.dd_replicas - 1u)) * 0x61C88647u) & a.dd_mask;
+            uint32_t i = (h + (bid & (a.dd_replicas - 1u)) * 0x61C88647u) & a.dd_mask;
             for (int probe = 0; probe < 2; ++probe, i ^= 1u) {
                 // (a plain load first: the seats of frequent pieces are taken early and then only ever read, out of the CU's own cache;
                 // atomics on one address are served one after the other.  A stale zero only costs the compare-and-swap it leads to.)
@@ -2360,17 +2438,21 @@ __global__ __launch_bounds__(K_THREADS, TD_COLLECT_MIN_WAVES) void td_collect_mi
         wave_sync_lds();
     }
 }
+__global__ __launch_bounds__(K_THREADS, TD_COLLECT_MIN_WAVES) void td_collect_misses(const EncodeArgs a) {
+    __shared__ uint32_t s_lds[COLLECT_LDS_WORDS];
+    collect_misses_body(a, blockIdx.x, gridDim.x, s_lds);
+}
 
 // td_copy_dups (behind td_merge_pieces): a lane per repeat — the other piece's finished slot (its id count), this piece's slot (TOK_DUPREF:
 // the seat that names the other piece + the count; the ids themselves are NOT copied, the pack kernels read them where they are), and the tile's
 // extra ids with one atomic per tile of the wavefront's 64 repeats (they come from two or three tiles).
-__global__ __launch_bounds__(K_THREADS) void td_copy_dups(const EncodeArgs a) {
+__device__ __forceinline__ void copy_dups_body(const EncodeArgs& a, const uint32_t bid, const uint32_t nb) {
     const int lane = threadIdx.x & 63;
-    const uint32_t gw = (blockIdx.x * (uint32_t)K_THREADS + threadIdx.x) >> 6, nw = gridDim.x * (uint32_t)(K_THREADS / 64);
+    const uint32_t gw = (bid * (uint32_t)K_THREADS + threadIdx.x) >> 6, nw = nb * (uint32_t)(K_THREADS / 64);
     // With allowed special tokens (td_special_ids puts a literal's id where its first piece's ids were) or a generic pattern (markers of its
     // own behind this kernel) a piece's place in merge_out does not keep its ids until the pack kernels run: the ids are copied here then.
     const bool by_ref = a.sp.n == 0u && !(a.pat_flags & PV_GENERIC);
-    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(K_MISS_CLASSES + 1) * COLL_SUBS) {  // (statistics: TD_INFO_REPEATS, TD_INFO_LISTED_PIECES; a thread per list)
+    if (bid == 0 && threadIdx.x < (unsigned)(K_MISS_CLASSES + 1) * COLL_SUBS) {  // (statistics: TD_INFO_REPEATS, TD_INFO_LISTED_PIECES; a thread per list)
         const uint32_t q = threadIdx.x, c = a.coll_count[q * COLL_STRIDE];
         uint32_t cap = a.dup_cap;
 #pragma unroll
@@ -2425,6 +2507,7 @@ __global__ __launch_bounds__(K_THREADS) void td_copy_dups(const EncodeArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(K_THREADS) void td_copy_dups(const EncodeArgs a) { copy_dups_body(a, blockIdx.x, gridDim.x); }
 
 // ------------------------------------------------------------------ td_merge_pieces ---------
 // Every wavefront works alone (no workgroup barrier).  Its work comes as ROWS of the miss lists — K_MISS_CLASSES lists the tile
@@ -2447,10 +2530,11 @@ static_assert(MG_LISTS <= 64, "a lane per list");
 #define TD_MERGE_THREADS 256
 #endif
 constexpr int MG_THREADS = TD_MERGE_THREADS;  // (a wavefront's key + id arrays are 8 KB)
-__global__ __launch_bounds__(MG_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces(const EncodeArgs a) {
+constexpr int MERGE_LDS_WORDS = 2 * (MG_THREADS / 64) * 64 * MG_UNIT;
+__device__ __forceinline__ void merge_pieces_body(const EncodeArgs& a, const uint32_t bid, const uint32_t nb, uint32_t* const lds) {  // lds: 16-byte aligned
     constexpr int NW = MG_THREADS / 64;
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[NW][64 * MG_UNIT];
-    __shared__ __attribute__((aligned(16))) uint32_t s_ids[NW][64 * MG_UNIT];
+    uint32_t (*const s_keys)[64 * MG_UNIT] = reinterpret_cast<uint32_t (*)[64 * MG_UNIT]>(lds);
+    uint32_t (*const s_ids)[64 * MG_UNIT] = reinterpret_cast<uint32_t (*)[64 * MG_UNIT]>(lds + NW * 64 * MG_UNIT);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Tables T = uniform_tables(a.Tp);
@@ -2543,7 +2627,7 @@ __global__ __launch_bounds__(MG_THREADS, TD_MERGE_MIN_WAVES) void td_merge_piece
     const uint32_t l_rows = (l_cnt + l_per - 1u) / l_per;
     const uint32_t l_incl = wave_incl_scan(l_rows, lane), l_excl = l_incl - l_rows;
     const uint32_t total_rows = (uint32_t)__builtin_amdgcn_readlane((int)l_incl, 63);
-    const uint32_t gw = (uint32_t)blockIdx.x * NW + (uint32_t)wv, nwaves_all = gridDim.x * NW;
+    const uint32_t gw = bid * NW + (uint32_t)wv, nwaves_all = nb * NW;
 
     // One call site of run_batch (the batch code is large: the kernel must stay inside the instruction cache): first the rows, then —
     // normally never — the overflow scan.
@@ -2596,10 +2680,14 @@ __global__ __launch_bounds__(MG_THREADS, TD_MERGE_MIN_WAVES) void td_merge_piece
         run_batch(rec, t0, wide);
     }
 #ifdef TD_MERGE_TIMING
-    if (lane == 0 && (blockIdx.x % 97) == 0 && wv == 0)
-        printf("merge wave b%d: total %llu init %llu rounds %llu out %llu cycles, %llu batches %llu rounds\n", (int)blockIdx.x,
+    if (lane == 0 && (bid % 97) == 0 && wv == 0)
+        printf("merge wave b%d: total %llu init %llu rounds %llu out %llu cycles, %llu batches %llu rounds\n", (int)bid,
                (unsigned long long)(__builtin_readcyclecounter() - t_total0), t_init, t_rounds, t_out, n_batches, n_rounds);
 #endif
+}
+__global__ __launch_bounds__(MG_THREADS, TD_MERGE_MIN_WAVES) void td_merge_pieces(const EncodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_lds[MERGE_LDS_WORDS];
+    merge_pieces_body(a, blockIdx.x, gridDim.x, s_lds);
 }
 
 // ------------------------------------------------------------------ td_long_pieces ----------
@@ -3037,13 +3125,14 @@ __device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Ta
 
 constexpr int LP_WAVE_WORDS = 8 * (2 * LP_TINY + 2 * LP_TINY / 4);  // LDS words per wavefront: 8 pieces x (ids, ranks, links)
 static_assert(LP_WAVE_WORDS >= 2 * LP_MEDIUM, "the wavefront-per-piece pass reuses the same LDS");
-__global__ __launch_bounds__(256, 4) void td_long_pieces(const EncodeArgs a) {  // (four wavefronts per SIMD is what the LDS allows: the registers must not allow less)
-    __shared__ uint32_t s_parts[4][LP_WAVE_WORDS];  // per wavefront: ids | ranks (| links)
+constexpr int LONG_LDS_WORDS = 4 * LP_WAVE_WORDS;
+__device__ __forceinline__ void long_pieces_body(const EncodeArgs& a, const uint32_t bid, const uint32_t nb, uint32_t* const lds) {
+    uint32_t (*const s_parts)[LP_WAVE_WORDS] = reinterpret_cast<uint32_t (*)[LP_WAVE_WORDS]>(lds);  // per wavefront: ids | ranks (| links)
     const Tables T = uniform_tables(a.Tp);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nlong = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
-    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + wv;
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_global = bid * (blockDim.x >> 6) + wv;
+    const uint32_t nwaves = nb * (blockDim.x >> 6);
 
     // pass 0: pieces <= 128 B, an 8-lane group each (linked parts)
     {
@@ -3079,6 +3168,10 @@ __global__ __launch_bounds__(256, 4) void td_long_pieces(const EncodeArgs a) {  
         }
     }
     // (pieces above LP_MEDIUM bytes: td_giant_pieces)
+}
+__global__ __launch_bounds__(256, 4) void td_long_pieces(const EncodeArgs a) {  // (four wavefronts per SIMD is what the LDS allows: the registers must not allow less)
+    __shared__ uint32_t s_lds[LONG_LDS_WORDS];
+    long_pieces_body(a, blockIdx.x, gridDim.x, s_lds);
 }
 
 // ------------------------------------------------------------------ td_giant_pieces ---------
@@ -3561,7 +3654,7 @@ __device__ bool gp_piece(const EncodeArgs& a, const Tables& T, const uint32_t j,
     return true;
 }
 
-__global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a) {
+__device__ __forceinline__ void giant_pieces_body(const EncodeArgs& a) {  // (its workgroups are the launch's: blockIdx.x / gridDim.x)
     __shared__ int s_w[GP_THREADS / 64];
     __shared__ uint32_t s_m[GP_THREADS / 64];
     __shared__ unsigned long long s_off;
@@ -3641,6 +3734,7 @@ __global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a
     // (every workgroup has read pool_used before the first listed piece's first barrier, which workgroup 0 is behind by now)
     if (ncoop && tid == 0 && blockIdx.x == 0u) atomicAdd(a.pool_used, off - used0);
 }
+__global__ __launch_bounds__(GP_THREADS) void td_giant_pieces(const EncodeArgs a) { giant_pieces_body(a); }
 
 // ------------------------------------------------------------------ td_scan_tiles -----------
 // Device-wide exclusive scan of the per-tile token counts (n_tiles = N/4096: 65 536 entries for 256 MiB), two levels
@@ -3657,13 +3751,11 @@ __device__ __forceinline__ bool pk_rest_tile(uint32_t tc) {  // (what td_scan_ti
 __device__ __forceinline__ bool pk_simple(uint32_t tc, int64_t base, uint32_t extra, int64_t out_cap) {
     return !pk_rest_tile(tc) && base + (int64_t)(int32_t)((tc & TILE_COUNT_MASK) + extra) <= out_cap;
 }
-__global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
-    __shared__ unsigned long long s_wsum[16];
-    __shared__ uint32_t s_last;
+// one chunk of 4096 tiles by the whole (1024-thread) workgroup: tile_base inside the chunk, rest_mask, the chunk's total -> chunk_pref[chunk]
+__device__ __forceinline__ void scan_chunk(const EncodeArgs& a, const int chunk, unsigned long long* const s_wsum) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nchunks = (a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK;
     {
-        const int c0 = blockIdx.x * K_SCAN_CHUNK;
+        const int c0 = chunk * K_SCAN_CHUNK;
         const int e0 = c0 + tid * 4;
         uint32_t v[4] = {0, 0, 0, 0};
         uint32_t nib = 0;  // bit k: tile e0 + k is td_pack_rest's whatever its base (pk_rest_tile)
@@ -3701,16 +3793,13 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
             if (e0 + k < a.n_tiles) a.tile_base[e0 + k] = (int64_t)run;
             run += v[k];
         }
-        if (tid == 1023) {
-            a.chunk_pref[blockIdx.x] = (int64_t)run;  // chunk total for now; the last workgroup turns it into a prefix
-            __threadfence();
-            s_last = (atomicAdd(a.scan_done, 1u) == (uint32_t)nchunks - 1u) ? 1u : 0u;
-        }
-        __syncthreads();
+        if (tid == 1023) a.chunk_pref[chunk] = (int64_t)run;  // chunk total for now; scan_totals turns it into a prefix
+        __syncthreads();  // (s_wsum is free again)
     }
-    if (!s_last) return;
-    __threadfence();
-    // exclusive scan of the chunk totals (at most a few hundred), one wavefront
+}
+// exclusive scan of the chunk totals (at most a few hundred), one wavefront
+__device__ __forceinline__ void scan_totals(const EncodeArgs& a, const int nchunks) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (wv == 0) {
         unsigned long long carry = 0;
         for (int c0 = 0; c0 < nchunks; c0 += 64) {
@@ -3732,6 +3821,212 @@ __global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
             if (total > a.out_cap) raise(a, TD_E_CAPACITY, total);
         }
     }
+}
+// every workgroup its chunks; the one that finishes the last chunk scans the totals
+__device__ __forceinline__ void scan_tiles_parallel(const EncodeArgs& a, unsigned long long* const s_wsum, uint32_t* const s_last) {
+    const int nchunks = (a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK;
+    uint32_t last = 0;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        scan_chunk(a, c, s_wsum);
+        if (threadIdx.x == 1023) {
+            __threadfence();
+            *s_last = (atomicAdd(a.scan_done, 1u) == (uint32_t)nchunks - 1u) ? 1u : 0u;
+        }
+        __syncthreads();
+        last |= *s_last;
+        __syncthreads();
+    }
+    if (!last) return;
+    __threadfence();
+    scan_totals(a, nchunks);
+}
+__global__ __launch_bounds__(1024) void td_scan_tiles(const EncodeArgs a) {
+    __shared__ unsigned long long s_wsum[16];
+    __shared__ uint32_t s_last;
+    scan_tiles_parallel(a, s_wsum, &s_last);
+}
+
+// ------------------------------------------------------------------ several phases in one launch (round 6) ----
+// A launch costs a step ~5 us whatever it finds to do (the queue's barrier between two dependent kernels), and on plain text eight of a
+// step's fifteen kernels found nothing: at 128 MiB per call — one rank's share of the 1024 MiB corpus on eight GPUs — that was 40 of
+// 415 us.  Kernels whose work is usually absent are now PHASES of one launch: every workgroup reads the counters the kernels in front
+// left (final: a kernel boundary lies in between), phases without work are skipped by all workgroups alike without any
+// synchronisation, and only where a phase with work feeds another one do the workgroups meet at a grid barrier.  The first such
+// barrier asks whether the launch's workgroups are resident together (ph_meet: as gp_grid_meet of td_giant_pieces — several handles
+// or processes with such launches at once could each hold part of the CUs and wait for the rest); if they are not, workgroup 0 walks
+// the phases alone, the others leave: slower, never wrong, never stuck.  Data crosses a phase boundary through agent-scope release /
+// acquire fences (each XCD has an L2 of its own).
+//   td_far_probe   (the dense sequence)   td_split_far_pieces | td_split_far_tiles | td_probe_tiles over the deferred tiles
+//   td_tail        (the sparse sequence)  the same three | td_collect_misses + td_long_pieces | td_merge_pieces | td_copy_dups
+//   td_giant_scan  (the sparse sequence)  td_giant_pieces | td_scan_tiles
+struct PhaseSync {
+    uint32_t* bar;   // arrivals (zero at launch)
+    uint32_t nb;     // workgroups that meet
+    int* s_flag;
+    bool solo;       // this workgroup walks the phases alone (the others have left)
+};
+constexpr unsigned long long PH_MEET_TIMEOUT = 5000000ull;    // wall_clock64 ticks (100 MHz): 50 ms
+constexpr unsigned long long PH_BAR_TIMEOUT = 400000000ull;   // 4 s: a fault
+constexpr uint32_t PH_DEAD = 0x80000000u;
+__device__ __forceinline__ bool ph_meet(const PhaseSync& c) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const uint32_t old = __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old & PH_DEAD) {
+            ok = 0;
+        } else {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                uint32_t v = __hip_atomic_load(c.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v & PH_DEAD) { ok = 0; break; }
+                if (v >= c.nb) break;
+                if (wall_clock64() - t0 > PH_MEET_TIMEOUT) {
+                    if (__hip_atomic_compare_exchange_strong(c.bar, &v, v | PH_DEAD, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+                    continue;  // (somebody arrived meanwhile: look again)
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        *c.s_flag = ok;
+    }
+    __syncthreads();
+    return *c.s_flag != 0;
+}
+// end of a phase: what this workgroup wrote is visible to the others behind it (and the other way round).  false: a fault (TD_E_HIP raised).
+__device__ __forceinline__ bool ph_sync(const EncodeArgs& a, const PhaseSync& c) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (!c.solo) {
+        if (threadIdx.x == 0) {
+            const uint32_t old = __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = ((old & ~PH_DEAD) / c.nb + 1u) * c.nb;
+            const unsigned long long t0 = wall_clock64();
+            int ok = (old & PH_DEAD) ? 0 : 1;
+            while (ok) {
+                const uint32_t v = __hip_atomic_load(c.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v & PH_DEAD) { ok = 0; break; }
+                if (v >= target) break;
+                if (wall_clock64() - t0 > PH_BAR_TIMEOUT) {
+                    __hip_atomic_fetch_or(c.bar, PH_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    raise(a, TD_E_HIP, 0);
+                    ok = 0;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            *c.s_flag = ok;
+        }
+        __syncthreads();
+        if (!*c.s_flag) return false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+__device__ __forceinline__ uint32_t ph_count(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// what td_split_tiles left for the window it could not see through: far pieces -> chains of flagged tiles -> the deferred token tiles.
+// -> false: this workgroup is done (it is not the one that walks alone, or a barrier failed)
+__device__ __forceinline__ bool far_probe_phases(const EncodeArgs& a, PhaseSync& c, uint32_t& bid, uint32_t& nb, const uint32_t nslow,
+                                                 const uint32_t nfar, const uint32_t ndef, bool& met) {
+    if (!(nslow | nfar | ndef)) return true;
+    if (!met) {
+        met = true;
+        if (!ph_meet(c)) {
+            if (blockIdx.x != 0u) return false;
+            c.solo = true; bid = 0u; nb = 1u;
+        }
+    }
+    if (nslow) { far_pieces_body(a, bid, nb); if (!ph_sync(a, c)) return false; }
+    if (nfar) { far_tiles_body(a, bid, nb); if (!ph_sync(a, c)) return false; }
+    if (ndef) {
+        EncodeArgs ad = a;
+        ad.probe_deferred = 1;
+        probe_tiles_body(ad, bid, nb);
+    }
+    return true;
+}
+__global__ __launch_bounds__(K_THREADS) void td_far_probe(const EncodeArgs a) {
+    __shared__ int s_flag;
+    const uint32_t nslow = *a.slow_count, nfar = *a.far_count, ndef = a.fused ? *a.deferred_count : 0u;
+    if (!(nslow | nfar | ndef)) return;
+    PhaseSync c{a.ph_bar, gridDim.x, &s_flag, false};
+    uint32_t bid = blockIdx.x, nb = gridDim.x;
+    bool met = false;
+    (void)far_probe_phases(a, c, bid, nb, nslow, nfar, ndef, met);
+}
+
+// The sparse sequence's one kernel between the tile loop and the scan (launch_encode takes it when the handle's last counters say the
+// text has next to nothing but listed pieces: plain prose).  Correct for ANY text — a call that brings many flagged tiles or long
+// pieces after all is only slower here than in the kernels of their own, which run at two to three times the occupancy.
+constexpr int TAIL_LDS_WORDS = LONG_LDS_WORDS > MERGE_LDS_WORDS ? (LONG_LDS_WORDS > COLLECT_LDS_WORDS ? LONG_LDS_WORDS : COLLECT_LDS_WORDS)
+                                                                : (MERGE_LDS_WORDS > COLLECT_LDS_WORDS ? MERGE_LDS_WORDS : COLLECT_LDS_WORDS);
+static_assert(MG_THREADS == K_THREADS, "td_tail runs td_merge_pieces' body with its own workgroup size");
+__global__ __launch_bounds__(K_THREADS, 2) void td_tail(const EncodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_arena[TAIL_LDS_WORDS];  // collect | merge | long, one after the other
+    __shared__ int s_flag;
+    const uint32_t nslow = *a.slow_count, nfar = *a.far_count, ndef = *a.deferred_count;
+    uint32_t nflag = *a.flagged_count, nlong = *a.long_count;
+    uint32_t bid = blockIdx.x, nb = gridDim.x;
+    if (!(nslow | nfar | ndef | nflag)) {  // the usual case: the lists the tile loop filled, a long piece here and there — nothing waits for anything
+        merge_pieces_body(a, bid, nb, s_arena);
+        if (nlong) {
+            __syncthreads();
+            long_pieces_body(a, bid, nb, s_arena);
+        }
+        return;
+    }
+    PhaseSync c{a.ph_bar, gridDim.x, &s_flag, false};
+    bool met = false;
+    if (!far_probe_phases(a, c, bid, nb, nslow, nfar, ndef, met)) return;
+    if (nslow | nfar | ndef) {  // (the deferred tiles' lookups may have listed pieces, flagged tiles, found long pieces)
+        if (!ph_sync(a, c)) return;
+        nflag = ph_count(a.flagged_count);
+        nlong = ph_count(a.long_count);
+    }
+    // (the long pieces wait for nobody and nobody in here waits for them: every workgroup does its share BEFORE it asks whether the
+    // launch meets — a workgroup that learns it does not and leaves has done that share, whenever it started)
+    if (nlong) { long_pieces_body(a, bid, nb, s_arena); __syncthreads(); }
+    if (nflag) {
+        if (!met) {
+            met = true;
+            if (!ph_meet(c)) {
+                if (blockIdx.x != 0u) return;
+                c.solo = true; bid = 0u; nb = 1u;
+            }
+        }
+        collect_misses_body(a, bid, nb, s_arena);
+        if (!ph_sync(a, c)) return;
+    }
+    merge_pieces_body(a, bid, nb, s_arena);
+    if (nflag && a.dedupe) {
+        if (!ph_sync(a, c)) return;
+        copy_dups_body(a, bid, nb);
+    }
+}
+
+// td_giant_pieces and td_scan_tiles in one launch (the sparse sequence): without a piece above 1 KiB — the usual case — every workgroup
+// scans its chunks at once; with one, the workgroup that leaves the giant pieces last scans all chunks alone (no workgroup waits for
+// another one here: correct whatever is resident; a call with giant pieces pays milliseconds for them anyway).
+__global__ __launch_bounds__(GP_THREADS) void td_giant_scan(const EncodeArgs a) {
+    static_assert(GP_THREADS == 1024, "td_scan_tiles' workgroup");
+    __shared__ unsigned long long s_wsum[16];
+    __shared__ uint32_t s_last;
+    if (*a.giant_count == 0u) {
+        scan_tiles_parallel(a, s_wsum, &s_last);
+        return;
+    }
+    giant_pieces_body(a);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(a.gs_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int nchunks = (a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK;
+    for (int ch = 0; ch < nchunks; ++ch) scan_chunk(a, ch, s_wsum);
+    __threadfence();
+    __syncthreads();
+    scan_totals(a, nchunks);
 }
 
 // ------------------------------------------------------------------ td_pack_tokens ----------
@@ -4606,23 +4901,48 @@ static int split_grid_blocks() {
     return g_blocks_split;
 }
 
+static int tail_grid_blocks() {  // td_tail: what is resident (its merge rows are dealt to the wavefronts; its barriers need every workgroup on a CU)
+    static int blocks = 0;
+    if (!blocks) blocks = resident_blocks((const void*)td_tail, 2, K_THREADS, 2);
+    const char* e = getenv("TD_TAIL_BLOCKS_PER_CU");
+    if (e && atoi(e) > 0) return 256 * atoi(e);
+    return blocks;
+}
+static int far_probe_grid_blocks() {
+    static int blocks = 0;
+    if (!blocks) blocks = resident_blocks((const void*)td_far_probe, 2, K_THREADS, 2);
+    return blocks;
+}
+
 hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev, const LaunchAux* aux) {
     if (a.n_tiles <= 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], stream);
-    {   // one launch clears what was seven memsets: document bits, per-tile long-piece counts, first-document
-        // indices (0xFFFFFFFF = none) and the per-call counters
-        const int64_t words = (a.n + 31) / 32 + 2;
-        int pb = (int)((words / 4 + 255) / 256);
-        if (pb > 2048) pb = 2048;
+    static const bool prepare_split = getenv("TD_PREPARE_SPLIT") && atoi(getenv("TD_PREPARE_SPLIT")) > 0;  // (A/B: rounds 1-5's two launches)
+    if (!prepare_split) {
+        // one launch: the per-call state cleared, the document bitmap and the tiles' first documents written by text range
+        const int64_t nranges = (((a.n + 31) / 32 + 2) * 32 + PM_RANGE - 1) / PM_RANGE;
+        int64_t pb = nranges, zb = ((a.dedupe ? ((int64_t)a.dd_mask + 1) / 2 : 0) + a.n_tiles + 255) / 256;  // (the table of distinct pieces: 16 bytes a thread)
+        if (zb > 4096) zb = 4096;
+        if (pb < zb) pb = zb;
+        if (pb > (1 << 20)) pb = 1 << 20;
         if (pb < 1) pb = 1;
-        hipLaunchKernelGGL(td_prepare, dim3(pb), dim3(256), 0, stream, a);
-    }
-    {
-        const int64_t nd = a.n_docs;
-        int blocks = (int)((nd + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(td_mark_docs, dim3(blocks), dim3(256), 0, stream, a.doc_offsets, nd, a.n, a.docbits, a.tile_first_doc);
+        hipLaunchKernelGGL(td_prepare_mark, dim3((int)pb), dim3(256), 0, stream, a);
+    } else {
+        {   // one launch clears what was seven memsets: document bits, per-tile long-piece counts, first-document
+            // indices (0xFFFFFFFF = none) and the per-call counters
+            const int64_t words = (a.n + 31) / 32 + 2;
+            int pb = (int)((words / 4 + 255) / 256);
+            if (pb > 2048) pb = 2048;
+            if (pb < 1) pb = 1;
+            hipLaunchKernelGGL(td_prepare, dim3(pb), dim3(256), 0, stream, a);
+        }
+        {
+            const int64_t nd = a.n_docs;
+            int blocks = (int)((nd + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            if (blocks < 1) blocks = 1;
+            hipLaunchKernelGGL(td_mark_docs, dim3(blocks), dim3(256), 0, stream, a.doc_offsets, nd, a.n, a.docbits, a.tile_first_doc);
+        }
     }
     if (a.sp.n) {  // allowed special tokens: their two ends become ends of subject
         const hipError_t se = launch_special_cuts(a, stream);
@@ -4659,25 +4979,37 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         }
 #undef TD_LAUNCH_SPLIT
     }
-    hipLaunchKernelGGL(td_split_far_pieces, dim3(64), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(td_split_far_tiles, dim3(256), dim3(256), 0, stream, a);
-    if (ev) (void)hipEventRecord(ev[2], stream);
 #ifdef TD_ABLATE
     const bool tokens = a.stop_after != 2 && a.stop_after != 11 && a.stop_after != 12;
     const bool merges = a.stop_after != 3 && a.stop_after != 30 && a.stop_after != 31 && a.stop_after != 32;
 #else
     const bool tokens = true, merges = true;
 #endif
-    if (tokens) {
-        if (fused) {  // only the token tiles the fused loop deferred (normally none)
-            EncodeArgs ad = a;
-            ad.probe_deferred = 1;
-            hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks < 512 ? pblocks : 512), dim3(K_THREADS), 0, stream, ad);
-        } else {
-            hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
-        }
+    // The SPARSE sequence (a.sparse: the handle's last counters say plain text — td_api.cpp): everything between the tile loop and the
+    // packing is two launches, td_tail and td_giant_scan (see "several phases in one launch").  Six launches a step instead of fifteen.
+    const bool sparse = a.sparse && fused && tokens && merges && !a.sp.n && !a.direct;
+    if (sparse) {
+        if (ev) { (void)hipEventRecord(ev[2], stream); (void)hipEventRecord(ev[3], stream); }
+        const int tb = tail_grid_blocks();
+        hipLaunchKernelGGL(td_tail, dim3(tb), dim3(K_THREADS), 0, stream, a);
+        if (ev) (void)hipEventRecord(ev[4], stream);
+        const int nchunks = (a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK;
+        int gb = giant_grid_blocks();
+        if (gb < nchunks) gb = nchunks < GP_MAX_BLOCKS ? nchunks : GP_MAX_BLOCKS;
+        hipLaunchKernelGGL(td_giant_scan, dim3(gb), dim3(GP_THREADS), 0, stream, a);
+    } else {
+    // the DENSE sequence: the kernels of their own, at their own occupancies
+    if (fused && tokens) {
+        // far pieces, chains of flagged tiles, the token tiles the fused loop deferred (normally none of the three): one launch
+        hipLaunchKernelGGL(td_far_probe, dim3(far_probe_grid_blocks()), dim3(K_THREADS), 0, stream, a);
+        if (ev) { (void)hipEventRecord(ev[2], stream); (void)hipEventRecord(ev[3], stream); }
+    } else {
+        hipLaunchKernelGGL(td_split_far_pieces, dim3(64), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(td_split_far_tiles, dim3(256), dim3(256), 0, stream, a);
+        if (ev) (void)hipEventRecord(ev[2], stream);
+        if (tokens) hipLaunchKernelGGL(td_probe_tiles, dim3(pblocks), dim3(K_THREADS), 0, stream, a);
+        if (ev) (void)hipEventRecord(ev[3], stream);
     }
-    if (ev) (void)hipEventRecord(ev[3], stream);
     // the long pieces beside the chain of the short ones (see LaunchAux); with per-segment events (ev) everything stays in line
     const bool fork = aux && !ev && tokens;
     if (fork) {
@@ -4717,6 +5049,9 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
             if (se != hipSuccess) return se;
         }
         hipLaunchKernelGGL(td_scan_tiles, dim3((a.n_tiles + K_SCAN_CHUNK - 1) / K_SCAN_CHUNK), dim3(1024), 0, stream, a);
+    }
+    }
+    if (tokens) {
         if (ev) (void)hipEventRecord(ev[5], stream);
         if (a.pack_split) {
             const int pwg = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
