@@ -1,4 +1,8 @@
-"""td_giant_pieces over all workgroups of the launch (round 5; TD_OPT_GIANT_COOP_MIN): a piece above the limit is
+"""CHECKER HERE = the heap form of the reference's merge loop (oracle/port.py), not the compiled reference: tiktoken.cpp:322-343 is quadratic
+and a single piece of 50 KB takes it seconds, a megabyte hours; the heap form is pinned to the quadratic loop and to the compiled reference
+on pieces up to 20 KB (tests/test_oracle.py), and test_grid_path_equals_the_compiled_reference_up_to_20_kb below puts pieces of that size
+through the compiled reference itself on the grid path.
+td_giant_pieces over all workgroups of the launch (round 5; TD_OPT_GIANT_COOP_MIN): a piece above the limit is
 swept by every workgroup together, with grid barriers between the sweeps — same ids as one workgroup per piece and as the heap form of
 the reference's merge loop (oracle/port.py, pinned against tiktoken.cpp:322-343 by tests/test_oracle.py).  The limit is turned down
 to 1 KiB so that pieces of every shape take the grid path: stretches of a few parts, borders between workgroups inside runs of equal
@@ -70,6 +74,30 @@ def test_grid_path_equals_the_heap_oracle_and_the_single_workgroup(tok):
             assert np.array_equal(tok.encode(d), O.encode(d)), d[:16]
     finally:
         port.set_heap_threshold(4096)
+        tok.set_option(capi.TD_OPT_GIANT_COOP_MIN, 16384)
+
+
+def test_grid_path_equals_the_compiled_reference_up_to_20_kb(tok):
+    """Pieces of 1.5 .. 20 KB — what the reference's quadratic loop (tiktoken.cpp:322-343) still answers in seconds — through the COMPILED
+    REFERENCE, on the grid path (limit 1 KiB) and with a workgroup each."""
+    from oracle import ref
+    from tokendagger_amd import capi
+    assert ref.available(), "oracle/_ref/libtdref.so is missing: build it where /root/reference exists (oracle/build_ref.sh)"
+    R = H.ref_tokenizer()
+    rng = random.Random(17)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    docs = ["".join(rng.choice(letters) for _ in range(20_000)).encode(), b"a" * 12_000, ("ab" * 5_000).encode(), ("xyz" * 2_000 + "q").encode(),
+            "".join(rng.choice("ACGT") for _ in range(9_000)).encode(), ("的" * 2_000).encode("utf-8"), b" " * 1_500, b"=" * 4_097,
+            "".join(rng.choice("eeeetttaaooinshrdlu") for _ in range(15_000)).encode(), b"an ordinary sentence in between."]
+    text, offs = H.pack_docs(docs)
+    _, want_t, want_o = R.encode_batch(np.frombuffer(text, dtype=np.uint8), np.asarray(offs, dtype=np.int64), n_threads=8, want_tokens=True)
+    try:
+        for coop_min in (1024, 1 << 30):
+            tok.set_option(capi.TD_OPT_GIANT_COOP_MIN, coop_min)
+            got_t, got_o = tok.encode_batch(text, offs)
+            assert np.array_equal(got_o, want_o), coop_min
+            assert np.array_equal(got_t, want_t), coop_min
+    finally:
         tok.set_option(capi.TD_OPT_GIANT_COOP_MIN, 16384)
 
 

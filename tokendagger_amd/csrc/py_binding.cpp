@@ -158,7 +158,16 @@ public:
     // ids[0..n) cut at offs[0..n_docs] -> list[list[int]] (GIL held on entry and on return)
     py::list lists(const int32_t* ids, const int64_t* offs, int64_t n_docs) {
         const int64_t n = offs[n_docs];
-        if (n < (1 << 16)) {  // small calls: one reference at a time (no histogram of the id range to clear)
+        // The bulk path below writes PyListObject's fields itself (ob_item from PyMem_Malloc, allocated, size set last) and adds reference
+        // counts in bulk: that is the layout and the allocator pairing of the default CPython builds 3.8 .. 3.13 (list_dealloc frees ob_item
+        // with PyMem_Free).  Free-threaded builds (Py_GIL_DISABLED: a _PyListArray header in front of the items, per-thread reference
+        // counts), PyPy and versions nobody has looked at take the portable path — one PyList_New(len) + one reference at a time.
+#if defined(Py_GIL_DISABLED) || defined(PYPY_VERSION) || PY_VERSION_HEX < 0x03080000 || PY_VERSION_HEX >= 0x030E0000
+        constexpr bool kBulkLists = false;
+#else
+        constexpr bool kBulkLists = true;
+#endif
+        if (!kBulkLists || n < (1 << 16)) {  // small calls: one reference at a time (no histogram of the id range to clear)
             int32_t mx = -1;
             for (int64_t i = 0; i < n; ++i) {
                 if (ids[i] < 0) throw std::runtime_error("negative token id");
@@ -223,6 +232,7 @@ public:
         // frees it with; until it is filled its size stays 0, so a list that is dropped half-way (an allocation fails) frees its
         // array and touches no item.
         py::list outer((size_t)n_docs);
+        PyObject_GC_UnTrack(outer.ptr());  // (the outer list too: it is the way to the half-made inner ones — ADVICE r5; list_dealloc untracks again, which is allowed)
         std::vector<PyObject**> items((size_t)n_docs, nullptr);
         for (int64_t d = 0; d < n_docs; ++d) {
             const Py_ssize_t len = (Py_ssize_t)(offs[d + 1] - offs[d]);
@@ -266,6 +276,7 @@ public:
             Py_SET_SIZE(l, (Py_ssize_t)(offs[d + 1] - offs[d]));
             PyObject_GC_Track(l);
         }
+        PyObject_GC_Track(outer.ptr());
         lap("track");
         return outer;
     }

@@ -207,12 +207,13 @@ __global__ void td_prepare(const EncodeArgs a) {
 // in it or not: no zero pass, no atomics in HBM, and the cost does not depend on how long a document is (a thread per document that
 // also clears the words up to the next document would leave a single 1 GiB document to one wavefront).  The other per-call state
 // (tile_extra, tile_flag / tile_carry / tile_state, the counters, the table of distinct pieces) is cleared grid-stride as before.
+__device__ __forceinline__ void wave_sync_lds();  // (below)
 constexpr int PM_RANGE = 32768;
-__global__ __launch_bounds__(256) void td_prepare_mark(const EncodeArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_bits[PM_RANGE / 32];
-    __shared__ uint32_t s_first[PM_RANGE / K_TILE];
-    __shared__ long long s_lo;
-    const int tid = threadIdx.x, lane = tid & 63;
+constexpr int PM_WAVES = 4;  // wavefronts per workgroup, a range each (nothing in here is workgroup-wide: no barrier)
+__global__ __launch_bounds__(64 * PM_WAVES) void td_prepare_mark(const EncodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[PM_WAVES][PM_RANGE / 32];
+    __shared__ uint32_t s_first[PM_WAVES][PM_RANGE / K_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + tid, gsz = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = gid; i <= a.n_tiles; i += gsz) a.tile_extra[i] = 0;
     for (int64_t i = gid; i <= a.n_stiles; i += gsz) {
@@ -229,43 +230,60 @@ __global__ __launch_bounds__(256) void td_prepare_mark(const EncodeArgs a) {
     const int64_t words = (a.n + 31) / 32 + 2;  // (what td_prepare cleared; the buffer is padded to whole 16-byte pieces)
     const int64_t nranges = (words * 32 + PM_RANGE - 1) / PM_RANGE;
     const int64_t nd = a.n_docs;
-    for (int64_t r = blockIdx.x; r < nranges; r += gridDim.x) {
+    uint32_t* const bits = s_bits[wv];
+    uint32_t* const first = s_first[wv];
+    static_assert(PM_RANGE / 32 == 16 * 64, "four 16-byte pieces of the range's bitmap per lane");
+    for (int64_t r = (int64_t)blockIdx.x * PM_WAVES + wv; r < nranges; r += (int64_t)gridDim.x * PM_WAVES) {
         const int64_t b0 = r * PM_RANGE, b1 = b0 + PM_RANGE;
-        reinterpret_cast<uint4*>(s_bits)[tid] = make_uint4(0, 0, 0, 0);
-        static_assert(PM_RANGE / 32 == 4 * 256, "a 16-byte piece of the range's bitmap per thread");
-        if (tid < PM_RANGE / K_TILE) s_first[tid] = 0xFFFFFFFFu;
-        if (tid < 64) {  // first document d with doc_offsets[d] >= b0 (nd: none)
-            int64_t lo = 0, hi = nd;
-            while (hi - lo > 64) {
-                const int64_t idx = lo + ((hi - lo) * (int64_t)(lane + 1)) / 65;  // lo < idx < hi
-                const uint64_t b = __ballot(a.doc_offsets[idx] < b0);             // (sorted offsets: a prefix of the lanes)
-                const int c = (int)__popcll((unsigned long long)b);
-                const int64_t below = __shfl((long long)idx, c > 0 ? c - 1 : 0), above = __shfl((long long)idx, c < 64 ? c : 63);
-                if (c > 0) lo = below + 1;
-                if (c < 64) hi = above;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<uint4*>(bits)[lane + 64 * q] = make_uint4(0, 0, 0, 0);
+        if (lane < PM_RANGE / K_TILE) first[lane] = 0xFFFFFFFFu;
+        // first document d with doc_offsets[d] >= b0 (nd: none).  Documents of about one size start near b0 / n of the way through
+        // the offsets: the first round looks there, 64 offsets a 128th of a range's documents apart, and only when that misses does
+        // the search start from both ends (64-ary: 3-4 dependent loads for 1.7 M documents)
+        int64_t lo = 0, hi = nd;
+        if (a.n > 0 && nd > 64) {
+            const int64_t per_range = nd * PM_RANGE / a.n + 1, step = per_range / 64 + 1;
+            const int64_t g = (int64_t)((__int128)b0 * nd / a.n);
+            int64_t idx = g + (lane - 32) * step;
+            idx = idx < 0 ? 0 : idx >= nd ? nd - 1 : idx;
+            const uint64_t b = __ballot(a.doc_offsets[idx] < b0);  // (sorted offsets, non-decreasing idx: a prefix of the lanes)
+            const int c = (int)__popcll((unsigned long long)b);
+            if (c > 0 && c < 64 && !(b & (b + 1ull))) {  // the answer lies between two of the probes
+                lo = __shfl((long long)idx, c - 1) + 1;
+                hi = __shfl((long long)idx, c);
             }
+        }
+        while (hi - lo > 64) {
+            const int64_t idx = lo + ((hi - lo) * (int64_t)(lane + 1)) / 65;  // lo < idx < hi
+            const uint64_t b = __ballot(a.doc_offsets[idx] < b0);
+            const int c = (int)__popcll((unsigned long long)b);
+            const int64_t below = __shfl((long long)idx, c > 0 ? c - 1 : 0), above = __shfl((long long)idx, c < 64 ? c : 63);
+            if (c > 0) lo = below + 1;
+            if (c < 64) hi = above;
+        }
+        {
             const bool less = lo + lane < hi && a.doc_offsets[lo + lane] < b0;
             lo += (int64_t)__popcll((unsigned long long)__ballot(less));
-            if (lane == 0) s_lo = lo;
         }
-        __syncthreads();
-        for (int64_t d = (int64_t)s_lo + tid;; d += 256) {
+        wave_sync_lds();
+        for (int64_t d = lo + lane;; d += 64) {
             const int64_t p = d < nd ? a.doc_offsets[d] : b1;
-            const bool in = p >= b0 && p < b1 && p < a.n;
-            if (in) {
-                atomicOr(&s_bits[(p - b0) >> 5], 1u << (p & 31));
-                atomicMin(&s_first[(p - b0) / K_TILE], (uint32_t)d);
+            if (p >= b0 && p < b1 && p < a.n) {
+                atomicOr(&bits[(p - b0) >> 5], 1u << (p & 31));
+                atomicMin(&first[(p - b0) / K_TILE], (uint32_t)d);
             }
-            if (!__any(p < b1 && d < nd)) break;  // (sorted: nothing of this wavefront's later rounds lies in the range either)
+            if (!__any(p < b1 && d < nd)) break;  // (sorted: nothing of the later rounds lies in the range either)
         }
-        __syncthreads();
-        {
-            const int64_t gw = (b0 >> 5) + 4 * tid;
-            if (gw < words) reinterpret_cast<uint4*>(a.docbits)[gw >> 2] = reinterpret_cast<const uint4*>(s_bits)[tid];
-            const int64_t t = b0 / K_TILE + tid;
-            if (tid < PM_RANGE / K_TILE && t <= a.n_tiles) a.tile_first_doc[t] = s_first[tid];
+        wave_sync_lds();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t gw = (b0 >> 5) + 4 * (lane + 64 * q);
+            if (gw < words) reinterpret_cast<uint4*>(a.docbits)[gw >> 2] = reinterpret_cast<const uint4*>(bits)[lane + 64 * q];
         }
-        __syncthreads();
+        const int64_t t = b0 / K_TILE + lane;
+        if (lane < PM_RANGE / K_TILE && t <= a.n_tiles) a.tile_first_doc[t] = first[lane];
+        wave_sync_lds();
     }
 }
 
@@ -4114,6 +4132,14 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
     // for all of the four that are (one more round trip), then the tiles.  When the output is too small (total > out_cap)
     // every tile is looked at: the ones behind the end of the output are nobody's otherwise.
     const bool walk_all = SKIP_PLAIN && total > a.out_cap;  // (uniform)
+    // ... and in the sparse launch sequence (plain text: a tile of td_pack_rest's every few thousand) a LANE per mask word: a wavefront
+    // looks at 64 words = 1024 tiles per round trip, in a grid of a few dozen workgroups instead of 16 384 that each find nothing
+    // (9 us -> ? at 128 MiB, 34 us per GiB)
+    const bool lane_walk = SKIP_PLAIN && a.sparse != 0;  // (uniform)
+    const int n_mwords = (a.n_tiles + 15) >> 4;
+    int lw_base = (int)(blockIdx.x * (K_THREADS / 64) + wv) * 64 - nwaves * 64, lw_index = 0;
+    uint32_t lw_mine = 0, lw_cur = 0;
+    uint64_t lw_nz = 0;
     int t0 = tile_first - 4 * nwaves;
     uint32_t cmask = 0, c_tc[4] = {0, 0, 0, 0}, c_df[4] = {0, 0, 0, 0}, c_ex[4] = {0, 0, 0, 0};
     int64_t c_base[4] = {0, 0, 0, 0};
@@ -4125,7 +4151,30 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
         uint4 sx0 = cx0, sx1 = cx0, sx2 = cx0, sx3 = cx0;
         uint32_t sh0 = 0, stl = 0, sdsl = 0;
         int64_t sdpos = 0;
-        if constexpr (SKIP_PLAIN) {
+        if (SKIP_PLAIN && lane_walk) {
+            bool done = false;
+            while (!lw_cur) {
+                if (!lw_nz) {
+                    lw_base += nwaves * 64;
+                    if (lw_base >= n_mwords) { done = true; break; }
+                    lw_mine = lw_base + lane < n_mwords ? (walk_all ? 0xFFFFu : (uint32_t)a.rest_mask[lw_base + lane]) : 0u;
+                    lw_nz = __ballot(lw_mine != 0u);
+                    if (!lw_nz) continue;
+                }
+                const int l = td_ctz64(lw_nz);
+                lw_nz &= lw_nz - 1ull;
+                lw_cur = (uint32_t)__shfl((int)lw_mine, l);
+                lw_index = lw_base + l;
+            }
+            if (done) break;
+            const int bq = (int)td_ctz32(lw_cur);
+            lw_cur &= lw_cur - 1u;
+            tile = lw_index * 16 + bq;
+            if (tile >= a.n_tiles) continue;
+            tc = a.tile_count[tile]; ex = a.tile_extra[tile]; dfirst = (int64_t)a.tile_first_doc[tile];
+            base = a.tile_base[tile] + a.chunk_pref[tile / K_SCAN_CHUNK];
+            if (pk_simple(tc, base, ex, a.out_cap)) continue;
+        } else if constexpr (SKIP_PLAIN) {
             if (!cmask) {
                 t0 += 4 * nwaves;
                 if (t0 >= a.n_tiles) break;
@@ -4921,12 +4970,12 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
     if (!prepare_split) {
         // one launch: the per-call state cleared, the document bitmap and the tiles' first documents written by text range
         const int64_t nranges = (((a.n + 31) / 32 + 2) * 32 + PM_RANGE - 1) / PM_RANGE;
-        int64_t pb = nranges, zb = ((a.dedupe ? ((int64_t)a.dd_mask + 1) / 2 : 0) + a.n_tiles + 255) / 256;  // (the table of distinct pieces: 16 bytes a thread)
+        int64_t pb = (nranges + PM_WAVES - 1) / PM_WAVES, zb = ((a.dedupe ? ((int64_t)a.dd_mask + 1) / 2 : 0) + a.n_tiles + 255) / 256;  // (the table of distinct pieces: 16 bytes a thread)
         if (zb > 4096) zb = 4096;
         if (pb < zb) pb = zb;
         if (pb > (1 << 20)) pb = 1 << 20;
         if (pb < 1) pb = 1;
-        hipLaunchKernelGGL(td_prepare_mark, dim3((int)pb), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(td_prepare_mark, dim3((int)pb), dim3(64 * PM_WAVES), 0, stream, a);
     } else {
         {   // one launch clears what was seven memsets: document bits, per-tile long-piece counts, first-document
             // indices (0xFFFFFFFF = none) and the per-call counters
@@ -5060,7 +5109,12 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
             // the 2048 of rounds 2-4 — a wavefront that walks fewer tiles ends its pipeline sooner — and the 47 us it takes to find
             // nothing to do on English are the walk over the tiles' count words)
             static const int rest_max = getenv("TD_PACK_REST_BLOCKS") ? atoi(getenv("TD_PACK_REST_BLOCKS")) : 16384;
-            hipLaunchKernelGGL(td_pack_rest, dim3(pwg < rest_max ? pwg : rest_max), dim3(K_THREADS), 0, stream, a);
+            int rwg = pwg < rest_max ? pwg : rest_max;
+            if (sparse) {  // (a lane per word of the scan's masks: 1024 tiles a wavefront and round trip)
+                rwg = (a.n_tiles + 4095) / 4096;
+                if (rwg > 2048) rwg = 2048;
+            }
+            hipLaunchKernelGGL(td_pack_rest, dim3(rwg), dim3(K_THREADS), 0, stream, a);
         } else {
             hipLaunchKernelGGL(td_pack_tokens, dim3(256 * 8), dim3(K_THREADS), 0, stream, a);
         }

@@ -316,7 +316,7 @@ __global__ void td_pipe_publish(const uint32_t* ctl, uint32_t ctl_words, uint32_
     for (int64_t i = gid; i < n_off; i += gsz) h_toff[i] = d_toff[i];
     __threadfence_system();
 }
-// ... and a chunk's ids: device buffer -> pinned host buffer by a kernel (stores over PCIe), TD_PIPE_D2H_KERNEL=1
+// ... and a chunk's ids: device buffer -> pinned host buffer by a kernel (stores over PCIe), TD_PIPE_D2H_KERNEL=<workgroups> (default 32; 0: hipMemcpyAsync instead)
 __global__ __launch_bounds__(256) void td_pipe_copy_out(const uint32_t* src, uint32_t* dst, int64_t n_words) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
     const int64_t n4 = n_words >> 2;
