@@ -21,6 +21,7 @@
 #include "td_tables.h"
 #include "td_vocab.h"
 
+namespace td { hipError_t launch_mid_done(const void* ctl, uint32_t ctl_bytes, void* h_ctl, unsigned long long* h_seq, unsigned long long seq, hipStream_t stream); }  // td_special.hip
 namespace td { hipError_t launch_pipe_copy_out(const void* src, void* dst, int64_t n_words, int blocks, hipStream_t stream); }  // td_special.hip
 namespace td { hipError_t launch_pipe_publish(const void* ctl, uint32_t ctl_bytes, void* h_ctl, const int64_t* d_toff, int64_t n_off, int64_t* h_toff, hipStream_t stream); }  // td_special.hip
 using namespace td;
@@ -151,6 +152,7 @@ struct Ctl {  // small control block in device memory
     uint32_t far_tiles;      // pre-tokenizer tiles without a synchronisation point in their left halo (td_split_far_tiles)
     uint32_t ph_bar;         // td_far_probe / td_tail: arrivals at their grid barriers
     uint32_t gs_done;        // td_giant_scan: workgroups that have left the giant pieces
+    uint32_t lp_next;        // td_long_pieces: chunks of the long-piece list drawn so far
 };
 static_assert(K_MISS_CLASSES <= 6, "Ctl::miss_count");
 constexpr size_t CTL_BYTES = 256;  // the control block's place in its buffer; behind it: td_giant_pieces' scratch (TD_GP_SCRATCH_BYTES)
@@ -265,6 +267,12 @@ struct td_tokenizer {
     void* small_dec_in = nullptr;   // td_small_decode: ids in, status + bytes out
     void* small_dec_out = nullptr;
     unsigned long long small_seq = 0;
+    // host batches between the one-launch path and the pipeline (td_encode_batch, 4 KiB .. 4 MiB): pinned in / out buffers
+    void* mid_in = nullptr; size_t mid_in_cap = 0;
+    void* mid_out = nullptr; size_t mid_out_cap = 0;
+    DevBuf mid_dev;               // [offsets | text] on the device
+    unsigned long long mid_seq = 0;
+    bool mid_enabled = true;      // (TD_MID_PATH=0 at td_create time: the copies-and-synchronise path of rounds 1-5, A/B)
     bool small_enabled = true;
 };
 
@@ -506,6 +514,13 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.far_count = &ctl->far_tiles;
     a.ph_bar = &ctl->ph_bar;
     a.gs_done = &ctl->gs_done;
+    a.lp_next = &ctl->lp_next;
+    {
+        static const int lp_chunked = getenv("TD_LP_CHUNKED") ? atoi(getenv("TD_LP_CHUNKED")) : 0;
+        static const int far_light = getenv("TD_FAR_LIGHT") ? atoi(getenv("TD_FAR_LIGHT")) : 1;
+        a.lp_chunked = lp_chunked;
+        a.far_light = far_light;
+    }
     a.slow_count = &ctl->slow_count;
     a.pool = (uint32_t*)t->pool.p;
     a.pool_cap = t->pool.cap / 4;
@@ -666,6 +681,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     return order_after(t, stream);
 }
 
+int absorb_ctl(td_tokenizer* t, Ctl c, hipStream_t stream, int64_t* err_pos);
 int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) {
     if (!t->ctl.p) { HIP_TRY(t, hipStreamSynchronize(stream)); return TD_OK; }
     int rc0 = own_streams(t);
@@ -674,7 +690,12 @@ int device_status_locked(td_tokenizer* t, hipStream_t stream, int64_t* err_pos) 
     HIP_TRY(t, hipMemcpyAsync(t->h_ctl, t->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, stream));  // (behind the call's kernels)
     HIP_TRY(t, hipStreamSynchronize(stream));
     if (!t->has_last || t->last_stream == stream) bury(t);  // nothing of this handle is in flight any more
-    Ctl c = *(const Ctl*)t->h_ctl;
+    return absorb_ctl(t, *(const Ctl*)t->h_ctl, stream, err_pos);
+}
+
+// the control block of a finished call, on the host: counters the launch sequence / second stream are chosen by, the device's error (if any)
+int absorb_ctl(td_tokenizer* t, Ctl c, hipStream_t stream, int64_t* err_pos) {
+    int rc0;
     if (c.err == TD_E_BAD_TOKEN) c.err_pos = 0x7FFFFFFFFFFFFFFFll - c.err_pos;  // (td_decode_len keeps the LOWEST invalid index as a maximum)
     t->last_long = c.long_count;
     t->last_far = (int64_t)c.slow_count + c.far_tiles;
@@ -731,6 +752,7 @@ int td_create(const char* pat_str, int64_t n_vocab, const uint8_t* token_bytes, 
     if (const char* e = getenv("TD_PACK_SPLIT")) t->pack_split = atoi(e) != 0;
     if (const char* e = getenv("TD_DEDUPE")) t->dedupe = atoi(e) != 0;
     if (const char* e = getenv("TD_OVERLAP")) t->overlap = atoi(e) != 0;
+    if (const char* e = getenv("TD_MID_PATH")) t->mid_enabled = atoi(e) != 0;
     if (const char* e = getenv("TD_SPARSE")) { const int v = atoi(e); if (v >= -1 && v <= 1) t->sparse_opt = v; }
     if (const char* e = getenv("TD_GP_COOP_MIN")) { if (atol(e) >= 1024) t->gp_coop_min = (uint32_t)std::min<long>(atol(e), 0x7FFFFFFF); }
     if (const char* e = getenv("TD_DD_REPLICAS")) { const int v = atoi(e); if (v >= 1 && v <= 16 && !(v & (v - 1))) t->dd_replicas = (uint32_t)v; }
@@ -828,7 +850,7 @@ int td_clone(td_tokenizer* src, td_tokenizer** out) {
         t->dT = src->dT; t->dTp = src->dTp; t->device = src->device;
         t->d_rx = src->d_rx; t->d_rx_s1 = src->d_rx_s1; t->d_rx_s2 = src->d_rx_s2;
         t->pool_bytes_opt = src->pool_bytes_opt; t->graphs = src->graphs; t->fused = src->fused; t->direct = src->direct; t->pack_split = src->pack_split; t->dedupe = src->dedupe; t->overlap = src->overlap; t->sparse_opt = src->sparse_opt; t->gp_coop_min = src->gp_coop_min; t->dd_entries_opt = src->dd_entries_opt; t->dd_minlen = src->dd_minlen; t->dd_replicas = src->dd_replicas; t->coll_shrink = src->coll_shrink;
-        t->device_specials = src->device_specials; t->small_enabled = src->small_enabled;
+        t->device_specials = src->device_specials; t->small_enabled = src->small_enabled; t->mid_enabled = src->mid_enabled;
         t->pipe_chunk_bytes = src->pipe_chunk_bytes; t->pipe_threads = src->pipe_threads;
     }
     DeviceGuard dg(t->device);
@@ -863,6 +885,8 @@ void td_destroy(td_tokenizer* t) {
         for (hipEvent_t e : {t->e_fork, t->e_join}) if (e) (void)hipEventDestroy(e);
         if (t->h_ctl) (void)hipHostFree(t->h_ctl);
         if (t->small_in) (void)hipHostFree(t->small_in);
+        if (t->mid_in) (void)hipHostFree(t->mid_in);
+        if (t->mid_out) (void)hipHostFree(t->mid_out);
         if (t->small_dec_in) (void)hipHostFree(t->small_dec_in);
         if (t->small_dec_out) (void)hipHostFree(t->small_dec_out);
         if (t->small_out) (void)hipHostFree(t->small_out);
@@ -1298,6 +1322,67 @@ int encode_batch_small(td_tokenizer* t, const uint8_t* text, const int64_t* doc_
     return TD_OK;
 }
 
+// Host batches of 4 KiB .. 4 MiB (a document, a file, a chat transcript — the calls /root/reference/tests/code_performance_benchmark.py:338-396
+// times one by one).  Rounds 1-5: two pageable H2D copies, the step, then THREE copy-and-synchronise round trips (control block, offsets, ids):
+// 64 KB of English took 226 us of which the kernels' work was under 20.  Round 6: text and offsets go through ONE pinned buffer and one
+// asynchronous copy; the step's pack kernels write ids and offsets STRAIGHT into pinned host memory (they are its output buffers); a last
+// one-workgroup kernel copies the control block there and releases a sequence number (system scope) the host spins on — no
+// hipStreamSynchronize, no D2H copy on the way back.
+constexpr int64_t MID_MAX_BYTES = 4ll << 20, MID_MAX_DOCS = 1ll << 18;
+int encode_batch_mid(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
+                     int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
+    const int64_t n = doc_offsets[n_docs];
+    int rc;
+    const size_t offs_bytes = (((size_t)(n_docs + 1) * 8) + 63) & ~(size_t)63;
+    const size_t in_bytes = offs_bytes + (size_t)n + 64;
+    const size_t out_bytes = 512 + offs_bytes + (size_t)n * 4 + 64;
+    if ((rc = pinned_ensure(t, t->mid_in, t->mid_in_cap, in_bytes))) return rc;
+    if (!t->mid_out || t->mid_out_cap < out_bytes) {
+        if ((rc = pinned_ensure(t, t->mid_out, t->mid_out_cap, out_bytes))) return rc;
+        memset(t->mid_out, 0, 512);
+    }
+    if ((rc = ensure(t, t->mid_dev, in_bytes))) return rc;
+    if ((rc = own_streams(t))) return rc;
+    hipStream_t s = t->s_own;
+    if ((rc = order_before(t, s))) return rc;
+    uint8_t* in = (uint8_t*)t->mid_in;
+    memcpy(in, doc_offsets, (size_t)(n_docs + 1) * 8);
+    memcpy(in + offs_bytes, text, (size_t)n);
+    HIP_TRY(t, hipMemcpyAsync(t->mid_dev.p, in, offs_bytes + (size_t)n, hipMemcpyHostToDevice, s));
+    uint8_t* out = (uint8_t*)t->mid_out;  // [0, 256): control block | [256]: sequence number | 512: offsets | ids
+    int64_t* h_offs = (int64_t*)(out + 512);
+    int32_t* h_tok = (int32_t*)(out + 512 + offs_bytes);
+    rc = encode_device_locked(t, (uint8_t*)t->mid_dev.p + offs_bytes, n, t->mid_dev.p, n_docs, mode, h_tok, std::max<int64_t>(n, 1), h_offs, s);
+    if (rc) return rc;
+    const unsigned long long seq = ++t->mid_seq;
+    HIP_TRY(t, launch_mid_done(t->ctl.p, (uint32_t)sizeof(Ctl), out, (unsigned long long*)(out + 256), seq, s));
+    volatile unsigned long long* seqp = (volatile unsigned long long*)(out + 256);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            HIP_TRY(t, hipStreamSynchronize(s));  // (a launch failure surfaces here)
+            if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == seq) break;
+            t->err = "td_encode_batch: the step did not complete";
+            return TD_E_HIP;
+        }
+    }
+    if (!t->has_last || t->last_stream == s) bury(t);  // (the sequence number is written behind the step's last kernel: nothing of this handle is in flight)
+    if ((rc = absorb_ctl(t, *(const Ctl*)out, s, nullptr))) return rc;
+    memcpy(out_offsets, h_offs, (size_t)(n_docs + 1) * 8);
+    const int64_t total = out_offsets[n_docs];
+    if (n_tokens) *n_tokens = total;
+    if (total > out_capacity) {
+        t->err = "output capacity too small: " + std::to_string(total) + " tokens needed";
+        return TD_E_CAPACITY;
+    }
+    if (total > 0) {
+        if (!out_tokens) { t->err = "null out_tokens"; return TD_E_INVALID; }
+        memcpy(out_tokens, h_tok, (size_t)total * 4);
+    }
+    return TD_OK;
+}
+
 int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
                         int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens) {
     int rc;
@@ -1308,6 +1393,8 @@ int encode_batch_locked(td_tokenizer* t, const uint8_t* text, const int64_t* doc
         rc = encode_batch_small(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
         if (rc != -1) return rc;  // (-1: a piece above 64 bytes; the general path below handles it)
     }
+    if (n > 0 && n <= MID_MAX_BYTES && n_docs <= MID_MAX_DOCS && t->mid_enabled && !with_prefix)
+        return encode_batch_mid(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
     if (n >= t->pipe_chunk_bytes / 2 && out_tokens && !with_prefix)  // (default: from 32 MiB on)
         return encode_batch_pipelined(t, text, doc_offsets, n_docs, mode, out_tokens, out_capacity, out_offsets, n_tokens);
     if ((rc = ensure(t, t->h2d_text, (size_t)n + 64))) return rc;

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * PM_WAVES) void td_prepare_mark(const EncodeArg
                 atomicOr(&bits[(p - b0) >> 5], 1u << (p & 31));
                 atomicMin(&first[(p - b0) / K_TILE], (uint32_t)d);
             }
-            if (!__any(p < b1 && d < nd)) break;  // (sorted: nothing of the later rounds lies in the range either)
+            if (!((__ballot(p < b1 && d < nd) >> 63) & 1ull)) break;  // (sorted: when the LAST lane's document lies behind the range, so does everything of the later rounds — no further round trip to find that out)
         }
         wave_sync_lds();
 #pragma unroll
@@ -1905,7 +1905,8 @@ struct FarScan {  // one wavefront's view of the text for the far kernels
     }
     __device__ __forceinline__ void carry_to(int64_t from_tile, int64_t p) const {  // tiles (from_tile, tile of p]: first piece start = p
         const int64_t last = p >= a.n ? (int64_t)a.n_stiles - 1 : p / KS_TILE;
-        for (int64_t t = from_tile + 1 + lane; t <= last; t += 64) a.tile_carry[t] = p;
+        // (agent scope: td_far_probe / td_tail read it behind a grid barrier that does no cache maintenance, ph_sync_light)
+        for (int64_t t = from_tile + 1 + lane; t <= last; t += 64) __hip_atomic_store(&a.tile_carry[t], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
 
@@ -1952,7 +1953,7 @@ __device__ __forceinline__ void far_tiles_body(const EncodeArgs& a, const uint32
             int64_t p = -1;
             for (int64_t tt = t; tt < a.n_stiles && a.tile_flag[tt]; ++tt) {
                 const int64_t tg0 = tt * (int64_t)KS_TILE;
-                if (p < tg0) p = a.tile_carry[tt];
+                if (p < tg0) p = __hip_atomic_load(&a.tile_carry[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by td_split_tiles or by the far pieces' phase of this launch)
                 if (p < tg0) { if (lane == 0) raise(a, TD_E_SCRATCH, tg0); break; }  // (cannot happen: nobody told this tile)
                 if (p >= tg0 + KS_TILE || p >= a.n) continue;                        // a piece covers the whole tile
                 p = F.mark_to_tile_end(p, false);
@@ -2024,7 +2025,10 @@ __device__ __forceinline__ void probe_tiles_body(const EncodeArgs& a, const uint
     const int64_t nwords = (a.n + 31) >> 5;
     auto load_startword = [&](int64_t wg0_) -> uint32_t {
         const int64_t gw = (wg0_ >> 5) + tid;
-        return (tid < K_BWIN / 32 + 3 && gw < nwords) ? a.startbits[gw] : 0u;
+        if (!(tid < K_BWIN / 32 + 3 && gw < nwords)) return 0u;
+        // (the deferred tiles' START bits were completed by the far phases of this very launch, with atomics at agent scope and no cache
+        // maintenance at the barrier in between: read them past this XCD's caches)
+        return a.probe_deferred ? __hip_atomic_load(&a.startbits[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.startbits[gw];
     };
     // the token tiles this launch looks up: all of them, or (behind the fused tile loop) the ones it deferred
     const uint32_t* const tlist = a.probe_deferred ? a.deferred_list : nullptr;
@@ -2091,7 +2095,7 @@ __device__ __forceinline__ void probe_tiles_body(const EncodeArgs& a, const uint
                     int64_t found = a.n;
                     for (int64_t gw0 = g >> 5; gw0 < nwords; gw0 += 64) {
                         const int64_t gw = gw0 + tid;
-                        uint32_t sw = gw < nwords ? a.startbits[gw] : 0u;
+                        uint32_t sw = gw < nwords ? (a.probe_deferred ? __hip_atomic_load(&a.startbits[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.startbits[gw]) : 0u;
                         if (gw == (g >> 5)) sw &= ~((1u << (g & 31)) - 1u);
                         const uint64_t b = __ballot(sw != 0);
                         if (b) {
@@ -3009,9 +3013,15 @@ __device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Ta
         };
         for (;;) {
             // my stripe's two lowest keys (rank << 8 | position: ties go left, like the reference's strict '<' scan)
+            // (the groups of a wavefront start their stripes G x group slots apart: their arrays lie a multiple of 64 words apart, so with
+            // every group at slot gl + k G the lanes of ALL groups asked the same G banks — 49 % of this kernel's LDS cycles were conflicts)
             uint32_t b0 = INF, b1 = INF;
-            for (uint32_t q = gl; q < len; q += G) {
-                const uint32_t r = rk[q];
+            const uint32_t nk = (len + G - 1) / G;  // (> the group's number: len > 8 G)
+            for (uint32_t kk = 0; kk < nk; ++kk) {
+                uint32_t k = kk + (uint32_t)grp;
+                if (k >= nk) k -= nk;
+                const uint32_t q = (uint32_t)gl + k * G;
+                const uint32_t r = q < len ? rk[q] : (uint32_t)NO_RANK;
                 if (r != (uint32_t)NO_RANK) {
                     const uint32_t key = (r << 8) | q;
                     if (key < b0) { b1 = b0; b0 = key; } else if (key < b1) b1 = key;
@@ -3143,6 +3153,20 @@ __device__ __forceinline__ void lp_do_piece_linked(const EncodeArgs& a, const Ta
 
 constexpr int LP_WAVE_WORDS = 8 * (2 * LP_TINY + 2 * LP_TINY / 4);  // LDS words per wavefront: 8 pieces x (ids, ranks, links)
 static_assert(LP_WAVE_WORDS >= 2 * LP_MEDIUM, "the wavefront-per-piece pass reuses the same LDS");
+// ascending bitonic sort of one key per lane across the wavefront
+__device__ __forceinline__ uint32_t wave_sort_asc(uint32_t key, const int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)key, j);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            const uint32_t mn = o < key ? o : key, mx = o < key ? key : o;
+            key = (lower == up) ? mn : mx;
+        }
+    }
+    return key;
+}
 constexpr int LONG_LDS_WORDS = 4 * LP_WAVE_WORDS;
 __device__ __forceinline__ void long_pieces_body(const EncodeArgs& a, const uint32_t bid, const uint32_t nb, uint32_t* const lds) {
     uint32_t (*const s_parts)[LP_WAVE_WORDS] = reinterpret_cast<uint32_t (*)[LP_WAVE_WORDS]>(lds);  // per wavefront: ids | ranks (| links)
@@ -3152,6 +3176,7 @@ __device__ __forceinline__ void long_pieces_body(const EncodeArgs& a, const uint
     const uint32_t wave_global = bid * (blockDim.x >> 6) + wv;
     const uint32_t nwaves = nb * (blockDim.x >> 6);
 
+    if (!a.lp_chunked) {
     // pass 0: pieces <= 128 B, an 8-lane group each (linked parts)
     {
         const int grp = lane >> 3, gl = lane & 7;
@@ -3176,7 +3201,65 @@ __device__ __forceinline__ void long_pieces_body(const EncodeArgs& a, const uint
             else if (len == LP_SMALL) lp_do_piece<16>(a, T, j, id, rk, gl);
         }
     }
-    // pass 2: pieces <= 1024 B, a wavefront each
+    } else {
+    // The list is taken 64 entries (a CHUNK) at a time: a lane reads an entry's length, the wavefront SORTS its chunk by length (bitonic, six
+    // stages of shuffles) and deals the pieces to its lane groups in that order — the eight pieces a wavefront merges side by side advance
+    // in lockstep (a row takes as long as its slowest piece), and pieces of one length need about the same number of rounds; dealt in list
+    // order a row held lengths from 65 to 128 bytes and 25 of 64 lanes were active on average.  Chunks are DRAWN from a counter (the draw
+    // for the next chunk is issued in front of this chunk's work, its answer read behind it): dealt by stride the wavefronts were done at
+    // very different times — 1.95 of 4 wavefronts per SIMD resident on average over the kernel (round 5's counters).
+    // (a chunk is 8 .. 64 entries: at least four chunks per wavefront of the grid — with 64 entries a chunk, 256 MiB of mixed-script text
+    // (132 000 long pieces, 4096 wavefronts) kept half of the wavefronts without any: 0.81 -> 1.19 ms)
+    uint32_t csh = 6;
+    while (csh > 3 && (nlong >> csh) < 4u * nwaves) --csh;
+    const uint32_t C = 1u << csh;
+    const uint32_t nchunks = (nlong + C - 1u) >> csh;
+    uint32_t chunk = wave_global;
+    while (chunk < nchunks) {
+        uint32_t drawn = 0;
+        if (lane == 0) drawn = atomicAdd(a.lp_next, 1u);
+        const uint32_t j0 = (chunk << csh) + (uint32_t)lane;
+        const uint32_t len_l = ((uint32_t)lane < C && j0 < nlong) ? a.long_list[j0].len : 0u;
+        constexpr uint32_t INF = 0xFFFFFFFFu;
+        // pass 0: pieces <= 128 B, an 8-lane group each (linked parts)
+        {
+            const int grp = lane >> 3, gl = lane & 7;
+            volatile uint32_t* id = &s_parts[wv][grp * (LP_WAVE_WORDS / 8)];
+            volatile uint32_t* rk = id + LP_TINY;
+            volatile uint8_t* nx = reinterpret_cast<volatile uint8_t*>(rk + LP_TINY);
+            volatile uint8_t* pv = nx + LP_TINY;
+            const uint32_t key = wave_sort_asc((len_l != 0u && len_l <= (uint32_t)LP_TINY) ? ((len_l << 6) | (uint32_t)lane) : INF, lane);
+            const uint32_t cnt = (uint32_t)__popcll((unsigned long long)__ballot(key != INF));
+            for (uint32_t r = 0; r * 8u < cnt; ++r) {
+                const uint32_t k = (uint32_t)__shfl((int)key, (int)(r * 8u) + grp);
+                if (k != INF) lp_do_piece_linked<8>(a, T, (chunk << csh) + (k & 63u), id, rk, nx, pv, grp, gl);
+            }
+        }
+        wave_sync_lds();
+        // pass 1: pieces <= 255 B, a 16-lane group each (linked parts); 256 B: the dense variant
+        {
+            const int grp = lane >> 4, gl = lane & 15;
+            volatile uint32_t* id = &s_parts[wv][grp * (LP_WAVE_WORDS / 4)];
+            volatile uint32_t* rk = id + LP_SMALL;
+            volatile uint8_t* nx = reinterpret_cast<volatile uint8_t*>(rk + LP_SMALL);
+            volatile uint8_t* pv = nx + LP_SMALL;
+            const uint32_t key = wave_sort_asc((len_l > (uint32_t)LP_TINY && len_l <= (uint32_t)LP_SMALL) ? ((len_l << 6) | (uint32_t)lane) : INF, lane);
+            const uint32_t cnt = (uint32_t)__popcll((unsigned long long)__ballot(key != INF));
+            for (uint32_t r = 0; r * 4u < cnt; ++r) {
+                const uint32_t k = (uint32_t)__shfl((int)key, (int)(r * 4u) + grp);
+                if (k != INF) {
+                    const uint32_t len = k >> 6, j = (chunk << csh) + (k & 63u);
+                    if (len <= (uint32_t)LP_LINKED) lp_do_piece_linked<16>(a, T, j, id, rk, nx, pv, grp, gl);
+                    else lp_do_piece<16>(a, T, j, id, rk, gl);
+                }
+            }
+        }
+        wave_sync_lds();
+        chunk = nwaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+    }
+    }
+    // pass 2: pieces <= 1024 B, a wavefront each — dealt by stride over the whole list (they come in clusters — a file of emoji
+    // sequences — and a chunk's wavefront would take its cluster alone)
     {
         volatile uint32_t* id = &s_parts[wv][0];
         volatile uint32_t* rk = id + LP_MEDIUM;
@@ -3940,6 +4023,36 @@ __device__ __forceinline__ bool ph_sync(const EncodeArgs& a, const PhaseSync& c)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return true;
 }
+// ... between phases whose only traffic is agent-scope atomics and agent-scope loads / stores (the far phases: START bits by atomicOr,
+// tile_carry, the error word): no cache write-back or invalidation, just "my accesses have arrived" and the counter (the fences above
+// cost the code file set 40 us per step: two barriers of 512 workgroups each writing back and invalidating its XCD's L2)
+__device__ __forceinline__ bool ph_sync_light(const EncodeArgs& a, const PhaseSync& c) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (!c.solo) {
+        if (threadIdx.x == 0) {
+            const uint32_t old = __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = ((old & ~PH_DEAD) / c.nb + 1u) * c.nb;
+            const unsigned long long t0 = wall_clock64();
+            int ok = (old & PH_DEAD) ? 0 : 1;
+            while (ok) {
+                const uint32_t v = __hip_atomic_load(c.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v & PH_DEAD) { ok = 0; break; }
+                if (v >= target) break;
+                if (wall_clock64() - t0 > PH_BAR_TIMEOUT) {
+                    __hip_atomic_fetch_or(c.bar, PH_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    raise(a, TD_E_HIP, 0);
+                    ok = 0;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            *c.s_flag = ok;
+        }
+        __syncthreads();
+        if (!*c.s_flag) return false;
+    }
+    return true;
+}
 __device__ __forceinline__ uint32_t ph_count(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // what td_split_tiles left for the window it could not see through: far pieces -> chains of flagged tiles -> the deferred token tiles.
@@ -3954,8 +4067,8 @@ __device__ __forceinline__ bool far_probe_phases(const EncodeArgs& a, PhaseSync&
             c.solo = true; bid = 0u; nb = 1u;
         }
     }
-    if (nslow) { far_pieces_body(a, bid, nb); if (!ph_sync(a, c)) return false; }
-    if (nfar) { far_tiles_body(a, bid, nb); if (!ph_sync(a, c)) return false; }
+    if (nslow) { far_pieces_body(a, bid, nb); if (!(a.far_light ? ph_sync_light(a, c) : ph_sync(a, c))) return false; }
+    if (nfar) { far_tiles_body(a, bid, nb); if (!(a.far_light ? ph_sync_light(a, c) : ph_sync(a, c))) return false; }
     if (ndef) {
         EncodeArgs ad = a;
         ad.probe_deferred = 1;

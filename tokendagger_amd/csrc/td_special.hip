@@ -326,6 +326,18 @@ __global__ __launch_bounds__(256) void td_pipe_copy_out(const uint32_t* src, uin
     if (gid < (n_words & 3)) dst[(n4 << 2) + gid] = src[(n4 << 2) + gid];
     __threadfence_system();
 }
+// td_encode_batch's path for 4 KiB .. 4 MiB (td_api.cpp: encode_batch_mid): behind the step's last kernel — whose outputs ARE pinned host
+// buffers — the control block goes to pinned memory too and a sequence number is released at system scope: the host spins on it
+__global__ __launch_bounds__(64) void td_mid_done(const uint32_t* ctl, uint32_t ctl_words, uint32_t* h_ctl, unsigned long long* h_seq, unsigned long long seq) {
+    if (threadIdx.x < ctl_words) h_ctl[threadIdx.x] = ctl[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_mid_done(const void* ctl, uint32_t ctl_bytes, void* h_ctl, unsigned long long* h_seq, unsigned long long seq, hipStream_t stream) {
+    hipLaunchKernelGGL(td_mid_done, dim3(1), dim3(64), 0, stream, (const uint32_t*)ctl, ctl_bytes / 4u, (uint32_t*)h_ctl, h_seq, seq);
+    return hipGetLastError();
+}
 hipError_t launch_pipe_copy_out(const void* src, void* dst, int64_t n_words, int blocks, hipStream_t stream) {
     hipLaunchKernelGGL(td_pipe_copy_out, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, n_words);
     return hipGetLastError();

@@ -19,9 +19,11 @@ PY
 timeout 400 python bench.py --gpus 2 --same-gpu --dist-backend gloo --no-cpu-baseline --steps 30 > $O/bench_2rank_same_gpu_gloo.json 2> $O/bench_2rank.err; python -c "
 import json,sys; j=json.loads(open('$O/bench_2rank_same_gpu_gloo.json').read().strip().splitlines()[-1]); print('2 ranks on one GPU (gloo):', j['value'], 'GB/s', j['config']['verified_vs_oracle'], j['config']['parallelism'][:60])" 2>&1 | tail -1
 bash tools/measure_workload.sh $tag english 1024 > $O/measure_english.log 2>&1; tail -14 $O/measure_english.log
+# (fabric traffic of configs 4 and 5 too, on the shipping sources; these also leave stats_<corpus>_256.txt)
+bash tools/measure_workload.sh $tag mixed 256 --pattern tekken > $O/measure_mixed_tekken.log 2>&1; tail -4 $O/measure_mixed_tekken.log; mv $O/stats_mixed_256.txt $O/stats_mixed_tekken_256.txt
+bash tools/measure_workload.sh $tag mixed 256 > $O/measure_mixed.log 2>&1; tail -4 $O/measure_mixed.log
+bash tools/measure_workload.sh $tag code_files 256 > $O/measure_code_files.log 2>&1; tail -4 $O/measure_code_files.log
 for cm in "english 1024" "mixed 256" "code_files 256"; do set -- $cm; bash tools/pmc_workload.sh $tag $1 $2 > /dev/null 2>&1; head -12 $O/pmc_$1_$2.txt | cut -c1-230; rm -rf $O/pmc_$1_$2; done
-bash tools/prof_workload.sh $tag mixed 256 > $O/prof_mixed.log 2>&1; tail -6 $O/prof_mixed.log
-bash tools/prof_workload.sh $tag code_files 256 > $O/prof_code_files.log 2>&1; tail -6 $O/prof_code_files.log
 cp $R/profiles/hbm_traffic.json $O/hbm_traffic.json
 timeout 200 python tools/gpu_pybatch.py 256 > $O/pybatch.txt 2>&1; grep -v amdgpu $O/pybatch.txt
 timeout 200 python tools/gpu_latency.py > $O/latency.txt 2>&1; grep -v amdgpu $O/latency.txt | tail -12

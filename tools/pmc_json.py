@@ -27,7 +27,7 @@ for f in sorted(prof.glob(f"r{rn}_0[456]_pmc_*.txt")):
         stalls = {"parked on s_waitcnt / a barrier": d.get("SQ_WAIT_ANY", 0) / wc, "waiting to issue": d.get("SQ_WAIT_INST_ANY", 0) / wc,
                   "issuing": d.get("SQ_ACTIVE_INST_ANY", 0) / wc}
         ent[k] = {"us_at_2.4GHz": round(dur / 2400, 1),
-                  "valu_busy_frac_of_simd_cycles": round(d.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (dur * 1024), 3),
+                  "valu_busy_if_4_cycles_per_instruction": round(d.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (dur * 1024), 3),
                   "lanes_per_valu_instruction": round(d.get("SQ_THREAD_CYCLES_VALU", 0) / max(d.get("SQ_ACTIVE_INST_VALU", 1), 1), 1),
                   "wave_cycles": {k2: round(v, 3) for k2, v in stalls.items()},
                   "top_wave_state": max(stalls, key=stalls.get),
@@ -35,7 +35,8 @@ for f in sorted(prof.glob(f"r{rn}_0[456]_pmc_*.txt")):
                   "valu_instructions_per_input_byte_x64": None,
                   "l2_hit_rate": round(d.get("TCC_HIT_sum", 0) / max(d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0), 1), 3),
                   "lds_bank_conflict_frac": round(d.get("SQ_LDS_BANK_CONFLICT", 0) / d["SQ_LDS_IDX_ACTIVE"], 3) if d.get("SQ_LDS_IDX_ACTIVE") else None,
-                  "valu_wave_instructions": int(d.get("SQ_INSTS_VALU", 0))}
+                  "valu_wave_instructions": int(d.get("SQ_INSTS_VALU", 0)),
+                  "valu_note": "SQ_ACTIVE_INST_VALU counts instructions; a wave64 instruction issues in 2 or 4 cycles by kind (profiles/r6_00_valu_issue_rate.txt): the busy figure is an upper bound, x 0.8 for the fused loop's mix"}
         ent[k].pop("valu_instructions_per_input_byte_x64")
     out[key] = ent
 (prof / "pmc_counters.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")

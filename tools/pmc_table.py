@@ -23,8 +23,9 @@ A = {k: {c: acc[k][c] / cnt[k][c] for c in acc[k]} for k in acc}
 SIMDS = 256 * 4
 print(f"# {title}\n# per kernel LAUNCH (averages over the launches of the run); separate rocprofv3 --kernel-trace --pmc passes (tools/pmc_workload.sh)")
 print("# rocprofv3 sums a counter over the 8 XCDs: GRBM_GUI_ACTIVE / 8 = the kernel's duration in cycles (x 1/2.4 GHz = the kernel-trace duration);")
-print("# cyc/wave = SQ_WAVE_CYCLES x 4 / waves (SQ_*_CYCLES and SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles); VALU busy% = SQ_ACTIVE_INST_VALU x 4 / (duration x 1024 SIMDs):")
-print("# the share of the chip's SIMD issue cycles that issued a vector instruction; lanes/VALU = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64);")
+print("# cyc/wave = SQ_WAVE_CYCLES x 4 / waves (SQ_*_CYCLES and SQ_WAIT_* count quad-cycles); VALU busy% = SQ_ACTIVE_INST_VALU x 4 / (duration x 1024 SIMDs):")
+print("# SQ_ACTIVE_INST_VALU counts INSTRUCTIONS (= SQ_INSTS_VALU) and a wave64 instruction issues in 2 or 4 cycles by kind (profiles/r6_00_valu_issue_rate.txt), so")
+print("# this is the busy share if every instruction took 4 cycles — an upper bound (the fused loop's mix averages ~3.3: x 0.8); lanes/VALU = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64);")
 print("# active / issue-stall / parked = SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY / SQ_WAIT_ANY as shares of the wavefronts' resident cycles (parked = s_waitcnt or barrier)")
 hdr = f"{'kernel':<34} {'waves':>9} {'VALU/wave':>10} {'SALU/wave':>10} {'LDS/wave':>9} {'VMEM/wave':>10} {'cyc/wave':>10} {'active%':>8} {'issue-stall%':>12} {'parked%':>8} {'VALU busy%':>10} {'lanes/VALU':>10} {'LDS confl%':>10} {'occ waves/SIMD':>14} {'L2 hit%':>8} {'us @2.4GHz':>10}"
 print(hdr)

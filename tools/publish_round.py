@@ -11,7 +11,7 @@ rn = int(sys.argv[2])
 prof = ROOT / "profiles"
 shutil.copy(src / "stats_english_1024.txt", prof / f"r{rn}_01_kernel_stats_english_1024.txt")
 with open(prof / f"r{rn}_02_kernel_stats_other_corpora.txt", "w") as f:
-    for name in ("stats_mixed_256.txt", "stats_code_files_256.txt"):
+    for name in ("stats_mixed_256.txt", "stats_code_files_256.txt", "stats_mixed_tekken_256.txt"):
         if (src / name).exists():
             f.write((src / name).read_text().rstrip("\n") + "\n\n")
 t = json.loads((src / "hbm_traffic.json").read_text())
@@ -27,11 +27,12 @@ except Exception:  # noqa: BLE001
 for key in sorted(k for k, v in t.items() if isinstance(v, dict)):
     tot = t[key]["_all"]
     head = f"## {key}: all kernels of a step {tot / 1e9:.3f} GB"
-    if key in ALG:
-        head += f" = {tot / ALG[key]:.2f} x algorithmic ({ALG[key] / 1e9:.3f} GB)"
+    alg = t[key].get("algorithmic_bytes") or ALG.get(key)
+    if alg:
+        head += f" = {tot / alg:.2f} x algorithmic ({alg / 1e9:.3f} GB = text + 4 x ids + 8 x (documents + 1), SURVEY 8d)"
     lines.append(head)
     for k, v in sorted(t[key]["per_kernel"].items(), key=lambda kv: -kv[1]):
-        lines.append(f"  {k:<32} {v / 1e6:8.1f} MB")
+        lines.append(f"  {k:<32} {v / 1e6:8.1f} MB" + (f"   {v / alg:5.2f} x algorithmic" if alg else ""))
     lines.append("")
 (prof / f"r{rn}_03_hbm_traffic.txt").write_text("\n".join(lines))
 shutil.copy(src / "hbm_traffic.json", prof / "hbm_traffic.json")
@@ -40,7 +41,7 @@ for i, name in enumerate(("pmc_english_1024.txt", "pmc_mixed_256.txt", "pmc_code
         shutil.copy(src / name, prof / f"r{rn}_0{4 + i}_{name}")
 bdir = prof / f"r{rn}_bench"
 bdir.mkdir(exist_ok=True)
-for name in ("bench_default.json", "bench_default.time", "bench_2rank_same_gpu_gloo.json", "pybatch.txt", "host.txt", "pytest_gpu.log", "smoke.log", "latency.txt", "giant_pieces.txt", "hostpath.txt", "bench_128_weak.json"):
+for name in ("bench_default.json", "bench_default.time", "latency_files.txt", "resource_usage.txt", "bench_2rank_same_gpu_gloo.json", "pybatch.txt", "host.txt", "pytest_gpu.log", "smoke.log", "latency.txt", "giant_pieces.txt", "hostpath.txt", "bench_128_weak.json"):
     if (src / name).exists():
         shutil.copy(src / name, bdir / name)
 print("published", src, "->", prof)

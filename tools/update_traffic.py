@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 import bench
 key, root = sys.argv[1], sys.argv[2]
 note = sys.argv[3] if len(sys.argv) > 3 else ""
-SEG = {"td_prepare": "td_prepare+td_mark_docs", "td_mark_docs": "td_prepare+td_mark_docs",
+SEG = {"td_prepare": "td_prepare+td_mark_docs", "td_mark_docs": "td_prepare+td_mark_docs", "td_prepare_mark": "td_prepare+td_mark_docs",
+       "td_far_probe": "td_split_tiles", "td_tail": "td_merge_pieces", "td_giant_scan": "td_long_pieces+td_giant_pieces+td_scan_tiles",
        "td_split_tiles": "td_split_tiles", "td_split_far_pieces": "td_split_tiles", "td_split_far_tiles": "td_split_tiles",
        "td_probe_tiles": "td_probe_tiles", "td_merge_pieces": "td_merge_pieces",  # (segments = the events of TD_OPT_PROFILE)
        "td_long_pieces": "td_long_pieces+td_giant_pieces+td_scan_tiles", "td_giant_pieces": "td_long_pieces+td_giant_pieces+td_scan_tiles",
@@ -34,6 +35,15 @@ for k, v in kern.items():
     if k in SEG:
         ent[SEG[k]] = ent.get(SEG[k], 0) + v
 ent["_all"] = sum(kern.values())
+if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):  # the bench line of the measured command: the launch's algorithmic bytes
+    try:
+        j = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+        c = j["config"]
+        ent["algorithmic_bytes"] = int(c["bytes_rank0"] + 4 * c["tokens_rank0"] + 8 * (c["docs_rank0"] + 1))
+        ent["ratio_to_algorithmic"] = round(ent["_all"] / ent["algorithmic_bytes"], 3)
+        ent["per_kernel_ratio"] = {k: round(v / ent["algorithmic_bytes"], 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]) if v >= 0.005 * ent["_all"]}
+    except Exception as e:  # noqa: BLE001
+        ent["algorithmic_bytes_error"] = str(e)
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 doc = json.load(open(path)) if os.path.exists(path) else {}
 sha = bench.kernel_source_sha()
