@@ -2765,6 +2765,143 @@ __device__ __forceinline__ uint32_t lp_merge_lds(const Tables& T, volatile uint3
     return m;
 }
 
+// Round 6: EVERY pair of the lowest rank per round, as far as that is what the sequential loop does (one wavefront, parts dense in LDS,
+// m <= 1024: td_small_encode's pieces above 64 bytes — a lone run of one letter, of blanks, of dashes was a chain of one merge per ~3 us:
+// 'a' * 1000 2.9 ms where the reference's quadratic loop takes 0.37).  r = the lowest rank present; its pairs are taken greedily from the
+// left (in a run of consecutive ones every second one: the others lose a part to their left neighbour's merge).  The sequential loop
+// (tiktoken.cpp:322-343: lowest rank first, leftmost on ties) merges exactly these, in this order, as long as no pair the merges create —
+// (part in front, merged part), where the part in front is itself merged when the pair two positions to the left was taken, and (merged
+// part, the still unmerged part behind it) — ranks at or below r: such a pair lies LEFT of every rank-r pair still to come, so the loop
+// would take it first.  A round applies the selected merges up to and including the first one that creates such a pair; the next round
+// starts from the lowest rank again.  At least the plain sequential step per round, hundreds of merges on repetitive pieces.  The rule as
+// a CPU model against the reference's loop, vocabularies with ranks out of merge order included: tools/sim_rank_batches.py,
+// tests/test_rank_batches_model.py; this function against the compiled reference: tests/test_gpu_rank_batches.py.
+// A lane owns sixteen consecutive positions; everything a round needs is read into registers first, the compacted arrays written last.
+__device__ __forceinline__ uint32_t lp_merge_batched(const Tables& T, volatile uint32_t* vid, volatile uint32_t* vrk, uint32_t m, const int lane) {
+    uint32_t* const id = const_cast<uint32_t*>(vid);
+    uint32_t* const rk = const_cast<uint32_t*>(vrk);
+    constexpr uint32_t NR = (uint32_t)NO_RANK;
+    typedef const uint64_t __attribute__((address_space(1)))* gpair_t;
+    gpair_t const ps = (gpair_t)(uintptr_t)T.pair_slots;
+    const uint32_t q0 = 16u * (uint32_t)lane;
+    auto wave_min = [](uint32_t v) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o < v ? o : v; }
+        return v;
+    };
+    while (m >= 2u) {
+        uint32_t iv[16], rv[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint4 a4 = reinterpret_cast<const uint4*>(id + q0)[t], b4 = reinterpret_cast<const uint4*>(rk + q0)[t];
+            iv[4 * t] = a4.x; iv[4 * t + 1] = a4.y; iv[4 * t + 2] = a4.z; iv[4 * t + 3] = a4.w;
+            rv[4 * t] = b4.x; rv[4 * t + 1] = b4.y; rv[4 * t + 2] = b4.z; rv[4 * t + 3] = b4.w;
+        }
+        uint32_t best = NR;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (q0 + (uint32_t)j + 1u >= m) rv[j] = NR;  // (no pair starts at the last part or behind it)
+            best = rv[j] < best ? rv[j] : best;
+        }
+        const uint32_t r = wave_min(best);
+        if (r >= NR) break;
+        uint32_t cand = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cand |= (rv[j] == r ? 1u : 0u) << j;
+        // the run of rank-r pairs that reaches my first position from the left: odd or even?  (a lane that is all candidates hands the
+        // question on: sixteen is even)
+        const uint32_t top = cand == 0xFFFFu ? 16u : (uint32_t)__clz(~(cand << 16));  // candidates at my upper end
+        const uint64_t full = __ballot(cand == 0xFFFFu), odd = __ballot((top & 1u) != 0u);
+        const uint64_t below = ~full & ((1ull << lane) - 1ull);
+        uint32_t par = below ? (uint32_t)((odd >> (63 - __clzll((long long)below))) & 1ull) : 0u;
+        uint32_t sel = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t c = (cand >> j) & 1u;
+            sel |= (c & (par ^ 1u)) << j;
+            par = c ? (par ^ 1u) : 0u;
+        }
+        // what the neighbours hold
+        uint32_t sel_prev = (uint32_t)__shfl_up((int)sel, 1), iv15_prev = (uint32_t)__shfl_up((int)iv[15], 1);
+        if (lane == 0) { sel_prev = 0; iv15_prev = 0; }
+        const uint32_t iv0_next = (uint32_t)__shfl_down((int)iv[0], 1), iv1_next = (uint32_t)__shfl_down((int)iv[1], 1);
+        // pass A: the two pairs every selected merge creates; positions 2 s and 2 s + 1 cannot both be selected: a slot per pair of positions
+        uint32_t L8[8], R8[8], vpos = 0xFFFFFFFFu;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint64_t eL1[4], eL2[4], eR1[4], eR2[4];
+            uint32_t pv[4], nx[4];
+            bool hp[4], hn[4], has[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s8 = 4 * h + u, ja = 2 * s8, jb = ja + 1;
+                const bool ta = (sel >> ja) & 1u, tb = (sel >> jb) & 1u;
+                has[u] = ta || tb;
+                const uint32_t q = q0 + (uint32_t)(tb ? jb : ja);
+                const bool ps_a = s8 >= 1 ? ((sel >> (ja - 2 >= 0 ? ja - 2 : 0)) & 1u) : ((sel_prev >> 14) & 1u);
+                const bool ps_b = s8 >= 1 ? ((sel >> (jb - 2)) & 1u) : ((sel_prev >> 15) & 1u);
+                const uint32_t pp_a = s8 >= 1 ? iv[ja - 1 >= 0 ? ja - 1 : 0] : iv15_prev, pp_b = iv[ja];
+                const uint32_t nn_a = ja + 2 <= 15 ? iv[ja + 2 <= 15 ? ja + 2 : 15] : iv0_next;
+                const uint32_t nn_b = jb + 2 <= 15 ? iv[jb + 2 <= 15 ? jb + 2 : 15] : (jb + 2 == 16 ? iv0_next : iv1_next);
+                pv[u] = (tb ? ps_b : ps_a) ? r : (tb ? pp_b : pp_a);
+                nx[u] = tb ? nn_b : nn_a;
+                hp[u] = has[u] && q > 0u;
+                hn[u] = has[u] && q + 2u < m;
+                eL1[u] = eL2[u] = eR1[u] = eR2[u] = PAIR_EMPTY;
+                if (hp[u]) { eL1[u] = ps[hash_pair(pv[u], r) & T.pair_mask]; eL2[u] = ps[hash_pair2(pv[u], r) & T.pair_mask]; }
+                if (hn[u]) { eR1[u] = ps[hash_pair(r, nx[u]) & T.pair_mask]; eR2[u] = ps[hash_pair2(r, nx[u]) & T.pair_mask]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s8 = 4 * h + u;
+                L8[s8] = hp[u] ? (uint32_t)pair_match(eL1[u], eL2[u], pv[u], r) : NR;
+                R8[s8] = hn[u] ? (uint32_t)pair_match(eR1[u], eR2[u], r, nx[u]) : NR;
+                if (has[u] && (L8[s8] <= r || R8[s8] <= r)) {
+                    const uint32_t q = q0 + (uint32_t)(((sel >> (2 * s8 + 1)) & 1u) ? 2 * s8 + 1 : 2 * s8);
+                    vpos = q < vpos ? q : vpos;
+                }
+            }
+        }
+        const uint32_t cut = wave_min(vpos);  // the first merge that turns the sequential order elsewhere: applied, and the last one of the round
+        uint32_t app = sel;
+        if (cut < q0) app = 0;
+        else if (cut - q0 < 15u) app &= (2u << (cut - q0)) - 1u;
+        // pass B: the compacted arrays
+        uint32_t app_prev = (uint32_t)__shfl_up((int)app, 1), app_next = (uint32_t)__shfl_down((int)app, 1);
+        const uint32_t L_next0 = (uint32_t)__shfl_down((int)L8[0], 1);
+        if (lane == 0) app_prev = 0;
+        if (lane == 63) app_next = 0;
+        const uint32_t absorbed = ((app << 1) | (app_prev >> 15)) & 0xFFFFu;
+        const uint32_t napp = (uint32_t)__popc(app);
+        const uint32_t incl = wave_incl_scan(napp, lane);
+        const uint32_t before = incl - napp, total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        wave_sync_lds();  // (every lane has read its parts: the arrays may change now)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t q = q0 + (uint32_t)j;
+            if (q < m && !((absorbed >> j) & 1u)) {
+                const bool mine = (app >> j) & 1u;
+                uint32_t nid, nrk;
+                if (mine) {  // the pair that starts at a merged part: with the next merged part (that one's pair in front) or with the unmerged part behind
+                    nid = r;
+                    const bool next_merged = j + 2 <= 15 ? ((app >> (j + 2 <= 15 ? j + 2 : 15)) & 1u) : ((app_next >> (j + 2 - 16)) & 1u);
+                    nrk = next_merged ? (j + 2 <= 15 ? L8[(j + 2 <= 15 ? j + 2 : 15) >> 1] : L_next0) : R8[j >> 1];
+                } else {
+                    nid = iv[j];
+                    const bool next_merged = j + 1 <= 15 ? ((app >> (j + 1 <= 15 ? j + 1 : 15)) & 1u) : (app_next & 1u);
+                    nrk = next_merged ? (j + 1 <= 15 ? L8[(j + 1 <= 15 ? j + 1 : 15) >> 1] : L_next0) : rv[j];
+                }
+                const uint32_t nq = q - (before + (uint32_t)__popc(app & ((1u << j) - 1u)));
+                id[nq] = nid;
+                rk[nq] = nrk;
+            }
+        }
+        m -= total;
+        wave_sync_lds();
+    }
+    return m;
+}
+
 // one group of G lanes handles entry j entirely in LDS; returns through the entry + tile_extra
 template <int G>
 __device__ __forceinline__ void lp_do_piece(const EncodeArgs& a, const Tables& T, uint32_t j, volatile uint32_t* id,
@@ -4877,7 +5014,7 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
                     rk[q] = (q + 1 < len) ? (uint32_t)T.byte_pair[(b << 8) | pb[q + 1]] : (uint32_t)NO_RANK;
                 }
                 wave_sync_lds();
-                m = lp_merge_lds<64>(T, id, rk, len, lane);
+                m = lp_merge_batched(T, id, rk, len, lane);
             }
             wave_sync_lds();
             for (uint32_t q = (uint32_t)lane; q < m; q += 64u) {

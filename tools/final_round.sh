@@ -26,6 +26,7 @@ bash tools/measure_workload.sh $tag code_files 256 > $O/measure_code_files.log 2
 for cm in "english 1024" "mixed 256" "code_files 256"; do set -- $cm; bash tools/pmc_workload.sh $tag $1 $2 > /dev/null 2>&1; head -12 $O/pmc_$1_$2.txt | cut -c1-230; rm -rf $O/pmc_$1_$2; done
 cp $R/profiles/hbm_traffic.json $O/hbm_traffic.json
 timeout 200 python tools/gpu_pybatch.py 256 > $O/pybatch.txt 2>&1; grep -v amdgpu $O/pybatch.txt
-timeout 200 python tools/gpu_latency.py > $O/latency.txt 2>&1; grep -v amdgpu $O/latency.txt | tail -12
+timeout 300 python tools/gpu_latency.py > $O/latency.txt 2>&1; grep -v amdgpu $O/latency.txt | tail -12
+timeout 600 python tools/gpu_latency_files.py > $O/latency_files.txt 2>&1; grep -v amdgpu $O/latency_files.txt | tail -25
 timeout 200 python tools/gpu_giant.py > $O/giant_pieces.txt 2>&1; grep -v amdgpu $O/giant_pieces.txt | tail -16
 find $O -name "*.db" -size +20M -delete
