@@ -516,9 +516,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.gs_done = &ctl->gs_done;
     a.lp_next = &ctl->lp_next;
     {
-        static const int lp_chunked = getenv("TD_LP_CHUNKED") ? atoi(getenv("TD_LP_CHUNKED")) : 0;
         static const int far_light = getenv("TD_FAR_LIGHT") ? atoi(getenv("TD_FAR_LIGHT")) : 1;
-        a.lp_chunked = lp_chunked;
         a.far_light = far_light;
     }
     a.slow_count = &ctl->slow_count;

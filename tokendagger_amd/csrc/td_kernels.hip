@@ -2956,12 +2956,15 @@ __device__ __forceinline__ void lp_do_piece(const EncodeArgs& a, const Tables& T
 // and behind each of my part starts, read from the verdicts (all reads into registers, another fence), then the pair ranks of all my
 // parts as one batch of lookups, then the writes.  Returns the number of parts.  (= cseed_part_at at every byte; tests/test_char_seeds.py
 // holds that function to the reference's loop, the GPU parity tests hold this one to the reference.)
+#ifndef TD_LP_SEED_INLINE
+#define TD_LP_SEED_INLINE __forceinline__  // (__noinline__: 71 -> 105 spilled VGPRs and 448 B of scratch in td_long_pieces — measured at the compiler, round 6)
+#endif
 constexpr int LP_TINY = 128;      // eight lanes per piece up to here
 constexpr int LP_LINKED = 255;    // sixteen lanes per piece up to here (links are bytes)
 constexpr uint32_t LP_END = 255;  // "no neighbour" in the link arrays
 constexpr uint32_t LPS_SEEDED = 0x80000000u;  // verdict: a seeded character starts here | its length << 21 | its id
 template <int G>
-__device__ __forceinline__ uint32_t lp_seed_setup(const EncodeArgs& a, const Tables& T, int64_t gs, uint32_t len, uint32_t* id, uint32_t* rk,
+__device__ TD_LP_SEED_INLINE uint32_t lp_seed_setup(const EncodeArgs& a, const Tables& T, int64_t gs, uint32_t len, uint32_t* id, uint32_t* rk,
                                                   uint8_t* nx, uint8_t* pv, int gl) {
     const uint32_t c = (uint32_t)gl * 16u;
     uint32_t w[5];
@@ -3313,7 +3316,7 @@ __device__ __forceinline__ void long_pieces_body(const EncodeArgs& a, const uint
     const uint32_t wave_global = bid * (blockDim.x >> 6) + wv;
     const uint32_t nwaves = nb * (blockDim.x >> 6);
 
-    if (!a.lp_chunked) {
+#ifndef TD_LP_CHUNKED
     // pass 0: pieces <= 128 B, an 8-lane group each (linked parts)
     {
         const int grp = lane >> 3, gl = lane & 7;
@@ -3338,7 +3341,9 @@ __device__ __forceinline__ void long_pieces_body(const EncodeArgs& a, const uint
             else if (len == LP_SMALL) lp_do_piece<16>(a, T, j, id, rk, gl);
         }
     }
-    } else {
+#else
+    // (-DTD_LP_CHUNKED, measured and NOT in: mixed-script text 0.81 -> 0.93 ms per 256 MiB, the code file set 0.45 -> 0.50 — a chunk's pieces are one
+    // wavefront's, and the sort's gain in lockstep does not make up for the coarser deal; both forms in one kernel: 72 -> 239 spilled VGPRs)
     // The list is taken 64 entries (a CHUNK) at a time: a lane reads an entry's length, the wavefront SORTS its chunk by length (bitonic, six
     // stages of shuffles) and deals the pieces to its lane groups in that order — the eight pieces a wavefront merges side by side advance
     // in lockstep (a row takes as long as its slowest piece), and pieces of one length need about the same number of rounds; dealt in list
@@ -3394,7 +3399,7 @@ __device__ __forceinline__ void long_pieces_body(const EncodeArgs& a, const uint
         wave_sync_lds();
         chunk = nwaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
     }
-    }
+#endif
     // pass 2: pieces <= 1024 B, a wavefront each — dealt by stride over the whole list (they come in clusters — a file of emoji
     // sequences — and a chunk's wavefront would take its cluster alone)
     {
