@@ -89,9 +89,13 @@ const char* td_last_error(const td_tokenizer* t);
  * tokendagger/wrapper.py:212-235).  out_tokens (capacity out_capacity ids) receives all ids,
  * out_offsets[n_docs+1] the per-document token offsets, *n_tokens the total.  If the capacity is
  * too small the call fails with TD_E_CAPACITY and *n_tokens holds the required size.
- * Copies text to the device, runs the kernels, copies ids back; synchronous.  Inputs of two chunks (2 x 16 MiB) and more go through a
- * three-stage pipeline of pinned bounce buffers (host copy || H2D || kernels || D2H || host copy, TD_OPT_PIPE_*);
- * inputs of at most 4 KiB (and 1024 documents) take ONE kernel launch that reads and writes pinned host memory directly.
+ * Synchronous.  Three paths by size: inputs of at most 4 KiB (and 1024 documents) take ONE kernel launch that reads and writes pinned
+ * host memory directly (TD_OPT_SMALL_PATH); up to 4 MiB (and 262 144 documents) text and offsets travel through one pinned buffer and one
+ * asynchronous copy, the step's last kernels write ids and offsets straight into pinned host memory, and the host waits on a sequence
+ * number instead of stream synchronisations (TD_MID_PATH=0 in the environment at td_create time: the copy-and-synchronise path that
+ * inputs between 4 and 32 MiB still take); from half of TD_OPT_PIPE_CHUNK_BYTES on (default: 32 MiB) a four-slot pipeline of pinned bounce
+ * buffers (host copy || H2D || kernels || ids out by a kernel || host copy, TD_OPT_PIPE_*: about 4 x (64 + 256) MiB of device memory
+ * plus the pinned buffers while such calls are made).
  */
 int td_encode_batch(td_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, int mode,
                     int32_t* out_tokens, int64_t out_capacity, int64_t* out_offsets, int64_t* n_tokens);

@@ -243,8 +243,11 @@ __global__ __launch_bounds__(64 * PM_WAVES) void td_prepare_mark(const EncodeArg
         // the search start from both ends (64-ary: 3-4 dependent loads for 1.7 M documents)
         int64_t lo = 0, hi = nd;
         if (a.n > 0 && nd > 64) {
-            const int64_t per_range = nd * PM_RANGE / a.n + 1, step = per_range / 64 + 1;
-            const int64_t g = (int64_t)((__int128)b0 * nd / a.n);
+            // (in floating point: a guess needs no exact arithmetic, and 64- and 128-bit integer divisions are hundreds of instructions
+            // each — the first form of this kernel spent 1000 vector instructions per wavefront on them: 59 us per GiB of text)
+            const float dens = (float)nd / (float)a.n;
+            const int64_t step = (int64_t)(dens * (float)(PM_RANGE / 64)) + 1;
+            const int64_t g = (int64_t)((double)b0 * (double)dens);
             int64_t idx = g + (lane - 32) * step;
             idx = idx < 0 ? 0 : idx >= nd ? nd - 1 : idx;
             const uint64_t b = __ballot(a.doc_offsets[idx] < b0);  // (sorted offsets, non-decreasing idx: a prefix of the lanes)
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(64 * PM_WAVES) void td_prepare_mark(const EncodeArg
             }
         }
         while (hi - lo > 64) {
-            const int64_t idx = lo + ((hi - lo) * (int64_t)(lane + 1)) / 65;  // lo < idx < hi
+            const int64_t idx = lo + 1 + (((hi - lo - 1) * (int64_t)lane) >> 6);  // lo < idx < hi, non-decreasing in the lane
             const uint64_t b = __ballot(a.doc_offsets[idx] < b0);
             const int c = (int)__popcll((unsigned long long)b);
             const int64_t below = __shfl((long long)idx, c > 0 ? c - 1 : 0), above = __shfl((long long)idx, c < 64 ? c : 63);

@@ -1,4 +1,4 @@
-"""hipcc -Rpass-analysis=kernel-resource-usage of the device sources -> profiles/r4_resource_usage.txt
+"""hipcc -Rpass-analysis=kernel-resource-usage of the device sources -> profiles/r<round>_resource_usage.txt (usage: tools/resource_usage.py <round>)
 (VGPRs, spilled VGPRs, scratch bytes per lane, waves/SIMD, LDS bytes per workgroup of every kernel)."""
 import re
 import subprocess
@@ -27,5 +27,5 @@ for src in ("td_kernels.hip", "td_generic.hip", "td_special.hip"):
         if k.startswith("LDS"):
             name = cur["name"].replace("td::", "").replace("(td::EncodeArgs)", "")
             out.append(f"{name} | {cur['VGPRs']} | {cur['VGPRs Spill']} | {cur['ScratchSize [bytes/lane]']} | {cur['Occupancy [waves/SIMD]']} | {v}")
-(ROOT / "profiles" / "r4_resource_usage.txt").write_text("\n".join(out) + "\n")
+(ROOT / "profiles" / f"r{int(sys.argv[1]) if len(sys.argv) > 1 else 6}_resource_usage.txt").write_text("\n".join(out) + "\n")
 print("\n".join(out))
