@@ -515,9 +515,12 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     a.ph_bar = &ctl->ph_bar;
     a.gs_done = &ctl->gs_done;
     a.lp_next = &ctl->lp_next;
+    int pack_dense_opt = 1;
     {
         static const int far_light = getenv("TD_FAR_LIGHT") ? atoi(getenv("TD_FAR_LIGHT")) : 1;
         a.far_light = far_light;
+        static const int pack_dense = getenv("TD_PACK_DENSE") ? atoi(getenv("TD_PACK_DENSE")) : 1;
+        pack_dense_opt = pack_dense;
     }
     a.slow_count = &ctl->slow_count;
     a.pool = (uint32_t*)t->pool.p;
@@ -620,6 +623,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
         if (t->sparse_opt >= 0) sparse = t->sparse_opt != 0;
         a.sparse = (sparse && a.fused && !a.direct && !t->sp_active && t->H.pattern_kind != PATTERN_GENERIC && !t->stop_after) ? 1 : 0;
         t->last_sparse = a.sparse != 0;
+        a.pack_dense = (!a.sparse && a.pack_split && pack_dense_opt) ? 1 : 0;  // (the sparse sequence keeps its six launches: td_pack_rest takes the odd tile with many markers)
     }
     LaunchAux aux_v{nullptr, nullptr, nullptr};
     const LaunchAux* aux = nullptr;

@@ -81,6 +81,7 @@ struct EncodeArgs {
     uint32_t* tile_draw;        // fused tile loop: counter the workgroups draw their tiles from (0 at launch)
     uint32_t* far_count;        // pre-tokenizer tiles flagged in tile_flag (td_split_far_tiles looks for chains only when there is one; 0 at launch)
     uint32_t* ph_bar;           // td_far_probe / td_tail: arrivals at their grid barriers (0 at launch)
+    int pack_dense;             // the dense sequence: td_pack_dense takes the tiles with merged / long pieces (<= 1024 slots), td_pack_rest what is left (TD_PACK_DENSE=0: off, A/B)
     int far_light;              // td_far_probe / td_tail: the far phases' barriers without cache maintenance (TD_FAR_LIGHT=0: with, A/B)
     uint32_t* lp_next;          // td_long_pieces: chunks of 64 list entries handed out beyond every wavefront's first (0 at launch)
     uint32_t* gs_done;          // td_giant_scan: workgroups that have left the giant pieces (0 at launch)

@@ -3997,6 +3997,15 @@ __device__ __forceinline__ bool pk_rest_tile(uint32_t tc) {  // (what td_scan_ti
 __device__ __forceinline__ bool pk_simple(uint32_t tc, int64_t base, uint32_t extra, int64_t out_cap) {
     return !pk_rest_tile(tc) && base + (int64_t)(int32_t)((tc & TILE_COUNT_MASK) + extra) <= out_cap;
 }
+// td_pack_dense's tiles (round 6, the dense launch sequence): every tile that is not td_pack_plain's — many merged pieces, long pieces, more than
+// 1024 slots — unless the fused loop placed it or its ids do not fit the output: those are what is left to td_pack_rest.
+__device__ __forceinline__ bool pk_dense(uint32_t tc, int64_t base, uint32_t extra, int64_t out_cap) {
+    return ((tc & (TILE_HAS_LONG | TILE_HAS_MISS)) != 0u || (tc & TILE_COUNT_MASK) > 1024u) && !(tc & TILE_DIRECT) &&
+           base + (int64_t)(int32_t)((tc & TILE_COUNT_MASK) + extra) <= out_cap;
+}
+__device__ __forceinline__ bool pk_mask_bit(uint32_t tc, int dense) {  // what td_scan_tiles notes for td_pack_rest
+    return dense ? (tc & TILE_DIRECT) != 0u : pk_rest_tile(tc);
+}
 // one chunk of 4096 tiles by the whole (1024-thread) workgroup: tile_base inside the chunk, rest_mask, the chunk's total -> chunk_pref[chunk]
 __device__ __forceinline__ void scan_chunk(const EncodeArgs& a, const int chunk, unsigned long long* const s_wsum) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -4010,13 +4019,13 @@ __device__ __forceinline__ void scan_chunk(const EncodeArgs& a, const int chunk,
             const uint4 ext = *reinterpret_cast<const uint4*>(a.tile_extra + e0);
             v[0] = (cnt.x & TILE_COUNT_MASK) + ext.x; v[1] = (cnt.y & TILE_COUNT_MASK) + ext.y;
             v[2] = (cnt.z & TILE_COUNT_MASK) + ext.z; v[3] = (cnt.w & TILE_COUNT_MASK) + ext.w;
-            nib = (pk_rest_tile(cnt.x) ? 1u : 0u) | (pk_rest_tile(cnt.y) ? 2u : 0u) | (pk_rest_tile(cnt.z) ? 4u : 0u) | (pk_rest_tile(cnt.w) ? 8u : 0u);
+            nib = (pk_mask_bit(cnt.x, a.pack_dense) ? 1u : 0u) | (pk_mask_bit(cnt.y, a.pack_dense) ? 2u : 0u) | (pk_mask_bit(cnt.z, a.pack_dense) ? 4u : 0u) | (pk_mask_bit(cnt.w, a.pack_dense) ? 8u : 0u);
         } else {
             for (int k = 0; k < 4; ++k)
                 if (e0 + k < a.n_tiles) {
                     const uint32_t tc = a.tile_count[e0 + k];
                     v[k] = (tc & TILE_COUNT_MASK) + a.tile_extra[e0 + k];
-                    nib |= (pk_rest_tile(tc) ? 1u : 0u) << k;
+                    nib |= (pk_mask_bit(tc, a.pack_dense) ? 1u : 0u) << k;
                 }
         }
         {   // ... sixteen tiles a word: td_pack_rest walks these instead of every tile's count word
@@ -4393,7 +4402,7 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
     // ... and in the sparse launch sequence (plain text: a tile of td_pack_rest's every few thousand) a LANE per mask word: a wavefront
     // looks at 64 words = 1024 tiles per round trip, in a grid of a few dozen workgroups instead of 16 384 that each find nothing
     // (9 us -> ? at 128 MiB, 34 us per GiB)
-    const bool lane_walk = SKIP_PLAIN && a.sparse != 0;  // (uniform)
+    const bool lane_walk = SKIP_PLAIN && (a.sparse != 0 || a.pack_dense != 0);  // (uniform; with td_pack_dense too: next to nothing is left for this kernel)
     const int n_mwords = (a.n_tiles + 15) >> 4;
     int lw_base = (int)(blockIdx.x * (K_THREADS / 64) + wv) * 64 - nwaves * 64, lw_index = 0;
     uint32_t lw_mine = 0, lw_cur = 0;
@@ -4431,7 +4440,7 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
             if (tile >= a.n_tiles) continue;
             tc = a.tile_count[tile]; ex = a.tile_extra[tile]; dfirst = (int64_t)a.tile_first_doc[tile];
             base = a.tile_base[tile] + a.chunk_pref[tile / K_SCAN_CHUNK];
-            if (pk_simple(tc, base, ex, a.out_cap)) continue;
+            if (pk_simple(tc, base, ex, a.out_cap) || (a.pack_dense && pk_dense(tc, base, ex, a.out_cap))) continue;
         } else if constexpr (SKIP_PLAIN) {
             if (!cmask) {
                 t0 += 4 * nwaves;
@@ -4464,7 +4473,7 @@ __device__ __forceinline__ void pack_body(const EncodeArgs& a, unsigned long lon
             ex = q == 0 ? c_ex[0] : q == 1 ? c_ex[1] : q == 2 ? c_ex[2] : c_ex[3];
             dfirst = (int64_t)(q == 0 ? c_df[0] : q == 1 ? c_df[1] : q == 2 ? c_df[2] : c_df[3]);
             base = q == 0 ? c_base[0] : q == 1 ? c_base[1] : q == 2 ? c_base[2] : c_base[3];
-            if (pk_simple(tc, base, ex, a.out_cap)) continue;  // (the other kernel of the pair; the closing offsets with it when this is the last tile)
+            if (pk_simple(tc, base, ex, a.out_cap) || (a.pack_dense && pk_dense(tc, base, ex, a.out_cap))) continue;  // (the other kernels; the closing offsets with them when this is the last tile)
         } else {
             tile += nwaves;
             if (tile >= a.n_tiles) break;
@@ -4802,6 +4811,157 @@ __global__ __launch_bounds__(K_THREADS, TD_PACK_PLAIN_WAVES) void td_pack_plain(
             for (int64_t d = d_end + lane; d <= a.n_docs; d += 64) a.out_offsets[d] = total;
         }
     }
+}
+// td_pack_dense (round 6, the dense launch sequence): the tiles of mixed-script text and source code — dozens of merged pieces, a long piece
+// or two — in td_pack_plain's shape instead of td_pack_rest's persistent pipeline: a WAVEFRONT per tile in a grid of short workgroups, what
+// depends on the tile index in ONE round trip, then all sixteen rows of slots (+ the tile's documents, + the sizes of its long pieces), then
+// the offsets (a DPP add-scan per row that holds a marker), then all plain ids, the merged pieces through a list in LDS (a lane per piece, four
+// ids a round trip; a repeat's ids are read where the piece it repeats has them), the long pieces by the whole wavefront.  td_pack_rest went
+// through a tile in two groups of eight rows, every group's loads behind the stores of the one before (the shared counter), and its wavefronts
+// carried state from tile to tile: ~10 dependent round trips per tile where this one has ~6.
+// (MULTI: the tile has more than 1024 slots — source code, punctuation — and goes through them sixteen rows at a time; as ONE loop for both
+// cases the usual single pass lost a fifth of its speed: 282 -> 343 us per 256 MiB of mixed-script text)
+template <bool MULTI>
+__device__ __forceinline__ void pack_dense_tile(const EncodeArgs& a, unsigned long long* const elist, const int tile, const uint32_t cnt, const int64_t base,
+                                                const int64_t dfirst, const int lane) {
+    const uint32_t* src = a.stage + (size_t)tile * K_STAGE;
+    const int64_t g_lo = (int64_t)tile * K_TILE;
+    const int64_t g_hi = (g_lo + K_TILE < a.n) ? g_lo + K_TILE : a.n;
+    uint32_t ecount = 0;  // (uniform) merged pieces on the list
+    const uint64_t lt = (1ull << lane) - 1ull;
+    auto flush = [&]() {
+        wave_sync();
+        for (uint32_t c0 = 0; c0 < ecount; c0 += 64) {
+            const unsigned long long e = c0 + lane < ecount ? elist[c0 + lane] : 0ull;
+            const uint32_t n = (uint32_t)e & 127u;
+            const uint32_t* ps = marker_ids(a, (uint32_t)tile, (uint32_t)e);
+            const int64_t o = base + (int64_t)(uint32_t)(e >> 32);
+            for (uint32_t j = 0; __any(j < n); j += 4) {
+                uint32_t t[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) t[u] = j + u < n ? ps[j + u] : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u)
+                    if (j + u < n) a.out_tokens[o + j + u] = (int32_t)t[u];
+            }
+        }
+        ecount = 0;
+        wave_sync();
+    };
+    uint32_t carry = 0;  // ids of the segments (and rows) in front
+    // (a tile of source code or punctuation can hold more than 1024 pieces: sixteen rows of 64 slots at a time — nearly always ONE segment)
+    for (uint32_t s0 = 0;; s0 += 1024u) {
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t k = s0 + (uint32_t)lane + 64u * q;
+            v[q] = k < cnt ? src[k] : 0u;
+        }
+        // the first 64 documents of the tile (nearly always all of them), requested with the slots
+        int64_t dm = dfirst + lane;
+        bool dmine = dm < a.n_docs && a.doc_offsets[dm < a.n_docs ? dm : 0] < g_hi;
+        uint32_t dks = dmine ? a.doc_slot[dm] : 0u;
+        uint32_t lmask = 0, mmask = 0;  // bit q: my slot of row q is a long piece / a merged piece
+        uint32_t off[16];               // first: the slot's size; then: ids of the tile in front of it
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t k = s0 + (uint32_t)lane + 64u * q;
+            const bool is_long = k < cnt && (v[q] & TOK_LONGREF) != 0u, is_miss = k < cnt && !is_long && (v[q] & TOK_MISS) != 0u;
+            lmask |= (is_long ? 1u : 0u) << q;
+            mmask |= (is_miss ? 1u : 0u) << q;
+            off[q] = k < cnt ? (is_miss ? (v[q] & 127u) : 1u) : 0u;
+        }
+        const bool anylong = __any(lmask != 0u);
+        if (anylong) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if ((lmask >> q) & 1u) off[q] = a.long_list[v[q] & 0x7FFFFFFFu].ntok;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t r64 = s0 + 64u * (uint32_t)q, k = r64 + (uint32_t)lane;
+            const uint32_t sz = off[q];
+            const uint32_t incl = __any(((lmask | mmask) >> q) & 1u) ? wave_incl_scan(sz, lane)
+                                : ((r64 < cnt && cnt - r64 < 64u && k >= cnt) ? cnt - r64 : (r64 < cnt ? (uint32_t)lane + 1u : 0u));  // a row of plain ids
+            off[q] = carry + incl - sz;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        const bool last_seg = !MULTI || s0 + 1024u >= cnt;
+        // the documents that start in the tile: the offset of a document's slot lives in lane (slot mod 64), row (slot / 64) of its segment
+        for (;;) {
+            const uint32_t rel = dks - s0;
+            uint32_t pref = carry;  // (a document that starts behind the tile's last slot: behind all of the tile's ids)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint32_t t = (uint32_t)__shfl((int)off[q], (int)(rel & 63u));
+                if ((rel >> 6) == (uint32_t)q) pref = t;
+            }
+            const bool in_seg = dmine && dks < cnt && dks >= s0 && rel < 1024u, behind = dmine && dks >= cnt && last_seg;
+            if (in_seg || behind) a.out_offsets[dm] = base + (int64_t)(behind ? carry : pref);
+            if (!__all(dmine)) break;  // more than 64 documents start in this tile: the next 64
+            dm += 64;
+            dmine = dm < a.n_docs && a.doc_offsets[dm < a.n_docs ? dm : 0] < g_hi;
+            dks = dmine ? a.doc_slot[dm] : 0u;
+            if (!__any(dmine)) break;
+        }
+        // plain ids
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t k = s0 + (uint32_t)lane + 64u * q;
+            if (k < cnt && !(((lmask | mmask) >> q) & 1u)) a.out_tokens[base + off[q]] = (int32_t)v[q];
+        }
+        // merged pieces: onto the list in LDS, worked off a lane per piece
+        if (__any(mmask != 0u)) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool m = (mmask >> q) & 1u;
+                const uint64_t bm = __ballot(m);
+                if (bm) {
+                    if (m) elist[ecount + (uint32_t)__popcll((unsigned long long)(bm & lt))] = ((unsigned long long)off[q] << 32) | (v[q] & 0x1FFFFFFFu);
+                    ecount += (uint32_t)__popcll((unsigned long long)bm);
+                    if (ecount > (uint32_t)PK_ECAP - 64u) flush();
+                }
+            }
+        }
+        if (anylong) {  // long pieces: the whole wavefront copies
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                for (uint64_t lb = __ballot((lmask >> q) & 1u); lb; lb &= lb - 1ull) {
+                    const int l = (int)td_ctz64(lb);
+                    const LongEntry le = a.long_list[(uint32_t)__shfl((int)v[q], l) & 0x7FFFFFFFu];
+                    const int64_t lo = base + (int64_t)(uint32_t)__shfl((int)off[q], l);
+                    const uint32_t* ps = a.pool + le.pool_off;
+                    for (uint32_t j = lane; j < le.ntok; j += 64) a.out_tokens[lo + j] = (int32_t)ps[j];
+                }
+            }
+        }
+        if (last_seg) break;
+    }
+    if (ecount) flush();
+    if (tile == a.n_tiles - 1) {  // empty documents at the very end + the closing offset
+        const int64_t total = a.tile_base[a.n_tiles];
+        const int64_t d_end = lower_bound_i64(a.doc_offsets, a.n_docs, a.n);
+        for (int64_t d = d_end + lane; d <= a.n_docs; d += 64) a.out_offsets[d] = total;
+    }
+}
+#ifndef TD_PACK_DENSE_WAVES
+#define TD_PACK_DENSE_WAVES 5
+#endif
+// (two launches: the tiles of at most 1024 slots, then the ones above — both cases in ONE kernel cost the usual one a quarter of its speed: 282 -> 370 us)
+template <bool MULTI>
+__global__ __launch_bounds__(K_THREADS, MULTI ? 4 : TD_PACK_DENSE_WAVES) void td_pack_dense(const EncodeArgs a) {
+    __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * (K_THREADS / 64) + wv;
+    if (tile >= a.n_tiles) return;
+    const uint32_t tc = a.tile_count[tile], ex = a.tile_extra[tile];
+    const int64_t tb = a.tile_base[tile], cp = a.chunk_pref[tile / K_SCAN_CHUNK];
+    const int64_t dfirst = (int64_t)a.tile_first_doc[tile];
+    const uint32_t cnt = tc & TILE_COUNT_MASK;
+    const int64_t base = tb + cp;
+    if (!pk_dense(tc, base, ex, a.out_cap)) return;
+    if ((cnt > 1024u) != MULTI) return;
+    pack_dense_tile<MULTI>(a, s_elist[wv], tile, cnt, base, dfirst, lane);
 }
 __global__ __launch_bounds__(K_THREADS) void td_pack_rest(const EncodeArgs a) {
     __shared__ unsigned long long s_elist[K_THREADS / 64][PK_ECAP];
@@ -5363,12 +5523,16 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         if (a.pack_split) {
             const int pwg = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
             hipLaunchKernelGGL(td_pack_plain, dim3(pwg < (1 << 20) ? pwg : (1 << 20)), dim3(K_THREADS), 0, stream, a);
+            if (a.pack_dense) {
+                hipLaunchKernelGGL(td_pack_dense<false>, dim3(pwg), dim3(K_THREADS), 0, stream, a);
+                hipLaunchKernelGGL(td_pack_dense<true>, dim3(pwg), dim3(K_THREADS), 0, stream, a);
+            }
             // (a grid of 16 384 workgroups, eight times the resident ones: on mixed-script text 0.45 -> 0.36 ms per 256 MiB against
             // the 2048 of rounds 2-4 — a wavefront that walks fewer tiles ends its pipeline sooner — and the 47 us it takes to find
             // nothing to do on English are the walk over the tiles' count words)
             static const int rest_max = getenv("TD_PACK_REST_BLOCKS") ? atoi(getenv("TD_PACK_REST_BLOCKS")) : 16384;
             int rwg = pwg < rest_max ? pwg : rest_max;
-            if (sparse) {  // (a lane per word of the scan's masks: 1024 tiles a wavefront and round trip)
+            if (sparse || a.pack_dense) {  // (a lane per word of the scan's masks: 1024 tiles a wavefront and round trip)
                 rwg = (a.n_tiles + 4095) / 4096;
                 if (rwg > 2048) rwg = 2048;
             }
