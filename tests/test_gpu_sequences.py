@@ -138,3 +138,28 @@ def test_td_tail_alone_when_its_workgroups_cannot_meet():
         else:
             os.environ["TD_TAIL_BLOCKS_PER_CU"] = old
         tok.close()
+
+
+def test_td_far_probe_alone_when_its_workgroups_cannot_meet():
+    """The dense sequence's td_far_probe with a grid far larger than what is resident: same fallback, same ids."""
+    import torch
+    assert ref.available(), "oracle/_ref/libtdref.so is missing: build it where /root/reference exists (oracle/build_ref.sh)"
+    pat, mr, special = H.llama4()
+    tok = capi.HipTokenizer(pat, mr, special, device=0)
+    old = os.environ.get("TD_FAR_PROBE_BLOCKS_PER_CU")
+    try:
+        x, o = _texts()["english_with_rare_work"]
+        k = int(np.searchsorted(o, 1 << 20))
+        d0, d1 = k - 150, k + 9 + 100
+        x, o = x[int(o[d0]): int(o[d1])], (o[d0: d1 + 1] - o[d0]).astype(np.int64)
+        _, et, eo = H.ref_tokenizer().encode_batch(x, o, n_threads=os.cpu_count() or 1, want_tokens=True)
+        tok.set_option(capi.TD_OPT_SPARSE, 0)
+        os.environ["TD_FAR_PROBE_BLOCKS_PER_CU"] = "256"
+        _run(tok, torch, x, o, "td_far_probe with 65 536 workgroups", et, eo)
+        assert tok.info(capi.TD_INFO_FAR_PIECES) > 0, "the text has pieces the tile loop's window cannot see through"
+    finally:
+        if old is None:
+            os.environ.pop("TD_FAR_PROBE_BLOCKS_PER_CU", None)
+        else:
+            os.environ["TD_FAR_PROBE_BLOCKS_PER_CU"] = old
+        tok.close()

@@ -5376,6 +5376,8 @@ static int tail_grid_blocks() {  // td_tail: what is resident (its merge rows ar
     return blocks;
 }
 static int far_probe_grid_blocks() {
+    const char* e = getenv("TD_FAR_PROBE_BLOCKS_PER_CU");  // (tests: a grid that cannot be resident at once — workgroup 0 walks the phases alone)
+    if (e && atoi(e) > 0) return 256 * atoi(e);
     static int blocks = 0;
     if (!blocks) blocks = resident_blocks((const void*)td_far_probe, 2, K_THREADS, 2);
     return blocks;

@@ -29,4 +29,9 @@ timeout 200 python tools/gpu_pybatch.py 256 > $O/pybatch.txt 2>&1; grep -v amdgp
 timeout 300 python tools/gpu_latency.py > $O/latency.txt 2>&1; grep -v amdgpu $O/latency.txt | tail -12
 timeout 600 python tools/gpu_latency_files.py > $O/latency_files.txt 2>&1; grep -v amdgpu $O/latency_files.txt | tail -25
 timeout 200 python tools/gpu_giant.py > $O/giant_pieces.txt 2>&1; grep -v amdgpu $O/giant_pieces.txt | tail -16
+# (the direct placement against the staged form on the final sources, same box and corpus)
+timeout 300 python tools/gpu_opt_ab.py english 1024 20 DIRECT=1,0 > $O/direct_ab.txt 2>&1; grep -v amdgpu $O/direct_ab.txt | tail -12
+# (the sparse launch sequence against the dense one on plain text, 128 MiB and 1024 MiB)
+for mb in 128 1024; do for sp in 1 0; do TD_SPARSE=$sp timeout 300 python bench.py --corpus english --size-mb $mb --no-cpu-baseline --no-side-configs --steps 50 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('english $mb MiB, TD_SPARSE=$sp:', j['value'], 'GB/s', j['ms_per_step'], 'ms', j['launch_mode']['launch_sequence'], 'plain launches', j['launch_mode']['ms_per_step_plain_launches'], 'ms')"; done; done > $O/sequences_ab.txt 2>&1; cat $O/sequences_ab.txt
 find $O -name "*.db" -size +20M -delete

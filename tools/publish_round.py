@@ -41,7 +41,7 @@ for i, name in enumerate(("pmc_english_1024.txt", "pmc_mixed_256.txt", "pmc_code
         shutil.copy(src / name, prof / f"r{rn}_0{4 + i}_{name}")
 bdir = prof / f"r{rn}_bench"
 bdir.mkdir(exist_ok=True)
-for name in ("bench_default.json", "bench_default.time", "latency_files.txt", "resource_usage.txt", "bench_2rank_same_gpu_gloo.json", "pybatch.txt", "host.txt", "pytest_gpu.log", "smoke.log", "latency.txt", "giant_pieces.txt", "hostpath.txt", "bench_128_weak.json"):
+for name in ("bench_default.json", "bench_default.time", "latency_files.txt", "resource_usage.txt", "direct_ab.txt", "sequences_ab.txt", "bench_2rank_same_gpu_gloo.json", "pybatch.txt", "host.txt", "pytest_gpu.log", "smoke.log", "latency.txt", "giant_pieces.txt", "hostpath.txt", "bench_128_weak.json"):
     if (src / name).exists():
         shutil.copy(src / name, bdir / name)
 print("published", src, "->", prof)
