@@ -188,6 +188,7 @@ struct DecodeArgs {
 
 // One-launch path for inputs of at most 4 KiB (td_small_encode): everything the kernel reads and writes except the tables
 // lives in pinned host memory.
+constexpr int SM_MAXDOCS = 1024;  // documents of a td_small_encode call (td_api.cpp: SMALL_MAX_DOCS)
 struct SmallStatus {
     unsigned long long seq;  // written last (system-scope release): the call's sequence number
     long long err_pos;
@@ -206,6 +207,14 @@ struct SmallArgs {
     int n, n_docs, use_fastpath;
 };
 hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream);
+// ... and as a kernel that stays for a while (td_small_resident): a request = this header at the start of the pinned input buffer (offsets at
+// +64, the text behind them), its sequence number written last; the output buffer as for td_small_encode, with the generation of a kernel
+// that has left at byte 40
+struct SmallMailbox {
+    unsigned long long seq;
+    int n, n_docs, use_fastpath, offs_bytes;
+};
+hipError_t launch_small_resident(const Tables* Tp, void* in, void* out, unsigned long long gen, unsigned long long idle_ticks, hipStream_t stream);
 // The same for decode_bytes on at most SMALL_DEC_MAX_TOKENS ids (td_small_decode): ids in, bytes + status out, pinned host memory.
 constexpr int SMALL_DEC_MAX_TOKENS = 1024, SMALL_DEC_MAX_BYTES = 16384;
 struct SmallDecArgs {

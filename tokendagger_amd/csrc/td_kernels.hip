@@ -4986,7 +4986,7 @@ struct SmallCfAcc {  // scanner accessor over the class bytes in LDS; positions 
     __device__ __forceinline__ uint32_t cf(int i) const { return cfs[i]; }
     __device__ __forceinline__ uint32_t byte(int i) const { return txt[i]; }
 };
-__global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) {
+__device__ __forceinline__ void small_encode_body(const SmallArgs& a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[SM_MAXBYTES + 80];
     __shared__ __attribute__((aligned(16))) uint8_t s_cf[SM_MAXBYTES + 80];
     __shared__ uint32_t s_doc[SM_MAXBYTES / 32 + 4];
@@ -5003,10 +5003,16 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
     __shared__ uint32_t s_nmiss, s_err, s_errpos, s_fallback;
     __shared__ uint32_t s_nlong;
     __shared__ uint16_t s_long[SM_LONG_MAX];  // pieces of 65..1024 bytes (indices into s_plist)
+    __shared__ uint16_t s_doff[SM_MAXDOCS + 2];  // the document offsets (<= n <= 4096): read from the pinned host buffer ONCE, together with the text —
+                                                 // they were read twice, each time a PCIe round trip of its own behind a barrier (~2 us of a 14 us call)
 
     const int tid = threadIdx.x;
     const Tables T = uniform_tables(a.Tp);
     const int n = a.n;
+    for (int d = tid; d <= a.n_docs && d <= SM_MAXDOCS; d += K_THREADS) {
+        const int64_t p = a.doc_offsets[d];
+        s_doff[d] = (uint16_t)(p < 0 ? n : p > n ? n : p);
+    }
     for (int q = tid; q < 256; q += K_THREADS) s_byteid[q] = T.byte_id[q];
     // ---- text, document bits ----
     for (int q = tid; q < (SM_MAXBYTES + 80) / 16; q += K_THREADS) {
@@ -5021,8 +5027,8 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
     if (tid == 0) { s_nmiss = 0; s_err = 0; s_errpos = 0; s_fallback = 0; s_nlong = 0; }
     __syncthreads();
     for (int d = tid; d < a.n_docs; d += K_THREADS) {
-        const int64_t p = a.doc_offsets[d];
-        if (p >= 0 && p < n) atomicOr(&s_doc[p >> 5], 1u << (p & 31));
+        const int p = s_doff[d];
+        if (p < n) atomicOr(&s_doc[p >> 5], 1u << (p & 31));
     }
     __syncthreads();
     auto fail = [&](int code, int pos) { if (atomicCAS(&s_err, 0u, (uint32_t)code) == 0u) s_errpos = (uint32_t)pos; };
@@ -5209,7 +5215,7 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
             for (uint32_t m = vmask; m; m &= m - 1) a.out_tokens[o++] = (int32_t)s_tok[c0 + __ffs(m) - 1];
         __syncthreads();
         for (int d = tid; d <= a.n_docs; d += K_THREADS) {
-            const int64_t p = a.doc_offsets[d];
+            const int p = s_doff[d];
             a.out_offsets[d] = p >= n ? (int64_t)total : (int64_t)(s_off[p >> 4] + __popc((uint32_t)s_valid[p >> 4] & ((1u << (p & 15)) - 1u)));
         }
         __syncthreads();
@@ -5221,6 +5227,63 @@ __global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) 
             __hip_atomic_store(&a.status->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+__global__ __launch_bounds__(K_THREADS) void td_small_encode(const SmallArgs a) { small_encode_body(a); }
+
+// The same workgroup, RESIDENT for a while (round 6): calls that follow each other within the idle time — a loop over
+// chat messages, the reference's latency benchmark — find a kernel that is already running and pay neither a launch (~5 us on the host, ~5
+// on the device) nor the set-up of a fresh one.  The host writes a request into the pinned input buffer (header: what SmallArgs carries,
+// then offsets and text) and releases its sequence number; thread 0 polls that word over PCIe; the body answers exactly as the
+// one-launch kernel does (ids, offsets, status, the sequence number released last).  The kernel ENDS BY ITSELF when no request has come for
+// `idle_ticks` (100 MHz ticks; 200 us by default): an application's hipDeviceSynchronize waits at most that long, and the next small call
+// simply launches it again.  Leaving, it writes its generation into the output block: a host that finds the kernel gone while its request
+// is still unanswered launches the next generation, which starts from the last sequence number ANSWERED — every request is answered once.
+__global__ __launch_bounds__(K_THREADS) void td_small_resident(const Tables* Tp, uint8_t* in, uint8_t* out, unsigned long long gen, unsigned long long idle_ticks) {
+    __shared__ unsigned long long s_req;
+    __shared__ int s_hdr[4];
+    const SmallMailbox* const mb = reinterpret_cast<const SmallMailbox*>(in);
+    SmallStatus* const status = reinterpret_cast<SmallStatus*>(out);
+    unsigned long long served = 0, t_last = 0;
+    if (threadIdx.x == 0) {
+        served = __hip_atomic_load(&status->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        t_last = wall_clock64();
+    }
+    for (;;) {
+        if (threadIdx.x == 0) {
+            unsigned long long r;
+            for (;;) {
+                r = __hip_atomic_load(&mb->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (r != served && r != 0ull) break;
+                if (wall_clock64() - t_last > idle_ticks) { r = ~0ull; break; }
+            }
+            if (r != ~0ull) {
+                s_hdr[0] = __hip_atomic_load(&mb->n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_hdr[1] = __hip_atomic_load(&mb->n_docs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_hdr[2] = __hip_atomic_load(&mb->use_fastpath, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_hdr[3] = __hip_atomic_load(&mb->offs_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            s_req = r;
+        }
+        __syncthreads();
+        const unsigned long long req = s_req;
+        if (req == ~0ull) break;
+        SmallArgs a;
+        a.Tp = Tp;
+        a.doc_offsets = reinterpret_cast<const int64_t*>(in + 64);
+        a.text = in + 64 + s_hdr[3];
+        a.status = status;
+        a.out_offsets = reinterpret_cast<int64_t*>(out + 64);
+        a.out_tokens = reinterpret_cast<int32_t*>(out + 64 + s_hdr[3]);
+        a.seq = req;
+        a.n = s_hdr[0];
+        a.n_docs = s_hdr[1];
+        a.use_fastpath = s_hdr[2];
+        __syncthreads();
+        small_encode_body(a);
+        __syncthreads();
+        if (threadIdx.x == 0) { served = req; t_last = wall_clock64(); }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + 40), gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------ td_small_decode ---------
@@ -5292,6 +5355,10 @@ hipError_t launch_small_decode(const SmallDecArgs& a, hipStream_t stream) {
 
 hipError_t launch_small_encode(const SmallArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(td_small_encode, dim3(1), dim3(K_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_small_resident(const Tables* Tp, void* in, void* out, unsigned long long gen, unsigned long long idle_ticks, hipStream_t stream) {
+    hipLaunchKernelGGL(td_small_resident, dim3(1), dim3(K_THREADS), 0, stream, Tp, (uint8_t*)in, (uint8_t*)out, gen, idle_ticks);
     return hipGetLastError();
 }
 
