@@ -33,5 +33,5 @@ timeout 200 python tools/gpu_giant.py > $O/giant_pieces.txt 2>&1; grep -v amdgpu
 timeout 300 python tools/gpu_opt_ab.py english 1024 20 DIRECT=1,0 > $O/direct_ab.txt 2>&1; grep -v amdgpu $O/direct_ab.txt | tail -12
 # (the sparse launch sequence against the dense one on plain text, 128 MiB and 1024 MiB)
 for mb in 128 1024; do for sp in 1 0; do TD_SPARSE=$sp timeout 300 python bench.py --corpus english --size-mb $mb --no-cpu-baseline --no-side-configs --steps 50 2>/dev/null | python -c "
-import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('english $mb MiB, TD_SPARSE=$sp:', j['value'], 'GB/s', j['ms_per_step'], 'ms', j['launch_mode']['launch_sequence'], 'plain launches', j['launch_mode']['ms_per_step_plain_launches'], 'ms')"; done; done > $O/sequences_ab.txt 2>&1; cat $O/sequences_ab.txt
+import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('english $mb MiB, TD_SPARSE=$sp:', j['value'], 'GB/s', j['ms_per_step'], 'ms', j['launch_mode']['launch_sequence'], 'plain launches', j['launch_mode']['ms_per_step_plain_launches'], 'ms; graph replay', j['launch_mode']['ms_per_step_graph_replay'], 'ms')"; done; done > $O/sequences_ab.txt 2>&1; cat $O/sequences_ab.txt
 find $O -name "*.db" -size +20M -delete
