@@ -638,7 +638,7 @@ int encode_device_locked(td_tokenizer* t, const void* d_text, int64_t n, const v
     // entry point) decides; a handle that never reads them stays in line.
     if (t->overlap && t->last_long >= 2048 && !a.sparse) {
         hipError_t ae = hipSuccess;
-        if (!t->s_aux) ae = hipStreamCreateWithFlags(&t->s_aux, hipStreamNonBlocking);
+        if (!t->s_aux) ae = hipStreamCreateWithFlags(&t->s_aux, hipStreamNonBlocking);  // (a stream priority, either way, changes nothing: r6 call 17)
         if (ae == hipSuccess && !t->e_fork) ae = hipEventCreateWithFlags(&t->e_fork, hipEventDisableTiming);
         if (ae == hipSuccess && !t->e_join) ae = hipEventCreateWithFlags(&t->e_join, hipEventDisableTiming);
         if (ae == hipSuccess) { aux_v = LaunchAux{t->s_aux, t->e_fork, t->e_join}; aux = &aux_v; }

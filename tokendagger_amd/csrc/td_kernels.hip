@@ -5547,14 +5547,22 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         if (ev) (void)hipEventRecord(ev[3], stream);
     }
     // the long pieces beside the chain of the short ones (see LaunchAux); with per-segment events (ev) everything stays in line
+    // Which of the two runs on the caller's stream: the LONG pieces (few workgroups, the longest kernel of the branch) — they are
+    // dispatched the moment td_far_probe ends, and the short pieces' chain, which arrives over the second queue a few microseconds
+    // later, fills the chip around them.  The other way round (rounds 3-5) the short chain's 65 000 wavefronts held the slots when
+    // the long pieces' workgroups arrived, and as plain launches only half of the long pieces' time was hidden (mixed-script text,
+    // 256 MiB: 2.86 ms a step against 2.60 as a graph replay).  TD_FORK_LONG_FIRST=0 = the old assignment.
+    static const bool long_first = !(getenv("TD_FORK_LONG_FIRST") && atoi(getenv("TD_FORK_LONG_FIRST")) == 0);
     const bool fork = aux && !ev && tokens;
+    hipStream_t s_short = stream, s_long = stream;
     if (fork) {
+        if (long_first && merges) s_short = aux->s; else s_long = aux->s;
         hipError_t fe = hipEventRecord(aux->fork, stream);
         if (fe == hipSuccess) fe = hipStreamWaitEvent(aux->s, aux->fork, 0);
         if (fe != hipSuccess) return fe;
-        hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, aux->s, a);
-        hipLaunchKernelGGL(td_giant_pieces, dim3(giant_grid_blocks()), dim3(GP_THREADS), 0, aux->s, a);
-        if ((fe = hipEventRecord(aux->join, aux->s)) != hipSuccess) return fe;
+        hipLaunchKernelGGL(td_long_pieces, dim3(long_grid_blocks()), dim3(256), 0, s_long, a);
+        hipLaunchKernelGGL(td_giant_pieces, dim3(giant_grid_blocks()), dim3(GP_THREADS), 0, s_long, a);
+        if (s_long == aux->s && (fe = hipEventRecord(aux->join, aux->s)) != hipSuccess) return fe;
     }
     if (tokens && merges) {
         const int wtiles = (a.n_tiles + K_THREADS / 64 - 1) / (K_THREADS / 64);
@@ -5562,10 +5570,14 @@ hipError_t launch_encode(const EncodeArgs& a, hipStream_t stream, hipEvent_t* ev
         // (a wavefront per tile up to 16 384 workgroups: with the 2048 of the first form — a third more than are resident at 6 wavefronts per
         // SIMD — the last third ran alone: collect + merge + copy 0.66 -> 0.58 ms per 256 MiB of the code file set, 0.55 -> 0.50 on mixed-script text)
         static const int collect_max = getenv("TD_COLLECT_BLOCKS") ? atoi(getenv("TD_COLLECT_BLOCKS")) : 16384;
-        hipLaunchKernelGGL(td_collect_misses, dim3(wtiles < collect_max ? wtiles : collect_max), dim3(K_THREADS), 0, stream, a);
-        hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(MG_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(td_collect_misses, dim3(wtiles < collect_max ? wtiles : collect_max), dim3(K_THREADS), 0, s_short, a);
+        hipLaunchKernelGGL(td_merge_pieces, dim3(mblocks), dim3(MG_THREADS), 0, s_short, a);
         static const int copy_max = getenv("TD_COPY_BLOCKS") ? atoi(getenv("TD_COPY_BLOCKS")) : 256 * 4;
-        if (a.dedupe) hipLaunchKernelGGL(td_copy_dups, dim3(wtiles < copy_max ? wtiles : copy_max), dim3(K_THREADS), 0, stream, a);
+        if (a.dedupe) hipLaunchKernelGGL(td_copy_dups, dim3(wtiles < copy_max ? wtiles : copy_max), dim3(K_THREADS), 0, s_short, a);
+        if (fork && s_short == aux->s) {
+            const hipError_t fe = hipEventRecord(aux->join, aux->s);
+            if (fe != hipSuccess) return fe;
+        }
     }
     if (ev) (void)hipEventRecord(ev[4], stream);
     if (tokens) {
