@@ -119,6 +119,47 @@ __device__ __forceinline__ Tables uniform_tables(const Tables* p) {
     return t;
 }
 
+// A kernel's arguments, read where they are used.  The fused tile loop touches forty fields of EncodeArgs and six of the table
+// descriptor; loaded at entry (what the compiler does with a by-value argument) they were 100 scalar registers the loop had no room
+// for: the allocator parked them in the lanes of two vector registers and fetched them back with v_readlane_b32 in front of every
+// use — 594 of the loop's 3078 vector instructions, at 4 issue cycles each (profiles/r6_00_valu_issue_rate.txt), in a loop that is
+// bound by vector issue.  Read through a pointer the compiler cannot see through (refresh(): an empty asm that "changes" it), a field
+// is an s_load_dword from the kernarg segment at its use — the scalar unit's work, not the vector unit's — and does not outlive
+// the phase.  The pointer stays in the constant address space so that the loads are scalar ones.
+template <class P>
+__device__ __forceinline__ void forget_where_from(P& p) {  // (readfirstlane: behind a branch on a lane's value the compiler takes the pointer for a per-lane one)
+    uint32_t lo = (uint32_t)(uint64_t)p, hi = (uint32_t)((uint64_t)p >> 32);
+    lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    p = (P)(((uint64_t)hi << 32) | lo);
+}
+struct FreshArgs {
+    const __attribute__((address_space(4))) EncodeArgs* p;
+    __device__ __forceinline__ void refresh() { forget_where_from(p); }
+    __device__ __forceinline__ const EncodeArgs* operator->() const { return (const EncodeArgs*)p; }
+    __device__ __forceinline__ operator const EncodeArgs&() const { return *(const EncodeArgs*)p; }
+};
+__device__ __forceinline__ const __attribute__((address_space(4))) EncodeArgs* kernarg_args() {  // (EncodeArgs is the kernels' only argument)
+    return (const __attribute__((address_space(4))) EncodeArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+struct FreshTables {  // (the descriptor is written once, at td_create: constant memory as far as any kernel is concerned)
+    const __attribute__((address_space(4))) Tables* p;
+    __device__ __forceinline__ void refresh() { forget_where_from(p); }
+    __device__ __forceinline__ const Tables* operator->() const { return (const Tables*)p; }
+    __device__ __forceinline__ operator const Tables&() const { return *(const Tables*)p; }
+};
+struct KeptArgs {
+    const EncodeArgs* p;
+    __device__ __forceinline__ const EncodeArgs* operator->() const { return p; }
+    __device__ __forceinline__ operator const EncodeArgs&() const { return *p; }
+};
+struct KeptTables {
+    const Tables* p;
+    __device__ __forceinline__ const Tables* operator->() const { return p; }
+    __device__ __forceinline__ operator const Tables&() const { return *p; }
+};
+
 __device__ __forceinline__ void raise(const EncodeArgs& a, int code, int64_t pos) {
     if (atomicCAS(a.err, 0, code) == 0) *a.err_pos = pos;
 }
@@ -727,7 +768,7 @@ static_assert(SLAB_MAX_MISSES == 2 * K_MISS_LISTED_MAX, "slab layout");
 // see "placement" below).  An instantiation of its own: the code it adds (20 KB) and the registers it takes cost the loop
 // 5-7 % even on the tiles that do not use it.
 template <uint32_t PV, bool FUSED, bool DIRECT>
-__global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a) {
+__global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MIN_WAVES) void td_split_tiles(const EncodeArgs a_kern) {
     static_assert(FUSED || !DIRECT, "direct placement is part of the fused tile loop");
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[K_WIN];
     __shared__ __attribute__((aligned(16))) uint8_t s_R[FZ_R_BYTES];  // class masks | heads | cold list; FUSED: then piece list | slots
@@ -747,12 +788,24 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     const int tid = threadIdx.x;
 #ifdef TD_FUSED_TIMING
     unsigned long long tt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_readcyclecounter(), t_total0 = t_last, n_tiles_done = 0;
-#define FZ_TICK(i) { const unsigned long long t_now = __builtin_readcyclecounter(); tt[i] += t_now - t_last; t_last = t_now; }
+#define FZ_TICK(i) { const unsigned long long t_now = __builtin_readcyclecounter(); tt[i] += t_now - t_last; t_last = t_now; FZ_FRESH }
 #else
-#define FZ_TICK(i)
+#define FZ_TICK(i) FZ_FRESH
 #endif
-    const Tables T = uniform_tables(a.Tp);
-    for (int q = tid; q < 128; q += K_THREADS) s_lut[q] = (uint8_t)feature_of_class(T.ascii_cls[q]);
+    // The arguments and the table descriptor are READ WHERE THEY ARE USED (scalar loads from the kernarg segment / from the descriptor
+    // as constant memory) and forgotten at every phase boundary, see FreshArgs.  -DTD_ARGS_IN_REGISTERS: read once at entry (rounds 1-5).
+#ifndef TD_ARGS_IN_REGISTERS
+    (void)a_kern;
+    FreshArgs a{kernarg_args()};
+    FreshTables T{(const __attribute__((address_space(4))) Tables*)a->Tp};
+#define FZ_FRESH { a.refresh(); T.refresh(); }
+#else
+    const KeptArgs a{&a_kern};
+    const Tables T_kept = uniform_tables(a->Tp);
+    const KeptTables T{&T_kept};
+#define FZ_FRESH
+#endif
+    for (int q = tid; q < 128; q += K_THREADS) s_lut[q] = (uint8_t)feature_of_class(T->ascii_cls[q]);
     if (tid < 16) s_fcls[tid] = (uint8_t)feature_of_class((uint32_t)tid);
     if (tid == 0) s_nonascii = 0;
     // FUSED: state of the token phases (declared unconditionally; the plain instantiation never touches it and the
@@ -783,9 +836,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             if (b) {
                 const int leader = (int)td_ctz64(b);
                 uint32_t at = 0;
-                if (ln == leader) at = atomicAdd(&a.miss_count[q], (uint32_t)__popcll((unsigned long long)b));
+                if (ln == leader) at = atomicAdd(&a->miss_count[q], (uint32_t)__popcll((unsigned long long)b));
                 at = (uint32_t)__shfl((int)at, leader);
-                if (have && c == q) a.miss_list[(size_t)q * a.miss_cap + at + (uint32_t)__popcll((unsigned long long)(b & ((1ull << ln) - 1ull)))] = rec;
+                if (have && c == q) a->miss_list[(size_t)q * a->miss_cap + at + (uint32_t)__popcll((unsigned long long)(b & ((1ull << ln) - 1ull)))] = rec;
             }
         }
     };
@@ -812,10 +865,10 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     // with one, 1.95 with none (-DTD_FUSED_NPRE=3 / 1 / 0).
     constexpr int NPRE = FUSED ? TD_FUSED_NPRE : NPF;
     uint4 pf[NPF];
-    const int64_t nwords = (a.n + 31) >> 5;
+    const int64_t nwords = (a->n + 31) >> 5;
     // (uniform) the whole window lies inside the text and 16-byte loads are aligned: prefetched into registers; the others
     // (first / last windows, unaligned text) are staged by stage_window_edge when their turn comes
-    auto interior = [&](int64_t w0) { return a.text_aligned && w0 >= 0 && w0 + K_WIN <= a.n; };
+    auto interior = [&](int64_t w0) { return a->text_aligned && w0 >= 0 && w0 + K_WIN <= a->n; };
     // what a tile needs besides its text is requested with it: the document bits of the window (266 words: one per lane and
     // ten more) and, FUSED, the first documents of its two token tiles.  (Loaded when the tile's turn came they were a
     // global-memory round trip at the top of every tile and another one in front of the document slots: 13 % + 5 % of the
@@ -828,12 +881,12 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     auto load_window = [&](int64_t w0) {
         {
             const int64_t gw0 = (w0 >> 5) + tid, gw1 = gw0 + K_THREADS;
-            pfd0 = (gw0 >= 0 && gw0 < nwords) ? a.docbits[gw0] : 0u;
-            pfd1 = (tid < K_WIN / 32 - K_THREADS && gw1 >= 0 && gw1 < nwords) ? a.docbits[gw1] : 0u;
+            pfd0 = (gw0 >= 0 && gw0 < nwords) ? a->docbits[gw0] : 0u;
+            pfd1 = (tid < K_WIN / 32 - K_THREADS && gw1 >= 0 && gw1 < nwords) ? a->docbits[gw1] : 0u;
             if (FUSED) {
                 const int64_t t4 = (w0 + K_HL) / K_TILE;  // first token tile of the window's tile
-                pffd0 = t4 < a.n_tiles ? a.tile_first_doc[t4] : 0xFFFFFFFFu;
-                pffd1 = t4 + 1 < a.n_tiles ? a.tile_first_doc[t4 + 1] : 0xFFFFFFFFu;
+                pffd0 = t4 < a->n_tiles ? a->tile_first_doc[t4] : 0xFFFFFFFFu;
+                pffd1 = t4 + 1 < a->n_tiles ? a->tile_first_doc[t4 + 1] : 0xFFFFFFFFu;
             }
         }
         if (!interior(w0)) return;
@@ -842,9 +895,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         // above, and waiting for it at the top of its iteration is 14 % of the loop — so ONE byte per 64-byte line and lane, a
         // single register across the token phases that nobody looks at, pulls the window into this XCD's L2.  1.951 -> 2.007 ms
         // per GiB of English, 0.766 -> 0.791 ms per 256 MiB of code: the one register is 1 -> 5 spilled VGPRs at the cap.)
-        if (FUSED && NPRE == 0 && tid < (K_WIN + 63) / 64) pft = *reinterpret_cast<const volatile uint8_t*>(a.text + w0 + 64 * tid);
+        if (FUSED && NPRE == 0 && tid < (K_WIN + 63) / 64) pft = *reinterpret_cast<const volatile uint8_t*>(a->text + w0 + 64 * tid);
 #endif
-        const uint4* src16 = reinterpret_cast<const uint4*>(a.text + w0);
+        const uint4* src16 = reinterpret_cast<const uint4*>(a->text + w0);
 #pragma unroll
         for (int q = 0; q < NPRE; ++q)
             if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = nt_load16(src16 + q * K_THREADS + tid);
@@ -856,12 +909,12 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     // the rest start when the first ones are done) then holds no tile the look-back of the others would wait for
     int first_tile = (int)blockIdx.x;
     if constexpr (DIRECT) {
-        if (tid == 0) s_next[0] = (int)atomicAdd(a.tile_draw, 1u);
+        if (tid == 0) s_next[0] = (int)atomicAdd(a->tile_draw, 1u);
         __syncthreads();
         first_tile = __builtin_amdgcn_readfirstlane(s_next[0]);
         __syncthreads();
     }
-    if (first_tile < a.n_stiles) load_window((int64_t)first_tile * KS_TILE - K_HL);
+    if (first_tile < a->n_stiles) load_window((int64_t)first_tile * KS_TILE - K_HL);
     const int tid_outer = tid;
     // FUSED: the workgroups DRAW their tiles.  The grid is persistent (as many workgroups as fit the chip) and the SIMDs
     // issue from their oldest wavefront first, so the workgroups that came to a CU first run faster than the ones that
@@ -881,7 +934,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
     // (FUSED with direct placement: the loop runs one more time than the workgroup has tiles — the iteration without a tile
     // places the last tile's ids, place_prev below)
     for (int tile = first_tile;; tile = DRAW ? next_tile : tile + (int)gridDim.x) {
-        const bool have = tile < a.n_stiles;  // (uniform)
+        const bool have = tile < a->n_stiles;  // (uniform)
         if (!have) {  // (s_pd: written in front of the barrier that ends an iteration)
             bool pending = false;
             if constexpr (DIRECT)
@@ -896,7 +949,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         const int tid = tid_opaque, lane = tid & 63;
         const int64_t tile_g0 = (int64_t)tile * KS_TILE;
         const int64_t wg0 = tile_g0 - K_HL;  // global offset of window index 0 (multiple of 64)
-        const int tile_hi = K_HL + (int)((a.n - tile_g0 < KS_TILE) ? (a.n - tile_g0) : KS_TILE);
+        const int tile_hi = K_HL + (int)((a->n - tile_g0 < KS_TILE) ? (a->n - tile_g0) : KS_TILE);
         static_assert(KS_CHUNK == 32, "a lane's stride is one 32-bit word of the masks");
         const uint32_t fd0 = pffd0, fd1 = pffd1;  // (FUSED) first documents of this tile's token tiles
         // ---- placement of an EARLIER tile of this workgroup, part 1 (direct placement, round 4) ----
@@ -922,7 +975,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         uint4 xs[3];
         int64_t pdm = 0, pdpos = 0;
         unsigned long long stw = 0;
-        const uint32_t* const pslab = a.slab + ((size_t)blockIdx.x * SLAB_RING + ring) * SLAB_WORDS;
+        const uint32_t* const pslab = a->slab + ((size_t)blockIdx.x * SLAB_RING + ring) * SLAB_WORDS;
         if (DIRECT && pkind) {
             B = (int)s_pd[ring][PD_TILE];
             pnp = s_pd[ring][PD_NP]; pn0 = s_pd[ring][PD_N0]; pcount = s_pd[ring][PD_COUNT]; pnm = s_pd[ring][PD_NMISS]; pext0 = s_pd[ring][PD_EXT0];
@@ -934,10 +987,10 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             }
             const uint32_t pfdd = s_pd[ring][PD_FDD];
             pdm = (int64_t)pfdd + tid;
-            pdpos = a.n;
-            if (pkind == 1u && pfdd != 0xFFFFFFFFu && pdm < a.n_docs) { pdpos = a.doc_offsets[pdm]; pdsl = a.doc_slot[pdm]; }
+            pdpos = a->n;
+            if (pkind == 1u && pfdd != 0xFFFFFFFFu && pdm < a->n_docs) { pdpos = a->doc_offsets[pdm]; pdsl = a->doc_slot[pdm]; }
             const int idx0 = B - 1 - tid;  // my predecessor (tile -1: an inclusive prefix of 0)
-            stw = (pkind == 1u && idx0 >= 0) ? __hip_atomic_load(&a.tile_state[idx0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (TS_PREFIX << 62);
+            stw = (pkind == 1u && idx0 >= 0) ? __hip_atomic_load(&a->tile_state[idx0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (TS_PREFIX << 62);
         }
         if (have) {
 #ifdef TD_TEXT_L2_PREFETCH
@@ -951,7 +1004,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             // (the pieces that are not prefetched — the window's tail, a few lanes — are requested now and staged last)
 #pragma unroll
             for (int q = NPRE; q < NPF; ++q)
-                if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = nt_load16(reinterpret_cast<const uint4*>(a.text + wg0) + q * K_THREADS + tid);
+                if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) pf[q] = nt_load16(reinterpret_cast<const uint4*>(a->text + wg0) + q * K_THREADS + tid);
 #pragma unroll
             for (int q = 0; q < NPF; ++q)
                 if (q < NPF - 1 || tid < K_WIN / 16 - (NPF - 1) * K_THREADS) {
@@ -959,7 +1012,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                     hib |= pf[q].x | pf[q].y | pf[q].z | pf[q].w;
                 }
         } else {
-            hib = stage_window_edge(s_txt, a.text, a.n, wg0, tid, K_WIN / 16);
+            hib = stage_window_edge(s_txt, a->text, a->n, wg0, tid, K_WIN / 16);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -967,17 +1020,17 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             if (w < K_WIN / 32) {
                 uint32_t dw = q ? pfd1 : pfd0;
                 const int64_t g = wg0 + (int64_t)w * 32;  // bytes past the end of the text: "end of subject" sentinels
-                if (g + 32 > a.n) dw |= (g >= a.n) ? 0xFFFFFFFFu : ~((1u << (int)(a.n - g)) - 1u);
+                if (g + 32 > a->n) dw |= (g >= a->n) ? 0xFFFFFFFFu : ~((1u << (int)(a->n - g)) - 1u);
                 s_doc[w] = dw;
             }
         }
         // DIRECT: the NEXT tile of this workgroup is drawn now and read behind the boundary phases (round 3 drew two tiles ahead: a
         // tile then ran one and a half iterations after its number was handed out, and since the workgroups of a CU do not
         // run at one speed, tiles next to each other were up to 15 us apart — what the look-back of the direct placement waits for)
-        if (DRAW && DIRECT && tid == 0) s_next[0] = (int)atomicAdd(a.tile_draw, 1u);
+        if (DRAW && DIRECT && tid == 0) s_next[0] = (int)atomicAdd(a->tile_draw, 1u);
         // next tile of this workgroup.  (FUSED: its document bits are requested behind the boundary phases instead, its text
         // when its turn comes)
-        if (!FUSED && tile + (int)gridDim.x < a.n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);
+        if (!FUSED && tile + (int)gridDim.x < a->n_stiles) load_window(wg0 + (int64_t)gridDim.x * KS_TILE);
         for (int w = tid; w < K_WIN / 32 + 3; w += K_THREADS) s_start[w] = 0;
         if (tid == 0) { s_nh = 0; s_cur = 0; s_ncold = 0; s_last = -1; s_cross = -1; s_defer = 0; }
         if (__ballot((hib & 0x80808080u) != 0) && lane == 0) s_nonascii = 1;  // (reset behind phase 1; __syncthreads_or costs extra barriers)
@@ -996,7 +1049,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         if (DIRECT && pkind) {
             const uint32_t* const slab = pslab;
             const uint32_t* const meta = slab + SLAB_META;
-            const int64_t pg0 = (int64_t)B * KS_TILE, pg1 = (pg0 + KS_TILE < a.n) ? pg0 + KS_TILE : a.n;
+            const int64_t pg0 = (int64_t)B * KS_TILE, pg1 = (pg0 + KS_TILE < a->n) ? pg0 + KS_TILE : a->n;
             long long base = -1;  // >= 0: the tile's base; -1: the chain is broken in front of it; -2: not known in time
             if (pkind == 1u) {
                 long long acc = 0;
@@ -1026,19 +1079,19 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                     }
                     __syncthreads();  // (everybody has read s_lbs)
                     const int idx = j - tid;
-                    lb_post(idx >= 0 ? __hip_atomic_load(&a.tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (TS_PREFIX << 62));
+                    lb_post(idx >= 0 ? __hip_atomic_load(&a->tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (TS_PREFIX << 62));
                     __syncthreads();
                 }
             }
             FZ_TICK(8)
             const int tB4 = B * (KS_TILE / K_TILE);
-            const bool ptwo = tB4 + 1 < a.n_tiles;
-            uint32_t* const st0 = a.stage + (size_t)tB4 * K_STAGE;
+            const bool ptwo = tB4 + 1 < a->n_tiles;
+            uint32_t* const st0 = a->stage + (size_t)tB4 * K_STAGE;
             auto shift_of = [&](uint32_t k, int& mine) { return fz_shift_of(meta, pnm, k, &mine); };
             if (pkind == 1u && base >= 0) {
                 // -- direct: slot k of the tile -> out_tokens[base + k + the extra ids of the merged pieces in front of it]
-                int32_t* const dst = a.out_tokens + base;
-                const bool fits = base + (long long)pcount <= (long long)a.out_cap;  // (else: td_scan_tiles raises TD_E_CAPACITY; nothing is written)
+                int32_t* const dst = a->out_tokens + base;
+                const bool fits = base + (long long)pcount <= (long long)a->out_cap;  // (else: td_scan_tiles raises TD_E_CAPACITY; nothing is written)
                 if (fits && pnm == 0u) {  // every slot an id: 16-byte stores (at dword-aligned addresses)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
@@ -1061,26 +1114,26 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                     if (pdpos < pg1) {
                         const uint32_t k = pdsl + (pdpos >= pg0 + K_TILE ? pn0 : 0u);
                         int mine = -1;
-                        TD_NT_STORE((int64_t)(base + (long long)(k + (pnm ? shift_of(k, mine) : 0u))), &a.out_offsets[pdm]);
+                        TD_NT_STORE((int64_t)(base + (long long)(k + (pnm ? shift_of(k, mine) : 0u))), &a->out_offsets[pdm]);
                     }
                     if (__all(pdpos < pg1) && tid >= K_THREADS - 64) {  // more than 256 documents start in the tile: the last wavefront takes the rest
-                        for (int64_t d = pdm + 64; d < a.n_docs; d += 64) {
-                            const int64_t pd = a.doc_offsets[d];
+                        for (int64_t d = pdm + 64; d < a->n_docs; d += 64) {
+                            const int64_t pd = a->doc_offsets[d];
                             if (pd >= pg1) break;
-                            const uint32_t k = a.doc_slot[d] + (pd >= pg0 + K_TILE ? pn0 : 0u);
+                            const uint32_t k = a->doc_slot[d] + (pd >= pg0 + K_TILE ? pn0 : 0u);
                             int mine = -1;
-                            a.out_offsets[d] = base + (long long)(k + (pnm ? shift_of(k, mine) : 0u));
+                            a->out_offsets[d] = base + (long long)(k + (pnm ? shift_of(k, mine) : 0u));
                         }
                     }
                 }
                 if (tid == 0) {
-                    a.tile_count[tB4] = pn0 | TILE_DIRECT;
-                    a.tile_extra[tB4] = pext0;
+                    a->tile_count[tB4] = pn0 | TILE_DIRECT;
+                    a->tile_extra[tB4] = pext0;
                     if (ptwo) {
-                        a.tile_count[tB4 + 1] = (pnp - pn0) | TILE_DIRECT;
-                        a.tile_extra[tB4 + 1] = pcount - pnp - pext0;
+                        a->tile_count[tB4 + 1] = (pnp - pn0) | TILE_DIRECT;
+                        a->tile_extra[tB4 + 1] = pcount - pnp - pext0;
                     }
-                    __hip_atomic_store(&a.tile_state[B], (TS_PREFIX << 62) | (unsigned long long)(base + (long long)pcount), __ATOMIC_RELAXED,
+                    __hip_atomic_store(&a->tile_state[B], (TS_PREFIX << 62) | (unsigned long long)(base + (long long)pcount), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                     s_stat[0] += 1u;
                 }
@@ -1100,19 +1153,19 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                     }
                     for (uint32_t k = 3072u + tid; k < pnp; k += K_THREADS) { const uint32_t v = slab[k]; if (k < pn0) st0[k] = v; else st0[K_STAGE + (k - pn0)] = v; }
                 } else {
-                    fz_stage_with_misses(slab, st0, a.merge_out + (size_t)tB4 * K_STAGE, pnp, pn0, pnm);
+                    fz_stage_with_misses(slab, st0, a->merge_out + (size_t)tB4 * K_STAGE, pnp, pn0, pnm);
                 }
                 if (pkind == 1u && tid == 0) {
                     uint32_t m0 = 0, m1 = 0;
                     for (uint32_t q = 0; q < pnm; ++q) { if (meta[SLAB_MAX_MISSES + q] >> 12) m1 = 1; else m0 = 1; }
-                    a.tile_count[tB4] = pn0 | (m0 ? TILE_MISS_LISTED : 0u);
-                    a.tile_extra[tB4] = pext0;
+                    a->tile_count[tB4] = pn0 | (m0 ? TILE_MISS_LISTED : 0u);
+                    a->tile_extra[tB4] = pext0;
                     if (ptwo) {
-                        a.tile_count[tB4 + 1] = (pnp - pn0) | (m1 ? TILE_MISS_LISTED : 0u);
-                        a.tile_extra[tB4 + 1] = pcount - pnp - pext0;
+                        a->tile_count[tB4 + 1] = (pnp - pn0) | (m1 ? TILE_MISS_LISTED : 0u);
+                        a->tile_extra[tB4 + 1] = pcount - pnp - pext0;
                     }
                     if (base == -1) {  // the chain is broken in front of this tile: the tiles behind it need not look further
-                        __hip_atomic_store(&a.tile_state[B], TS_BROKEN << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&a->tile_state[B], TS_BROKEN << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_brk = 1u;
                     } else {
                         s_stat[1] += 1u;  // (statistics: not known in time)
@@ -1139,7 +1192,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         src.txt = s_txt;
         src.docw = s_doc;
         src.lo = (wg0 < 0) ? -wg0 : 0;
-        src.hi = (a.n - wg0 < K_WIN) ? (a.n - wg0) : K_WIN;
+        src.hi = (a->n - wg0 < K_WIN) ? (a->n - wg0) : K_WIN;
         if (tid < MK_COUNT) s_mask[K_MWORDS * MK_COUNT + tid] = 0;  // zero word behind the last one
         // masks of one item from its eight feature bytes and the feature byte in front of them
         auto emit_masks = [&](int it, uint32_t flo, uint32_t fhi, uint32_t pf) {
@@ -1177,6 +1230,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         static_assert(P1_ITEMS - P1_WAVES * P1_PER_WAVE <= 64, "the items left over are one more pass of the last wavefront");
         uint32_t carry_st = 0x100u, carry_pf = 0;
         const int n_pass = P1_PER_WAVE / 64 + ((tid >> 6) == P1_WAVES - 1 ? 1 : 0);
+        const uint8_t* const t_ascii = T->ascii_cls;  // (read once for the phase, not in front of every character)
+        const uint16_t* const t_u1 = T->ucls1;
+        const uint8_t* const t_u2 = T->ucls2;
         for (int q = 0; q < n_pass; ++q) {
             const int it = (tid >> 6) * P1_PER_WAVE + q * 64 + lane;
             if (it >= P1_ITEMS) break;
@@ -1238,10 +1294,10 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                     cpj[j] = tbj[j] ? c : 0u;
                     kj[j] = (uint32_t)k;
                     ndj[j] = ok ? need : 0u;
-                    uj[j] = T.ucls1[cpj[j] >> 8];  // (unconditional, independent loads: they leave back to back)
+                    uj[j] = t_u1[cpj[j] >> 8];  // (unconditional, independent loads: they leave back to back)
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) uj[j] = T.ucls2[uj[j] * 256u + (cpj[j] & 255u)];
+                for (int j = 0; j < 4; ++j) uj[j] = t_u2[uj[j] * 256u + (cpj[j] & 255u)];
                 uint64_t cov = 0;  // flags of the bytes the well-formed characters span
                 int remaining = 0, last_lead = -1;
 #pragma unroll
@@ -1260,7 +1316,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 const uint64_t lcm = bytes_below(lead_conts);
                 for (uint64_t gen = na & ~cov & ~lcm; gen; gen &= gen - 1ull) {  // (rare)
                     const int k = td_ctz64(gen) >> 3;
-                    const uint32_t f = feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, pos0 + k);
+                    const uint32_t f = feature_at_v(t_ascii, t_u1, t_u2, s_txt, s_doc, (int)src.lo, (int)src.hi, pos0 + k);
                     F = (F & ~(0xFFull << (8 * k))) | ((uint64_t)f << (8 * k));
                 }
                 F &= ~lcm;
@@ -1283,7 +1339,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                     const bool known = !(st_in & 0x100u);
                     const int claim = (int)(st_in >> 9);
                     for (int k = 0; k < lead_conts; ++k) {
-                        const uint32_t f = (known && k < claim) ? ((st_in & 0xFFu) | FB_C) : feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 + k);
+                        const uint32_t f = (known && k < claim) ? ((st_in & 0xFFu) | FB_C) : feature_at_v(t_ascii, t_u1, t_u2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 + k);
                         if (k < 4) flo |= f << (8 * k); else fhi |= f << (8 * (k - 4));
                     }
                 }
@@ -1296,7 +1352,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 pf = 0;
                 if (it > 0) {
                     const uint32_t pb = s_txt[it * 8 - 1];
-                    pf = (pb < 0x80) ? (uint32_t)s_lut[pb] : feature_at_v(T.ascii_cls, T.ucls1, T.ucls2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 - 1);
+                    pf = (pb < 0x80) ? (uint32_t)s_lut[pb] : feature_at_v(t_ascii, t_u1, t_u2, s_txt, s_doc, (int)src.lo, (int)src.hi, it * 8 - 1);
                 }
             }
             emit_masks(it, flo, fhi, pf);
@@ -1326,15 +1382,15 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             auto dword_at = [](int j) { return (j >> 1) * (MK_COUNT * 2) + (j & 1); };  // mask 0 of dword j; mask k: + 2 k
             auto defer = [&](int64_t g) {
                 if (FUSED) s_defer = 1;
-                const uint32_t q = atomicAdd(a.slow_count, 1u);
-                if (q < a.slow_cap) a.slow_list[q] = g;
+                const uint32_t q = atomicAdd(a->slow_count, 1u);
+                if (q < a->slow_cap) a->slow_list[q] = g;
                 else raise(a, TD_E_SCRATCH, g);
             };
             auto mark = [&](int q) { atomicOr(&s_start[q >> 5], 1u << (q & 31)); };
             auto sync_at = [&](int q) { return (s_mask32[dword_at(q >> 5) + 2 * MK_SYNC] >> (q & 31)) & 1u; };
             auto crossed = [&](int e) {  // first piece start of the next tile
                 if (FUSED) s_cross = e;
-                if (tile + 1 < a.n_stiles) a.tile_carry[tile + 1] = wg0 + e;
+                if (tile + 1 < a->n_stiles) a->tile_carry[tile + 1] = wg0 + e;
             };
             // general matcher from the piece start p (marked) to the end of its chain
             auto walk = [&](int p) {
@@ -1394,7 +1450,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                             if (w == 0) m &= ~0xFull;
                             if (m) sp = w * 64 + td_top64(m) - 1;
                         }
-                        if (sp < 0) { a.tile_flag[tile] = 1; atomicAdd(a.far_count, 1u); if (FUSED) s_defer = 1; }
+                        if (sp < 0) { a->tile_flag[tile] = 1; atomicAdd(a->far_count, 1u); if (FUSED) s_defer = 1; }
                         else p = sp;
                     }
                 }
@@ -1456,10 +1512,10 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
         // ---- publish the tile's own START bits (tile-aligned words: no other workgroup writes them) ----
         if (tid < KS_TILE / 32) {
             const int64_t g = tile_g0 + (int64_t)tid * 32;
-            if (g < a.n) {
+            if (g < a->n) {
                 uint32_t v = s_start[K_HL / 32 + tid];
-                if (g + 32 > a.n) v &= (1u << (int)(a.n - g)) - 1u;
-                TD_NT_STORE(v, &a.startbits[(tile_g0 >> 5) + tid]);
+                if (g + 32 > a->n) v &= (1u << (int)(a->n - g)) - 1u;
+                TD_NT_STORE(v, &a->startbits[(tile_g0 >> 5) + tid]);
             }
         }
         if constexpr (DRAW) {
@@ -1467,13 +1523,13 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             // register until the next tile's text is waited for was no faster and cost spills)
             if constexpr (!DIRECT) {
                 next_tile = __builtin_amdgcn_readfirstlane(s_next[par]);  // (written one iteration ago; uniform: a scalar register)
-                if (tid == 0) s_next[par ^ 1] = (int)(2u * gridDim.x + atomicAdd(a.tile_draw, 1u));
+                if (tid == 0) s_next[par ^ 1] = (int)(2u * gridDim.x + atomicAdd(a->tile_draw, 1u));
                 par = __builtin_amdgcn_readfirstlane(par ^ 1);
             } else {
                 next_tile = __builtin_amdgcn_readfirstlane(s_next[0]);  // (drawn at the top of this iteration; uniform: a scalar register)
             }
-            if (next_tile < a.n_stiles) load_window((int64_t)next_tile * KS_TILE - K_HL);
-        } else if (FUSED && tile + (int)gridDim.x < a.n_stiles) {
+            if (next_tile < a->n_stiles) load_window((int64_t)next_tile * KS_TILE - K_HL);
+        } else if (FUSED && tile + (int)gridDim.x < a->n_stiles) {
             load_window(wg0 + (int64_t)gridDim.x * KS_TILE);
         }
         }  // (the boundary phases)
@@ -1507,14 +1563,14 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             // iteration later) unless the chain of counts is known to be broken already
             const bool cand = DIRECT && !s_brk;  // (uniform; s_brk: written in front of the barriers of the boundary phases)
             auto break_chain = [&]() {  // (thread 0) this tile's id count is not settled inside the loop
-                __hip_atomic_store(&a.tile_state[tile], TS_BROKEN << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a->tile_state[tile], TS_BROKEN << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_brk = 1u;  // (this workgroup's later tiles take the staged path from the start; the others find out when they look back)
             };
             if (tile_deferred || np > (uint32_t)FZ_NPC) {  // (uniform) td_probe_tiles takes these token tiles, behind the far kernels
                 if (tid == 0) {
-                    const uint32_t at = atomicAdd(a.deferred_count, two ? 2u : 1u);
-                    a.deferred_list[at] = (uint32_t)tile4;
-                    if (two) a.deferred_list[at + 1] = (uint32_t)tile4 + 1u;
+                    const uint32_t at = atomicAdd(a->deferred_count, two ? 2u : 1u);
+                    a->deferred_list[at] = (uint32_t)tile4;
+                    if (two) a->deferred_list[at + 1] = (uint32_t)tile4 + 1u;
                     if (DIRECT) break_chain();
                 }
             } else {
@@ -1534,15 +1590,15 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 // slot stores waits for every one of them)
                 if (cand && tid == 0) { s_pd[ring][PD_FDD] = (uint32_t)fdd; s_pd[ring][PD_TILE] = (uint32_t)tile; s_pd[ring][PD_NP] = np; s_pd[ring][PD_N0] = n0; }
                 const int64_t dmine = (int64_t)fdd + tid;
-                const int64_t dpos = (fdd != 0xFFFFFFFFu && dmine < a.n_docs) ? a.doc_offsets[dmine] : a.n;  // (used in the last phase)
+                const int64_t dpos = (fdd != 0xFFFFFFFFu && dmine < a->n_docs) ? a->doc_offsets[dmine] : a->n;  // (used in the last phase)
                 __syncthreads();
                 FZ_TICK(4)
                 // ---- lookups.  Piece k -> lane k mod 256, FZ_PB pieces of a lane at a time: first all their keys and loads
                 //      (three dwords cut out of LDS with funnel shifts, masked by length; ONE 16-byte load of the first slot of
                 //      the exact-key table each), then the compares and the slot stores.  An empty slot is a miss; a slot held
                 //      by another key and longer pieces are put aside (probe_piece_cold behind the loop). ----
-                uint32_t* const slab = a.slab + ((size_t)blockIdx.x * SLAB_RING + ring) * SLAB_WORDS;
-                uint32_t* const dst0 = cand ? slab : a.stage + (size_t)tile4 * K_STAGE;
+                uint32_t* const slab = a->slab + ((size_t)blockIdx.x * SLAB_RING + ring) * SLAB_WORDS;
+                uint32_t* const dst0 = cand ? slab : a->stage + (size_t)tile4 * K_STAGE;
                 uint32_t* const dst1 = cand ? slab : dst0 + K_STAGE - n0;  // (slot k >= n0 is slot k - n0 of the second token tile)
                 auto note_miss = [&](uint32_t k, uint32_t res) {  // res: TOK_MISS | position in ITS token tile << 7 | length
                     const uint32_t h = k >= n0 ? 1u : 0u;
@@ -1552,7 +1608,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 auto miss_marker = [&](int i, uint32_t len) { return TOK_MISS | ((uint32_t)((i - K_HL) & (K_TILE - 1)) << 7) | len; };
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 typedef const u32x4 __attribute__((address_space(1)))* gslot_t;  // (global loads, not flat ones)
-                gslot_t const p12 = (gslot_t)(uintptr_t)T.piece12_slots;
+                gslot_t const p12 = (gslot_t)(uintptr_t)T->piece12_slots;
+                const uint32_t p12_mask = T->piece12_mask;
+                const bool fastpath = a->use_fastpath != 0;
                 for (uint32_t kb = tid; kb < np; kb += K_THREADS * FZ_PB) {
                     u32x4 sl[FZ_PB];
                     uint32_t kk0[FZ_PB], kk1[FZ_PB], kk2[FZ_PB], il[FZ_PB];
@@ -1570,7 +1628,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                         kk1[q] = __funnelshift_r(w1, w2, sh) & km.y;
                         kk2[q] = __funnelshift_r(w2, w3, sh) & km.z;
                         il[q] = ((uint32_t)i << 16) | (len < 0xFFFFu ? len : 0xFFFFu);
-                        if (on) sl[q] = p12[hash_piece12(kk0[q], kk1[q], kk2[q], len) & T.piece12_mask];
+                        if (on) sl[q] = p12[hash_piece12(kk0[q], kk1[q], kk2[q], len) & p12_mask];
                     }
 #pragma unroll
                     for (int q = 0; q < FZ_PB; ++q) {
@@ -1579,7 +1637,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                             const int i = (int)(il[q] >> 16);
                             const uint32_t len = il[q] & 0xFFFFu;
                             const u32x4 e = sl[q];
-                            if (len <= P12_MAXLEN && a.use_fastpath &&
+                            if (len <= P12_MAXLEN && fastpath &&
                                 (e.w == 0u || (e.x == kk0[q] && e.y == kk1[q] && e.z == kk2[q] && (e.w >> 24) == (0x80u | len)))) {
                                 const bool miss = e.w == 0u;  // empty slot: not a token (a single byte that is no token is an error, not a merge)
                                 const uint32_t res = miss ? miss_marker(i, len) : (e.w & 0x1FFFFFu);
@@ -1605,7 +1663,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                         const int i = s_plist[k];
                         const uint32_t len = (uint32_t)s_plist[k + 1] - (uint32_t)i;
                         const uint32_t h = k >= n0 ? 1u : 0u;
-                        uint32_t res = probe_piece_cold<true>(a, T, s_txt, T.byte_id, &s_hflags[h], wg0, i, len);
+                        uint32_t res = probe_piece_cold<true>(a, T, s_txt, T->byte_id, &s_hflags[h], wg0, i, len);
                         if ((res & 0xC0000000u) == TOK_MISS) { res = miss_marker(i, len); note_miss(k, res); }
                         (h ? dst1 : dst0)[k] = res;
                     }
@@ -1617,9 +1675,9 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                                       s_nrec[1] <= (uint32_t)K_MISS_LISTED_MAX;
                 if (cold_overflow) {  // more pieces for the long route than the list holds: td_probe_tiles does the tile over
                     if (tid == 0) {
-                        const uint32_t at = atomicAdd(a.deferred_count, two ? 2u : 1u);
-                        a.deferred_list[at] = (uint32_t)tile4;
-                        if (two) a.deferred_list[at + 1] = (uint32_t)tile4 + 1u;
+                        const uint32_t at = atomicAdd(a->deferred_count, two ? 2u : 1u);
+                        a->deferred_list[at] = (uint32_t)tile4;
+                        if (two) a->deferred_list[at + 1] = (uint32_t)tile4 + 1u;
                         if (DIRECT) break_chain();
                     }
                 } else if (resolved) {
@@ -1636,7 +1694,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                                 hh = (uint32_t)lane >= nr0 ? 1u : 0u;
                                 rec = s_rec[hh][(uint32_t)lane - (hh ? nr0 : 0u)];
                             }
-                            const uint32_t nt = fz_merge_piece(a.Tp, a.text, a.n, reinterpret_cast<uint32_t*>(s_R), slab, rec, hh, n0, tile_g0, a.err, a.err_pos);
+                            const uint32_t nt = fz_merge_piece(a->Tp, a->text, a->n, reinterpret_cast<uint32_t*>(s_R), slab, rec, hh, n0, tile_g0, a->err, a->err_pos);
                             const uint32_t e0 = wave_incl_scan((nt && !hh) ? nt - 1u : 0u, lane), e1 = wave_incl_scan((nt && hh) ? nt - 1u : 0u, lane);
                             ext0 = (uint32_t)__builtin_amdgcn_readlane((int)e0, 63);
                             ext1 = (uint32_t)__builtin_amdgcn_readlane((int)e1, 63);
@@ -1645,7 +1703,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                         if (tid == 0) {
                             const uint32_t count = s_pd[ring][PD_NP] + ext0 + ext1;
                             s_pd[ring][PD_KIND] = 1u; s_pd[ring][PD_COUNT] = count; s_pd[ring][PD_NMISS] = nm; s_pd[ring][PD_EXT0] = ext0;
-                            __hip_atomic_store(&a.tile_state[s_pd[ring][PD_TILE]], (TS_AGG << 62) | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&a->tile_state[s_pd[ring][PD_TILE]], (TS_AGG << 62) | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                     FZ_TICK(7)
@@ -1657,11 +1715,11 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                             return k >= n0 ? k - n0 : k;
                         };
                         if (dpos < tile_end_g) {
-                            a.doc_slot[dmine] = slot_of(dpos);
-                            for (int64_t d = dmine + K_THREADS; d < a.n_docs; d += K_THREADS) {
-                                const int64_t p = a.doc_offsets[d];
+                            a->doc_slot[dmine] = slot_of(dpos);
+                            for (int64_t d = dmine + K_THREADS; d < a->n_docs; d += K_THREADS) {
+                                const int64_t p = a->doc_offsets[d];
                                 if (p >= tile_end_g) break;
-                                a.doc_slot[d] = slot_of(p);
+                                a->doc_slot[d] = slot_of(p);
                             }
                         }
                     }
@@ -1700,15 +1758,15 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                                 uint32_t nf = s_nflagl;
                                 s_flagl[nf++] = (uint32_t)tile4 + h;
                                 if (nf == 32u) {
-                                    const uint32_t at = atomicAdd(a.flagged_count, 32u);
-                                    for (uint32_t q = 0; q < 32u; ++q) a.flagged_list[at + q] = s_flagl[q];
+                                    const uint32_t at = atomicAdd(a->flagged_count, 32u);
+                                    for (uint32_t q = 0; q < 32u; ++q) a->flagged_list[at + q] = s_flagl[q];
                                     nf = 0;
                                 }
                                 s_nflagl = nf;
                             } else if (nr) {
                                 fl |= TILE_MISS_LISTED;
                             }
-                            a.tile_count[tile4 + h] = (h ? np - n0 : n0) | fl;
+                            a->tile_count[tile4 + h] = (h ? np - n0 : n0) | fl;
                         }
                     }
                 }
@@ -1721,11 +1779,11 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                         return k >= n0 ? k - n0 : k;
                     };
                     if (dpos < tile_end_g) {
-                        a.doc_slot[dmine] = slot_of(dpos);
-                        for (int64_t d = dmine + K_THREADS; d < a.n_docs; d += K_THREADS) {  // more than 256 documents start in this tile
-                            const int64_t p = a.doc_offsets[d];
+                        a->doc_slot[dmine] = slot_of(dpos);
+                        for (int64_t d = dmine + K_THREADS; d < a->n_docs; d += K_THREADS) {  // more than 256 documents start in this tile
+                            const int64_t p = a->doc_offsets[d];
                             if (p >= tile_end_g) break;
-                            a.doc_slot[d] = slot_of(p);
+                            a->doc_slot[d] = slot_of(p);
                         }
                     }
                 }
@@ -1747,12 +1805,12 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                tt[8], tt[9], tt[10], tt[11], tt[12], tt[13]);
 #endif
     if constexpr (FUSED) {
-        if (DIRECT && tid == 0 && s_stat[0]) atomicAdd(a.direct_tiles, s_stat[0]);
-        if (DIRECT && tid == 0 && s_stat[1]) atomicAdd(a.direct_tiles + 1, s_stat[1]);
+        if (DIRECT && tid == 0 && s_stat[0]) atomicAdd(a->direct_tiles, s_stat[0]);
+        if (DIRECT && tid == 0 && s_stat[1]) atomicAdd(a->direct_tiles + 1, s_stat[1]);
         if (tid < 64) append_pending(s_npend);  // (what is still waiting in LDS)
         if (tid == 0 && s_nflagl) {
-            const uint32_t nf = s_nflagl, at = atomicAdd(a.flagged_count, nf);
-            for (uint32_t q = 0; q < nf; ++q) a.flagged_list[at + q] = s_flagl[q];
+            const uint32_t nf = s_nflagl, at = atomicAdd(a->flagged_count, nf);
+            for (uint32_t q = 0; q < nf; ++q) a->flagged_list[at + q] = s_flagl[q];
         }
     }
 }
