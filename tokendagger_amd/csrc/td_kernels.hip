@@ -3607,7 +3607,15 @@ __device__ __forceinline__ bool gp_grid_barrier(const GpCoop& c) {
     __builtin_amdgcn_s_waitcnt(0);  // (this wavefront's write-through stores have arrived)
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (arrival = release, leaving = acquire, agent scope — ADVICE r5: with relaxed orders the barrier held on this hardware, the
+        // s_waitcnt + workgroup barrier in front and the agent-scope accesses of gp_ld / gp_st saw to that, but the HIP memory model did
+        // not say so; -DTD_GP_BARRIER_RELAXED = the old orders, for the A/B in profiles/r6_10_…)
+#ifndef TD_GP_BARRIER_RELAXED
+        constexpr int GP_ARRIVE = __ATOMIC_RELEASE, GP_LEAVE = __ATOMIC_ACQUIRE;
+#else
+        constexpr int GP_ARRIVE = __ATOMIC_RELAXED, GP_LEAVE = __ATOMIC_RELAXED;
+#endif
+        const uint32_t old = __hip_atomic_fetch_add(c.bar, 1u, GP_ARRIVE, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t target = (old / c.nblk + 1u) * c.nblk;
         const unsigned long long t0 = wall_clock64();
         int ok = 1;
@@ -3620,6 +3628,7 @@ __device__ __forceinline__ bool gp_grid_barrier(const GpCoop& c) {
             }
             __builtin_amdgcn_s_sleep(1);
         }
+        if (GP_LEAVE != __ATOMIC_RELAXED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (once, behind the polls)
         *c.s_flag = ok;
     }
     __syncthreads();
