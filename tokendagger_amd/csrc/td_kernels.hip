@@ -3649,7 +3649,11 @@ __device__ __forceinline__ bool gp_grid_meet(const GpCoop& c) {
     __syncthreads();
     if (threadIdx.x == 0) {
         int ok = 1;
+#ifndef TD_GP_BARRIER_RELAXED
+        const uint32_t old = __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // (orders as in gp_grid_barrier)
+#else
         const uint32_t old = __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         if (old & GP_BAR_DEAD) {
             ok = 0;
         } else {
@@ -3665,6 +3669,9 @@ __device__ __forceinline__ bool gp_grid_meet(const GpCoop& c) {
                 __builtin_amdgcn_s_sleep(1);
             }
         }
+#ifndef TD_GP_BARRIER_RELAXED
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         *c.s_flag = ok;
     }
     __syncthreads();
