@@ -1,6 +1,6 @@
-"""TD_OPT_OVERLAP (round 5): once a handle has seen long pieces, td_long_pieces / td_giant_pieces run on a second stream of the handle
-beside td_collect_misses -> td_merge_pieces -> td_copy_dups (fork behind the lookups, join in front of the scan; parallel branches when
-the step is captured into a hipGraph).  Same ids either way, with plain launches and with graph replay, against the compiled reference
+"""TD_OPT_OVERLAP (round 5): once a handle has seen long pieces, td_long_pieces / td_giant_pieces run beside td_collect_misses ->
+td_merge_pieces -> td_copy_dups on two streams (fork behind the lookups, join in front of the scan; parallel branches when the step is
+captured into a hipGraph; since round 6 the long pieces keep the caller's stream and the short pieces' chain takes the handle's second one).  Same ids either way, with plain launches and with graph replay, against the compiled reference
 (CoreBPE::encode, /root/reference/src/tiktoken/tiktoken.cpp:169-234); the switch must actually engage (TD_INFO_LONG_PIECES >= 2048)."""
 from __future__ import annotations
 
