@@ -1281,6 +1281,23 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                     const bool have = ld != 0;
                     const int k = have ? td_ctz64(ld) >> 3 : 0;
                     ld &= ld - 1ull;
+#ifndef TD_DECODE_BRANCHY
+                    // bytes k .. k+3 of the 16-byte window as ONE dword (32-bit funnel shift over the pair of dwords the lead lies in), and
+                    // everything below WITHOUT a branch: written with && and ?: the compiler turned the three lengths into three divergent
+                    // blocks per character slot, and mixed-script text has all three in every wavefront
+                    const uint32_t dlo = k < 4 ? t8.x : t8.y, dhi = k < 4 ? t8.y : t8n.x;
+                    const uint32_t x = __funnelshift_r(dlo, dhi, 8u * ((uint32_t)k & 3u));
+                    const uint32_t b = x & 0xFFu;
+                    const uint32_t need = utf8_declared_len(b) - 1u;  // 0 .. 3
+                    const int pos = pos0 + k;
+                    const uint32_t cm = (0xC0C0C000u >> (8u * (3u - need))) & 0xC0C0C000u;  // the two top bits of the `need` continuation bytes
+                    const bool ok = have & (need > 0) & (pos + (int)need < (int)src.hi) & (pos >= (int)src.lo) & (((docb >> (k + 1)) & ((1u << need) - 1u)) == 0u) &
+                                    ((x & cm) == (cm & 0x80808000u));
+                    const uint32_t c1 = (x >> 8) & 0x3Fu, c2 = (x >> 16) & 0x3Fu, c3 = (x >> 24) & 0x3Fu;
+                    uint32_t c = ((b & (0x3Fu >> need)) << 6) | c1;
+                    c = need >= 2u ? (c << 6) | c2 : c;
+                    c = need >= 3u ? (c << 6) | c3 : c;
+#else
                     const uint64_t w = (lo8 >> (8 * k)) | ((hi8 << 8) << (56 - 8 * k));  // bytes k .. k+7
                     const uint32_t b = (uint32_t)w & 0xFFu, c1 = (uint32_t)(w >> 8) & 0xFFu, c2 = (uint32_t)(w >> 16) & 0xFFu, c3 = (uint32_t)(w >> 24) & 0xFFu;
                     const uint32_t need = utf8_declared_len(b) - 1u;
@@ -1290,6 +1307,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                     const uint32_t c = (need == 1) ? ((b & 0x1F) << 6) | (c1 & 0x3F)
                                      : (need == 2) ? ((b & 0x0F) << 12) | ((c1 & 0x3F) << 6) | (c2 & 0x3F)
                                                    : ((b & 0x07) << 18) | ((c1 & 0x3F) << 12) | ((c2 & 0x3F) << 6) | (c3 & 0x3F);
+#endif
                     tbj[j] = ok && c <= 0x10FFFFu && !(c >= 0xD800u && c <= 0xDFFFu);  // (class_of_cp: everything else is C_OTHER)
                     cpj[j] = tbj[j] ? c : 0u;
                     kj[j] = (uint32_t)k;
