@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 // bytes they span.  What is left (invalid leads, truncated sequences, stray continuation bytes, a fifth
                 // lead) takes the general per-byte route (feature_at_v).
                 const uint2 t8n = (it + 1 < K_WIN / 8) ? reinterpret_cast<const uint2*>(s_txt)[it + 1] : make_uint2(0, 0);
-                const uint64_t lo8 = ((uint64_t)t8.y << 32) | t8.x, hi8 = ((uint64_t)t8n.y << 32) | t8n.x;
+                const uint64_t lo8 = ((uint64_t)t8.y << 32) | t8.x;
                 const uint32_t docb = (uint32_t)reinterpret_cast<const uint8_t*>(s_doc)[it] |
                                       ((it + 1 < K_WIN / 8) ? (uint32_t)reinterpret_cast<const uint8_t*>(s_doc)[it + 1] << 8 : 0u);
                 const int pos0 = it * 8;
@@ -1298,6 +1298,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                     c = need >= 2u ? (c << 6) | c2 : c;
                     c = need >= 3u ? (c << 6) | c3 : c;
 #else
+                    const uint64_t hi8 = ((uint64_t)t8n.y << 32) | t8n.x;
                     const uint64_t w = (lo8 >> (8 * k)) | ((hi8 << 8) << (56 - 8 * k));  // bytes k .. k+7
                     const uint32_t b = (uint32_t)w & 0xFFu, c1 = (uint32_t)(w >> 8) & 0xFFu, c2 = (uint32_t)(w >> 16) & 0xFFu, c3 = (uint32_t)(w >> 24) & 0xFFu;
                     const uint32_t need = utf8_declared_len(b) - 1u;
