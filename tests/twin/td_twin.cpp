@@ -281,11 +281,17 @@ int twin_split_tiled(void* h, const uint8_t* text, int64_t n, const int64_t* off
             }
             uint32_t sy = (uint32_t)bw.m[MK_SYNC];
             if (tile_hi - b0 < 32) sy &= (1u << (tile_hi - b0)) - 1u;
-            const uint32_t un = (uint32_t)split_unresolved_heads(bw, T.pat_flags) & sy;
+            uint64_t extra = 0;
+            const uint32_t un = (uint32_t)split_unresolved_heads(bw, T.pat_flags, &extra) & sy;
+            extra &= (uint64_t)sy << 3;  // (as the kernel: behind this stride's heads, inside the tile)
+            const int room = tile_hi - b0;
+            extra &= room >= 64 ? ~0ull : room <= 0 ? 0ull : ((1ull << room) - 1ull);
             for (int i = 0; i < 32; ++i) {
                 if ((sy >> i) & 1u) { w.mark(b0 + i); last_head = b0 + i; }
                 if ((un >> i) & 1u) heads.push_back(b0 + i);
             }
+            for (int i = 0; i < 64; ++i)
+                if ((extra >> i) & 1ull) w.mark(b0 + i);
             if (stats) { stats[3] += __builtin_popcount(sy); stats[4] += __builtin_popcount(un); }
         }
         if (!is_sync(w.cf(K_HL - 1), w.cf(K_HL), T.pat_flags)) {
@@ -561,8 +567,11 @@ int64_t twin_word_rules_check(void* h, const uint8_t* text, int64_t n, const int
         for (int k = 0; k < MK_COUNT; ++k) w.m[k] = 0;
         for (int i = 0; i < 64; ++i)
             for (int k = 0; k < MK_COUNT; ++k) w.m[k] |= (uint64_t)((bits[(size_t)(base + i)] >> k) & 1u) << i;
-        const uint64_t un = split_unresolved_heads(w, T.pat_flags);
+        uint64_t extra = 0;
+        const uint64_t un = split_unresolved_heads(w, T.pat_flags, &extra);
         if (un & ~w.m[MK_SYNC]) ++bad;
+        for (int i = 0; i < 64 && base + i < n; ++i)  // an extra start is a piece start, whatever its region counts as
+            if (((extra >> i) & 1ull) && !start[(size_t)(base + i)]) ++bad;
         for (int i = 0; i < 32 && base + i < n; ++i) {
             if (!((w.m[MK_SYNC] >> i) & 1ull)) continue;
             const int64_t hd = base + i;
@@ -574,7 +583,12 @@ int64_t twin_word_rules_check(void* h, const uint8_t* text, int64_t n, const int
             ++heads; pieces += np;
             if (head_state) head_state[hd] = ((un >> i) & 1ull) ? 2 : 1;
             if ((un >> i) & 1ull) { ++unres; upieces += np; }
-            else if (np != 1) ++bad;
+            else {
+                // resolved: the pieces of the region are its head and the extra starts the rules placed inside it
+                int64_t ne = 0;
+                for (int64_t q = hd + 1; q < nx && q < base + 64; ++q) ne += (extra >> (q - base)) & 1ull;
+                if (np != 1 + ne) ++bad;
+            }
         }
     }
     if (stats) { stats[0] = heads; stats[1] = unres; stats[2] = pieces; stats[3] = upieces; }

@@ -837,8 +837,12 @@ TD_HD uint64_t td_brev64(uint64_t x) {
 constexpr uint32_t PV_WORD_RULES_OK = PV_NO_CONTRACTION | PV_SINGLE_DIGIT;  // patterns the rules below are written for
 // -> the heads (MK_SYNC bits) of the window whose region is NOT proven to be exactly one piece.  A region that is not
 // closed by a synchronisation point inside the window is unresolved.
-TD_HD uint64_t split_unresolved_heads(const BitWin& w, uint32_t pv) {
+// `extra` (optional): piece starts INSIDE regions that the rules can place as well — so far the second piece of a run of four to six
+// ASCII digits (\p{N}{1,3} takes three, what is left is one more piece): half of the unresolved heads of the reference's code file set
+// were such numbers.  The positions are piece starts whether or not their region counts as resolved.
+TD_HD uint64_t split_unresolved_heads(const BitWin& w, uint32_t pv, uint64_t* extra = nullptr) {
     const uint64_t SY = w.m[MK_SYNC];
+    if (extra) *extra = 0;
     if (pv & ~PV_WORD_RULES_OK) return SY;
     const uint64_t nD = ~w.m[MK_D];
     const uint64_t U = w.m[MK_U] & nD, W = w.m[MK_W] & nD, X = w.m[MK_X] & nD, S = w.m[MK_S] & nD, N = w.m[MK_N] & nD;
@@ -853,7 +857,17 @@ TD_HD uint64_t split_unresolved_heads(const BitWin& w, uint32_t pv) {
     // digits
     const uint64_t hn = H & N;
     const uint64_t near = (pv & PV_SINGLE_DIGIT) ? (hn << 1) : ((hn << 1) | (hn << 2) | (hn << 3));
-    good |= td_land(N, hn) & near;
+    const uint64_t ln = td_land(N, hn);
+    good |= ln & near;
+    if (extra && hn && !(pv & PV_SINGLE_DIGIT)) {
+        // head + 3 when the head and the two bytes behind it are one-byte digits and head + 3 is a digit's first byte: the piece that
+        // starts at the head is exactly those three, the next one starts there; it ends the region when what is left is at most three
+        // bytes (the rule above, from the new start)
+        const uint64_t NC = N & ~C;
+        const uint64_t e3 = (hn << 3) & NC & (NC << 1) & (NC << 2);
+        good |= ln & ((e3 << 1) | (e3 << 2) | (e3 << 3));
+        *extra = e3;
+    }
     // other
     const uint64_t b1 = (H & Xn) | ((H & SP & (Xn >> 1)) << 1);
     good |= td_land(TR, td_land(Xn, b1));

@@ -1425,6 +1425,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             // (a)
             const int b0 = K_HL + tid * 32;
             uint32_t mine = 0;  // unresolved heads of my stride that found no room on the list
+            uint32_t extra_hi = 0;
             {
                 const uint32_t* lo = s_mask32 + dword_at(b0 >> 5);
                 const uint32_t* hi = s_mask32 + dword_at((b0 >> 5) + 1);
@@ -1434,8 +1435,18 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
                 uint32_t sy = (uint32_t)wv.m[MK_SYNC];
                 const int room = tile_hi - b0;
                 if (room < 32) sy = room <= 0 ? 0u : sy & ((1u << room) - 1u);
-                s_start[b0 >> 5] = sy;
-                uint32_t un = (uint32_t)split_unresolved_heads(wv, PV) & sy;
+                uint32_t st0 = sy, un;
+                if (wv.m[MK_N] != 0ull) {  // digits in my window (no lane of a wavefront of plain prose comes here: the rules twice in the code, once in its time)
+                    uint64_t extra = 0;  // piece starts inside the regions of my heads that the rules place too (td_common.h)
+                    un = (uint32_t)split_unresolved_heads(wv, PV, &extra) & sy;
+                    extra &= (uint64_t)sy << 3;  // (behind MY heads, inside the tile)
+                    extra &= room >= 64 ? ~0ull : room <= 0 ? 0ull : ((1ull << room) - 1ull);
+                    st0 |= (uint32_t)extra;
+                    extra_hi = (uint32_t)(extra >> 32);  // (the next lane's word: behind the barrier)
+                } else {
+                    un = (uint32_t)split_unresolved_heads(wv, PV) & sy;
+                }
+                s_start[b0 >> 5] = st0;
                 if (sy) atomicMax(&s_last, b0 + 31 - (int)__clz(sy));
                 const uint32_t cnt = __popc(un);
                 const uint32_t incl = wave_incl_scan(cnt, lane);
@@ -1452,6 +1463,7 @@ __global__ __launch_bounds__(K_THREADS, FUSED ? TD_FUSED_MIN_WAVES : TD_SPLIT_MI
             }
             __syncthreads();
             FZ_TICK(2)
+            if (extra_hi) atomicOr(&s_start[(b0 >> 5) + 1], extra_hi);
             if (TD_STOP(13)) continue;
             // (b)
             {
